@@ -1,0 +1,276 @@
+// ORACLE (test infrastructure, not product code) — see oracle.h.
+//
+// Restatement of rust-bio 4.0.1's FM-index path:
+//   suffix_array      /root/reference/src/data_structures/suffix_array.rs:264-284, 426-466
+//   bwt / less / Occ  /root/reference/src/data_structures/bwt.rs:39-49, 94-125, 129-182, 186-199
+//   backward_search   /root/reference/src/data_structures/fmindex.rs:144-208
+//   Alphabet          /root/reference/src/alphabets/mod.rs:49-60, 91-116
+// The suffix array uses prefix doubling instead of SA-IS: the reference's sentinel transform
+// (transform_text) makes every suffix distinct, so the suffix array is unique and any correct
+// construction reproduces it.
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+#include <thread>
+#include <vector>
+
+#include "oracle.h"
+
+namespace {
+
+// alphabets/mod.rs:37-116 — a set of bytes
+struct Alphabet {
+    bool has[256] = {};
+    Alphabet(const uint8_t* syms, uint64_t n) {
+        for (uint64_t i = 0; i < n; i++) has[syms[i]] = true;
+    }
+    int max_symbol() const {
+        for (int c = 255; c >= 0; c--)
+            if (has[c]) return c;
+        return -1;
+    }
+    size_t len() const {
+        size_t k = 0;
+        for (bool b : has) k += b;
+        return k;
+    }
+};
+
+}  // namespace
+
+struct orc_occ {
+    std::vector<std::vector<uint64_t>> occ;
+    uint32_t k;
+};
+
+// suffix_array.rs:426-441 sentinel / sentinel_count, 444-466 transform_text, 264-284 suffix_array
+extern "C" int orc_suffix_array(const uint8_t* text, uint64_t n, uint64_t* sa_out) {
+    if (n == 0) return -1;  // text[text.len() - 1] panics
+    const uint8_t sentinel = text[n - 1];
+    uint64_t sentinel_count = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        if (text[i] < sentinel) return -1;  // assert!(text.iter().all(|&a| a >= sentinel))
+        sentinel_count += text[i] == sentinel;
+    }
+    // RankTransform over Alphabet::new(text): rank = index among present symbols
+    Alphabet alpha(text, n);
+    uint32_t ranks[256];
+    uint32_t r = 0;
+    for (int c = 0; c < 256; c++)
+        if (alpha.has[c]) ranks[c] = r++;
+    const uint64_t offset = sentinel_count - 1;
+    std::vector<uint64_t> t(n);
+    uint64_t s = sentinel_count;
+    for (uint64_t i = 0; i < n; i++) {
+        if (text[i] == sentinel) {
+            s -= 1;
+            t[i] = s;  // first sentinel gets the largest sentinel rank, the last one 0
+        } else {
+            t[i] = ranks[text[i]] + offset;
+        }
+    }
+    // prefix doubling on the transformed text
+    std::vector<uint64_t> sa(n), rank(t), tmp(n);
+    std::iota(sa.begin(), sa.end(), 0);
+    for (uint64_t k = 1;; k <<= 1) {
+        auto key2 = [&](uint64_t i) -> int64_t { return i + k < n ? (int64_t)rank[i + k] : -1; };
+        auto cmp = [&](uint64_t a, uint64_t b) {
+            if (rank[a] != rank[b]) return rank[a] < rank[b];
+            return key2(a) < key2(b);
+        };
+        if (k == 1) {
+            std::sort(sa.begin(), sa.end(), [&](uint64_t a, uint64_t b) {
+                if (rank[a] != rank[b]) return rank[a] < rank[b];
+                return key2(a) < key2(b);
+            });
+        } else {
+            std::sort(sa.begin(), sa.end(), cmp);
+        }
+        tmp[sa[0]] = 0;
+        for (uint64_t i = 1; i < n; i++) tmp[sa[i]] = tmp[sa[i - 1]] + (cmp(sa[i - 1], sa[i]) ? 1 : 0);
+        rank = tmp;
+        if (rank[sa[n - 1]] == n - 1) break;
+        if (k > n) break;
+    }
+    std::copy(sa.begin(), sa.end(), sa_out);
+    return 0;
+}
+
+// bwt.rs:39-49
+extern "C" void orc_bwt(const uint8_t* text, const uint64_t* pos, uint64_t n, uint8_t* bwt) {
+    for (uint64_t r = 0; r < n; r++) {
+        uint64_t p = pos[r];
+        bwt[r] = p > 0 ? text[p - 1] : text[n - 1];
+    }
+}
+
+// bwt.rs:186-199 (+ utils::prescan, utils/mod.rs:25-34: exclusive prefix sum)
+extern "C" uint64_t orc_less(const uint8_t* bwt, uint64_t n, const uint8_t* alphabet,
+                             uint64_t n_sym, uint64_t* less_out) {
+    Alphabet alpha(alphabet, n_sym);
+    const uint64_t m = (uint64_t)alpha.max_symbol() + 2;
+    if (!less_out) return m;
+    std::vector<uint64_t> less(m, 0);
+    for (uint64_t i = 0; i < n; i++) {
+        if (bwt[i] >= m) return 0;  // index out of bounds panic
+        less[bwt[i]] += 1;
+    }
+    uint64_t acc = 0;
+    for (uint64_t i = 0; i < m; i++) {
+        uint64_t v = less[i];
+        less[i] = acc;
+        acc += v;
+    }
+    std::copy(less.begin(), less.end(), less_out);
+    return m;
+}
+
+// bwt.rs:94-125
+extern "C" orc_occ* orc_occ_new(const uint8_t* bwt, uint64_t n, uint32_t k,
+                                const uint8_t* alphabet, uint64_t n_sym) {
+    Alphabet alphab(alphabet, n_sym);
+    const uint64_t m = (uint64_t)alphab.max_symbol() + 1;
+    std::vector<uint64_t> alpha;
+    for (int c = 0; c < 256; c++)
+        if (alphab.has[c]) alpha.push_back(c);
+    // include sentinel '$'
+    if ((uint64_t)'$' < m && !alphab.has['$']) alpha.push_back('$');
+    auto* o = new orc_occ;
+    o->k = k;
+    o->occ.assign(m, {});
+    std::vector<uint64_t> curr_occ(m, 0);
+    for (uint64_t a : alpha) o->occ[a].reserve(n / k);
+    for (uint64_t i = 0; i < n; i++) {
+        uint8_t c = bwt[i];
+        if (c >= m) {  // curr_occ[c as usize] out of bounds → panic
+            delete o;
+            return nullptr;
+        }
+        curr_occ[c] += 1;
+        if (i % k == 0)
+            for (uint64_t a : alpha) o->occ[a].push_back(curr_occ[a]);
+    }
+    return o;
+}
+
+extern "C" void orc_occ_free(orc_occ* o) { delete o; }
+
+extern "C" const uint64_t* orc_occ_row(const orc_occ* o, uint32_t a, uint64_t* len) {
+    if (a >= o->occ.size()) {
+        *len = 0;
+        return nullptr;
+    }
+    *len = o->occ[a].size();
+    return o->occ[a].data();
+}
+
+static inline uint64_t bytecount(const uint8_t* b, uint64_t lo, uint64_t hi_incl, uint8_t a) {
+    // bytecount::count(&bwt[lo..=hi_incl], a)
+    uint64_t c = 0;
+    for (uint64_t i = lo; i <= hi_incl && i + 1 != 0; i++) c += b[i] == a;
+    return c;
+}
+
+// bwt.rs:129-182
+extern "C" int orc_occ_get(const orc_occ* o, const uint8_t* bwt, uint64_t n, uint64_t r,
+                           uint8_t a, uint64_t* out) {
+    const uint64_t k = o->k;
+    if (a >= o->occ.size()) return -1;
+    const std::vector<uint64_t>& row = o->occ[a];
+    const uint64_t lo_checkpoint = r / k;
+    if (lo_checkpoint >= row.size()) return -1;
+    const uint64_t lo_occ = row[lo_checkpoint];
+    if (k > 64) {
+        const uint64_t hi_checkpoint = lo_checkpoint + 1;
+        if (hi_checkpoint < row.size()) {
+            const uint64_t hi_occ = row[hi_checkpoint];
+            if (lo_occ == hi_occ) {
+                *out = lo_occ;
+                return 0;
+            }
+            const uint64_t hi_idx = hi_checkpoint * k;
+            if ((hi_idx - r) < (k / 2)) {
+                if (hi_idx >= n) return -1;
+                *out = hi_occ - (r + 1 <= hi_idx ? bytecount(bwt, r + 1, hi_idx, a) : 0);
+                return 0;
+            }
+        }
+    }
+    const uint64_t lo_idx = lo_checkpoint * k;
+    if (r >= n) return -1;
+    *out = (lo_idx + 1 <= r ? bytecount(bwt, lo_idx + 1, r, a) : 0) + lo_occ;
+    return 0;
+}
+
+// fmindex.rs:144-208
+extern "C" int orc_backward_search(const uint8_t* bwt, uint64_t n, const uint64_t* less,
+                                   uint64_t less_len, const orc_occ* occ, const uint8_t* pattern,
+                                   uint64_t plen, uint64_t* lower, uint64_t* upper,
+                                   uint64_t* matched_len_out) {
+    uint64_t l = 0, r = n - 1;
+    uint64_t pl = l, pr = r;
+    uint64_t matched_len = 0;
+    bool complete_match = true;
+    *lower = *upper = *matched_len_out = 0;
+
+    for (uint64_t t = plen; t-- > 0;) {
+        const uint8_t a = pattern[t];
+        if (a >= less_len) return ORC_BS_PANIC;  // self.less.borrow()[a as usize]
+        const uint64_t less_a = less[a];
+        pl = l;
+        pr = r;
+        uint64_t occ_r;
+        if (orc_occ_get(occ, bwt, n, r, a, &occ_r)) return ORC_BS_PANIC;
+        if (occ_r == 0) {
+            complete_match = false;
+            break;
+        }
+        uint64_t occ_l = 0;
+        if (l > 0 && orc_occ_get(occ, bwt, n, l - 1, a, &occ_l)) return ORC_BS_PANIC;
+        l = less_a + (l > 0 ? occ_l : 0);
+        r = less_a + occ_r - 1;
+        if (l > r) {
+            complete_match = false;
+            break;
+        }
+        matched_len += 1;
+    }
+
+    if (matched_len > 0) {
+        if (complete_match) {
+            *lower = l;
+            *upper = r + 1;
+            *matched_len_out = matched_len;
+            return ORC_BS_COMPLETE;
+        }
+        *lower = pl;
+        *upper = pr + 1;
+        *matched_len_out = matched_len;
+        return ORC_BS_PARTIAL;
+    }
+    return ORC_BS_ABSENT;
+}
+
+extern "C" void orc_backward_search_batch(const uint8_t* bwt, uint64_t n, const uint64_t* less,
+                                          uint64_t less_len, const orc_occ* occ, uint64_t n_q,
+                                          const uint8_t* pat, const uint64_t* pat_off,
+                                          uint8_t* tag, uint64_t* lower, uint64_t* upper,
+                                          uint64_t* matched_len, int threads) {
+    if (threads < 1) threads = 1;
+    auto work = [&](int t) {
+        // contiguous shards: one shared read-only index, as in the reference's Arc example
+        // (src/lib.rs:173-210)
+        uint64_t lo = n_q * t / threads, hi = n_q * (t + 1) / threads;
+        for (uint64_t q = lo; q < hi; q++)
+            tag[q] = (uint8_t)orc_backward_search(bwt, n, less, less_len, occ, pat + pat_off[q],
+                                                  pat_off[q + 1] - pat_off[q], &lower[q],
+                                                  &upper[q], &matched_len[q]);
+    };
+    if (threads == 1) {
+        work(0);
+        return;
+    }
+    std::vector<std::thread> th;
+    for (int t = 0; t < threads; t++) th.emplace_back(work, t);
+    for (auto& t : th) t.join();
+}

@@ -1,0 +1,343 @@
+"""ctypes loader for the CPU oracle (oracle/liboracle.so).
+
+TEST INFRASTRUCTURE ONLY — importable from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  Nothing under rust-bio_amd/ imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "liboracle.so")
+
+MIN_SCORE = -858993459
+MODES = {"custom": 0, "global": 1, "semiglobal": 2, "local": 3}
+OP_NAMES = ["M", "S", "D", "I", "X", "Y"]
+TAGS = ["complete", "partial", "absent", "panic"]
+
+
+class Scoring(C.Structure):
+    _fields_ = [("gap_open", C.c_int32), ("gap_extend", C.c_int32),
+                ("xclip_prefix", C.c_int32), ("xclip_suffix", C.c_int32),
+                ("yclip_prefix", C.c_int32), ("yclip_suffix", C.c_int32),
+                ("match_score", C.c_int32), ("mismatch_score", C.c_int32),
+                ("match_scores_some", C.c_int32),
+                ("matrix", C.POINTER(C.c_int32))]
+
+
+class AlignmentRec(C.Structure):
+    _fields_ = [("score", C.c_int32), ("ystart", C.c_uint64), ("xstart", C.c_uint64),
+                ("yend", C.c_uint64), ("xend", C.c_uint64), ("ylen", C.c_uint64),
+                ("xlen", C.c_uint64), ("n_ops", C.c_uint64), ("mode", C.c_int32)]
+
+
+ALN_DTYPE = np.dtype([("score", "<i4"), ("_p0", "<i4"), ("ystart", "<u8"), ("xstart", "<u8"),
+                      ("yend", "<u8"), ("xend", "<u8"), ("ylen", "<u8"), ("xlen", "<u8"),
+                      ("n_ops", "<u8"), ("mode", "<i4"), ("_p1", "<i4")])
+assert ALN_DTYPE.itemsize == C.sizeof(AlignmentRec)
+
+
+def build(force=False):
+    if force or not os.path.exists(_SO):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        u8p, u64p, u32p = C.POINTER(C.c_uint8), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)
+        L.orc_align.restype = C.c_int
+        L.orc_align.argtypes = [C.POINTER(Scoring), C.c_int, C.c_void_p, C.c_uint64, C.c_void_p,
+                                C.c_uint64, C.POINTER(AlignmentRec), C.c_void_p, C.c_uint64]
+        L.orc_align_batch.restype = C.c_int
+        L.orc_align_batch.argtypes = [C.POINTER(Scoring), C.c_int, C.c_uint64, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_uint64, C.c_int]
+        L.orc_suffix_array.restype = C.c_int
+        L.orc_suffix_array.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
+        L.orc_bwt.restype = None
+        L.orc_bwt.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+        L.orc_less.restype = C.c_uint64
+        L.orc_less.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p]
+        L.orc_occ_new.restype = C.c_void_p
+        L.orc_occ_new.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint64]
+        L.orc_occ_free.restype = None
+        L.orc_occ_free.argtypes = [C.c_void_p]
+        L.orc_occ_row.restype = C.POINTER(C.c_uint64)
+        L.orc_occ_row.argtypes = [C.c_void_p, C.c_uint32, u64p]
+        L.orc_occ_get.restype = C.c_int
+        L.orc_occ_get.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint8, u64p]
+        L.orc_backward_search.restype = C.c_int
+        L.orc_backward_search.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
+                                          C.c_void_p, C.c_void_p, C.c_uint64, u64p, u64p, u64p]
+        L.orc_backward_search_batch.restype = None
+        L.orc_backward_search_batch.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
+                                                C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
+                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                C.c_int]
+        for name, res, args in [
+            ("orc_banded_align", C.c_int,
+             [C.POINTER(Scoring), C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64,
+              C.c_void_p, C.c_uint64, C.POINTER(AlignmentRec), C.c_void_p, C.c_uint64, u64p]),
+            ("orc_banded_align_batch", C.c_int,
+             [C.POINTER(Scoring), C.c_int, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p,
+              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p,
+              C.c_int]),
+            ("orc_band_create", C.c_uint64,
+             [C.POINTER(Scoring), C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p,
+              C.c_uint64, C.c_void_p, C.c_void_p]),
+            ("orc_find_kmer_matches", C.c_uint64,
+             [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint64]),
+            ("orc_sdpkpp", C.c_uint64,
+             [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32, C.c_void_p,
+              C.c_uint64, u32p]),
+            ("orc_lcskpp", C.c_uint64,
+             [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint64, u32p]),
+        ]:
+            if hasattr(L, name):
+                f = getattr(L, name)
+                f.restype = res
+                f.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _buf(b):
+    """bytes / bytearray / ndarray -> contiguous uint8 ndarray"""
+    if isinstance(b, np.ndarray):
+        return np.ascontiguousarray(b, dtype=np.uint8)
+    return np.frombuffer(bytes(b), dtype=np.uint8)
+
+
+def make_scoring(gap_open, gap_extend, match=0, mismatch=0, xclip_prefix=MIN_SCORE,
+                 xclip_suffix=MIN_SCORE, yclip_prefix=MIN_SCORE, yclip_suffix=MIN_SCORE,
+                 matrix=None, match_scores_some=None):
+    """Returns (Scoring, keepalive). matrix: int32[256,256] tabulated match_fn or None."""
+    sc = Scoring()
+    sc.gap_open, sc.gap_extend = gap_open, gap_extend
+    sc.xclip_prefix, sc.xclip_suffix = xclip_prefix, xclip_suffix
+    sc.yclip_prefix, sc.yclip_suffix = yclip_prefix, yclip_suffix
+    sc.match_score, sc.mismatch_score = match, mismatch
+    keep = None
+    if matrix is not None:
+        keep = np.ascontiguousarray(matrix, dtype=np.int32).reshape(256 * 256)
+        sc.matrix = keep.ctypes.data_as(C.POINTER(C.c_int32))
+        sc.match_scores_some = 0 if match_scores_some is None else int(match_scores_some)
+    else:
+        sc.matrix = None
+        sc.match_scores_some = 1 if match_scores_some is None else int(match_scores_some)
+    return sc, keep
+
+
+def decode_ops(ops_u64):
+    out = []
+    for v in ops_u64:
+        kind, ln = int(v) & 0xFF, int(v) >> 8
+        out.append(OP_NAMES[kind] + (str(ln) if kind >= 4 else ""))
+    return out
+
+
+def _rec_to_dict(rec, ops):
+    return {"score": int(rec.score), "xstart": int(rec.xstart), "xend": int(rec.xend),
+            "ystart": int(rec.ystart), "yend": int(rec.yend), "xlen": int(rec.xlen),
+            "ylen": int(rec.ylen), "mode": int(rec.mode), "ops": ops}
+
+
+def align(scoring, mode, x, y):
+    """One pair through the oracle Aligner; returns dict with ops as token list."""
+    sc = scoring[0] if isinstance(scoring, tuple) else scoring
+    xb, yb = _buf(x), _buf(y)
+    cap = len(xb) + len(yb) + 8
+    ops = np.zeros(cap, dtype=np.uint64)
+    rec = AlignmentRec()
+    rc = lib().orc_align(C.byref(sc), MODES[mode] if isinstance(mode, str) else mode,
+                         xb.ctypes.data, len(xb), yb.ctypes.data, len(yb), C.byref(rec),
+                         ops.ctypes.data, cap)
+    if rc:
+        raise RuntimeError(f"oracle align failed rc={rc}")
+    return _rec_to_dict(rec, decode_ops(ops[:rec.n_ops]))
+
+
+def align_batch(scoring, mode, x, x_off, y, y_off, threads=1, want_ops=True):
+    sc = scoring[0] if isinstance(scoring, tuple) else scoring
+    xb, yb = _buf(x), _buf(y)
+    x_off = np.ascontiguousarray(x_off, dtype=np.uint64)
+    y_off = np.ascontiguousarray(y_off, dtype=np.uint64)
+    n = len(x_off) - 1
+    out = np.zeros(n, dtype=ALN_DTYPE)
+    stride = 0
+    ops = None
+    if want_ops and n:
+        stride = int((np.diff(x_off) + np.diff(y_off)).max()) + 8
+        ops = np.zeros(n * stride, dtype=np.uint64)
+    rc = lib().orc_align_batch(C.byref(sc), MODES[mode] if isinstance(mode, str) else mode, n,
+                               xb.ctypes.data, x_off.ctypes.data, yb.ctypes.data,
+                               y_off.ctypes.data, out.ctypes.data,
+                               ops.ctypes.data if ops is not None else None, stride, threads)
+    if rc:
+        raise RuntimeError(f"oracle align_batch failed rc={rc}")
+    return out, ops, stride
+
+
+def banded_align(scoring, mode, k, w, x, y):
+    sc = scoring[0] if isinstance(scoring, tuple) else scoring
+    xb, yb = _buf(x), _buf(y)
+    cap = len(xb) + len(yb) + 8
+    ops = np.zeros(cap, dtype=np.uint64)
+    rec = AlignmentRec()
+    cells = C.c_uint64(0)
+    rc = lib().orc_banded_align(C.byref(sc), MODES[mode] if isinstance(mode, str) else mode, k, w,
+                                xb.ctypes.data, len(xb), yb.ctypes.data, len(yb), C.byref(rec),
+                                ops.ctypes.data, cap, C.byref(cells))
+    if rc:
+        raise RuntimeError(f"oracle banded_align failed rc={rc}")
+    d = _rec_to_dict(rec, decode_ops(ops[:rec.n_ops]))
+    d["band_cells"] = int(cells.value)
+    return d
+
+
+def banded_align_batch(scoring, mode, k, w, x, x_off, y, y_off, threads=1, want_ops=True):
+    sc = scoring[0] if isinstance(scoring, tuple) else scoring
+    xb, yb = _buf(x), _buf(y)
+    x_off = np.ascontiguousarray(x_off, dtype=np.uint64)
+    y_off = np.ascontiguousarray(y_off, dtype=np.uint64)
+    n = len(x_off) - 1
+    out = np.zeros(n, dtype=ALN_DTYPE)
+    cells = np.zeros(n, dtype=np.uint64)
+    stride = 0
+    ops = None
+    if want_ops and n:
+        stride = int((np.diff(x_off) + np.diff(y_off)).max()) + 8
+        ops = np.zeros(n * stride, dtype=np.uint64)
+    rc = lib().orc_banded_align_batch(C.byref(sc), MODES[mode] if isinstance(mode, str) else mode,
+                                      k, w, n, xb.ctypes.data, x_off.ctypes.data, yb.ctypes.data,
+                                      y_off.ctypes.data, out.ctypes.data,
+                                      ops.ctypes.data if ops is not None else None, stride,
+                                      cells.ctypes.data, threads)
+    if rc:
+        raise RuntimeError(f"oracle banded_align_batch failed rc={rc}")
+    return out, ops, stride, cells
+
+
+def band_create(scoring, k, w, x, y):
+    sc = scoring[0] if isinstance(scoring, tuple) else scoring
+    xb, yb = _buf(x), _buf(y)
+    n = len(yb)
+    start = np.zeros(n + 1, dtype=np.uint32)
+    end = np.zeros(n + 1, dtype=np.uint32)
+    cells = lib().orc_band_create(C.byref(sc), k, w, xb.ctypes.data, len(xb), yb.ctypes.data, n,
+                                  start.ctypes.data, end.ctypes.data)
+    return start, end, int(cells)
+
+
+def find_kmer_matches(x, y, k):
+    xb, yb = _buf(x), _buf(y)
+    cnt = lib().orc_find_kmer_matches(xb.ctypes.data, len(xb), yb.ctypes.data, len(yb), k, None, 0)
+    out = np.zeros((max(cnt, 1), 2), dtype=np.uint32)
+    lib().orc_find_kmer_matches(xb.ctypes.data, len(xb), yb.ctypes.data, len(yb), k,
+                                out.ctypes.data, cnt)
+    return out[:cnt]
+
+
+def sdpkpp(matches, k, match_score, gap_open, gap_extend):
+    mm = np.ascontiguousarray(matches, dtype=np.uint32).reshape(-1, 2)
+    path = np.zeros(max(len(mm), 1), dtype=np.uint32)
+    score = C.c_uint32(0)
+    cnt = lib().orc_sdpkpp(mm.ctypes.data, len(mm), k, match_score, gap_open, gap_extend,
+                           path.ctypes.data, len(path), C.byref(score))
+    return path[:cnt].tolist(), int(score.value)
+
+
+def lcskpp(matches, k):
+    mm = np.ascontiguousarray(matches, dtype=np.uint32).reshape(-1, 2)
+    path = np.zeros(max(len(mm), 1), dtype=np.uint32)
+    score = C.c_uint32(0)
+    cnt = lib().orc_lcskpp(mm.ctypes.data, len(mm), k, path.ctypes.data, len(path),
+                           C.byref(score))
+    return path[:cnt].tolist(), int(score.value)
+
+
+# ---------------------------------------------------------------- FM index
+def suffix_array(text):
+    t = _buf(text)
+    sa = np.zeros(len(t), dtype=np.uint64)
+    if lib().orc_suffix_array(t.ctypes.data, len(t), sa.ctypes.data):
+        raise ValueError("Expecting extra sentinel symbol being lexicographically smallest at "
+                         "the end of the text.")
+    return sa
+
+
+def bwt(text, sa):
+    t = _buf(text)
+    sa = np.ascontiguousarray(sa, dtype=np.uint64)
+    out = np.zeros(len(t), dtype=np.uint8)
+    lib().orc_bwt(t.ctypes.data, sa.ctypes.data, len(t), out.ctypes.data)
+    return out
+
+
+def less(bwt_arr, alphabet):
+    b, a = _buf(bwt_arr), _buf(alphabet)
+    m = lib().orc_less(b.ctypes.data, len(b), a.ctypes.data, len(a), None)
+    out = np.zeros(m, dtype=np.uint64)
+    if lib().orc_less(b.ctypes.data, len(b), a.ctypes.data, len(a), out.ctypes.data) == 0:
+        raise IndexError("bwt symbol beyond max_symbol+1")
+    return out
+
+
+class Occ:
+    def __init__(self, bwt_arr, k, alphabet):
+        self.bwt = _buf(bwt_arr)
+        a = _buf(alphabet)
+        self.k = k
+        self.h = lib().orc_occ_new(self.bwt.ctypes.data, len(self.bwt), k, a.ctypes.data, len(a))
+        if not self.h:
+            raise IndexError("bwt symbol beyond alphabet max_symbol")
+
+    def row(self, a):
+        ln = C.c_uint64(0)
+        p = lib().orc_occ_row(self.h, a, C.byref(ln))
+        return [int(p[i]) for i in range(ln.value)]
+
+    def get(self, r, a):
+        out = C.c_uint64(0)
+        if lib().orc_occ_get(self.h, self.bwt.ctypes.data, len(self.bwt), r, a, C.byref(out)):
+            raise IndexError("index out of bounds (non-alphabet symbol)")
+        return int(out.value)
+
+    def __del__(self):
+        try:
+            lib().orc_occ_free(self.h)
+        except Exception:
+            pass
+
+
+def backward_search(bwt_arr, less_arr, occ, pattern):
+    b, p = _buf(bwt_arr), _buf(pattern)
+    ls = np.ascontiguousarray(less_arr, dtype=np.uint64)
+    lo, hi, ml = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+    tag = lib().orc_backward_search(b.ctypes.data, len(b), ls.ctypes.data, len(ls), occ.h,
+                                    p.ctypes.data, len(p), C.byref(lo), C.byref(hi), C.byref(ml))
+    return TAGS[tag], int(lo.value), int(hi.value), int(ml.value)
+
+
+def backward_search_batch(bwt_arr, less_arr, occ, pat, pat_off, threads=1):
+    b, p = _buf(bwt_arr), _buf(pat)
+    ls = np.ascontiguousarray(less_arr, dtype=np.uint64)
+    off = np.ascontiguousarray(pat_off, dtype=np.uint64)
+    n = len(off) - 1
+    tag = np.zeros(n, dtype=np.uint8)
+    lo = np.zeros(n, dtype=np.uint64)
+    hi = np.zeros(n, dtype=np.uint64)
+    ml = np.zeros(n, dtype=np.uint64)
+    lib().orc_backward_search_batch(b.ctypes.data, len(b), ls.ctypes.data, len(ls), occ.h, n,
+                                    p.ctypes.data, off.ctypes.data, tag.ctypes.data,
+                                    lo.ctypes.data, hi.ctypes.data, ml.ctypes.data, threads)
+    return tag, lo, hi, ml

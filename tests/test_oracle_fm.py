@@ -1,0 +1,157 @@
+"""Pins the FM-index ORACLE (suffix array, BWT, less, Occ, backward_search) against the
+reference's known-answer tests (tests/golden/fm_kats.json, transcribed from
+/root/reference/src/data_structures/{suffix_array,bwt,fmindex}.rs)."""
+import numpy as np
+import pytest
+
+import oracle_py as orc
+from kat_util import load
+
+K = load("fm_kats.json")
+
+
+def _text(case):
+    return bytes(case["text_bytes"]) if "text_bytes" in case else case["text"].encode()
+
+
+@pytest.mark.parametrize("case", K["suffix_array"], ids=lambda c: c["text"][:12])
+def test_suffix_array_kat(case):
+    assert orc.suffix_array(case["text"].encode()).tolist() == case["sa"]
+
+
+@pytest.mark.parametrize("text", K["sorts_lexically"]["texts"], ids=lambda t: t[:10])
+def test_sorts_lexically(text):
+    # suffix_array.rs:868-909: every suffix (cut at its first '$') is <= the next one
+    t = text.encode()
+    sa = orc.suffix_array(t)
+
+    def s(i):
+        return t[int(sa[i]):].split(b"$")[0] + b"$"
+    for i in range(len(sa) - 2):
+        assert s(i) <= s(i + 1)
+    assert sorted(sa.tolist()) == list(range(len(t)))
+
+
+def test_multi_sentinel_order():
+    # suffix_array.rs:444-466: the first '$' gets the largest sentinel rank, the last one rank 0
+    t = b"A$A$T$T$"
+    sa = orc.suffix_array(t).tolist()
+    assert sa[:4] == [7, 5, 3, 1]
+
+
+def test_sentinel_assert():
+    with pytest.raises(ValueError):
+        orc.suffix_array(b"AC#GT$")  # '#' < '$' breaks "sentinel is smallest"
+
+
+def test_bwt_kat():
+    for c in K["bwt"]:
+        t = c["text"].encode()
+        assert bytes(orc.bwt(t, orc.suffix_array(t))) == c["bwt"].encode()
+
+
+def test_bwtfind_pins_bwt():
+    # bwt.rs:223-231: bwtfind of cabca$ — recomputed here from bwt + less
+    c = K["bwtfind"]
+    t = c["text"].encode()
+    b = orc.bwt(t, orc.suffix_array(t))
+    less = orc.less(b, c["alphabet"].encode()).tolist()
+    find = [0] * len(b)
+    for r, ch in enumerate(b):
+        find[less[ch]] = r
+        less[ch] += 1
+    assert find == c["bwtfind"]
+
+
+def test_occ_kat():
+    c = K["occ"]
+    occ = orc.Occ(np.array(c["bwt"], dtype=np.uint8), c["k"], bytes(c["alphabet"]))
+    assert [occ.row(a) for a in range(4)] == c["table"]
+    for g in c["get"]:
+        assert occ.get(g["r"], g["a"]) == g["count"]
+
+
+def test_occ_equals_naive_rank_all_positions():
+    # bwt.rs:253-270 (Occ == WaveletMatrix rank for every position/symbol): the wavelet
+    # matrix is out of scope, a naive count is the same oracle
+    t = b"GCCTTAACATTATTACGCCTA$"
+    b = orc.bwt(t, orc.suffix_array(t))
+    for k in (1, 3, 7, 65, 128):
+        occ = orc.Occ(b, k, b"ACGTNacgtn$")
+        for c in b"ACGT$":
+            for p in range(len(t)):
+                assert occ.get(p, c) == int((b[:p + 1] == c).sum())
+
+
+@pytest.mark.parametrize("case", K["backward_search"], ids=lambda c: c["name"])
+def test_backward_search_kat(case):
+    t = _text(case)
+    alpha = bytes(case["alphabet_bytes"]) if "alphabet_bytes" in case else case["alphabet"].encode()
+    pat = bytes(case["pattern_bytes"]) if "pattern_bytes" in case else case["pattern"].encode()
+    sa = orc.suffix_array(t)
+    b = orc.bwt(t, sa)
+    less = orc.less(b, alpha)
+    occ = orc.Occ(b, case["k"], alpha)
+    tag, lo, hi, ml = orc.backward_search(b, less, occ, pat)
+    if "positions" in case:
+        pos = [] if tag == "absent" else [int(sa[i]) for i in range(lo, hi)]
+        assert pos == case["positions"]
+    if "tag" in case:
+        assert tag == case["tag"]
+    if "matched_len" in case:
+        assert ml == case["matched_len"]
+    if "not_tag" in case:
+        assert tag != case["not_tag"] and tag != "panic"
+
+
+def test_backward_search_out_of_alphabet_panics():
+    # fmindex.rs:229 / bwt.rs:158: index out of bounds on a byte outside the alphabet —
+    # but only if the loop reaches it
+    t = b"GATTACA$"
+    sa = orc.suffix_array(t)
+    b = orc.bwt(t, sa)
+    less = orc.less(b, b"ACGTNacgtn")
+    occ = orc.Occ(b, 3, b"ACGTNacgtn")
+    assert orc.backward_search(b, less, occ, b"ATXACA")[0] == "panic"   # 'X' not in alphabet
+    assert orc.backward_search(b, less, occ, b"A~ACA")[0] == "panic"    # beyond less.len()
+    assert orc.backward_search(b, less, occ, b"XGGACA")[0] == "partial"  # breaks before 'X'
+    assert orc.backward_search(b, less, occ, b"")[0] == "absent"
+    assert orc.backward_search(b, less, occ, b"N")[0] == "absent"       # in alphabet, absent
+
+
+def test_backward_search_vs_bruteforce():
+    rng = np.random.default_rng(11)
+    for trial in range(20):
+        n = int(rng.integers(5, 400))
+        t = bytes(rng.choice(list(b"ACGT"), size=n).astype(np.uint8)) + b"$"
+        sa = orc.suffix_array(t)
+        b = orc.bwt(t, sa)
+        k = int(rng.choice([1, 3, 16, 64, 65, 128]))
+        less = orc.less(b, b"ACGTNacgtn")
+        occ = orc.Occ(b, k, b"ACGTNacgtn")
+        for _ in range(30):
+            plen = int(rng.integers(1, 12))
+            if rng.random() < 0.6:
+                s = int(rng.integers(0, max(1, n - plen)))
+                p = t[s:s + plen].replace(b"$", b"A")
+            else:
+                p = bytes(rng.choice(list(b"ACGT"), size=plen).astype(np.uint8))
+            tag, lo, hi, ml = orc.backward_search(b, less, occ, p)
+            # longest suffix of p that occurs in t
+            best = 0
+            for L in range(1, len(p) + 1):
+                if t.find(p[len(p) - L:]) >= 0:
+                    best = L
+                else:
+                    break
+            if best == len(p):
+                assert tag == "complete" and ml == len(p)
+            elif best == 0:
+                assert tag == "absent"
+            else:
+                assert tag == "partial" and ml == best
+            if tag != "absent":
+                suf = p[len(p) - ml:]
+                occs = sorted(int(sa[i]) for i in range(lo, hi))
+                want = sorted(i for i in range(len(t)) if t.startswith(suf, i))
+                assert occs == want
