@@ -1,0 +1,177 @@
+/*
+ * biogpu.h — C ABI of the MI355X-native engine that sits behind rust-bio's
+ *   bio::alignment::pairwise::Aligner            (src/alignment/pairwise/mod.rs:472-1016)
+ *   bio::alignment::pairwise::banded::Aligner    (src/alignment/pairwise/banded.rs:122-1004)
+ *   bio::data_structures::fmindex::FMIndex       (src/data_structures/fmindex.rs:98-248)
+ * and the host-side table builders they are fed from
+ *   suffix_array / bwt / less / Occ::new         (suffix_array.rs:264, bwt.rs:39,186,94).
+ *
+ * rust-bio has no FFI of its own; these are the entry points a Rust shim
+ * inside `bio` binds with `extern "C"` (INTEGRATION.md shows the binding).  Plain pointers
+ * and sizes only.  Every function returns BG_OK (0) or a negative bg_status; nothing panics
+ * or throws across the boundary.  Where the reference would `panic!` (assert on positive
+ * penalties, index-out-of-bounds on a byte outside the alphabet, missing sentinel) the
+ * matching error code is returned and documented at the function.
+ *
+ * Two flavours per batched op:
+ *   bg_*_batch      caller passes HOST buffers (the drop-in boundary; includes PCIe copies)
+ *   bg_*_batch_dev  caller passes DEVICE pointers + a hipStream_t (as void*): inputs already
+ *                   resident in HBM, results left in HBM, asynchronous on that stream.
+ */
+#ifndef BIOGPU_H
+#define BIOGPU_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    BG_OK = 0,
+    BG_ERR_INVALID_ARG = -1,
+    BG_ERR_NO_DEVICE = -2,       /* no usable HIP device / extension cannot run */
+    BG_ERR_HIP = -3,             /* a HIP runtime call failed (see bg_last_error) */
+    BG_ERR_OOM = -4,
+    BG_ERR_SENTINEL = -5,        /* suffix_array.rs:431-437 assert: last byte must be the smallest */
+    BG_ERR_POSITIVE_PENALTY = -6,/* pairwise/mod.rs:265-266,292-293,554-571 asserts */
+    BG_ERR_OUT_OF_ALPHABET = -7, /* fmindex.rs:229 / bwt.rs:114,158 index-out-of-bounds panics */
+    BG_ERR_TOO_LARGE = -8,       /* text >= 2^32-1 symbols or sequence too long for the engine */
+    BG_ERR_OPS_CAP = -9,         /* caller's ops buffer too small (ops_used reports the need) */
+    BG_ERR_TRACEBACK = -10,      /* traceback did not terminate (reference would loop forever) */
+    BG_ERR_UNSUPPORTED = -11     /* legal for rust-bio, not yet covered by the device layout */
+} bg_status;
+
+#define BG_MIN_SCORE (-858993459) /* pairwise::MIN_SCORE, mod.rs:174 */
+
+typedef struct bg_ctx bg_ctx; /* one per device; not thread-safe (like `&mut Aligner`) */
+typedef struct bg_fm bg_fm;   /* device-resident FM index; immutable, shareable (like Arc<FMIndex>) */
+
+int bg_device_count(void);
+int bg_init(int device, bg_ctx** out);
+int bg_free(bg_ctx* ctx);
+const char* bg_strerror(int status);
+const char* bg_last_error(void); /* text of the last HIP failure on this thread */
+/* Tunables (0 keeps the default): pairs per sub-batch of the SW pipeline. */
+int bg_set_option(bg_ctx* ctx, const char* key, int64_t value);
+
+/* ------------------------------------------------------------------ host table builders
+ * Same contracts as the reference functions; pure host code (usable without a GPU). */
+
+/* suffix_array(text) — suffix_array.rs:264-284.  text must end in a sentinel <= every other
+ * byte, else BG_ERR_SENTINEL (the reference asserts).  Several sentinels are ordered by
+ * position: the first occurrence sorts last among them (transform_text, 444-466). */
+int bg_suffix_array(const uint8_t* text, uint64_t n, uint64_t* sa_out);
+/* bwt(text, pos) — bwt.rs:39-49 */
+int bg_bwt(const uint8_t* text, const uint64_t* sa, uint64_t n, uint8_t* bwt_out);
+/* less(bwt, alphabet) — bwt.rs:186-199.  less_out must hold max_symbol+2 entries;
+ * *less_len receives that length (call with less_out == NULL to query it). */
+int bg_less(const uint8_t* bwt, uint64_t n, const uint8_t* alphabet, uint32_t n_sym,
+            uint64_t* less_out, uint32_t* less_len);
+
+/* ------------------------------------------------------------------ FM index
+ * bg_fm_build replaces `Occ::new(&bwt, k, &alphabet)` + `FMIndex::new(bwt, less, occ)`
+ * (bwt.rs:94-125, fmindex.rs:245-247): the sampled-Occ table layout on the device is the
+ * engine's own, `occ_k` is accepted for API fidelity and only validated (>= 1):
+ * Occ::get's result does not depend on k.  BG_ERR_OUT_OF_ALPHABET when a BWT byte exceeds
+ * the alphabet's max symbol (Occ::new would panic, bwt.rs:114). */
+int bg_fm_build(bg_ctx* ctx, const uint8_t* bwt, uint64_t n, const uint64_t* less,
+                uint32_t less_len, uint32_t occ_k, const uint8_t* alphabet, uint32_t n_sym,
+                bg_fm** out);
+int bg_fm_free(bg_fm* fm);
+uint64_t bg_fm_device_bytes(const bg_fm* fm);
+
+/* Result tags of FMIndexable::backward_search (fmindex.rs:92-96). */
+enum { BG_FM_COMPLETE = 0, BG_FM_PARTIAL = 1, BG_FM_ABSENT = 2,
+       BG_FM_PANIC = 3 /* this query reached a byte outside the alphabet */ };
+
+/* backward_search for n_q patterns (fmindex.rs:144-208).  Pattern q is
+ * pat[pat_off[q] .. pat_off[q+1]).  Outputs per query: tag, Interval{lower,upper} (for
+ * Partial: the interval of the maximal matching suffix), matched_len (Complete: |P|).
+ * Returns BG_ERR_OUT_OF_ALPHABET if any query has tag BG_FM_PANIC (all other queries are
+ * still valid). */
+int bg_fm_backward_search_batch(bg_fm* fm, uint64_t n_q, const uint8_t* pat,
+                                const uint64_t* pat_off, uint8_t* tag, uint64_t* lower,
+                                uint64_t* upper, uint32_t* matched_len);
+/* Same with device pointers; asynchronous on `stream`; no panic scan (tags tell). */
+int bg_fm_backward_search_batch_dev(bg_fm* fm, uint64_t n_q, const uint8_t* d_pat,
+                                    const uint64_t* d_pat_off, uint8_t* d_tag, uint64_t* d_lower,
+                                    uint64_t* d_upper, uint32_t* d_matched_len, void* stream);
+
+/* ------------------------------------------------------------------ pairwise alignment */
+
+/* Scoring<F> (pairwise/mod.rs:238-247) as the *effective* values `custom` sees.  match_fn is
+ * MatchParams{match_score,mismatch_score} when matrix == NULL, else the closure tabulated by
+ * the host: matrix[a*256+b] = F(a,b) (int32[65536]).  match_scores_some mirrors
+ * `match_scores: Option<(i32,i32)>`, read only by the banded aligner (banded.rs:1315-1318). */
+typedef struct {
+    int32_t gap_open, gap_extend;
+    int32_t xclip_prefix, xclip_suffix, yclip_prefix, yclip_suffix;
+    int32_t match_score, mismatch_score;
+    int32_t match_scores_some;
+    const int32_t* matrix;
+} bg_scoring_t;
+
+/* AlignmentMode (bio-types) */
+enum { BG_MODE_CUSTOM = 0, BG_MODE_GLOBAL = 1, BG_MODE_SEMIGLOBAL = 2, BG_MODE_LOCAL = 3 };
+/* AlignmentOperation, one byte each in the ops buffer.  Xclip/Yclip lengths are the
+ * entries of bg_alignment_t.clip_len, in the order the clip ops appear. */
+enum { BG_OP_MATCH = 0, BG_OP_SUBST = 1, BG_OP_DEL = 2, BG_OP_INS = 3, BG_OP_XCLIP = 4,
+       BG_OP_YCLIP = 5 };
+
+/* bio_types::alignment::Alignment (fields as constructed at pairwise/mod.rs:911-921) */
+typedef struct {
+    int32_t score;
+    uint32_t xstart, xend, ystart, yend, xlen, ylen;
+    uint32_t n_ops;
+    uint64_t ops_off;     /* offset of this alignment's first op in the ops buffer */
+    uint32_t clip_len[4]; /* lengths of the Xclip/Yclip ops, in order of appearance */
+    uint8_t n_clips;
+    uint8_t mode;         /* BG_MODE_* */
+    int8_t status;        /* BG_OK or BG_ERR_TRACEBACK for this pair */
+    uint8_t _pad;
+} bg_alignment_t;
+
+/* Aligner::{custom,global,semiglobal,local} for n_pairs independent pairs
+ * (mod.rs:591,925,954,986).  `mode` selects the wrapper: GLOBAL/SEMIGLOBAL/LOCAL overwrite
+ * the four clip penalties exactly as the reference does (and SEMIGLOBAL/LOCAL drop the clip
+ * ops, mod.rs:974,1006); CUSTOM uses sc as given.  x/y are concatenated sequences with
+ * n_pairs+1 offsets each.  Returns BG_ERR_POSITIVE_PENALTY when a penalty is > 0.
+ * ops_buf may be NULL (scores/coordinates only). */
+int bg_align_batch(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint64_t n_pairs,
+                   const uint8_t* x, const uint64_t* x_off, const uint8_t* y,
+                   const uint64_t* y_off, bg_alignment_t* out, uint8_t* ops_buf,
+                   uint64_t ops_cap, uint64_t* ops_used);
+/* Device-resident flavour.  d_ops must hold n_pairs * ops_stride bytes where
+ * ops_stride >= max(xlen+ylen)+4 over the batch; alignment p's ops end at
+ * d_ops + (p+1)*ops_stride and ops_off points at its first op.  sc->matrix (if any) is a
+ * HOST pointer (it is compacted and uploaded by the call).  max_xlen/max_ylen are upper
+ * bounds on the sequence lengths in the batch. */
+int bg_align_batch_dev(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint64_t n_pairs,
+                       const uint8_t* d_x, const uint64_t* d_x_off, const uint8_t* d_y,
+                       const uint64_t* d_y_off, uint32_t max_xlen, uint32_t max_ylen,
+                       bg_alignment_t* d_out, uint8_t* d_ops, uint64_t ops_stride, void* stream);
+
+/* banded::Aligner::{custom,global,semiglobal,local} (banded.rs:282,872,901,972) with k-mer
+ * length k and window w.  The band (k-mer matching, sparse DP chaining, Band construction,
+ * banded.rs:1278-1367) is built on the host by this call; pairs whose band exceeds MAX_CELLS
+ * (banded.rs:104) get the reference's sentinel alignment {score: MIN_SCORE, all zero, no ops,
+ * mode Custom} (banded.rs:407-420).  band_cells (optional) receives Band::num_cells. */
+int bg_align_banded_batch(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint32_t k, uint32_t w,
+                          uint64_t n_pairs, const uint8_t* x, const uint64_t* x_off,
+                          const uint8_t* y, const uint64_t* y_off, bg_alignment_t* out,
+                          uint8_t* ops_buf, uint64_t ops_cap, uint64_t* ops_used,
+                          uint64_t* band_cells);
+
+/* Timing of the last *_dev / batch call's kernels on this ctx, measured with HIP events on
+ * the stream the kernels ran on (used by bench.py for the roofline line). */
+typedef struct {
+    float fill_ms, traceback_ms, fm_ms;
+    uint32_t fill_launches, traceback_launches, fm_launches;
+} bg_timing_t;
+int bg_get_timing(bg_ctx* ctx, bg_timing_t* out);
+int bg_enable_timing(bg_ctx* ctx, int on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

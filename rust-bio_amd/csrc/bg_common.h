@@ -1,0 +1,63 @@
+// Shared internals of libbiogpu (gfx950 only).
+#ifndef BG_COMMON_H
+#define BG_COMMON_H
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "biogpu.h"
+
+extern thread_local std::string bg_tls_error;
+
+#define BG_HIP(call)                                                                     \
+    do {                                                                                 \
+        hipError_t e__ = (call);                                                         \
+        if (e__ != hipSuccess) {                                                         \
+            bg_tls_error = std::string(#call) + ": " + hipGetErrorString(e__);           \
+            return e__ == hipErrorOutOfMemory ? BG_ERR_OOM : BG_ERR_HIP;                 \
+        }                                                                                \
+    } while (0)
+
+struct bg_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;  // internal stream of the host-buffer API
+    // reusable device scratch of the SW pipeline (grown on demand)
+    void* tb = nullptr;
+    size_t tb_bytes = 0;
+    void* aux = nullptr;
+    size_t aux_bytes = 0;
+    void* bnd = nullptr;
+    size_t bnd_bytes = 0;
+    void* table = nullptr;  // compacted scoring table + code map
+    size_t table_bytes = 0;
+    int64_t chunk_pairs = 0;  // 0 = default
+    // timing
+    bool timing = false;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    bg_timing_t last = {};
+};
+
+// grow-only device scratch
+int bg_reserve(void** p, size_t* cur, size_t need);
+
+// ---- device helpers -------------------------------------------------------------------
+// DPP cross-lane moves (gfx9 encodings): lane i <- lane i-1 / lane i+1 across the 64-lane wave.
+// Lane 0 (resp. 63) keeps `old`.  Must be executed with all lanes active.
+__device__ __forceinline__ int wave_shr1(int v, int old = 0) {
+    return __builtin_amdgcn_update_dpp(old, v, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
+}
+__device__ __forceinline__ int wave_shl1(int v, int old = 0) {
+    return __builtin_amdgcn_update_dpp(old, v, 0x130 /*wave_shl:1*/, 0xf, 0xf, false);
+}
+// sum over the 4 lanes of a quad, result in all 4
+__device__ __forceinline__ unsigned quad_sum(unsigned v) {
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1 /*quad_perm:[1,0,3,2]*/, 0xf, 0xf, true);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E /*quad_perm:[2,3,0,1]*/, 0xf, 0xf, true);
+    return v;
+}
+
+#endif

@@ -1,0 +1,106 @@
+// Context management and shared utilities of libbiogpu.
+#include "bg_common.h"
+
+thread_local std::string bg_tls_error;
+
+int bg_reserve(void** p, size_t* cur, size_t need) {
+    if (need <= *cur) return BG_OK;
+    if (*p) {
+        hipFree(*p);
+        *p = nullptr;
+        *cur = 0;
+    }
+    need = (need + 255) & ~(size_t)255;
+    BG_HIP(hipMalloc(p, need));
+    *cur = need;
+    return BG_OK;
+}
+
+extern "C" int bg_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int bg_init(int device, bg_ctx** out) {
+    if (!out) return BG_ERR_INVALID_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) {
+        bg_tls_error = "no usable HIP device";
+        return BG_ERR_NO_DEVICE;
+    }
+    BG_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    BG_HIP(hipGetDeviceProperties(&prop, device));
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0) {
+        // the code objects in this library are gfx950-only
+        bg_tls_error = std::string("device is ") + prop.gcnArchName + ", library is built for gfx950";
+        return BG_ERR_NO_DEVICE;
+    }
+    bg_ctx* ctx = new bg_ctx;
+    ctx->device = device;
+    BG_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    BG_HIP(hipEventCreate(&ctx->ev[0]));
+    BG_HIP(hipEventCreate(&ctx->ev[1]));
+    *out = ctx;
+    return BG_OK;
+}
+
+extern "C" int bg_free(bg_ctx* ctx) {
+    if (!ctx) return BG_OK;
+    hipSetDevice(ctx->device);
+    hipFree(ctx->tb);
+    hipFree(ctx->aux);
+    hipFree(ctx->bnd);
+    hipFree(ctx->table);
+    if (ctx->ev[0]) hipEventDestroy(ctx->ev[0]);
+    if (ctx->ev[1]) hipEventDestroy(ctx->ev[1]);
+    if (ctx->stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return BG_OK;
+}
+
+extern "C" const char* bg_strerror(int s) {
+    switch (s) {
+        case BG_OK: return "ok";
+        case BG_ERR_INVALID_ARG: return "invalid argument";
+        case BG_ERR_NO_DEVICE: return "no usable gfx950 device";
+        case BG_ERR_HIP: return "HIP runtime error";
+        case BG_ERR_OOM: return "out of device memory";
+        case BG_ERR_SENTINEL:
+            return "Expecting extra sentinel symbol being lexicographically smallest at the end of the text.";
+        case BG_ERR_POSITIVE_PENALTY: return "gap/clip penalty can't be positive";
+        case BG_ERR_OUT_OF_ALPHABET: return "symbol outside the alphabet (index out of bounds in the reference)";
+        case BG_ERR_TOO_LARGE: return "input too large for the engine";
+        case BG_ERR_OPS_CAP: return "operations buffer too small";
+        case BG_ERR_TRACEBACK: return "traceback did not terminate";
+        case BG_ERR_UNSUPPORTED: return "not supported by the device layout";
+        default: return "unknown status";
+    }
+}
+
+extern "C" const char* bg_last_error(void) { return bg_tls_error.c_str(); }
+
+extern "C" int bg_set_option(bg_ctx* ctx, const char* key, int64_t value) {
+    if (!ctx || !key) return BG_ERR_INVALID_ARG;
+    if (!strcmp(key, "chunk_pairs")) {
+        ctx->chunk_pairs = value;
+        return BG_OK;
+    }
+    return BG_ERR_INVALID_ARG;
+}
+
+extern "C" int bg_enable_timing(bg_ctx* ctx, int on) {
+    if (!ctx) return BG_ERR_INVALID_ARG;
+    ctx->timing = on != 0;
+    ctx->last = {};
+    return BG_OK;
+}
+
+extern "C" int bg_get_timing(bg_ctx* ctx, bg_timing_t* out) {
+    if (!ctx || !out) return BG_ERR_INVALID_ARG;
+    *out = ctx->last;
+    ctx->last = {};
+    return BG_OK;
+}

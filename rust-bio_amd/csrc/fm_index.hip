@@ -1,0 +1,427 @@
+// FM-index backward search on gfx950 (kernel K5) + the device index builder.
+//
+// Replaces, for a batch of patterns, FMIndexable::backward_search
+// (/root/reference/src/data_structures/fmindex.rs:144-208) with Occ::get
+// (/root/reference/src/data_structures/bwt.rs:129-182) and Less[a] (fmindex.rs:228-230).
+//
+// Device layout (ours; results equal the byte-table definition for every (r, a)):
+//   * the BWT is re-coded to 2 bits/symbol: the four most frequent byte values get codes
+//     0..3; every other byte value that occurs (the sentinel `$`, stray N, ...) is an
+//     *exception*: stored as code 0 in the packed stream and listed (sorted) on the side;
+//   * one 64-byte block per 192 symbols, self-contained for a rank query:
+//       uint32 cnt[4]   occurrences of code c in bwt[0 .. 192*b)      (16 B)
+//       uint32 sym[12]  192 symbols, 16 per word, symbol s at bits [2s, 2s+2)   (48 B)
+//     so Occ::get(r, a) = cnt[code(a)] + popcount(matches in the first r%192+1 symbols)
+//     costs exactly one 64-B line;
+//   * a quad of 4 lanes serves one query: lane t of the quad loads bytes [16t, 16t+16) of
+//     the block (one coalesced 64-B request per rank), counts its share, and the quad
+//     reduces with two DPP adds.  rank(l-1) and rank(r) are issued together; when both fall
+//     in the same block (the common case once the interval is narrow) the line is loaded once;
+//   * symbol classes, Less[] and the exception list are staged in LDS.
+// No MFMA: this is a latency/bandwidth-bound table walk (DESIGN.md §FM roofline).
+#include <algorithm>
+#include <numeric>
+
+#include "bg_common.h"
+
+namespace {
+
+constexpr uint32_t kSymPerBlock = 192;
+constexpr uint32_t kMaxExcLds = 1024;   // exception positions staged in LDS
+constexpr uint32_t kMaxExcSyms = 32;    // distinct exception byte values supported
+constexpr uint8_t kClsZero = 4;         // in alphabet, never occurs in the BWT
+constexpr uint8_t kClsExc = 8;          // kClsExc + e : exception symbol e
+constexpr uint8_t kClsPanic = 255;      // not in the alphabet: the reference panics
+
+struct FmDev {
+    const uint4* blocks;
+    const uint32_t* exc_pos;      // all exception positions, sorted
+    const uint32_t* exc_sym_pos;  // per exception symbol, sorted, concatenated
+    const uint8_t* sym_class;     // [256]
+    const uint32_t* less;         // [256]
+    uint32_t exc_sym_off[kMaxExcSyms + 1];
+    uint32_t n;
+    uint32_t n_exc;
+};
+
+// number of entries <= r in a sorted array
+template <typename P>
+__device__ __forceinline__ uint32_t count_le(P arr, uint32_t lo, uint32_t hi, uint32_t r) {
+    while (lo < hi) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (arr[mid] <= r)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+
+// this lane's share of rank(code c) inside one block: lane t==0 holds the counters,
+// lanes 1..3 hold 64 symbols each
+__device__ __forceinline__ uint32_t block_part(const uint4 v, uint32_t t, uint32_t o, uint32_t c) {
+    if (t == 0) {
+        uint32_t lo = (c & 1) ? v.y : v.x;
+        uint32_t hi = (c & 1) ? v.w : v.z;
+        return (c & 2) ? hi : lo;
+    }
+    const int have = (int)o + 1 - (int)(t - 1) * 64;  // symbols of this lane inside [0, o]
+    if (have <= 0) return 0;
+    const uint64_t pat = (uint64_t)c * 0x5555555555555555ull;
+    uint64_t w0 = ((uint64_t)v.y << 32) | v.x;
+    uint64_t w1 = ((uint64_t)v.w << 32) | v.z;
+    uint64_t e0 = ~(w0 ^ pat), e1 = ~(w1 ^ pat);
+    e0 = e0 & (e0 >> 1) & 0x5555555555555555ull;
+    e1 = e1 & (e1 >> 1) & 0x5555555555555555ull;
+    const int t0 = have >= 32 ? 32 : have;
+    const int t1 = have >= 64 ? 32 : (have > 32 ? have - 32 : 0);
+    const uint64_t m0 = t0 == 32 ? ~0ull : ((1ull << (2 * t0)) - 1);
+    const uint64_t m1 = t1 == 32 ? ~0ull : ((1ull << (2 * t1)) - 1);
+    return (uint32_t)(__popcll(e0 & m0) + __popcll(e1 & m1));
+}
+
+__global__ __launch_bounds__(256) void fm_backward_search_kernel(
+    FmDev fm, uint64_t n_q, const uint8_t* __restrict__ pat, const uint64_t* __restrict__ pat_off,
+    uint8_t* __restrict__ tag, uint64_t* __restrict__ lower, uint64_t* __restrict__ upper,
+    uint32_t* __restrict__ matched_len) {
+    __shared__ uint8_t s_class[256];
+    __shared__ uint32_t s_less[256];
+    __shared__ uint32_t s_exc[kMaxExcLds];
+    for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) {
+        s_class[i] = fm.sym_class[i];
+        s_less[i] = fm.less[i];
+    }
+    const bool exc_in_lds = fm.n_exc <= kMaxExcLds;
+    if (exc_in_lds)
+        for (uint32_t i = threadIdx.x; i < fm.n_exc; i += blockDim.x) s_exc[i] = fm.exc_pos[i];
+    __syncthreads();
+
+    const uint32_t t = threadIdx.x & 3;
+    const uint64_t n_quads = (uint64_t)gridDim.x * (blockDim.x >> 2);
+    uint64_t q = (uint64_t)blockIdx.x * (blockDim.x >> 2) + (threadIdx.x >> 2);
+
+    // per-query state (uniform inside a quad)
+    bool active = false;
+    uint64_t off = 0;
+    uint32_t len = 0, pos = 0, l = 0, r = 0, matched = 0;
+    uint32_t a_next = 0;
+
+    auto emit = [&](uint32_t tg, uint32_t lo, uint32_t hi, uint32_t ml) {
+        if (t == 0) {
+            tag[q] = (uint8_t)tg;
+            lower[q] = lo;
+            upper[q] = hi;
+            matched_len[q] = ml;
+        }
+    };
+    // load the next non-empty query into the state; empty patterns are Absent at once
+    // (matched_len == 0, fmindex.rs:185-207)
+    auto fetch = [&]() {
+        active = false;
+        while (q < n_q) {
+            off = pat_off[q];
+            len = (uint32_t)(pat_off[q + 1] - off);
+            if (len) {
+                pos = len;
+                l = 0;
+                r = fm.n - 1;  // fmindex.rs:148
+                matched = 0;
+                a_next = pat[off + len - 1];
+                active = true;
+                return;
+            }
+            emit(BG_FM_ABSENT, 0, 0, 0);
+            q += n_quads;
+        }
+    };
+    fetch();
+
+    while (__any(active)) {
+        if (active) {
+            // one iteration of the loop at fmindex.rs:160-182
+            const uint32_t a = a_next;
+            pos -= 1;
+            if (pos) a_next = pat[off + pos - 1];  // prefetch; address independent of the ranks
+            const uint32_t cls = s_class[a];
+            const uint32_t less_a = s_less[a];
+            uint32_t occ_r = 0, occ_l = 0;
+            bool stop = false;
+            uint32_t stop_tag = BG_FM_PARTIAL;
+            if (cls == kClsPanic) {
+                stop = true;
+                stop_tag = BG_FM_PANIC;
+            } else if (cls < 4) {
+                const uint32_t br = r / kSymPerBlock, orr = r - br * kSymPerBlock;
+                const uint4 vr = fm.blocks[(uint64_t)br * 4 + t];
+                uint4 vl = vr;
+                uint32_t ol = 0;
+                if (l > 0) {
+                    const uint32_t bl = (l - 1) / kSymPerBlock;
+                    ol = (l - 1) - bl * kSymPerBlock;
+                    if (bl != br) vl = fm.blocks[(uint64_t)bl * 4 + t];
+                }
+                occ_r = quad_sum(block_part(vr, t, orr, cls));
+                if (l > 0) occ_l = quad_sum(block_part(vl, t, ol, cls));
+                if (cls == 0 && fm.n_exc) {  // exceptions sit in the stream as code 0
+                    if (exc_in_lds) {
+                        occ_r -= count_le(s_exc, 0u, fm.n_exc, r);
+                        if (l > 0) occ_l -= count_le(s_exc, 0u, fm.n_exc, l - 1);
+                    } else {
+                        occ_r -= count_le(fm.exc_pos, 0u, fm.n_exc, r);
+                        if (l > 0) occ_l -= count_le(fm.exc_pos, 0u, fm.n_exc, l - 1);
+                    }
+                }
+            } else if (cls >= kClsExc) {
+                const uint32_t e = cls - kClsExc;
+                const uint32_t lo = fm.exc_sym_off[e], hi = fm.exc_sym_off[e + 1];
+                occ_r = count_le(fm.exc_sym_pos, lo, hi, r) - lo;
+                if (l > 0) occ_l = count_le(fm.exc_sym_pos, lo, hi, l - 1) - lo;
+            }  // kClsZero: both stay 0
+            const uint32_t pl = l, pr = r;
+            if (!stop) {
+                if (occ_r == 0) {  // fmindex.rs:167-170
+                    stop = true;
+                } else {
+                    l = less_a + occ_l;  // fmindex.rs:171
+                    r = less_a + occ_r - 1;
+                    if (l > r)  // fmindex.rs:177-180
+                        stop = true;
+                    else
+                        matched += 1;
+                }
+            }
+            if (stop) {
+                if (stop_tag == BG_FM_PANIC)
+                    emit(BG_FM_PANIC, 0, 0, matched);
+                else if (matched)
+                    emit(BG_FM_PARTIAL, pl, pr + 1, matched);
+                else
+                    emit(BG_FM_ABSENT, 0, 0, 0);
+                q += n_quads;
+                fetch();
+            } else if (pos == 0) {
+                emit(BG_FM_COMPLETE, l, r + 1, matched);
+                q += n_quads;
+                fetch();
+            }
+        }
+    }
+}
+
+}  // namespace
+
+struct bg_fm {
+    bg_ctx* ctx = nullptr;
+    FmDev dev = {};
+    void* d_blocks = nullptr;
+    void* d_exc_pos = nullptr;
+    void* d_exc_sym_pos = nullptr;
+    void* d_class = nullptr;
+    void* d_less = nullptr;
+    uint64_t bytes = 0;
+};
+
+extern "C" int bg_fm_build(bg_ctx* ctx, const uint8_t* bwt, uint64_t n, const uint64_t* less,
+                           uint32_t less_len, uint32_t occ_k, const uint8_t* alphabet,
+                           uint32_t n_sym, bg_fm** out) {
+    if (!ctx || !bwt || !less || !alphabet || !out || n == 0 || n_sym == 0 || occ_k == 0)
+        return BG_ERR_INVALID_ARG;
+    if (n >= 0xFFFFFFFFull) return BG_ERR_TOO_LARGE;
+    // Alphabet (alphabets/mod.rs:49-60): set of bytes; m = max_symbol + 1 (bwt.rs:96-99)
+    bool in_alpha[256] = {};
+    uint32_t max_symbol = 0;
+    for (uint32_t i = 0; i < n_sym; i++) {
+        in_alpha[alphabet[i]] = true;
+        max_symbol = std::max<uint32_t>(max_symbol, alphabet[i]);
+    }
+    const uint32_t m = max_symbol + 1;
+    if (less_len != max_symbol + 2) return BG_ERR_INVALID_ARG;
+    if ((uint32_t)'$' < m) in_alpha['$'] = true;  // bwt.rs:101-104: '$' is always tabulated
+
+    uint64_t hist[256] = {};
+    for (uint64_t i = 0; i < n; i++) hist[bwt[i]]++;
+    for (uint32_t c = m; c < 256; c++)
+        if (hist[c]) return BG_ERR_OUT_OF_ALPHABET;  // Occ::new: curr_occ[c] out of bounds
+
+    // the four most frequent byte values get the 2-bit codes (ties: smaller byte first)
+    int order[256];
+    std::iota(order, order + 256, 0);
+    std::stable_sort(order, order + 256, [&](int a, int b) { return hist[a] > hist[b]; });
+    int code_of[256];
+    std::fill(code_of, code_of + 256, -1);
+    int n_codes = 0;
+    for (int i = 0; i < 4 && hist[order[i]] > 0; i++) code_of[order[i]] = n_codes++;
+    std::vector<int> exc_syms;
+    uint64_t n_exc = 0;
+    for (int c = 0; c < 256; c++)
+        if (hist[c] && code_of[c] < 0) {
+            exc_syms.push_back(c);
+            n_exc += hist[c];
+        }
+    if (exc_syms.size() > kMaxExcSyms || n_exc > (1u << 26)) return BG_ERR_UNSUPPORTED;
+
+    uint8_t cls[256];
+    for (int c = 0; c < 256; c++) {
+        if (!in_alpha[c])
+            cls[c] = kClsPanic;
+        else if (code_of[c] >= 0)
+            cls[c] = (uint8_t)code_of[c];
+        else if (hist[c] == 0)
+            cls[c] = kClsZero;
+        else
+            cls[c] = (uint8_t)(kClsExc +
+                               (std::find(exc_syms.begin(), exc_syms.end(), c) - exc_syms.begin()));
+    }
+
+    const uint64_t nblk = (n + kSymPerBlock - 1) / kSymPerBlock;
+    std::vector<uint32_t> blocks(nblk * 16, 0);
+    std::vector<uint32_t> exc_pos;
+    std::vector<std::vector<uint32_t>> exc_by_sym(exc_syms.size());
+    exc_pos.reserve(n_exc);
+    uint32_t running[4] = {0, 0, 0, 0};
+    for (uint64_t b = 0; b < nblk; b++) {
+        uint32_t* blk = &blocks[b * 16];
+        for (int c = 0; c < 4; c++) blk[c] = running[c];
+        const uint64_t lo = b * kSymPerBlock, hi = std::min<uint64_t>(n, lo + kSymPerBlock);
+        for (uint64_t i = lo; i < hi; i++) {
+            const uint8_t ch = bwt[i];
+            int code = code_of[ch];
+            if (code < 0) {
+                code = 0;
+                exc_pos.push_back((uint32_t)i);
+                exc_by_sym[std::find(exc_syms.begin(), exc_syms.end(), (int)ch) - exc_syms.begin()]
+                    .push_back((uint32_t)i);
+            }
+            const uint32_t s = (uint32_t)(i - lo);
+            blk[4 + (s >> 4)] |= (uint32_t)code << (2 * (s & 15));
+            running[code]++;
+        }
+    }
+    std::vector<uint32_t> exc_sym_pos;
+    bg_fm* fm = new bg_fm;
+    fm->ctx = ctx;
+    fm->dev.exc_sym_off[0] = 0;
+    for (size_t e = 0; e < exc_by_sym.size(); e++) {
+        exc_sym_pos.insert(exc_sym_pos.end(), exc_by_sym[e].begin(), exc_by_sym[e].end());
+        fm->dev.exc_sym_off[e + 1] = (uint32_t)exc_sym_pos.size();
+    }
+    for (size_t e = exc_by_sym.size(); e < kMaxExcSyms; e++)
+        fm->dev.exc_sym_off[e + 1] = fm->dev.exc_sym_off[e];
+    uint32_t less32[256] = {};
+    for (uint32_t i = 0; i < less_len && i < 256; i++) less32[i] = (uint32_t)less[i];
+
+    auto fail = [&](int rc) {
+        bg_fm_free(fm);
+        return rc;
+    };
+    if (hipSetDevice(ctx->device) != hipSuccess) return fail(BG_ERR_NO_DEVICE);
+    auto upload = [&](void** dptr, const void* src, size_t bytes) -> int {
+        const size_t alloc = std::max<size_t>(bytes, 16);
+        BG_HIP(hipMalloc(dptr, alloc));
+        if (bytes) BG_HIP(hipMemcpy(*dptr, src, bytes, hipMemcpyHostToDevice));
+        fm->bytes += alloc;
+        return BG_OK;
+    };
+    int rc;
+    if ((rc = upload(&fm->d_blocks, blocks.data(), blocks.size() * 4))) return fail(rc);
+    if ((rc = upload(&fm->d_exc_pos, exc_pos.data(), exc_pos.size() * 4))) return fail(rc);
+    if ((rc = upload(&fm->d_exc_sym_pos, exc_sym_pos.data(), exc_sym_pos.size() * 4)))
+        return fail(rc);
+    if ((rc = upload(&fm->d_class, cls, 256))) return fail(rc);
+    if ((rc = upload(&fm->d_less, less32, sizeof(less32)))) return fail(rc);
+    fm->dev.blocks = (const uint4*)fm->d_blocks;
+    fm->dev.exc_pos = (const uint32_t*)fm->d_exc_pos;
+    fm->dev.exc_sym_pos = (const uint32_t*)fm->d_exc_sym_pos;
+    fm->dev.sym_class = (const uint8_t*)fm->d_class;
+    fm->dev.less = (const uint32_t*)fm->d_less;
+    fm->dev.n = (uint32_t)n;
+    fm->dev.n_exc = (uint32_t)exc_pos.size();
+    *out = fm;
+    return BG_OK;
+}
+
+extern "C" int bg_fm_free(bg_fm* fm) {
+    if (!fm) return BG_OK;
+    hipFree(fm->d_blocks);
+    hipFree(fm->d_exc_pos);
+    hipFree(fm->d_exc_sym_pos);
+    hipFree(fm->d_class);
+    hipFree(fm->d_less);
+    delete fm;
+    return BG_OK;
+}
+
+extern "C" uint64_t bg_fm_device_bytes(const bg_fm* fm) { return fm ? fm->bytes : 0; }
+
+extern "C" int bg_fm_backward_search_batch_dev(bg_fm* fm, uint64_t n_q, const uint8_t* d_pat,
+                                               const uint64_t* d_pat_off, uint8_t* d_tag,
+                                               uint64_t* d_lower, uint64_t* d_upper,
+                                               uint32_t* d_matched_len, void* stream) {
+    if (!fm || (n_q && (!d_pat_off || !d_tag || !d_lower || !d_upper || !d_matched_len)))
+        return BG_ERR_INVALID_ARG;
+    if (n_q == 0) return BG_OK;
+    bg_ctx* ctx = fm->ctx;
+    hipStream_t st = (hipStream_t)stream;
+    const uint64_t quads_per_block = 64;
+    uint64_t blocks = (n_q + quads_per_block - 1) / quads_per_block;
+    blocks = std::min<uint64_t>(blocks, 256 * 8);  // 8 resident 256-thread blocks per CU
+    if (ctx->timing) BG_HIP(hipEventRecord(ctx->ev[0], st));
+    fm_backward_search_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(
+        fm->dev, n_q, d_pat, d_pat_off, d_tag, d_lower, d_upper, d_matched_len);
+    BG_HIP(hipGetLastError());
+    if (ctx->timing) {
+        BG_HIP(hipEventRecord(ctx->ev[1], st));
+        BG_HIP(hipEventSynchronize(ctx->ev[1]));
+        float ms = 0;
+        BG_HIP(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+        ctx->last.fm_ms += ms;
+        ctx->last.fm_launches += 1;
+    }
+    return BG_OK;
+}
+
+extern "C" int bg_fm_backward_search_batch(bg_fm* fm, uint64_t n_q, const uint8_t* pat,
+                                           const uint64_t* pat_off, uint8_t* tag, uint64_t* lower,
+                                           uint64_t* upper, uint32_t* matched_len) {
+    if (!fm || (n_q && (!pat_off || !tag || !lower || !upper || !matched_len)))
+        return BG_ERR_INVALID_ARG;
+    if (n_q == 0) return BG_OK;
+    bg_ctx* ctx = fm->ctx;
+    BG_HIP(hipSetDevice(ctx->device));
+    const uint64_t pat_bytes = pat_off[n_q];
+    if (pat_bytes && !pat) return BG_ERR_INVALID_ARG;
+    uint8_t *d_pat = nullptr, *d_tag = nullptr;
+    uint64_t *d_off = nullptr, *d_lo = nullptr, *d_hi = nullptr;
+    uint32_t* d_ml = nullptr;
+    int rc = BG_OK;
+    auto run = [&]() -> int {
+        BG_HIP(hipMalloc((void**)&d_pat, std::max<uint64_t>(pat_bytes, 16)));
+        BG_HIP(hipMalloc((void**)&d_off, (n_q + 1) * 8));
+        BG_HIP(hipMalloc((void**)&d_tag, n_q));
+        BG_HIP(hipMalloc((void**)&d_lo, n_q * 8));
+        BG_HIP(hipMalloc((void**)&d_hi, n_q * 8));
+        BG_HIP(hipMalloc((void**)&d_ml, n_q * 4));
+        hipStream_t st = ctx->stream;
+        if (pat_bytes) BG_HIP(hipMemcpyAsync(d_pat, pat, pat_bytes, hipMemcpyHostToDevice, st));
+        BG_HIP(hipMemcpyAsync(d_off, pat_off, (n_q + 1) * 8, hipMemcpyHostToDevice, st));
+        int r2 = bg_fm_backward_search_batch_dev(fm, n_q, d_pat, d_off, d_tag, d_lo, d_hi, d_ml, st);
+        if (r2) return r2;
+        BG_HIP(hipMemcpyAsync(tag, d_tag, n_q, hipMemcpyDeviceToHost, st));
+        BG_HIP(hipMemcpyAsync(lower, d_lo, n_q * 8, hipMemcpyDeviceToHost, st));
+        BG_HIP(hipMemcpyAsync(upper, d_hi, n_q * 8, hipMemcpyDeviceToHost, st));
+        BG_HIP(hipMemcpyAsync(matched_len, d_ml, n_q * 4, hipMemcpyDeviceToHost, st));
+        BG_HIP(hipStreamSynchronize(st));
+        return BG_OK;
+    };
+    rc = run();
+    hipFree(d_pat);
+    hipFree(d_off);
+    hipFree(d_tag);
+    hipFree(d_lo);
+    hipFree(d_hi);
+    hipFree(d_ml);
+    if (rc) return rc;
+    for (uint64_t q = 0; q < n_q; q++)
+        if (tag[q] == BG_FM_PANIC) return BG_ERR_OUT_OF_ALPHABET;
+    return BG_OK;
+}

@@ -1,0 +1,261 @@
+// C-ABI entry points of the full-matrix aligner: bg_align_batch / bg_align_batch_dev.
+// Host side of `Aligner::{custom,global,semiglobal,local}` (pairwise/mod.rs:591,925,954,986):
+// validates the scoring like the reference's asserts, applies the clip-penalty overrides of
+// the three wrappers, compacts a tabulated match function, and drives K1 + K2 over
+// sub-batches that share one reusable scratch (traceback words, aux rows, strip buffer).
+#include <algorithm>
+#include <map>
+#include <type_traits>
+
+#include "sw_kernels.h"
+
+namespace bgsw {
+sw_fill_fn get_fill_params(int lp, int r);
+sw_fill_fn get_fill_matrix(int lp, int r, int sm);
+void launch_traceback(const SwArgs& a, bool wide, hipStream_t st);
+
+struct Config {
+    int lp, r;
+};
+// rows of x covered per strip = lp * r; short reads pack several pairs into one wavefront
+static Config pick_config(uint32_t m_cap, int sm) {
+    if (sm == SCORE_PARAMS) {
+        if (m_cap <= 192) return {16, std::max(2, 2 * (int)((m_cap + 31) / 32))};
+        if (m_cap <= 384) return {32, std::max(8, 2 * (int)((m_cap + 63) / 64))};
+        return {64, 8};
+    }
+    if (m_cap <= 96) return {16, 6};
+    if (m_cap <= 192) return {16, 12};
+    if (m_cap <= 384) return {32, 12};
+    return {64, 8};
+}
+
+// Bytes with identical rows and columns in the 256x256 table are interchangeable: compact the
+// closure's table to one code per class so that it fits LDS (A <= 64) whatever bytes occur.
+static int compact_matrix(const int32_t* matrix, std::vector<uint8_t>& code_map,
+                          std::vector<int32_t>& table) {
+    std::map<std::vector<int32_t>, int> classes;
+    code_map.assign(256, 0);
+    std::vector<int> rep;
+    for (int b = 0; b < 256; b++) {
+        std::vector<int32_t> sig(512);
+        for (int c = 0; c < 256; c++) {
+            sig[c] = matrix[b * 256 + c];
+            sig[256 + c] = matrix[c * 256 + b];
+        }
+        auto it = classes.find(sig);
+        if (it == classes.end()) {
+            it = classes.emplace(std::move(sig), (int)rep.size()).first;
+            rep.push_back(b);
+        }
+        code_map[b] = (uint8_t)it->second;
+    }
+    const int A = (int)rep.size();
+    table.assign((size_t)A * A, 0);
+    for (int p = 0; p < A; p++)
+        for (int q = 0; q < A; q++) table[(size_t)p * A + q] = matrix[rep[p] * 256 + rep[q]];
+    return A;
+}
+}  // namespace bgsw
+
+using namespace bgsw;
+
+static int check_scoring(const bg_scoring_t* sc) {
+    // asserts of Scoring::new/from_scores (mod.rs:265-266,292-293) and
+    // Aligner::with_capacity_and_scoring (mod.rs:554-571)
+    if (sc->gap_open > 0 || sc->gap_extend > 0 || sc->xclip_prefix > 0 || sc->xclip_suffix > 0 ||
+        sc->yclip_prefix > 0 || sc->yclip_suffix > 0)
+        return BG_ERR_POSITIVE_PENALTY;
+    return BG_OK;
+}
+
+extern "C" int bg_align_batch_dev(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint64_t n_pairs,
+                                  const uint8_t* d_x, const uint64_t* d_x_off, const uint8_t* d_y,
+                                  const uint64_t* d_y_off, uint32_t max_xlen, uint32_t max_ylen,
+                                  bg_alignment_t* d_out, uint8_t* d_ops, uint64_t ops_stride,
+                                  void* stream) {
+    if (!ctx || !sc || mode < BG_MODE_CUSTOM || mode > BG_MODE_LOCAL) return BG_ERR_INVALID_ARG;
+    int rc = check_scoring(sc);
+    if (rc) return rc;
+    if (n_pairs == 0) return BG_OK;
+    if (!d_x_off || !d_y_off || !d_out) return BG_ERR_INVALID_ARG;
+    if (d_ops && ops_stride < (uint64_t)max_xlen + max_ylen + 4) return BG_ERR_OPS_CAP;
+    if (max_xlen > (1u << 24) || max_ylen > (1u << 24)) return BG_ERR_TOO_LARGE;
+    hipStream_t st = (hipStream_t)stream;
+    BG_HIP(hipSetDevice(ctx->device));
+
+    SwArgs a = {};
+    a.x = d_x;
+    a.x_off = d_x_off;
+    a.y = d_y;
+    a.y_off = d_y_off;
+    a.sc = {sc->gap_open,     sc->gap_extend,   sc->xclip_prefix, sc->xclip_suffix,
+            sc->yclip_prefix, sc->yclip_suffix, sc->match_score,  sc->mismatch_score};
+    // the three wrappers overwrite the clip penalties (mod.rs:934-938, 963-967, 995-999)
+    if (mode == BG_MODE_GLOBAL) a.sc.xp = a.sc.xs = a.sc.yp = a.sc.ys = BG_MIN_SCORE;
+    if (mode == BG_MODE_SEMIGLOBAL) {
+        a.sc.xp = a.sc.xs = BG_MIN_SCORE;
+        a.sc.yp = a.sc.ys = 0;
+    }
+    if (mode == BG_MODE_LOCAL) a.sc.xp = a.sc.xs = a.sc.yp = a.sc.ys = 0;
+    a.mode = mode;
+    a.filter_clips = (mode == BG_MODE_SEMIGLOBAL || mode == BG_MODE_LOCAL);
+    a.out = d_out;
+    a.ops = d_ops;
+    a.ops_stride = ops_stride;
+
+    int sm = SCORE_PARAMS;
+    if (sc->matrix) {
+        std::vector<uint8_t> code_map;
+        std::vector<int32_t> table;
+        const int A = compact_matrix(sc->matrix, code_map, table);
+        sm = A <= kMaxLdsAlphabet ? SCORE_LDS : SCORE_GLOBAL;
+        const size_t bytes = 256 + table.size() * 4;
+        if ((rc = bg_reserve(&ctx->table, &ctx->table_bytes, bytes))) return rc;
+        BG_HIP(hipMemcpyAsync((uint8_t*)ctx->table + 256, table.data(), table.size() * 4,
+                              hipMemcpyHostToDevice, st));
+        BG_HIP(hipMemcpyAsync(ctx->table, code_map.data(), 256, hipMemcpyHostToDevice, st));
+        BG_HIP(hipStreamSynchronize(st));  // the host vectors go out of scope
+        a.code_map = (const uint8_t*)ctx->table;
+        a.table = (const int32_t*)((uint8_t*)ctx->table + 256);
+        a.alpha = A;
+    }
+
+    const Config cfg = pick_config(max_xlen, sm);
+    sw_fill_fn fill = sm == SCORE_PARAMS ? get_fill_params(cfg.lp, cfg.r)
+                                         : get_fill_matrix(cfg.lp, cfg.r, sm);
+    if (!fill) return BG_ERR_UNSUPPORTED;
+    const bool wide = cfg.r * 5 > 32;
+    const uint32_t pw = 64 / cfg.lp;
+    SwGeom& g = a.g;
+    g.lp = cfg.lp;
+    g.r = cfg.r;
+    g.m_cap = max_xlen;
+    g.n_cap = max_ylen;
+    g.nsteps = max_ylen ? max_ylen + cfg.lp - 1 : 0;
+    g.nstrips = std::max<uint32_t>(1, (max_xlen + cfg.lp * cfg.r - 1) / (cfg.lp * cfg.r));
+    g.aux_stride = SwGeom::stride_for(max_xlen, max_ylen);
+
+    // scratch per wavefront job / per pair
+    const size_t tb_per_job = (size_t)g.nstrips * g.nsteps * 64 * (wide ? 8 : 4);
+    const size_t aux_per_pair = (size_t)g.aux_stride * 4;
+    const size_t bnd_per_pair = g.nstrips > 1 ? (size_t)(g.n_cap + 1) * 16 : 0;
+    const size_t per_pair = tb_per_job / pw + aux_per_pair + bnd_per_pair + 1;
+    uint64_t chunk = ctx->chunk_pairs > 0 ? (uint64_t)ctx->chunk_pairs : 262144;
+    const uint64_t budget = 24ull << 30;  // scratch budget
+    chunk = std::min<uint64_t>(chunk, std::max<uint64_t>(pw, budget / per_pair));
+    chunk = std::min<uint64_t>(chunk, n_pairs);
+    chunk = (chunk + pw - 1) / pw * pw;
+    const uint64_t jobs = chunk / pw;
+    if ((rc = bg_reserve(&ctx->tb, &ctx->tb_bytes, std::max<size_t>(jobs * tb_per_job, 64)))) return rc;
+    if ((rc = bg_reserve(&ctx->aux, &ctx->aux_bytes, chunk * aux_per_pair))) return rc;
+    if ((rc = bg_reserve(&ctx->bnd, &ctx->bnd_bytes, std::max<size_t>(chunk * bnd_per_pair, 64)))) return rc;
+    a.tb = ctx->tb;
+    a.aux = (int32_t*)ctx->aux;
+    a.bnd = (int4*)ctx->bnd;
+
+    for (uint64_t p0 = 0; p0 < n_pairs; p0 += chunk) {
+        a.pair0 = p0;
+        a.n_pairs = (uint32_t)std::min<uint64_t>(chunk, n_pairs - p0);
+        const uint32_t njobs = (a.n_pairs + pw - 1) / pw;
+        if (ctx->timing) BG_HIP(hipEventRecord(ctx->ev[0], st));
+        fill<<<dim3((njobs + 3) / 4), dim3(256), 0, st>>>(a);
+        BG_HIP(hipGetLastError());
+        if (ctx->timing) {
+            BG_HIP(hipEventRecord(ctx->ev[1], st));
+            BG_HIP(hipEventSynchronize(ctx->ev[1]));
+            float ms = 0;
+            BG_HIP(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+            ctx->last.fill_ms += ms;
+            ctx->last.fill_launches += 1;
+            BG_HIP(hipEventRecord(ctx->ev[0], st));
+        }
+        launch_traceback(a, wide, st);
+        BG_HIP(hipGetLastError());
+        if (ctx->timing) {
+            BG_HIP(hipEventRecord(ctx->ev[1], st));
+            BG_HIP(hipEventSynchronize(ctx->ev[1]));
+            float ms = 0;
+            BG_HIP(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+            ctx->last.traceback_ms += ms;
+            ctx->last.traceback_launches += 1;
+        }
+    }
+    return BG_OK;
+}
+
+extern "C" int bg_align_batch(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint64_t n_pairs,
+                              const uint8_t* x, const uint64_t* x_off, const uint8_t* y,
+                              const uint64_t* y_off, bg_alignment_t* out, uint8_t* ops_buf,
+                              uint64_t ops_cap, uint64_t* ops_used) {
+    if (!ctx || !sc) return BG_ERR_INVALID_ARG;
+    int rc = check_scoring(sc);
+    if (rc) return rc;
+    if (ops_used) *ops_used = 0;
+    if (n_pairs == 0) return BG_OK;
+    if (!x_off || !y_off || !out) return BG_ERR_INVALID_ARG;
+    BG_HIP(hipSetDevice(ctx->device));
+    uint64_t max_x = 0, max_y = 0, max_sum = 0;
+    for (uint64_t p = 0; p < n_pairs; p++) {
+        if (x_off[p + 1] < x_off[p] || y_off[p + 1] < y_off[p]) return BG_ERR_INVALID_ARG;
+        const uint64_t lx = x_off[p + 1] - x_off[p], ly = y_off[p + 1] - y_off[p];
+        max_x = std::max(max_x, lx);
+        max_y = std::max(max_y, ly);
+        max_sum = std::max(max_sum, lx + ly);
+    }
+    if (max_x > (1u << 24) || max_y > (1u << 24)) return BG_ERR_TOO_LARGE;
+    const uint64_t xb = x_off[n_pairs], yb = y_off[n_pairs];
+    const uint64_t stride = ops_buf ? max_sum + 4 : 0;
+    uint8_t *d_x = nullptr, *d_y = nullptr, *d_ops = nullptr;
+    uint64_t *d_xo = nullptr, *d_yo = nullptr;
+    bg_alignment_t* d_out = nullptr;
+    std::vector<uint8_t> h_ops;
+    hipStream_t st = ctx->stream;
+    auto run = [&]() -> int {
+        BG_HIP(hipMalloc((void**)&d_x, std::max<uint64_t>(xb, 16)));
+        BG_HIP(hipMalloc((void**)&d_y, std::max<uint64_t>(yb, 16)));
+        BG_HIP(hipMalloc((void**)&d_xo, (n_pairs + 1) * 8));
+        BG_HIP(hipMalloc((void**)&d_yo, (n_pairs + 1) * 8));
+        BG_HIP(hipMalloc((void**)&d_out, n_pairs * sizeof(bg_alignment_t)));
+        if (stride) BG_HIP(hipMalloc((void**)&d_ops, n_pairs * stride));
+        if (xb) BG_HIP(hipMemcpyAsync(d_x, x, xb, hipMemcpyHostToDevice, st));
+        if (yb) BG_HIP(hipMemcpyAsync(d_y, y, yb, hipMemcpyHostToDevice, st));
+        BG_HIP(hipMemcpyAsync(d_xo, x_off, (n_pairs + 1) * 8, hipMemcpyHostToDevice, st));
+        BG_HIP(hipMemcpyAsync(d_yo, y_off, (n_pairs + 1) * 8, hipMemcpyHostToDevice, st));
+        int r2 = bg_align_batch_dev(ctx, sc, mode, n_pairs, d_x, d_xo, d_y, d_yo, (uint32_t)max_x,
+                                    (uint32_t)max_y, d_out, d_ops, stride, st);
+        if (r2) return r2;
+        BG_HIP(hipMemcpyAsync(out, d_out, n_pairs * sizeof(bg_alignment_t), hipMemcpyDeviceToHost, st));
+        if (stride) {
+            h_ops.resize(n_pairs * stride);
+            BG_HIP(hipMemcpyAsync(h_ops.data(), d_ops, n_pairs * stride, hipMemcpyDeviceToHost, st));
+        }
+        BG_HIP(hipStreamSynchronize(st));
+        return BG_OK;
+    };
+    rc = run();
+    hipFree(d_x);
+    hipFree(d_y);
+    hipFree(d_xo);
+    hipFree(d_yo);
+    hipFree(d_out);
+    hipFree(d_ops);
+    if (rc) return rc;
+    // compact the strided ops into the caller's buffer
+    uint64_t used = 0;
+    int status = BG_OK;
+    for (uint64_t p = 0; p < n_pairs; p++) {
+        if (out[p].status) status = out[p].status;
+        const uint64_t src = out[p].ops_off;
+        out[p].ops_off = used;
+        if (ops_buf) {
+            if (used + out[p].n_ops <= ops_cap)
+                memcpy(ops_buf + used, h_ops.data() + src, out[p].n_ops);
+            else if (status == BG_OK)
+                status = BG_ERR_OPS_CAP;
+        }
+        used += out[p].n_ops;
+    }
+    if (ops_used) *ops_used = used;
+    return status;
+}

@@ -1,0 +1,14 @@
+// K1 instantiations for tabulated match functions (closures / BLOSUM / PAM, scores/mod.rs):
+// SCORE_LDS keeps the compacted A x A table in LDS, SCORE_GLOBAL (A > 64) reads it from HBM/L2.
+#include <type_traits>
+#include "sw_fill.inc"
+namespace bgsw {
+sw_fill_fn get_fill_matrix(int lp, int r, int sm) {
+#define CASE(LP, R)                                                                   \
+    if (lp == LP && r == R)                                                           \
+        return sm == SCORE_LDS ? sw_fill_kernel<R, LP, SCORE_LDS> : sw_fill_kernel<R, LP, SCORE_GLOBAL>;
+    CASE(16, 6) CASE(16, 12) CASE(32, 12) CASE(64, 8)
+#undef CASE
+    return nullptr;
+}
+}  // namespace bgsw

@@ -1,0 +1,99 @@
+"""FMIndex / backward_search — reference: src/data_structures/fmindex.rs:69-248."""
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib
+
+COMPLETE, PARTIAL, ABSENT, PANIC = 0, 1, 2, 3
+
+
+@dataclass(frozen=True)
+class Interval:  # fmindex.rs:69-80
+    lower: int
+    upper: int
+
+    def occ(self, sa):
+        return [int(sa[p]) for p in range(self.lower, self.upper)]
+
+
+@dataclass(frozen=True)
+class BackwardSearchResult:  # fmindex.rs:92-96
+    kind: str  # "Complete" | "Partial" | "Absent"
+    interval: Interval = None
+    matched_len: int = 0
+
+    @staticmethod
+    def from_raw(tag, lo, hi, ml):
+        if tag == COMPLETE:
+            return BackwardSearchResult("Complete", Interval(int(lo), int(hi)), int(ml))
+        if tag == PARTIAL:
+            return BackwardSearchResult("Partial", Interval(int(lo), int(hi)), int(ml))
+        if tag == ABSENT:
+            return BackwardSearchResult("Absent")
+        raise _lib.AlphabetError(-7, "backward_search")
+
+
+class FMIndex:
+    """FMIndex::new(bwt, less, occ) (fmindex.rs:245-247): uploads the index to the device."""
+
+    def __init__(self, bwt_arr, less_arr, occ, ctx=None):
+        self.ctx = ctx or _lib.default_context()
+        self._bwt = _lib.as_u8(bwt_arr)
+        self._less = np.ascontiguousarray(less_arr, dtype=np.uint64)
+        alpha = _lib.as_u8(occ.alphabet)
+        self.h = C.c_void_p()
+        _lib.check(_lib.lib().bg_fm_build(self.ctx.h, self._bwt.ctypes.data, len(self._bwt),
+                                          self._less.ctypes.data, len(self._less), occ.k,
+                                          alpha.ctypes.data, len(alpha), C.byref(self.h)),
+                   "FMIndex::new")
+
+    def bwt(self):
+        return self._bwt
+
+    def device_bytes(self):
+        return int(_lib.lib().bg_fm_device_bytes(self.h))
+
+    def backward_search_arrays(self, pat, pat_off):
+        """Batch over concatenated patterns; returns (tag u8, lower u64, upper u64, matched u32).
+        Raises AlphabetError if any query reached a byte outside the alphabet."""
+        p = _lib.as_u8(pat)
+        off = np.ascontiguousarray(pat_off, dtype=np.uint64)
+        n = len(off) - 1
+        tag = np.zeros(n, dtype=np.uint8)
+        lo = np.zeros(n, dtype=np.uint64)
+        hi = np.zeros(n, dtype=np.uint64)
+        ml = np.zeros(n, dtype=np.uint32)
+        rc = _lib.lib().bg_fm_backward_search_batch(self.h, n, p.ctypes.data, off.ctypes.data,
+                                                    tag.ctypes.data, lo.ctypes.data,
+                                                    hi.ctypes.data, ml.ctypes.data)
+        self.last_raw = (tag, lo, hi, ml)
+        _lib.check(rc, "backward_search")
+        return tag, lo, hi, ml
+
+    def backward_search_batch(self, patterns):
+        buf, off = _lib.concat(patterns)
+        tag, lo, hi, ml = self.backward_search_arrays(buf, off)
+        return [BackwardSearchResult.from_raw(*r) for r in zip(tag, lo, hi, ml)]
+
+    def backward_search(self, pattern):
+        """FMIndexable::backward_search (fmindex.rs:144-208) for one pattern (batch of 1)."""
+        return self.backward_search_batch([bytes(pattern)])[0]
+
+    def backward_search_dev(self, n_q, d_pat, d_off, d_tag, d_lo, d_hi, d_ml, stream=0):
+        """Device-resident batch: arguments are device pointers (ints), asynchronous."""
+        _lib.check(_lib.lib().bg_fm_backward_search_batch_dev(self.h, n_q, d_pat, d_off, d_tag,
+                                                              d_lo, d_hi, d_ml, stream),
+                   "backward_search_dev")
+
+    def close(self):
+        if self.h:
+            _lib.lib().bg_fm_free(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

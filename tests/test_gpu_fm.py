@@ -1,0 +1,120 @@
+"""GPU parity tests of FM-index backward search (kernel K5 through the C ABI) against the
+reference's KATs and the CPU oracle — bit-exact tags, intervals and matched lengths."""
+import numpy as np
+import pytest
+
+import oracle_py as orc
+from kat_util import load
+from rust_bio_amd import _lib, synth
+from rust_bio_amd.bwt import Occ, bwt, less
+from rust_bio_amd.fmindex import FMIndex
+from rust_bio_amd.suffix_array import suffix_array
+
+pytestmark = pytest.mark.gpu
+K = load("fm_kats.json")
+TAGS = ["Complete", "Partial", "Absent"]
+
+
+def build(text, alphabet, k):
+    sa = suffix_array(text)
+    b = bwt(text, sa)
+    ls = less(b, alphabet)
+    return sa, b, ls, FMIndex(b, ls, Occ(b, k, alphabet))
+
+
+@pytest.mark.parametrize("case", K["backward_search"], ids=lambda c: c["name"])
+def test_reference_kat(case):
+    t = bytes(case["text_bytes"]) if "text_bytes" in case else case["text"].encode()
+    alpha = bytes(case["alphabet_bytes"]) if "alphabet_bytes" in case else case["alphabet"].encode()
+    pat = bytes(case["pattern_bytes"]) if "pattern_bytes" in case else case["pattern"].encode()
+    sa, b, ls, fm = build(t, alpha, case["k"])
+    res = fm.backward_search(pat)
+    if "positions" in case:
+        pos = [] if res.kind == "Absent" else res.interval.occ(sa)
+        assert pos == case["positions"]
+    if "tag" in case:
+        assert res.kind.lower() == case["tag"]
+    if "matched_len" in case:
+        assert res.matched_len == case["matched_len"]
+    if "not_tag" in case:
+        assert res.kind.lower() != case["not_tag"]
+
+
+def compare_with_oracle(text, alphabet, k, pats):
+    sa, b, ls, fm = build(text, alphabet, k)
+    occ = orc.Occ(b, k, alphabet)
+    buf, off = _lib.concat(pats)
+    otag, olo, ohi, oml = orc.backward_search_batch(b, ls, occ, buf, off, threads=4)
+    panics = otag == 3
+    try:
+        tag, lo, hi, ml = fm.backward_search_arrays(buf, off)
+        assert not panics.any()
+    except _lib.AlphabetError:
+        assert panics.any()
+        tag, lo, hi, ml = fm.last_raw
+    assert (tag == otag).all()
+    ok = ~panics
+    assert (lo[ok] == olo[ok]).all() and (hi[ok] == ohi[ok]).all()
+    assert (ml[ok].astype(np.uint64) == oml[ok]).all()
+    return tag
+
+
+def test_random_texts_all_result_kinds():
+    rng = np.random.default_rng(21)
+    for trial in range(12):
+        n = int(rng.integers(1, 3000))
+        t = bytes(rng.choice(list(b"ACGT"), size=n).astype(np.uint8)) + b"$"
+        pats = []
+        for _ in range(400):
+            L = int(rng.integers(0, 40))
+            if rng.random() < 0.5 and n > L:
+                s = int(rng.integers(0, n - L + 1))
+                p = bytearray(t[s:s + L])
+                if rng.random() < 0.3 and L:
+                    p[int(rng.integers(0, L))] = int(rng.choice(list(b"ACGTN")))
+            else:
+                p = bytearray(rng.choice(list(b"ACGTNacgtn$"), size=L).astype(np.uint8))
+            pats.append(bytes(p))
+        tag = compare_with_oracle(t, b"ACGTNacgtn", int(rng.choice([1, 3, 64, 128])), pats)
+        assert set(tag.tolist()) >= {0, 1, 2}
+
+
+def test_out_of_alphabet_bytes_match_reference_panics():
+    t = b"GATTACAGATTACCA$"
+    pats = [b"ATXACA", b"A~ACA", b"XGGACA", b"", b"N", b"GATTACA", b"\xff", b"TTAC"]
+    compare_with_oracle(t, b"ACGTNacgtn", 3, pats)
+
+
+def test_multi_sentinel_and_stray_symbols():
+    # sentinels and N occupy BWT positions as exceptions of the packed layout
+    rng = np.random.default_rng(33)
+    reads = [bytes(rng.choice(list(b"ACGTN"), p=[.24, .24, .24, .24, .04], size=int(rng.integers(5, 80))).astype(np.uint8))
+             for _ in range(40)]
+    t = b"$".join(reads) + b"$"
+    pats = [r[int(rng.integers(0, len(r))):][:int(rng.integers(1, 30))] for r in reads for _ in range(5)]
+    pats += [b"$", b"A$", b"N", b"NN", b"$A"]
+    compare_with_oracle(t, b"ACGTNacgtn", 8, pats)
+    compare_with_oracle(t, b"ACGT", 8, pats)   # N becomes a panic symbol, '$' stays searchable
+
+
+def test_two_symbol_text_and_smallest_symbol():
+    t = b"AAA\x00"
+    compare_with_oracle(t, b"\x00A", 3, [b"A\x00\x00", b"A", b"AA", b"AAA", b"AAAA", b"\x00", b"A\x00"])
+
+
+def test_genome_1m_sample_bit_exact():
+    g = synth.genome(1_000_000, 3)
+    sa, b, ls, fm = build(g, b"ACGTNacgtn", 128)
+    pat, off = synth.fm_patterns(g, 200_000, 100, seed=4)
+    occ = orc.Occ(b, 128, b"ACGTNacgtn")
+    otag, olo, ohi, oml = orc.backward_search_batch(b, ls, occ, pat, off, threads=8)
+    tag, lo, hi, ml = fm.backward_search_arrays(pat, off)
+    assert (tag == otag).all() and (lo == olo).all() and (hi == ohi).all()
+    assert (ml.astype(np.uint64) == oml).all()
+    assert (tag == 0).mean() > 0.7 and (tag == 1).any()
+    # size-independent property: every Complete interval lists exactly the occurrences
+    for q in np.nonzero(tag == 0)[0][:200]:
+        p = bytes(pat[int(off[q]):int(off[q + 1])])
+        for r in range(int(lo[q]), int(hi[q])):
+            s = int(sa[r])
+            assert bytes(g[s:s + len(p)]) == p

@@ -1,0 +1,193 @@
+"""GPU parity tests of the full-matrix aligner (kernels K1 + K2 through the C ABI) against the
+reference's KATs and the CPU oracle: score, coordinates and the complete operation list must be
+identical for every pair."""
+import numpy as np
+import pytest
+
+import oracle_py as orc
+from kat_util import blosum62_matrix, check_expect, load, scoring_kwargs
+from rust_bio_amd import _lib, synth
+from rust_bio_amd.pairwise import (MIN_SCORE, MODE_NAMES, Aligner, MatchParams, Scoring,
+                                   decode_ops)
+
+pytestmark = pytest.mark.gpu
+KATS = load("pairwise_kats.json")
+MODES = {"custom": 0, "global": 1, "semiglobal": 2, "local": 3}
+
+
+def engine_scoring(kw):
+    if "matrix" in kw:
+        fn = kw["matrix"]
+        s = Scoring(kw["gap_open"], kw["gap_extend"], fn, None)
+    else:
+        s = Scoring.from_scores(kw["gap_open"], kw["gap_extend"], kw["match"], kw["mismatch"])
+    for c in ("xclip_prefix", "xclip_suffix", "yclip_prefix", "yclip_suffix"):
+        setattr(s, c, kw[c])
+    return s
+
+
+def as_dict(a):
+    return {"score": a.score, "xstart": a.xstart, "xend": a.xend, "ystart": a.ystart,
+            "yend": a.yend, "xlen": a.xlen, "ylen": a.ylen, "ops": a.operations}
+
+
+@pytest.mark.parametrize("case", KATS["cases"], ids=[c["name"] for c in KATS["cases"]])
+def test_reference_kat(case):
+    kw = scoring_kwargs(case["scoring"])
+    al = Aligner.with_scoring(engine_scoring(kw))
+    got = al.align_batch(MODES[case["mode"]], [case["x"].encode()], [case["y"].encode()])[0]
+    check_expect(as_dict(got), case["expect"], case["name"])
+    assert got.mode == MODE_NAMES[MODES[case["mode"]]]
+    # and the whole struct equals the oracle's
+    want = orc.align(orc.make_scoring(**kw), case["mode"], case["x"].encode(), case["y"].encode())
+    assert as_dict(got) == {k: want[k] for k in as_dict(got)}
+
+
+def test_aligner_reuse_across_modes():
+    r = KATS["aligner_reuse"]
+    al = Aligner.with_scoring(engine_scoring(scoring_kwargs(r["scoring"])))
+    for step in r["sequence"]:
+        fn = {"semiglobal": al.semiglobal, "local": al.local, "global": al.global_}[step["mode"]]
+        check_expect(as_dict(fn(r["x"].encode(), r["y"].encode())), step["expect"])
+
+
+def differential(kw, mode, xs, ys, ctx_opts=None):
+    """engine vs oracle on a batch; returns the number of compared pairs"""
+    al = Aligner.with_scoring(engine_scoring(kw))
+    if ctx_opts:
+        for k, v in ctx_opts.items():
+            al.ctx.set_option(k, v)
+    x, xo = _lib.concat(xs)
+    y, yo = _lib.concat(ys)
+    out, ops = al.align_arrays(MODES[mode], x, xo, y, yo)
+    if ctx_opts:
+        for k in ctx_opts:
+            al.ctx.set_option(k, 0)
+    oout, oops, stride = orc.align_batch(orc.make_scoring(**kw), mode, x, xo, y, yo, threads=8)
+    for f in ("score", "xstart", "xend", "ystart", "yend", "xlen", "ylen"):
+        bad = np.nonzero(out[f].astype(np.int64) != oout[f].astype(np.int64))[0]
+        assert len(bad) == 0, (f, mode, kw, bad[:5], xs[bad[0]], ys[bad[0]], out[f][bad[0]], oout[f][bad[0]])
+    assert (out["status"] == 0).all()
+    assert (out["n_ops"] == oout["n_ops"]).all()
+    for p in range(len(xs)):
+        want = orc.decode_ops(oops[p * stride:p * stride + int(oout["n_ops"][p])])
+        got = decode_ops(out[p], ops)
+        assert got == want, (mode, kw, p, xs[p], ys[p], got, want)
+    return len(xs)
+
+
+BASE = dict(gap_open=-5, gap_extend=-1, match=1, mismatch=-1, xclip_prefix=MIN_SCORE,
+            xclip_suffix=MIN_SCORE, yclip_prefix=MIN_SCORE, yclip_suffix=MIN_SCORE)
+
+
+@pytest.mark.parametrize("mode", ["local", "semiglobal", "global"])
+def test_ragged_batches_including_empty(mode):
+    xs, ys = synth.ragged_pairs(600, 70, seed=1)
+    xs += [b"", b"ACGT", b"", b"A", b"C"]
+    ys += [b"", b"", b"ACGT", b"A", b"G"]
+    differential(BASE, mode, xs, ys)
+
+
+def test_custom_clip_fuzz():
+    # the recipe of fuzz/fuzz_targets/banded_aligner.rs:58-105 (random scoring and clip
+    # penalties), seeded, against the oracle instead of the stale validator
+    rng = np.random.default_rng(2)
+    for trial in range(25):
+        kw = dict(gap_open=-int(rng.integers(0, 8)), gap_extend=-int(rng.integers(0, 4)),
+                  match=int(rng.integers(0, 6)), mismatch=-int(rng.integers(0, 6)))
+        for c in ("xclip_prefix", "xclip_suffix", "yclip_prefix", "yclip_suffix"):
+            kw[c] = MIN_SCORE if rng.random() < 0.35 else -int(rng.integers(0, 12))
+        xs, ys = synth.ragged_pairs(120, 48, seed=100 + trial)
+        differential(kw, "custom", xs, ys)
+
+
+def test_rows_per_lane_configs_and_wave_packing():
+    # lengths chosen to hit every (LP, R) instantiation and partial waves
+    for max_len, n_pairs in [(20, 33), (60, 17), (90, 9), (120, 13), (150, 70), (190, 5),
+                             (230, 6), (300, 3), (380, 5), (500, 3)]:
+        xs, ys = synth.ragged_pairs(n_pairs, max_len, seed=max_len, min_len=max_len // 2)
+        xs[0] = xs[0][:1] if xs[0] else b"A"
+        differential(BASE, "local", xs, ys)
+        differential(BASE, "global", xs, ys)
+
+
+def test_multi_strip_long_sequences():
+    # x longer than one strip (64 lanes x 8 rows): the row buffer hand-over between strips
+    xs, ys = synth.ragged_pairs(3, 1500, seed=8, min_len=900)
+    differential(BASE, "semiglobal", xs, ys)
+    kw = dict(BASE, xclip_prefix=-3, xclip_suffix=-4, yclip_prefix=-2, yclip_suffix=0)
+    differential(kw, "custom", xs, ys)
+
+
+def test_sub_batching_reuses_scratch():
+    xs, ys = synth.ragged_pairs(300, 40, seed=12)
+    differential(BASE, "local", xs, ys, ctx_opts={"chunk_pairs": 64})
+
+
+def test_blosum62_protein_batches():
+    rng = np.random.default_rng(4)
+    aa = b"ARNDCQEGHILKMFPSTWYVBZX"
+    xs = [bytes(rng.choice(list(aa), size=int(rng.integers(1, 120))).astype(np.uint8)) for _ in range(150)]
+    ys = [bytes(rng.choice(list(aa), size=int(rng.integers(1, 120))).astype(np.uint8)) for _ in range(150)]
+    kw = dict(gap_open=-10, gap_extend=-1, matrix=blosum62_matrix(), xclip_prefix=MIN_SCORE,
+              xclip_suffix=MIN_SCORE, yclip_prefix=MIN_SCORE, yclip_suffix=MIN_SCORE)
+    for mode in ("local", "global", "semiglobal"):
+        differential(kw, mode, xs, ys)
+
+
+def test_closure_with_many_classes_uses_global_table():
+    # a match function whose 256 bytes are all distinct classes (A > 64)
+    fn = np.fromfunction(lambda a, b: ((a * 7 + b * 13) % 11) - 5, (256, 256), dtype=np.int64).astype(np.int32)
+    rng = np.random.default_rng(6)
+    xs = [bytes(rng.integers(0, 256, size=int(rng.integers(1, 60))).astype(np.uint8)) for _ in range(60)]
+    ys = [bytes(rng.integers(0, 256, size=int(rng.integers(1, 60))).astype(np.uint8)) for _ in range(60)]
+    kw = dict(gap_open=-4, gap_extend=-2, matrix=fn, xclip_prefix=MIN_SCORE, xclip_suffix=MIN_SCORE,
+              yclip_prefix=MIN_SCORE, yclip_suffix=MIN_SCORE)
+    differential(kw, "local", xs, ys)
+    differential(kw, "global", xs, ys)
+
+
+def test_positive_penalty_is_rejected_like_the_reference_asserts():
+    s = Scoring.from_scores(-5, -1, 1, -1)
+    s.xclip_prefix = 3
+    with pytest.raises(AssertionError):
+        Aligner.with_scoring(s)
+    al = Aligner.with_scoring(Scoring.from_scores(-5, -1, 1, -1))
+    al.scoring.gap_open = 2  # bypass the Python-side assert: the C ABI must refuse too
+    with pytest.raises(_lib.PenaltyError):
+        al.local(b"ACGT", b"ACGT")
+
+
+def test_cfg2_sample_150bp_local_bit_exact():
+    # BASELINE config 2 at a size the oracle finishes in seconds: 20k pairs of 150 bp
+    x, xo, y, yo = synth.sw_pairs(20_000, 150, seed=2)
+    kw = BASE
+    al = Aligner.with_scoring(engine_scoring(kw))
+    out, ops = al.align_arrays(3, x, xo, y, yo)
+    oout, oops, stride = orc.align_batch(orc.make_scoring(**kw), "local", x, xo, y, yo, threads=8)
+    for f in ("score", "xstart", "xend", "ystart", "yend"):
+        assert (out[f].astype(np.int64) == oout[f].astype(np.int64)).all(), f
+    assert (out["n_ops"] == oout["n_ops"]).all()
+    kind = (oops.reshape(len(out), stride) & 0xFF).astype(np.uint8)
+    for p in range(len(out)):
+        k = int(out["n_ops"][p])
+        o = int(out["ops_off"][p])
+        assert (ops[o:o + k] == kind[p, :k]).all(), p
+    # size-independent property: re-scoring the path reproduces the score
+    for p in range(0, len(out), 97):
+        sc, i, j = 0, int(out["xstart"][p]), int(out["ystart"][p])
+        xs_, ys_ = x[int(xo[p]):int(xo[p + 1])], y[int(yo[p]):int(yo[p + 1])]
+        prev = None
+        for o in ops[int(out["ops_off"][p]):int(out["ops_off"][p]) + int(out["n_ops"][p])]:
+            if o in (0, 1):
+                sc += 1 if xs_[i] == ys_[j] else -1
+                i += 1
+                j += 1
+            else:
+                sc += -1 if prev == o else -5
+                if o == 3:
+                    i += 1
+                else:
+                    j += 1
+            prev = o
+        assert sc == int(out["score"][p]) and i == int(out["xend"][p]) and j == int(out["yend"][p])
