@@ -205,7 +205,8 @@ extern "C" int bg_align_batch(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uin
     }
     if (max_x > (1u << 24) || max_y > (1u << 24)) return BG_ERR_TOO_LARGE;
     const uint64_t xb = x_off[n_pairs], yb = y_off[n_pairs];
-    const uint64_t stride = ops_buf ? max_sum + 4 : 0;
+    const uint64_t stride = ops_buf ? max_x + max_y + 4 : 0;
+    (void)max_sum;
     uint8_t *d_x = nullptr, *d_y = nullptr, *d_ops = nullptr;
     uint64_t *d_xo = nullptr, *d_yo = nullptr;
     bg_alignment_t* d_out = nullptr;
