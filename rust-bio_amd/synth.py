@@ -27,18 +27,20 @@ def _unit(u64):
 
 
 def mutate_fixed(refs, seed, sub, ins, dele):
-    """refs: uint8[n, L].  Per base: `dele` deletion, `sub` substitution (to a different base),
-    then `ins` chance of one inserted base; result padded with random bases / truncated to L."""
+    """refs: uint8[n, L].  One SplitMix64 draw per base, split into bit fields:
+    bits 40-63 -> u in [0,1): deletion if u < dele, substitution if u < dele+sub;
+    bits 38-39 -> substitution shift 1..3 (mod 3 + 1); bits 12-35 -> insertion if < ins;
+    bits 10-11 -> inserted base.  Result padded with random bases / truncated to L."""
     n, L = refs.shape
-    r = splitmix64(seed, n * L * 4).reshape(n, L, 4)
-    u = _unit(r[:, :, 0])
+    r = splitmix64(seed, n * L).reshape(n, L)
+    u = (r >> np.uint64(40)).astype(np.float64) * (1.0 / (1 << 24))
     deleted = u < dele
     subst = (u >= dele) & (u < dele + sub)
     code = np.searchsorted(ACGT, refs).astype(np.uint8)  # A C G T -> 0..3
-    shift = (1 + (r[:, :, 1] >> np.uint64(62)) % np.uint64(3)).astype(np.uint8)
+    shift = (1 + ((r >> np.uint64(38)) & np.uint64(3)) % np.uint64(3)).astype(np.uint8)
     code = np.where(subst, (code + shift) & 3, code)
-    inserted = _unit(r[:, :, 2]) < ins
-    ins_code = (r[:, :, 3] >> np.uint64(62)).astype(np.uint8)
+    inserted = ((r >> np.uint64(12)) & np.uint64(0xFFFFFF)).astype(np.float64) * (1.0 / (1 << 24)) < ins
+    ins_code = ((r >> np.uint64(10)) & np.uint64(3)).astype(np.uint8)
     cand = np.empty((n, 2 * L), dtype=np.uint8)
     keep = np.empty((n, 2 * L), dtype=bool)
     cand[:, 0::2], cand[:, 1::2] = code, ins_code
