@@ -12,7 +12,7 @@
 namespace bgsw {
 sw_fill_fn get_fill_params(int lp, int r);
 sw_fill_fn get_fill_matrix(int lp, int r, int sm);
-void launch_traceback(const SwArgs& a, bool wide, hipStream_t st);
+void launch_traceback(const SwArgs& a, int nw, hipStream_t st);
 
 struct Config {
     int lp, r;
@@ -125,7 +125,7 @@ extern "C" int bg_align_batch_dev(bg_ctx* ctx, const bg_scoring_t* sc, int mode,
     sw_fill_fn fill = sm == SCORE_PARAMS ? get_fill_params(cfg.lp, cfg.r)
                                          : get_fill_matrix(cfg.lp, cfg.r, sm);
     if (!fill) return BG_ERR_UNSUPPORTED;
-    const bool wide = cfg.r * 5 > 32;
+    const int nw = tb_words(cfg.r);
     const uint32_t pw = 64 / cfg.lp;
     SwGeom& g = a.g;
     g.lp = cfg.lp;
@@ -137,7 +137,7 @@ extern "C" int bg_align_batch_dev(bg_ctx* ctx, const bg_scoring_t* sc, int mode,
     g.aux_stride = SwGeom::stride_for(max_xlen, max_ylen);
 
     // scratch per wavefront job / per pair
-    const size_t tb_per_job = (size_t)g.nstrips * g.nsteps * 64 * (wide ? 8 : 4);
+    const size_t tb_per_job = (size_t)g.nstrips * g.nsteps * 64 * (size_t)nw * 4;
     const size_t aux_per_pair = (size_t)g.aux_stride * 4;
     const size_t bnd_per_pair = g.nstrips > 1 ? (size_t)(g.n_cap + 1) * 16 : 0;
     const size_t per_pair = tb_per_job / pw + aux_per_pair + bnd_per_pair + 1;
@@ -170,7 +170,7 @@ extern "C" int bg_align_batch_dev(bg_ctx* ctx, const bg_scoring_t* sc, int mode,
             ctx->last.fill_launches += 1;
             BG_HIP(hipEventRecord(ctx->ev[0], st));
         }
-        launch_traceback(a, wide, st);
+        launch_traceback(a, nw, st);
         BG_HIP(hipGetLastError());
         if (ctx->timing) {
             BG_HIP(hipEventRecord(ctx->ev[1], st));

@@ -49,20 +49,20 @@ struct SwScoring {
 };
 
 // aux record of one pair (int32 words):
-//   [0] Sbits(m,0)   [1] fill-time Sbits(0,n)   [2..3] reserved
-//   colS[m_cap+1] colI[m_cap+1] Sn[m_cap+1] Ly[m_cap+1] Lx[n_cap+1] colBits[m_cap+1]
+//   [0] S nibble of (m,0)   [1] score = S[n%2][m] after the epilogue   [2] Lx[n] after the epilogue
+//   Ly[m_cap+1]  Lx[n_cap+1]  colBits[m_cap+1 bytes]: (S nibble | I nibble << 4) of column n
 struct SwGeom {
     uint32_t lp, r, nsteps, nstrips, m_cap, n_cap, aux_stride;
-    __host__ __device__ uint32_t off_colS() const { return 4; }
-    __host__ __device__ uint32_t off_colI() const { return 4 + (m_cap + 1); }
-    __host__ __device__ uint32_t off_Sn() const { return 4 + 2 * (m_cap + 1); }
-    __host__ __device__ uint32_t off_Ly() const { return 4 + 3 * (m_cap + 1); }
-    __host__ __device__ uint32_t off_Lx() const { return 4 + 4 * (m_cap + 1); }
-    __host__ __device__ uint32_t off_bits() const { return 4 + 4 * (m_cap + 1) + (n_cap + 1); }
+    __host__ __device__ uint32_t off_Ly() const { return 4; }
+    __host__ __device__ uint32_t off_Lx() const { return 4 + (m_cap + 1); }
+    __host__ __device__ uint32_t off_bits() const { return 4 + (m_cap + 1) + (n_cap + 1); }
     __host__ __device__ static uint32_t stride_for(uint32_t m_cap, uint32_t n_cap) {
-        return 4 + 5 * (m_cap + 1) + (n_cap + 1);
+        return 4 + (m_cap + 1) + (n_cap + 1) + (m_cap + 1 + 3) / 4;
     }
 };
+
+// packed traceback: R cells x 5 bits per lane per step, 6 cells per 32-bit word
+__host__ __device__ constexpr int tb_words(int r) { return (r + 5) / 6; }
 
 struct SwArgs {
     const uint8_t* x;
@@ -176,12 +176,26 @@ __device__ __forceinline__ Row0 row0_cell(const SwScoring& sc, uint32_t j) {
     return c;
 }
 
-typedef void (*sw_fill_fn)(const SwArgs);
+// reference S nibble of a packed 3-bit move code (`eq`: x[i-1] == y[j-1], mod.rs:762)
+__device__ __forceinline__ uint32_t s_nibble_of_code(uint32_t code, bool eq) {
+    switch (code) {
+        case C_DIAG: return eq ? TB_MATCH : TB_SUBST;
+        case C_INS: return TB_INS;
+        case C_DEL: return TB_DEL;
+        case C_XP: return TB_XCLIP_PREFIX;
+        case C_YP: return TB_YCLIP_PREFIX;
+        default: return TB_XCLIP_SUFFIX;  // mod.rs:757
+    }
+}
 
-template <int R>
-struct TbWord {
-    using type = typename std::conditional<(R * 5 <= 32), uint32_t, uint64_t>::type;
-};
+// In the last-column nibbles K1 publishes, a diagonal move is left unresolved (K1 may only hold
+// class codes of a tabulated match function, not the raw bytes): K2 turns it into MATCH/SUBST.
+constexpr uint32_t TB_DIAG_MARK = 15;
+__device__ __forceinline__ uint32_t s_nibble_unresolved(uint32_t code) {
+    return code == C_DIAG ? TB_DIAG_MARK : s_nibble_of_code(code, false);
+}
+
+typedef void (*sw_fill_fn)(const SwArgs);
 
 }  // namespace bgsw
 #endif
