@@ -35,6 +35,7 @@ struct bg_ctx {
     void* table = nullptr;  // compacted scoring table + code map
     size_t table_bytes = 0;
     int64_t chunk_pairs = 0;  // 0 = default
+    bool force_wide = false;  // tests: disable the NARROW (28-bit key) kernels
     // timing
     bool timing = false;
     hipEvent_t ev[2] = {nullptr, nullptr};

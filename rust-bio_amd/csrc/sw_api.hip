@@ -10,8 +10,9 @@
 #include "sw_kernels.h"
 
 namespace bgsw {
-sw_fill_fn get_fill_params(int lp, int r);
-sw_fill_fn get_fill_matrix(int lp, int r, int sm);
+sw_fill_fn get_fill_params_narrow(int lp, int r, bool local);
+sw_fill_fn get_fill_params_wide(int lp, int r, bool local);
+sw_fill_fn get_fill_matrix(int lp, int r, int sm, bool narrow);
 void launch_traceback(const SwArgs& a, int nw, hipStream_t st);
 
 struct Config {
@@ -122,8 +123,22 @@ extern "C" int bg_align_batch_dev(bg_ctx* ctx, const bg_scoring_t* sc, int mode,
     }
 
     const Config cfg = pick_config(max_xlen, sm);
-    sw_fill_fn fill = sm == SCORE_PARAMS ? get_fill_params(cfg.lp, cfg.r)
-                                         : get_fill_matrix(cfg.lp, cfg.r, sm);
+    const bool all_zero_clips = a.sc.xp == 0 && a.sc.xs == 0 && a.sc.yp == 0 && a.sc.ys == 0;
+    // NARROW kernels need every reachable score inside +-2^27 (sw_kernels.h): bound it by
+    // (longest path) x (largest finite magnitude in the scoring)
+    int64_t mag = std::max<int64_t>(std::abs((int64_t)a.sc.go), std::abs((int64_t)a.sc.ge));
+    for (int32_t c : {a.sc.xp, a.sc.xs, a.sc.yp, a.sc.ys})
+        if (c != BG_MIN_SCORE) mag = std::max<int64_t>(mag, std::abs((int64_t)c));
+    if (sc->matrix) {
+        for (size_t t = 0; t < 65536; t++) mag = std::max<int64_t>(mag, std::abs((int64_t)sc->matrix[t]));
+    } else {
+        mag = std::max<int64_t>(mag, std::max(std::abs((int64_t)a.sc.match), std::abs((int64_t)a.sc.mismatch)));
+    }
+    const bool narrow = !ctx->force_wide && mag * ((int64_t)max_xlen + max_ylen + 8) < (1 << 26);
+    sw_fill_fn fill = sm == SCORE_PARAMS
+                          ? (narrow ? get_fill_params_narrow(cfg.lp, cfg.r, all_zero_clips)
+                                    : get_fill_params_wide(cfg.lp, cfg.r, all_zero_clips))
+                          : get_fill_matrix(cfg.lp, cfg.r, sm, narrow);
     if (!fill) return BG_ERR_UNSUPPORTED;
     const int nw = tb_words(cfg.r);
     const uint32_t pw = 64 / cfg.lp;

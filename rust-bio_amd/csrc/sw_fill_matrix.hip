@@ -3,10 +3,11 @@
 #include <type_traits>
 #include "sw_fill.inc"
 namespace bgsw {
-sw_fill_fn get_fill_matrix(int lp, int r, int sm) {
+sw_fill_fn get_fill_matrix(int lp, int r, int sm, bool narrow) {
 #define CASE(LP, R)                                                                   \
     if (lp == LP && r == R)                                                           \
-        return sm == SCORE_LDS ? sw_fill_kernel<R, LP, SCORE_LDS> : sw_fill_kernel<R, LP, SCORE_GLOBAL>;
+        return sm == SCORE_LDS ? (narrow ? sw_fill_kernel<R, LP, SCORE_LDS, false, true> : sw_fill_kernel<R, LP, SCORE_LDS, false, false>) \
+                               : (narrow ? sw_fill_kernel<R, LP, SCORE_GLOBAL, false, true> : sw_fill_kernel<R, LP, SCORE_GLOBAL, false, false>);
     CASE(16, 6) CASE(16, 12) CASE(32, 12) CASE(64, 8)
 #undef CASE
     return nullptr;

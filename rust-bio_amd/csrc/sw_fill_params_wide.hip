@@ -10,5 +10,5 @@ static sw_fill_fn pick(int lp, int r) {
 #undef CASE
     return nullptr;
 }
-sw_fill_fn get_fill_params_narrow(int lp, int r, bool local) { return local ? pick<true, true>(lp, r) : pick<false, true>(lp, r); }
+sw_fill_fn get_fill_params_wide(int lp, int r, bool local) { return local ? pick<true, false>(lp, r) : pick<false, false>(lp, r); }
 }  // namespace bgsw

@@ -38,7 +38,12 @@ enum : uint32_t {
     TB_XCLIP_PREFIX = 5, TB_XCLIP_SUFFIX = 6, TB_YCLIP_PREFIX = 7, TB_YCLIP_SUFFIX = 8
 };
 // 3-bit S-move code of a packed cell; bit 3 = I extends, bit 4 = D extends
-enum : uint32_t { C_XS = 0, C_DIAG = 1, C_INS = 2, C_DEL = 3, C_XP = 4, C_YP = 5 };
+// (numbered by priority: on equal scores the reference keeps the earlier candidate, mod.rs:757-786)
+enum : uint32_t { C_XS = 5, C_DIAG = 4, C_INS = 3, C_DEL = 2, C_XP = 1, C_YP = 0 };
+// NARROW kernels order candidates with one integer max over keys (score << 3 | priority); scores
+// must stay inside +-2^27, 'minus infinity' style values are clamped to this floor first.
+constexpr int32_t kNarrowFloor = -(1 << 27);
+constexpr int32_t kNarrowKeyFloor = (int32_t)0x80000000;
 
 enum { SCORE_PARAMS = 0, SCORE_LDS = 1, SCORE_GLOBAL = 2 };
 constexpr int kMaxLdsAlphabet = 64;

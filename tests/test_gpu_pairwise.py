@@ -119,6 +119,20 @@ def test_multi_strip_long_sequences():
     differential(kw, "custom", xs, ys)
 
 
+def test_wide_kernels_forced_and_by_magnitude():
+    # the NARROW (score<<3|priority key) kernels are chosen when every score fits 28 bits; the
+    # wide kernels must give the same answers, and huge magnitudes must select them by themselves
+    xs, ys = synth.ragged_pairs(200, 90, seed=31)
+    differential(BASE, "local", xs, ys, ctx_opts={"force_wide": 1})
+    kw = dict(BASE, xclip_prefix=-3, xclip_suffix=-4, yclip_prefix=-2, yclip_suffix=0)
+    differential(kw, "custom", xs, ys, ctx_opts={"force_wide": 1})
+    differential(BASE, "semiglobal", xs, ys, ctx_opts={"force_wide": 1})
+    big = dict(gap_open=-3_000_000, gap_extend=-700_000, match=1_000_000, mismatch=-2_000_000,
+               xclip_prefix=MIN_SCORE, xclip_suffix=-5_000_000, yclip_prefix=-1_000_000, yclip_suffix=MIN_SCORE)
+    differential(big, "custom", xs, ys)
+    differential(big, "local", xs, ys)
+
+
 def test_sub_batching_reuses_scratch():
     xs, ys = synth.ragged_pairs(300, 40, seed=12)
     differential(BASE, "local", xs, ys, ctx_opts={"chunk_pairs": 64})
