@@ -124,7 +124,7 @@ extern "C" int bg_align_batch_dev(bg_ctx* ctx, const bg_scoring_t* sc, int mode,
 
     const Config cfg = pick_config(max_xlen, sm);
     const bool all_zero_clips = a.sc.xp == 0 && a.sc.xs == 0 && a.sc.yp == 0 && a.sc.ys == 0;
-    // NARROW kernels need every reachable score inside +-2^27 (sw_kernels.h): bound it by
+    // NARROW kernels need every reachable score inside +-2^25 (sw_kernels.h): bound it by
     // (longest path) x (largest finite magnitude in the scoring)
     int64_t mag = std::max<int64_t>(std::abs((int64_t)a.sc.go), std::abs((int64_t)a.sc.ge));
     for (int32_t c : {a.sc.xp, a.sc.xs, a.sc.yp, a.sc.ys})
@@ -134,7 +134,7 @@ extern "C" int bg_align_batch_dev(bg_ctx* ctx, const bg_scoring_t* sc, int mode,
     } else {
         mag = std::max<int64_t>(mag, std::max(std::abs((int64_t)a.sc.match), std::abs((int64_t)a.sc.mismatch)));
     }
-    const bool narrow = !ctx->force_wide && mag * ((int64_t)max_xlen + max_ylen + 8) < (1 << 26);
+    const bool narrow = !ctx->force_wide && mag * ((int64_t)max_xlen + max_ylen + 8) < (1 << 24);
     sw_fill_fn fill = sm == SCORE_PARAMS
                           ? (narrow ? get_fill_params_narrow(cfg.lp, cfg.r, all_zero_clips)
                                     : get_fill_params_wide(cfg.lp, cfg.r, all_zero_clips))
@@ -156,8 +156,8 @@ extern "C" int bg_align_batch_dev(bg_ctx* ctx, const bg_scoring_t* sc, int mode,
     const size_t aux_per_pair = (size_t)g.aux_stride * 4;
     const size_t bnd_per_pair = g.nstrips > 1 ? (size_t)(g.n_cap + 1) * 16 : 0;
     const size_t per_pair = tb_per_job / pw + aux_per_pair + bnd_per_pair + 1;
-    uint64_t chunk = ctx->chunk_pairs > 0 ? (uint64_t)ctx->chunk_pairs : 262144;
-    const uint64_t budget = 24ull << 30;  // scratch budget
+    uint64_t chunk = ctx->chunk_pairs > 0 ? (uint64_t)ctx->chunk_pairs : (1u << 20);
+    const uint64_t budget = 48ull << 30;  // scratch budget (of 288 GB HBM)
     chunk = std::min<uint64_t>(chunk, std::max<uint64_t>(pw, budget / per_pair));
     chunk = std::min<uint64_t>(chunk, n_pairs);
     chunk = (chunk + pw - 1) / pw * pw;

@@ -39,10 +39,13 @@ enum : uint32_t {
 };
 // 3-bit S-move code of a packed cell; bit 3 = I extends, bit 4 = D extends
 // (numbered by priority: on equal scores the reference keeps the earlier candidate, mod.rs:757-786)
-enum : uint32_t { C_XS = 5, C_DIAG = 4, C_INS = 3, C_DEL = 2, C_XP = 1, C_YP = 0 };
-// NARROW kernels order candidates with one integer max over keys (score << 3 | priority); scores
-// must stay inside +-2^27, 'minus infinity' style values are clamped to this floor first.
-constexpr int32_t kNarrowFloor = -(1 << 27);
+// MATCH and SUBST are told apart in the cell (only one of them is a candidate of a given cell), so
+// that K2 never has to re-read the sequences.
+enum : uint32_t { C_XS = 7, C_MATCH = 6, C_SUBST = 5, C_INS = 3, C_DEL = 2, C_XP = 1, C_YP = 0 };
+// NARROW kernels keep scores scaled by 16 and order candidates with one integer max over
+// (score << 4 | priority) keys; real scores must stay inside +-2^25, 'minus infinity' style values
+// are clamped to this floor (scaled: -2^30, so that floor + floor still fits an int32).
+constexpr int32_t kNarrowFloor = -(1 << 26);
 constexpr int32_t kNarrowKeyFloor = (int32_t)0x80000000;
 
 enum { SCORE_PARAMS = 0, SCORE_LDS = 1, SCORE_GLOBAL = 2 };
@@ -181,23 +184,17 @@ __device__ __forceinline__ Row0 row0_cell(const SwScoring& sc, uint32_t j) {
     return c;
 }
 
-// reference S nibble of a packed 3-bit move code (`eq`: x[i-1] == y[j-1], mod.rs:762)
-__device__ __forceinline__ uint32_t s_nibble_of_code(uint32_t code, bool eq) {
+// reference S nibble of a packed 3-bit move code
+__device__ __forceinline__ uint32_t s_nibble_of_code(uint32_t code) {
     switch (code) {
-        case C_DIAG: return eq ? TB_MATCH : TB_SUBST;
+        case C_MATCH: return TB_MATCH;  // mod.rs:762
+        case C_SUBST: return TB_SUBST;
         case C_INS: return TB_INS;
         case C_DEL: return TB_DEL;
         case C_XP: return TB_XCLIP_PREFIX;
         case C_YP: return TB_YCLIP_PREFIX;
         default: return TB_XCLIP_SUFFIX;  // mod.rs:757
     }
-}
-
-// In the last-column nibbles K1 publishes, a diagonal move is left unresolved (K1 may only hold
-// class codes of a tabulated match function, not the raw bytes): K2 turns it into MATCH/SUBST.
-constexpr uint32_t TB_DIAG_MARK = 15;
-__device__ __forceinline__ uint32_t s_nibble_unresolved(uint32_t code) {
-    return code == C_DIAG ? TB_DIAG_MARK : s_nibble_of_code(code, false);
 }
 
 typedef void (*sw_fill_fn)(const SwArgs);

@@ -16,8 +16,6 @@ __global__ __launch_bounds__(256) void sw_traceback_kernel(const SwArgs a) {
     const uint64_t xo = a.x_off[a.pair0 + pair], yo = a.y_off[a.pair0 + pair];
     const uint32_t m = (uint32_t)(a.x_off[a.pair0 + pair + 1] - xo);
     const uint32_t n = (uint32_t)(a.y_off[a.pair0 + pair + 1] - yo);
-    const uint8_t* x = a.x + xo;
-    const uint8_t* y = a.y + yo;
 
     const int32_t* aux = a.aux + (size_t)pair * geo.aux_stride;
     const int32_t* gLy = aux + geo.off_Ly();
@@ -28,12 +26,12 @@ __global__ __launch_bounds__(256) void sw_traceback_kernel(const SwArgs a) {
     const uint32_t lxn = (uint32_t)aux[2];
 
     const uint32_t job = pair / PW, grp = pair % PW;
-    const uint32_t* tbj = (const uint32_t*)a.tb + ((size_t)job * geo.nstrips * geo.nsteps * 64 + grp * LP) * NW;
+    const uint32_t* tbj = (const uint32_t*)a.tb + (((size_t)job * 64 + grp * LP) * geo.nstrips * geo.nsteps) * NW;
     // packed 5 bits of inner cell (1 <= i <= m, 1 <= j <= n)
     auto cell = [&](uint32_t i, uint32_t j) -> uint32_t {
         const uint32_t i1 = i - 1, lrow = i1 / R, rr = i1 - lrow * R;
         const uint32_t st = lrow / LP, llc = lrow - st * LP;
-        const uint32_t w = tbj[(((size_t)st * geo.nsteps + (j - 1 + llc)) * 64 + llc) * NW + rr / 6];
+        const uint32_t w = tbj[(((size_t)llc * geo.nstrips + st) * geo.nsteps + (j - 1 + llc)) * NW + rr / 6];
         return (w >> (5 * (rr % 6))) & 31u;
     };
     // S nibble of cell (i,j), j < n (or the fill-time value for j == n, never requested)
@@ -44,19 +42,15 @@ __global__ __launch_bounds__(256) void sw_traceback_kernel(const SwArgs a) {
             return col0_cell(sc, i, m, NEG).sbits;
         }
         if (i == 0) return row0_cell(sc, j).sbits;
-        return s_nibble_of_code(cell(i, j) & 7u, x[i - 1] == y[j - 1]);
+        return s_nibble_of_code(cell(i, j) & 7u);
     };
-    // column n comes from K1's epilogue; a diagonal move is resolved here on the raw bytes
-    auto resolve = [&](uint32_t v, uint32_t i) -> uint32_t {
-        if (v != TB_DIAG_MARK) return v;
-        return x[i - 1] == y[n - 1] ? TB_MATCH : TB_SUBST;  // mod.rs:762
-    };
+    // column n comes from K1's epilogue
     auto s_nib = [&](uint32_t i, uint32_t j) -> uint32_t {
-        if (j == n) return resolve((uint32_t)bits[i] & 15u, i);
+        if (j == n) return (uint32_t)bits[i] & 15u;
         return s_fill(i, j);
     };
     auto i_nib = [&](uint32_t i, uint32_t j) -> uint32_t {
-        if (j == n) return resolve((uint32_t)bits[i] >> 4, i - 1);  // a copy of (i-1, n)'s S nibble
+        if (j == n) return (uint32_t)bits[i] >> 4;  // INS, or a copy of (i-1, n)'s S nibble
         if (i == 0) return TB_START;
         if (j == 0) return col0_cell(sc, i, m, NEG).ibits;
         return (cell(i, j) & 8u) ? TB_INS : s_fill(i - 1, j);  // mod.rs:740-743
@@ -72,9 +66,18 @@ __global__ __launch_bounds__(256) void sw_traceback_kernel(const SwArgs a) {
     uint32_t clip_len[4] = {0, 0, 0, 0};
     uint32_t n_clips = 0;
     int status = BG_OK;
+    // ops are produced back to front; four of them are collected into one aligned dword store
+    const bool dword_ok = ops_end && (((uintptr_t)ops_end & 3) == 0);
+    uint32_t acc = 0;
     auto push = [&](uint32_t op) {
         ++n_ops;
-        if (ops_end) ops_end[-(int64_t)n_ops] = (uint8_t)op;
+        if (!ops_end) return;
+        if (dword_ok) {
+            acc = (acc << 8) | op;
+            if ((n_ops & 3) == 0) *(uint32_t*)(ops_end - n_ops) = acc;
+        } else {
+            ops_end[-(int64_t)n_ops] = (uint8_t)op;
+        }
     };
     auto push_clip = [&](uint32_t op, uint32_t len) {
         if (a.filter_clips) return;
@@ -148,6 +151,10 @@ __global__ __launch_bounds__(256) void sw_traceback_kernel(const SwArgs a) {
         layer = next;
     }
 
+    if (dword_ok) {  // the last partial group
+        const uint32_t k = n_ops & 3, done = n_ops - k;
+        for (uint32_t t = 0; t < k; t++) ops_end[-(int64_t)(done + t + 1)] = (uint8_t)(acc >> (8 * (k - 1 - t)));
+    }
     bg_alignment_t rec;
     rec.score = score;  // S[n % 2][m], mod.rs:912
     rec.xstart = xstart;
