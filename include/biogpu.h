@@ -162,6 +162,14 @@ int bg_align_banded_batch(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint32_
                           uint8_t* ops_buf, uint64_t ops_cap, uint64_t* ops_used,
                           uint64_t* band_cells);
 
+/* Band::create (banded.rs:1278-1367) for a batch, on host threads: k-mer matching, sparse DP
+ * chaining (sparse.rs:188-295) and band rasterisation under the clip penalties `mode` implies.
+ * Pair p's n_p+1 half-open row ranges [start, end) are written at band_off[p]; band_cells
+ * (optional) receives Band::num_cells.  Pure host code. */
+int bg_band_create_batch(const bg_scoring_t* sc, int mode, uint32_t k, uint32_t w, uint64_t n_pairs,
+                         const uint8_t* x, const uint64_t* x_off, const uint8_t* y, const uint64_t* y_off,
+                         const uint64_t* band_off, uint32_t* start, uint32_t* end, uint64_t* band_cells);
+
 /* Timing of the last *_dev / batch call's kernels on this ctx, measured with HIP events on
  * the stream the kernels ran on (used by bench.py for the roofline line). */
 typedef struct {

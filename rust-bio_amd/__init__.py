@@ -5,4 +5,4 @@ C ABI in include/biogpu.h implemented by rust-bio_amd/csrc).  Names follow rust-
     pairwise.{Scoring, MatchParams, Aligner, MIN_SCORE}, pairwise.banded.Aligner,
     suffix_array.suffix_array, bwt.{bwt, less, Occ}, fmindex.{FMIndex, Interval, ...}
 """
-__all__ = ["_lib", "alphabets", "bwt", "fmindex", "pairwise", "suffix_array", "synth"]
+__all__ = ["_lib", "alphabets", "banded", "bwt", "fmindex", "pairwise", "suffix_array", "synth"]

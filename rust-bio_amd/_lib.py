@@ -70,7 +70,7 @@ assert ALN_DTYPE.itemsize == 64, ALN_DTYPE.itemsize
 SYMBOLS = ["bg_device_count", "bg_init", "bg_free", "bg_strerror", "bg_last_error",
            "bg_set_option", "bg_suffix_array", "bg_bwt", "bg_less", "bg_fm_build", "bg_fm_free",
            "bg_fm_device_bytes", "bg_fm_backward_search_batch", "bg_fm_backward_search_batch_dev",
-           "bg_align_batch", "bg_align_batch_dev", "bg_align_banded_batch", "bg_get_timing",
+           "bg_align_batch", "bg_align_batch_dev", "bg_align_banded_batch", "bg_band_create_batch", "bg_get_timing",
            "bg_enable_timing"]
 
 
@@ -116,6 +116,7 @@ def lib():
                                          u32, vp, vp, u64, vp]
         L.bg_align_banded_batch.argtypes = [vp, C.POINTER(ScoringC), i32, u32, u32, u64, vp, vp,
                                             vp, vp, vp, vp, u64, C.POINTER(u64), vp]
+        L.bg_band_create_batch.argtypes = [C.POINTER(ScoringC), i32, u32, u32, u64, vp, vp, vp, vp, vp, vp, vp, vp]
         L.bg_get_timing.argtypes = [vp, C.POINTER(TimingC)]
         L.bg_enable_timing.argtypes = [vp, i32]
         for s in SYMBOLS:

@@ -1,0 +1,317 @@
+// Host-side band construction of the banded aligner (product code, runs on host threads inside
+// bg_align_banded_batch / bg_band_create_batch).  It stands where rust-bio's own host code runs
+//   sparse::find_kmer_matches   /root/reference/src/alignment/sparse.rs:337-402
+//   sparse::sdpkpp              /root/reference/src/alignment/sparse.rs:188-295 (+ PrevPtr 145-167,
+//                               MaxBitTree /root/reference/src/data_structures/bit_tree.rs:45-101)
+//   Band::create*               /root/reference/src/alignment/pairwise/banded.rs:1047-1380
+// and must produce identical per-column row ranges (the chain's tie-breaking included), because
+// the banded DP result depends on the exact band.  k-mer matching is a sort-merge join over
+// 64-bit rolling hashes (verified with memcmp) instead of a hash map; the sparse DP keeps the
+// reference's event order and candidate ordering; band rasterisation is the same integer maths.
+#include "band_host.h"
+
+#include <algorithm>
+#include <cstring>
+
+namespace bgband {
+
+namespace {
+
+struct KmerRef {
+    uint64_t h;
+    uint32_t pos;
+};
+
+inline uint64_t mix(uint64_t h, uint8_t c) { return (h ^ c) * 0x100000001B3ull + 0x9E3779B97F4A7C15ull; }
+
+void kmer_hashes(const uint8_t* s, size_t n, size_t k, std::vector<KmerRef>& out) {
+    out.clear();
+    if (k == 0 || n < k) {
+        if (k == 0)
+            for (size_t i = 0; i <= n; i++) out.push_back({0, (uint32_t)i});
+        return;
+    }
+    out.reserve(n - k + 1);
+    for (size_t i = 0; i + k <= n; i++) {
+        uint64_t h = 0xCBF29CE484222325ull;
+        for (size_t t = 0; t < k; t++) h = mix(h, s[i + t]);
+        out.push_back({h, (uint32_t)i});
+    }
+}
+
+// the reference's derived Ord on PrevPtr: (plane, score, d, id, x, y)
+struct Frag {
+    uint32_t plane = 0, score = 0, d = 0;
+    uint64_t id = 0;
+    uint32_t x = 0, y = 0;
+};
+inline bool frag_less(const Frag& a, const Frag& b) {
+    if (a.plane != b.plane) return a.plane < b.plane;
+    if (a.score != b.score) return a.score < b.score;
+    if (a.d != b.d) return a.d < b.d;
+    if (a.id != b.id) return a.id < b.id;
+    if (a.x != b.x) return a.x < b.x;
+    return a.y < b.y;
+}
+
+struct Event {
+    uint32_t x, y, tag;
+    bool operator<(const Event& o) const {
+        if (x != o.x) return x < o.x;
+        if (y != o.y) return y < o.y;
+        return tag < o.tag;
+    }
+};
+
+inline size_t ssub(size_t a, size_t b) { return a > b ? a - b : 0; }
+
+}  // namespace
+
+void find_kmer_matches(const uint8_t* x, size_t m, const uint8_t* y, size_t n, size_t k, std::vector<Match>& out) {
+    out.clear();
+    const bool hash_x = m < n;  // sparse.rs:338-344: the shorter sequence is indexed, y on ties
+    const uint8_t* hs = hash_x ? x : y;
+    const size_t hn = hash_x ? m : n;
+    const uint8_t* os = hash_x ? y : x;
+    const size_t on = hash_x ? n : m;
+    std::vector<KmerRef> idx, probe;
+    kmer_hashes(hs, hn, k, idx);
+    kmer_hashes(os, on, k, probe);
+    std::sort(idx.begin(), idx.end(), [](const KmerRef& a, const KmerRef& b) { return a.h < b.h || (a.h == b.h && a.pos < b.pos); });
+    for (const KmerRef& p : probe) {
+        auto lo = std::lower_bound(idx.begin(), idx.end(), p.h, [](const KmerRef& a, uint64_t h) { return a.h < h; });
+        for (; lo != idx.end() && lo->h == p.h; ++lo) {
+            if (k && memcmp(hs + lo->pos, os + p.pos, k) != 0) continue;
+            if (hash_x)
+                out.push_back({lo->pos, p.pos});
+            else
+                out.push_back({p.pos, lo->pos});
+        }
+    }
+    std::sort(out.begin(), out.end());
+}
+
+bool sdpkpp_path(const std::vector<Match>& matches, size_t k_, uint32_t match_score, int32_t gap_open,
+                 int32_t gap_extend, std::vector<uint32_t>& path) {
+    path.clear();
+    const uint32_t nm = (uint32_t)matches.size();
+    if (nm == 0) return true;
+    if (gap_open > 0 || gap_extend > 0) return false;
+    const uint32_t k = (uint32_t)k_;
+    const uint32_t go = (uint32_t)(-(int64_t)gap_open), ge = (uint32_t)(-(int64_t)gap_extend);
+    std::vector<Event> ev;
+    ev.reserve(2 * (size_t)nm);
+    uint32_t span = 0;
+    for (uint32_t i = 0; i < nm; i++) {
+        ev.push_back({matches[i].x, matches[i].y, i + nm});   // start of k-mer i
+        ev.push_back({matches[i].x + k, matches[i].y + k, i});  // end of k-mer i
+        span = std::max(span, std::max(matches[i].x + k, matches[i].y + k));
+    }
+    std::sort(ev.begin(), ev.end());
+    // prefix-max Fenwick tree over y of the best fragment ending at or before y
+    std::vector<Frag> tree((size_t)span + 1);
+    std::vector<uint32_t> score(nm, 0);
+    std::vector<int32_t> back(nm, 0);
+    uint32_t best_score = k;  // (k, 0): sparse.rs:234
+    int32_t best_idx = 0;
+    auto better = [](uint32_t s1, int32_t i1, uint32_t s2, int32_t i2) { return s1 > s2 || (s1 == s2 && i1 > i2); };
+    for (const Event& e : ev) {
+        const uint32_t p = e.tag % nm;
+        if (e.tag >= nm) {  // start event
+            score[p] = k * match_score;
+            back[p] = -1;
+            Frag bp;
+            for (size_t i = (size_t)e.y + 1; i > 0; i -= i & (~i + 1))
+                if (frag_less(bp, tree[i])) bp = tree[i];
+            if (bp.score > 0) {
+                const uint32_t gap = std::max(e.x - bp.x, e.y - bp.y);
+                const uint32_t pen = gap > 0 ? go + gap * ge : 0;
+                const uint32_t sum = bp.score + k * match_score;
+                const uint32_t ns = sum > pen ? sum - pen : 0;
+                if (better(ns, (int32_t)bp.id, score[p], back[p])) {
+                    score[p] = ns;
+                    back[p] = (int32_t)bp.id;
+                }
+                if (better(score[p], (int32_t)p, best_score, best_idx)) {
+                    best_score = score[p];
+                    best_idx = (int32_t)p;
+                }
+            }
+        } else {  // end event
+            if (e.x > k && e.y > k) {
+                const Match key{e.x - k - 1, e.y - k - 1};
+                auto it = std::lower_bound(matches.begin(), matches.end(), key);
+                if (it != matches.end() && it->x == key.x && it->y == key.y) {
+                    const int32_t c = (int32_t)(it - matches.begin());
+                    const uint32_t cs = score[c] + match_score;
+                    if (better(cs, c, score[p], back[p])) {
+                        score[p] = cs;
+                        back[p] = c;
+                    }
+                    if (better(score[p], (int32_t)p, best_score, best_idx)) {
+                        best_score = score[p];
+                        best_idx = (int32_t)p;
+                    }
+                }
+            }
+            Frag f;
+            f.d = e.x + e.y;
+            f.plane = score[p] + f.d * ge;
+            f.score = score[p];
+            f.id = p;
+            f.x = e.x;
+            f.y = e.y;
+            for (size_t i = (size_t)e.y + 1; i < tree.size(); i += i & (~i + 1))
+                if (frag_less(tree[i], f)) tree[i] = f;
+        }
+    }
+    for (int32_t q = best_idx; q >= 0; q = back[q]) path.push_back((uint32_t)q);
+    std::reverse(path.begin(), path.end());
+    return true;
+}
+
+// ---------------------------------------------------------------------------------- Band
+void Band::reset(size_t m, size_t n) {
+    rows = m + 1;
+    cols = n + 1;
+    start.assign(cols, (uint32_t)(m + 1));  // empty range m+1..0 (banded.rs:1061-1067)
+    end.assign(cols, 0);
+}
+
+void Band::add_entry(uint32_t r_, uint32_t c_, size_t w) {  // banded.rs:1111-1120
+    const size_t r = r_, c = c_;
+    const uint32_t lo = (uint32_t)ssub(r, w), hi = (uint32_t)std::min(r + w + 1, rows);
+    for (size_t j = ssub(c, w), je = std::min(c + w + 1, cols); j < je; j++) {
+        start[j] = std::min(start[j], lo);
+        end[j] = std::max(end[j], hi);
+    }
+}
+
+void Band::add_kmer(uint32_t r_, uint32_t c_, size_t k, size_t w) {  // banded.rs:1071-1107
+    if (k == 0) return;
+    const size_t r = r_, c = c_;
+    size_t i = ssub(r, w);
+    for (size_t j = ssub(c, w), je = std::min(c + w + 1, cols); j < je; j++) start[j] = std::min(start[j], (uint32_t)i);
+    for (size_t j = std::min(c + w, cols), je = std::min(c + k + w, cols); j < je; j++, i++)
+        start[j] = std::min(start[j], (uint32_t)i);
+    i = r + w + k;
+    for (size_t j = ssub(c + k - 1, w); j > ssub(c, w);) {
+        j--;
+        i--;
+        end[j] = std::max(end[j], (uint32_t)std::min(i, rows));
+    }
+    const uint32_t e = (uint32_t)std::min(r + w + k, rows);
+    for (size_t j = ssub(c + k - 1, w), je = std::min(c + k + w, cols); j < je; j++) end[j] = std::max(end[j], e);
+}
+
+void Band::add_gap(uint32_t r0, uint32_t c0, uint32_t r1, uint32_t c1, size_t w) {  // banded.rs:1123-1137
+    const uint32_t nr = r1 - r0, nc = c1 - c0;  // u32 arithmetic wraps like the reference's release build
+    if (nr > nc) {
+        for (uint32_t r = r0; r < r1; r++) add_entry(r, c0 + (c1 - c0) * (r - r0) / (r1 - r0), w);
+    } else {
+        for (uint32_t c = c0; c < c1; c++) add_entry(r0 + (r1 - r0) * (c - c0) / (c1 - c0), c, w);
+    }
+}
+
+void Band::set_boundaries(Match first, Match last, size_t k, size_t w, const ClipScores& cs) {  // banded.rs:1150-1276
+    const size_t lazy = 2 * k;
+    {
+        const size_t r = first.x, c = first.y;
+        if (r != 0 || c != 0) {
+            const int32_t to_start = (r > 0 ? cs.xclip_prefix : 0) + (c > 0 ? cs.yclip_prefix : 0);
+            if (to_start == 0) {
+                const size_t d = std::min(lazy, std::min(r, c));
+                add_kmer((uint32_t)(r - d), (uint32_t)(c - d), d, w);
+                add_gap((uint32_t)ssub(r, lazy), (uint32_t)ssub(c, lazy), (uint32_t)(r - d), (uint32_t)(c - d), w);
+            } else {
+                const int32_t diag = r > c ? cs.xclip_prefix : (r < c ? cs.yclip_prefix : 0);
+                if (diag == 0) {
+                    const size_t d = std::min(r, c);
+                    add_kmer((uint32_t)(r - d), (uint32_t)(c - d), d, w);
+                    const uint32_t sr = (uint32_t)ssub(r, lazy), sc = (uint32_t)ssub(c, lazy);
+                    const uint32_t er = (uint32_t)(r - d), ec = (uint32_t)(c - d);
+                    if (sr <= er && sc <= ec) add_gap(sr, sc, er, ec, w);
+                } else {
+                    add_gap(0, 0, first.x, first.y, w);
+                }
+            }
+        }
+    }
+    {
+        const size_t r = (size_t)last.x + k, c = (size_t)last.y + k;
+        if (!(r == rows && c == cols)) {
+            const int32_t from_end = (r == rows ? 0 : cs.xclip_suffix) + (c == cols ? 0 : cs.yclip_suffix);
+            const size_t dr = rows - r, dc = cols - c;
+            bool diagonal = false;
+            size_t d = 0;
+            if (from_end == 0) {
+                d = std::min(lazy, std::min(dr, dc));
+                diagonal = true;
+            } else {
+                const int32_t diag = dr > dc ? cs.xclip_suffix : (dr < dc ? cs.yclip_suffix : 0);
+                if (diag == 0) {
+                    d = std::min(dr, dc);
+                    diagonal = true;
+                }
+            }
+            if (diagonal) {
+                add_kmer((uint32_t)r, (uint32_t)c, d, w);
+                const size_t r1 = std::min(rows, r + d) - 1, c1 = std::min(cols, c + d) - 1;
+                const size_t r2 = std::min(rows, r + lazy), c2 = std::min(cols, c + lazy);
+                if (r1 <= r2 && c1 <= c2) add_gap((uint32_t)r1, (uint32_t)c1, (uint32_t)r2, (uint32_t)c2, w);
+            } else {
+                add_gap((uint32_t)r, (uint32_t)c, (uint32_t)rows, (uint32_t)cols, w);
+            }
+        }
+    }
+}
+
+uint64_t Band::num_cells() const {  // banded.rs:1374-1380
+    uint64_t cells = 0;
+    for (size_t j = 0; j < cols; j++) cells += end[j] > start[j] ? end[j] - start[j] : 0;
+    return cells;
+}
+
+bool Band::monotone() const {
+    uint32_t ps = 0, pe = 0;
+    bool any = false;
+    for (size_t j = 0; j < cols; j++) {
+        if (end[j] <= start[j]) continue;
+        if (any && (start[j] < ps || end[j] < pe)) return false;
+        ps = start[j];
+        pe = end[j];
+        any = true;
+    }
+    return true;
+}
+
+// Band::create (banded.rs:1278-1367)
+void Band::create(const uint8_t* x, size_t m, const uint8_t* y, size_t n, size_t k, size_t w, const ClipScores& cs,
+                  Workspace& ws) {
+    reset(m, n);
+    find_kmer_matches(x, m, y, n, k, ws.matches);
+    if (ws.matches.empty()) {  // banded.rs:1309-1313
+        std::fill(start.begin(), start.end(), 0u);
+        std::fill(end.begin(), end.end(), (uint32_t)rows);
+        return;
+    }
+    const uint32_t reward = (uint32_t)(cs.match_scores_some ? cs.match_score : 2);  // banded.rs:105,1315-1318
+    sdpkpp_path(ws.matches, k, reward, cs.gap_open, cs.gap_extend, ws.path);
+    const std::vector<Match>& mm = ws.matches;
+    set_boundaries(mm[ws.path.front()], mm[ws.path.back()], k, w, cs);
+    bool have = false;
+    Match prev{0, 0};
+    for (uint32_t idx : ws.path) {
+        const Match cur = mm[idx];
+        if (have && cur.x == prev.x + 1 && cur.y == prev.y + 1) {
+            add_entry(prev.x + (uint32_t)k, prev.y + (uint32_t)k, w);
+        } else {
+            if (have) add_gap(prev.x + (uint32_t)(k - 1), prev.y + (uint32_t)(k - 1), cur.x, cur.y, w);
+            add_kmer(cur.x, cur.y, k, w);
+        }
+        prev = cur;
+        have = true;
+    }
+}
+
+}  // namespace bgband

@@ -1,0 +1,82 @@
+// Kernels K3 (banded_fill) and K4 (banded_traceback): batched `banded::Aligner::compute_alignment`
+// (/root/reference/src/alignment/pairwise/banded.rs:406-869) on gfx950.
+//
+// The band arrives from the host (band_host.cpp) as per-ROW column ranges: for a band whose
+// per-column row ranges never move up (what Band::create produces; checked on the host), the
+// columns in which row i is inside the band form one interval [cf(i), cl(i)].  Everything the
+// reference reads outside the band is MIN_SCORE / TB_START (its rolling arrays are reset just
+// ahead of the band, banded.rs:556-561, 676-680, 689-691), except for the `S[curr][m]` slot and
+// the borders — those are modelled explicitly below.
+//
+// K3 — one wavefront per pair, lane-owned rows in strips of 64*R rows, columns skewed by one step
+//   per lane exactly like K1 (sw_kernels.h), but a strip only walks the columns its rows touch.
+//   Cells outside the band are skipped and forward MIN_SCORE to their neighbours.  The traceback
+//   is stored band-compact, ONE BYTE PER BAND CELL in row-major order (row i at
+//   row_off[i] + j - cf(i)), i.e. 1.3 MB instead of the reference's 200 MB for a 10 kb pair.
+//   Per column the running x-suffix-clip fold (`S[curr][m]`, Lx[j]) is published so that the
+//   y-suffix-clip of row m (banded.rs:665-670) can be folded over all columns afterwards.
+// K4 — one lane per pair: border passes (banded.rs:725-765), traceback (767-831) and the
+//   "ended outside the band" fix-up (833-855).
+#ifndef BG_BANDED_KERNELS_H
+#define BG_BANDED_KERNELS_H
+#include "sw_kernels.h"
+
+namespace bgband_dev {
+
+using namespace bgsw;
+
+enum : uint32_t { BP_OK = 0, BP_TOO_MANY_CELLS = 1, BP_UNSUPPORTED = 2 };
+
+// One pair of a banded batch (device copy, built on the host)
+struct BandPair {
+    uint64_t rowc_off;  // index of row 0 in the rowc / row_off arrays
+    uint64_t tb_off;    // byte offset of this pair's traceback bytes
+    uint64_t aux_off;   // int32 offset of this pair's aux record
+    uint32_t start_0, end_0;  // band of column 0 (banded.rs:443-444)
+    uint32_t start_n, end_n;  // band of the last column (banded.rs:689, 705)
+    uint32_t flags;           // BP_*
+    uint32_t _pad;
+};
+
+// aux record (int32 words): [0] score  [1] S nibble of (m,n)  [2] Lx[n]  [3] Ly[m]  [4..7] spare
+//   Ly[m+1]  Lx[n+1]  V[n+1] (S[curr][m] after each column)  Sn[m+1]  bits[m+1 bytes]  bnd int4[n+1]
+struct BandAux {
+    uint32_t m, n;
+    __host__ __device__ BandAux(uint32_t m_, uint32_t n_) : m(m_), n(n_) {}
+    __host__ __device__ uint64_t off_Ly() const { return 8; }
+    __host__ __device__ uint64_t off_Lx() const { return 8 + (uint64_t)(m + 1); }
+    __host__ __device__ uint64_t off_V() const { return off_Lx() + (n + 1); }
+    __host__ __device__ uint64_t off_Sn() const { return off_V() + (n + 1); }
+    __host__ __device__ uint64_t off_bits() const { return off_Sn() + (m + 1); }
+    __host__ __device__ uint64_t off_bnd() const { return (off_bits() + (m + 4) / 4 + 3) & ~3ull; }
+    __host__ __device__ uint64_t words() const { return off_bnd() + 4ull * (n + 1); }
+};
+
+struct BandArgs {
+    const uint8_t* x;
+    const uint64_t* x_off;
+    const uint8_t* y;
+    const uint64_t* y_off;
+    uint64_t pair0;
+    uint32_t n_pairs;
+    SwScoring sc;
+    const int32_t* table;
+    const uint8_t* code_map;
+    int32_t alpha;
+    const BandPair* pairs;   // [n_pairs]
+    const int2* rowc;        // per row {cf, cl}; cl < cf: the row is never inside the band
+    const uint32_t* row_off; // per row: offset of its traceback bytes inside the pair's block
+    uint8_t* tb;
+    int32_t* aux;
+    bg_alignment_t* out;
+    uint8_t* ops;
+    uint64_t ops_stride;
+    int32_t mode, filter_clips;
+};
+
+typedef void (*band_fill_fn)(const BandArgs);
+band_fill_fn get_band_fill(int sm);
+void launch_band_traceback(const BandArgs& a, hipStream_t st);
+
+}  // namespace bgband_dev
+#endif

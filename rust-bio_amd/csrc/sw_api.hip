@@ -61,6 +61,11 @@ static int compact_matrix(const int32_t* matrix, std::vector<uint8_t>& code_map,
 
 using namespace bgsw;
 
+// shared with banded_api.hip
+int bg_compact_matrix(const int32_t* matrix, std::vector<uint8_t>& code_map, std::vector<int32_t>& table) {
+    return compact_matrix(matrix, code_map, table);
+}
+
 static int check_scoring(const bg_scoring_t* sc) {
     // asserts of Scoring::new/from_scores (mod.rs:265-266,292-293) and
     // Aligner::with_capacity_and_scoring (mod.rs:554-571)
