@@ -39,6 +39,31 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measu
 N_ALPHABET = b"ACGTNacgtn"
 
 
+def host_cores():
+    """cores this process may actually run on (cgroup / affinity aware)"""
+    try:
+        return max(1, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+def pmc_traffic(kernel, shape_key, shape_val):
+    """HBM bytes per launch of `kernel` from the newest committed PMC pass (tools/collect_profiles.sh:
+    separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command).  None when no pass has
+    been recorded for this launch shape — the counters cannot be read from inside the process."""
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None
+    d = json.load(open(files[-1]))
+    if (d.get("launch_shape") or {}).get(shape_key) != shape_val:
+        return None
+    for name, c in d["kernels"].items():
+        if kernel in name:
+            return int(sum(v["mean_bytes"] for v in c.values()))
+    return None
+
+
 def timed_steps(fn, steps, warmup, device):
     for _ in range(warmup):
         fn()
@@ -64,6 +89,8 @@ def main():
     ap.add_argument("--queries", type=int, default=10_000_000, help="FM leg: patterns per GPU (configs[2]: 10M)")
     ap.add_argument("--pattern-len", type=int, default=100)
     ap.add_argument("--skip-fm", action="store_true")
+    ap.add_argument("--skip-banded", action="store_true")
+    ap.add_argument("--banded-pairs", type=int, default=2048, help="banded leg: 10 kb pairs per GPU (configs[3] is 100k over 8 GPUs)")
     ap.add_argument("--skip-cpu", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
@@ -115,41 +142,43 @@ def main():
     achieved = alg_bytes_pair * pairs_per_launch / (fill_ms * 1e-3) / 1e9
     roofline = {"bound": "hbm", "kernel": "sw_fill_kernel", "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": None, "launch_ms": round(fill_ms, 4),
+                "traffic": pmc_traffic("sw_fill_kernel", "sw_pairs_per_launch", int(pairs_per_launch)),
+                "launch_ms": round(fill_ms, 4),
                 "traceback_launch_ms": round(tb_ms, 4),
                 "alg_bytes_per_pair": round(alg_bytes_pair, 1),
                 "pairs_per_launch": int(pairs_per_launch),
                 "note": "VALU-bound integer DP; HBM fraction reported as required, see DESIGN.md"}
 
     # parity of a sample against the oracle + CPU baseline on the same sample (rank 0)
-    parity = None
+    parity = {} if (rank == 0 and not args.skip_cpu) else None
     cpu_baseline = None
     if rank == 0 and not args.skip_cpu:
         import oracle_py as orc
-        ns = min(n_pairs, 40_000)
+        threads = args.cpu_threads or host_cores()
+        # bounded sample: ~10-60 CPU-seconds of work spread over all host cores
+        ns = min(n_pairs, max(40_000, 1500 * threads))
         hx, hy = x[:ns * L].cpu().numpy(), y[:ns * L].cpu().numpy()
         ho = np.arange(ns + 1, dtype=np.uint64) * np.uint64(L)
-        threads = args.cpu_threads or (os.cpu_count() or 1)
         osc = orc.make_scoring(-5, -1, 1, -1)
         t0 = time.perf_counter()
         oout, oops, ostride = orc.align_batch(osc, "local", hx, ho, hy, ho, threads=threads)
         t_all = time.perf_counter() - t0
-        n1 = max(1, ns // 8)
+        n1 = min(ns, 5000)
         t0 = time.perf_counter()
         orc.align_batch(osc, "local", hx[:n1 * L], ho[:n1 + 1], hy[:n1 * L], ho[:n1 + 1], threads=1)
         t_one = time.perf_counter() - t0
         hrec = d_out[:ns * 64].cpu().numpy().view(_lib.ALN_DTYPE)
-        hops = d_ops[:ns * stride].cpu().numpy()
+        hops = d_ops[:ns * stride].cpu().numpy().reshape(ns, stride)
         ok = all((hrec[f].astype(np.int64) == oout[f].astype(np.int64)).all()
                  for f in ("score", "xstart", "xend", "ystart", "yend", "n_ops"))
-        kind = (oops.reshape(ns, ostride) & 0xFF).astype(np.uint8)
-        for p in range(ns):
-            k = int(hrec["n_ops"][p])
-            o = int(hrec["ops_off"][p])
-            if not (hops[o:o + k] == kind[p, :k]).all():
-                ok = False
-                break
-        parity = {"sw_sample_pairs": ns, "sw_bit_exact": bool(ok)}
+        if ok:  # every operation of every sampled pair (device ops are right-aligned in their slot)
+            kq = hrec["n_ops"].astype(np.int64)
+            ok = bool((hrec["ops_off"].astype(np.int64) == (np.arange(ns) + 1) * stride - kq).all())
+            dev_mask = np.arange(stride)[None, :] >= (stride - kq)[:, None]
+            or_mask = np.arange(ostride)[None, :] < kq[:, None]
+            kind = (oops.reshape(ns, ostride) & np.uint64(0xFF)).astype(np.uint8)
+            ok = ok and bool((hops[dev_mask] == kind[or_mask]).all())
+        parity.update({"sw_sample_pairs": ns, "sw_bit_exact": bool(ok)})
         cpu_baseline = {"value": round(ns * L * L / t_all / 1e9, 4), "unit": "GCUPS", "cores": threads,
                         "kind": "port",
                         "sample": f"{ns} of the {n_pairs} pairs, C++ restatement of rust-bio 4.0.1 "
@@ -214,12 +243,13 @@ def main():
                            "absent": int((d_tag == 2).sum().item())},
                   "roofline": {"bound": "hbm", "kernel": "fm_backward_search_kernel", "achieved": round(fm_ach, 2),
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(fm_ach / HBM_PEAK_GBS, 5),
-                               "traffic": None, "launch_ms": round(fm_ms, 4),
+                               "traffic": pmc_traffic("fm_backward_search_kernel", "fm_queries_per_launch", n_q),
+                               "launch_ms": round(fm_ms, 4), "queries_per_launch": n_q,
                                "alg_bytes_per_query": round(alg_bytes / n_q, 1)}}
         if rank == 0 and not args.skip_cpu:
             import oracle_py as orc
             nsq = min(n_q, 400_000)
-            threads = args.cpu_threads or (os.cpu_count() or 1)
+            threads = args.cpu_threads or host_cores()
             occ = orc.Occ(b, 128, N_ALPHABET)
             hp = pat[:nsq * P].cpu().numpy()
             hoff = np.arange(nsq + 1, dtype=np.uint64) * np.uint64(P)
@@ -242,6 +272,64 @@ def main():
                                                 "backward_search + Occ::get (oracle/), shared index",
                                       "single_thread_value": round(n1 / t_one, 1)}
         result["fm"] = fm_res
+
+    # ------------------------------------------------------------------ banded leg (configs[3] shape)
+    if not args.skip_banded:
+        from rust_bio_amd.banded import Aligner as BandedAligner
+        Pb, Lb, kb, wb = args.banded_pairs, 10_000, 16, 32
+        bx, bxo, by, byo = synth_gpu.sw_pairs_big(Pb, Lb, seed=4 + 100003 * rank, device=dev, sub=0.06, ins=0.02,
+                                                   dele=0.02, chunk=64)
+        hx, hy = bx.cpu().numpy(), by.cpu().numpy()
+        hoff = np.arange(Pb + 1, dtype=np.uint64) * np.uint64(Lb)
+        del bx, by
+        bal = BandedAligner.with_scoring(Scoring.from_scores(-5, -1, 1, -1), kb, wb, ctx=ctx)
+        bal.align_arrays(2, hx[:64 * Lb], hoff[:65], hy[:64 * Lb], hoff[:65])  # warm-up
+        ctx.enable_timing(True)
+        shard.barrier()
+        t0 = time.perf_counter()
+        bout, bops = bal.align_arrays(2, hx, hoff, hy, hoff)
+        bt = shard.max_over_ranks(time.perf_counter() - t0, dev)
+        tm = ctx.timing()
+        ctx.enable_timing(False)
+        bcells = float(bal.last_cells.sum())
+        # algorithmic bytes per pair: m + n + 8(n+1) + 2 x band_cells + 24 + n_ops
+        balg = float(Pb) * (2 * Lb + 8 * (Lb + 1) + 24) + 2.0 * bcells + float(bout["n_ops"].sum())
+        bfill_s = tm["fill_ms"] * 1e-3
+        Pb_launch = int(Pb / max(1, tm["fill_launches"]))
+        banded = {"value": round(world * bcells / bt / 1e9, 3), "unit": "GCUPS (band cells, host-buffer API: band "
+                  "construction on host threads + PCIe + K3 + K4)",
+                  "pairs_per_s": round(world * Pb / bt, 1),
+                  "config": {"workload": f"{Pb} x 10 kb read pairs per GPU (6% sub, 2% ins, 2% del), banded::Aligner::"
+                                         f"semiglobal, k-mer {kb}, w {wb} (BASELINE configs[3] shape)",
+                             "mean_band_cells": round(bcells / Pb, 1)},
+                  "kernel_ms": {"fill": round(tm["fill_ms"], 2), "traceback": round(tm["traceback_ms"], 2)},
+                  "roofline": {"bound": "hbm", "kernel": "banded_fill_kernel", "achieved": round(balg / bfill_s / 1e9, 2),
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(balg / bfill_s / 1e9 / HBM_PEAK_GBS, 5),
+                               "traffic": pmc_traffic("banded_fill_kernel", "banded_pairs_per_launch", Pb_launch),
+                               "alg_bytes_per_pair": round(balg / Pb, 1)},
+                  "pairs_per_launch": Pb_launch}
+        if rank == 0 and not args.skip_cpu:
+            import oracle_py as orc
+            nsb = min(Pb, max(8, (args.cpu_threads or host_cores()) // 2))
+            threads = min(nsb, args.cpu_threads or host_cores())
+            osc = orc.make_scoring(-5, -1, 1, -1)
+            t0 = time.perf_counter()
+            oout, oops, ostride, ocells = orc.banded_align_batch(osc, "semiglobal", kb, wb, hx[:nsb * Lb], hoff[:nsb + 1],
+                                                                 hy[:nsb * Lb], hoff[:nsb + 1], threads=threads)
+            t_all = time.perf_counter() - t0
+            okb = bool((bout["score"][:nsb] == oout["score"]).all() and (bout["n_ops"][:nsb] == oout["n_ops"]).all() and
+                       (bal.last_cells[:nsb] == ocells).all())
+            kind = (oops.reshape(nsb, ostride) & 0xFF).astype(np.uint8)
+            for p in range(nsb):
+                kq, oq = int(bout["n_ops"][p]), int(bout["ops_off"][p])
+                okb = okb and bool((bops[oq:oq + kq] == kind[p, :kq]).all())
+            parity["banded_sample_pairs"] = nsb
+            parity["banded_bit_exact"] = okb
+            banded["cpu_baseline"] = {"value": round(float(ocells.sum()) / t_all / 1e9, 4), "unit": "GCUPS (band cells)",
+                                      "cores": threads, "kind": "port",
+                                      "sample": f"{nsb} of the {Pb} pairs, C++ restatement of rust-bio 4.0.1 "
+                                                "banded::Aligner::semiglobal incl. band construction (oracle/)"}
+        result["banded"] = banded
 
     if rank == 0:
         if cpu_baseline is not None:

@@ -69,7 +69,8 @@ void rows_from_columns(const bgband::Band& b, HostPair& hp) {
         const int2 rc = hp.rowc[i];
         if (rc.y >= rc.x) {
             covered += (uint64_t)(rc.y - rc.x + 1);
-            if (i >= 1) off += (uint64_t)(rc.y - rc.x + 1);  // row 0 is a closed form, not stored
+            // row 0 is a closed form, not stored; rows start dword-aligned (K3 stores four cells at a time)
+            if (i >= 1) off += ((uint64_t)(rc.y - rc.x + 1) + 3) & ~3ull;
         }
     }
     hp.tb_bytes = (off + 15) & ~15ull;

@@ -125,8 +125,8 @@ __global__ __launch_bounds__(256) void banded_fill_kernel(const BandArgs a) {
         const uint32_t rb = (strip * 64 + lane) * R;
         const int32_t mrow = (int32_t)m - (int32_t)rb - 1;
         int32_t Sl[R], Dl[R], Il[R], Sn[R], cf[R], cl[R];
-        uint32_t Ly[R], px[R], celln[R], icase[R];
-        uint8_t* tbr[R];
+        uint32_t Ly[R], px[R], celln[R], icase[R], acc[R];
+        uint32_t* tbr[R];  // dword stream of the row: cells cf..cl, four per word
         bool any_row = false;
         int jlo = 0x7fffffff, jhi = -1;
 #pragma unroll
@@ -139,21 +139,23 @@ __global__ __launch_bounds__(256) void banded_fill_kernel(const BandArgs a) {
             icase[r] = IC_OPEN;
             cf[r] = 1;
             cl[r] = 0;
-            tbr[r] = tb;
+            tbr[r] = (uint32_t*)tb;
+            acc[r] = 0;
             if (i <= m) {
                 const int2 rc = rowc[i];
                 cf[r] = rc.x;
                 cl[r] = rc.y;
                 if (rc.y >= rc.x) {
                     any_row = true;
-                    tbr[r] = tb + roff[i] - rc.x;
+                    tbr[r] = (uint32_t*)(tb + roff[i]);
                     const uint32_t ch = x[i - 1];
                     px[r] = (SM == SCORE_PARAMS) ? ch : ((uint32_t)s_map[ch] | (ch << 8));
                     if (rc.x == 0) {  // (i, 0) is a band cell
                         const Col0 c = col0_cell(sc, i, m, fold0);
                         Sl[r] = c.S;
                         Il[r] = c.I;
-                        tbr[r][0] = (uint8_t)(c.sbits | (c.ibits << 4));  // column 0 keeps whole nibbles
+                        acc[r] = c.sbits | (c.ibits << 4);  // column 0 keeps whole nibbles
+                        if (rc.y == 0) tbr[r][0] = acc[r];
                     }
                     jlo = min(jlo, max(1, rc.x));
                     jhi = max(jhi, rc.y);
@@ -186,6 +188,10 @@ __global__ __launch_bounds__(256) void banded_fill_kernel(const BandArgs a) {
                 Sn_above = gSn[rb];
             }
         }
+        // the row below this lane's last one: while it is inside the band of a column, that lane (or the next
+        // strip) publishes the column's fold instead of this one
+        int2 rc_below = make_int2(1, 0);
+        if (rb + R + 1 <= m) rc_below = rowc[rb + R + 1];
         // S(rb, 0): the diagonal of this lane's first row at column 1
         int32_t diag0 = NEG;
         {
@@ -300,7 +306,11 @@ __global__ __launch_bounds__(256) void banded_fill_kernel(const BandArgs a) {
                         // banded.rs:655-660
                         if (best + sc.ys > Sn[r]) { Sn[r] = best + sc.ys; Ly[r] = n - (uint32_t)j; }
                         const uint32_t cell = code | (iext ? 8u : 0u) | (dext ? 16u : 0u);
-                        tbr[r][j] = (uint8_t)cell;
+                        {  // four cells per store: single-byte stores cost 6x their size in HBM write traffic
+                            const uint32_t cj = (uint32_t)(j - cf[r]);
+                            acc[r] = (cj & 3u) ? (acc[r] | (cell << (8 * (cj & 3u)))) : cell;
+                            if ((cj & 3u) == 3u || j == cl[r]) tbr[r][cj >> 2] = acc[r];
+                        }
                         if (last_col) {
                             celln[r] = cell;
                             icase[r] = ic;
@@ -318,7 +328,8 @@ __global__ __launch_bounds__(256) void banded_fill_kernel(const BandArgs a) {
                     diag = left_S;
                     Sn_prev = Sn[r];
                 }
-                if (any_in) {  // the lowest lane with band rows in this column writes last
+                // only the last band row of the column publishes (rows of a column's band are contiguous)
+                if (any_in && !(j >= rc_below.x && j <= rc_below.y)) {
                     gV[j] = m_here ? v_best_m : cm;
                     gLx[j] = ca;
                 }

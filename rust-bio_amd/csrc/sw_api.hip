@@ -157,7 +157,7 @@ extern "C" int bg_align_batch_dev(bg_ctx* ctx, const bg_scoring_t* sc, int mode,
     g.aux_stride = SwGeom::stride_for(max_xlen, max_ylen);
 
     // scratch per wavefront job / per pair
-    const size_t tb_per_job = (size_t)g.nstrips * g.nsteps * 64 * (size_t)nw * 4;
+    const size_t tb_per_job = (size_t)tb_job_words(g.nstrips, g.nsteps, nw) * 4;
     const size_t aux_per_pair = (size_t)g.aux_stride * 4;
     const size_t bnd_per_pair = g.nstrips > 1 ? (size_t)(g.n_cap + 1) * 16 : 0;
     const size_t per_pair = tb_per_job / pw + aux_per_pair + bnd_per_pair + 1;

@@ -71,6 +71,21 @@ struct SwGeom {
 
 // packed traceback: R cells x 5 bits per lane per step, 6 cells per 32-bit word
 __host__ __device__ constexpr int tb_words(int r) { return (r + 5) / 6; }
+// Traceback words of one wavefront job are stored in tiles of kTbTile(NW) steps: tile t holds, for each
+// of the 64 lanes, the lane's 64 bytes for those steps (tile = 4 KB).  A lane's cells of one diagonal
+// run stay contiguous for K2, and every 128-byte line is completed within one tile's steps by two
+// lanes, so L2 write-combines it (a pure lane-major layout was measured at 2.9x HBM write traffic,
+// a step-major one slows K2's dependent loads down by 1.75x).
+__host__ __device__ constexpr uint32_t tb_tile_steps(int nw) { return 16u / (uint32_t)nw; }
+__host__ __device__ inline uint64_t tb_job_words(uint32_t nstrips, uint32_t nsteps, int nw) {
+    const uint64_t g = (uint64_t)nstrips * nsteps, t = tb_tile_steps(nw);
+    return (g + t - 1) / t * 1024ull;
+}
+// word offset of (linear step g, lane) inside the job's block
+__host__ __device__ inline uint64_t tb_word_off(uint64_t g, uint32_t lane, int nw) {
+    const uint32_t t = tb_tile_steps(nw);
+    return (g / t) * 1024ull + lane * 16u + (uint32_t)(g % t) * (uint32_t)nw;
+}
 
 struct SwArgs {
     const uint8_t* x;

@@ -26,12 +26,12 @@ __global__ __launch_bounds__(256) void sw_traceback_kernel(const SwArgs a) {
     const uint32_t lxn = (uint32_t)aux[2];
 
     const uint32_t job = pair / PW, grp = pair % PW;
-    const uint32_t* tbj = (const uint32_t*)a.tb + (((size_t)job * 64 + grp * LP) * geo.nstrips * geo.nsteps) * NW;
+    const uint32_t* tbj = (const uint32_t*)a.tb + (size_t)job * tb_job_words(geo.nstrips, geo.nsteps, NW);
     // packed 5 bits of inner cell (1 <= i <= m, 1 <= j <= n)
     auto cell = [&](uint32_t i, uint32_t j) -> uint32_t {
         const uint32_t i1 = i - 1, lrow = i1 / R, rr = i1 - lrow * R;
         const uint32_t st = lrow / LP, llc = lrow - st * LP;
-        const uint32_t w = tbj[(((size_t)llc * geo.nstrips + st) * geo.nsteps + (j - 1 + llc)) * NW + rr / 6];
+        const uint32_t w = tbj[tb_word_off((uint64_t)st * geo.nsteps + (j - 1 + llc), grp * LP + llc, NW) + rr / 6];
         return (w >> (5 * (rr % 6))) & 31u;
     };
     // S nibble of cell (i,j), j < n (or the fill-time value for j == n, never requested)
