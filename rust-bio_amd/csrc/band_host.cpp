@@ -10,6 +10,9 @@
 // reference's event order and candidate ordering; band rasterisation is the same integer maths.
 #include "band_host.h"
 
+#include <atomic>
+#include <chrono>
+
 #include <algorithm>
 #include <cstring>
 
@@ -17,42 +20,33 @@ namespace bgband {
 
 namespace {
 
-struct KmerRef {
-    uint64_t h;
-    uint32_t pos;
-};
+// Rolling polynomial hash (mod 2^64) of every k-mer of s: h_i = sum_t s[i+t] * B^(k-1-t)
+constexpr uint64_t kHashBase = 0x9E3779B97F4A7C15ull | 1ull;
 
-inline uint64_t mix(uint64_t h, uint8_t c) { return (h ^ c) * 0x100000001B3ull + 0x9E3779B97F4A7C15ull; }
-
-void kmer_hashes(const uint8_t* s, size_t n, size_t k, std::vector<KmerRef>& out) {
+void kmer_hashes(const uint8_t* s, size_t n, size_t k, std::vector<uint64_t>& out) {
     out.clear();
-    if (k == 0 || n < k) {
-        if (k == 0)
-            for (size_t i = 0; i <= n; i++) out.push_back({0, (uint32_t)i});
-        return;
-    }
-    out.reserve(n - k + 1);
-    for (size_t i = 0; i + k <= n; i++) {
-        uint64_t h = 0xCBF29CE484222325ull;
-        for (size_t t = 0; t < k; t++) h = mix(h, s[i + t]);
-        out.push_back({h, (uint32_t)i});
+    if (n < k) return;
+    out.resize(n - k + 1);
+    uint64_t top = 1;  // B^(k-1)
+    for (size_t t = 1; t < k; t++) top *= kHashBase;
+    uint64_t h = 0;
+    for (size_t t = 0; t < k; t++) h = h * kHashBase + (uint64_t)s[t] + 1;
+    out[0] = h;
+    for (size_t i = 1; i + k <= n; i++) {
+        h = (h - ((uint64_t)s[i - 1] + 1) * top) * kHashBase + (uint64_t)s[i + k - 1] + 1;
+        out[i] = h;
     }
 }
 
-// the reference's derived Ord on PrevPtr: (plane, score, d, id, x, y)
+// the reference's derived Ord on PrevPtr: (plane, score, d, id, x, y).  x and y are functions of id
+// (the end point of k-mer id), so the order is decided by the first four fields: two 64-bit keys.
 struct Frag {
-    uint32_t plane = 0, score = 0, d = 0;
-    uint64_t id = 0;
-    uint32_t x = 0, y = 0;
+    uint64_t hi = 0;  // plane << 32 | score
+    uint64_t lo = 0;  // d << 32 | id
+    uint32_t score() const { return (uint32_t)hi; }
+    uint32_t id() const { return (uint32_t)lo; }
 };
-inline bool frag_less(const Frag& a, const Frag& b) {
-    if (a.plane != b.plane) return a.plane < b.plane;
-    if (a.score != b.score) return a.score < b.score;
-    if (a.d != b.d) return a.d < b.d;
-    if (a.id != b.id) return a.id < b.id;
-    if (a.x != b.x) return a.x < b.x;
-    return a.y < b.y;
-}
+inline bool frag_less(const Frag& a, const Frag& b) { return a.hi < b.hi || (a.hi == b.hi && a.lo < b.lo); }
 
 struct Event {
     uint32_t x, y, tag;
@@ -67,6 +61,9 @@ inline size_t ssub(size_t a, size_t b) { return a > b ? a - b : 0; }
 
 }  // namespace
 
+// All exact k-mer matches, sorted by (x, y) (sparse.rs:337-402: the reference hashes the shorter
+// sequence and probes with the other one; the hash-map iteration order is erased by its final sort).
+// Here: rolling hashes, a chained hash table over the indexed sequence, memcmp to confirm.
 void find_kmer_matches(const uint8_t* x, size_t m, const uint8_t* y, size_t n, size_t k, std::vector<Match>& out) {
     out.clear();
     const bool hash_x = m < n;  // sparse.rs:338-344: the shorter sequence is indexed, y on ties
@@ -74,18 +71,30 @@ void find_kmer_matches(const uint8_t* x, size_t m, const uint8_t* y, size_t n, s
     const size_t hn = hash_x ? m : n;
     const uint8_t* os = hash_x ? y : x;
     const size_t on = hash_x ? n : m;
-    std::vector<KmerRef> idx, probe;
-    kmer_hashes(hs, hn, k, idx);
-    kmer_hashes(os, on, k, probe);
-    std::sort(idx.begin(), idx.end(), [](const KmerRef& a, const KmerRef& b) { return a.h < b.h || (a.h == b.h && a.pos < b.pos); });
-    for (const KmerRef& p : probe) {
-        auto lo = std::lower_bound(idx.begin(), idx.end(), p.h, [](const KmerRef& a, uint64_t h) { return a.h < h; });
-        for (; lo != idx.end() && lo->h == p.h; ++lo) {
-            if (k && memcmp(hs + lo->pos, os + p.pos, k) != 0) continue;
+    if (hn < k || on < k) return;
+    thread_local std::vector<uint64_t> hi, hp;
+    thread_local std::vector<uint32_t> head, next;
+    kmer_hashes(hs, hn, k, hi);
+    kmer_hashes(os, on, k, hp);
+    const size_t ni = hi.size();
+    unsigned bits = 4;
+    while (((size_t)1 << bits) < 2 * ni) bits++;
+    head.assign((size_t)1 << bits, 0xFFFFFFFFu);
+    next.resize(ni);
+    auto bucket = [bits](uint64_t h) { return (size_t)((h * 0xD6E8FEB86659FD93ull) >> (64 - bits)); };
+    for (size_t i = ni; i-- > 0;) {  // descending, so that chains list positions in ascending order
+        const size_t bkt = bucket(hi[i]);
+        next[i] = head[bkt];
+        head[bkt] = (uint32_t)i;
+    }
+    for (size_t p = 0; p < hp.size(); p++) {
+        const uint64_t h = hp[p];
+        for (uint32_t i = head[bucket(h)]; i != 0xFFFFFFFFu; i = next[i]) {
+            if (hi[i] != h || (k && memcmp(hs + i, os + p, k) != 0)) continue;
             if (hash_x)
-                out.push_back({lo->pos, p.pos});
+                out.push_back({i, (uint32_t)p});
             else
-                out.push_back({p.pos, lo->pos});
+                out.push_back({(uint32_t)p, i});
         }
     }
     std::sort(out.begin(), out.end());
@@ -99,7 +108,11 @@ bool sdpkpp_path(const std::vector<Match>& matches, size_t k_, uint32_t match_sc
     if (gap_open > 0 || gap_extend > 0) return false;
     const uint32_t k = (uint32_t)k_;
     const uint32_t go = (uint32_t)(-(int64_t)gap_open), ge = (uint32_t)(-(int64_t)gap_extend);
-    std::vector<Event> ev;
+    thread_local std::vector<Event> ev;
+    thread_local std::vector<Frag> tree;
+    thread_local std::vector<uint32_t> score;
+    thread_local std::vector<int32_t> back;
+    ev.clear();
     ev.reserve(2 * (size_t)nm);
     uint32_t span = 0;
     for (uint32_t i = 0; i < nm; i++) {
@@ -109,9 +122,9 @@ bool sdpkpp_path(const std::vector<Match>& matches, size_t k_, uint32_t match_sc
     }
     std::sort(ev.begin(), ev.end());
     // prefix-max Fenwick tree over y of the best fragment ending at or before y
-    std::vector<Frag> tree((size_t)span + 1);
-    std::vector<uint32_t> score(nm, 0);
-    std::vector<int32_t> back(nm, 0);
+    tree.assign((size_t)span + 1, Frag());
+    score.assign(nm, 0);
+    back.assign(nm, 0);
     uint32_t best_score = k;  // (k, 0): sparse.rs:234
     int32_t best_idx = 0;
     auto better = [](uint32_t s1, int32_t i1, uint32_t s2, int32_t i2) { return s1 > s2 || (s1 == s2 && i1 > i2); };
@@ -123,14 +136,15 @@ bool sdpkpp_path(const std::vector<Match>& matches, size_t k_, uint32_t match_sc
             Frag bp;
             for (size_t i = (size_t)e.y + 1; i > 0; i -= i & (~i + 1))
                 if (frag_less(bp, tree[i])) bp = tree[i];
-            if (bp.score > 0) {
-                const uint32_t gap = std::max(e.x - bp.x, e.y - bp.y);
+            if (bp.score() > 0) {
+                const uint32_t bx = matches[bp.id()].x + k, by = matches[bp.id()].y + k;
+                const uint32_t gap = std::max(e.x - bx, e.y - by);
                 const uint32_t pen = gap > 0 ? go + gap * ge : 0;
-                const uint32_t sum = bp.score + k * match_score;
+                const uint32_t sum = bp.score() + k * match_score;
                 const uint32_t ns = sum > pen ? sum - pen : 0;
-                if (better(ns, (int32_t)bp.id, score[p], back[p])) {
+                if (better(ns, (int32_t)bp.id(), score[p], back[p])) {
                     score[p] = ns;
-                    back[p] = (int32_t)bp.id;
+                    back[p] = (int32_t)bp.id();
                 }
                 if (better(score[p], (int32_t)p, best_score, best_idx)) {
                     best_score = score[p];
@@ -155,12 +169,9 @@ bool sdpkpp_path(const std::vector<Match>& matches, size_t k_, uint32_t match_sc
                 }
             }
             Frag f;
-            f.d = e.x + e.y;
-            f.plane = score[p] + f.d * ge;
-            f.score = score[p];
-            f.id = p;
-            f.x = e.x;
-            f.y = e.y;
+            const uint32_t d = e.x + e.y;
+            f.hi = (uint64_t)(uint32_t)(score[p] + d * ge) << 32 | score[p];
+            f.lo = (uint64_t)d << 32 | p;
             for (size_t i = (size_t)e.y + 1; i < tree.size(); i += i & (~i + 1))
                 if (frag_less(tree[i], f)) tree[i] = f;
         }
@@ -285,11 +296,18 @@ bool Band::monotone() const {
     return true;
 }
 
+// BG_TRACE diagnostics: thread-CPU nanoseconds spent in k-mer matching / sparse DP / band rasterisation
+std::atomic<uint64_t> g_prof[4];
+static inline uint64_t cpu_ns() { timespec ts; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts); return (uint64_t)ts.tv_sec * 1000000000ull + ts.tv_nsec; }
+#define PROF_T0 uint64_t pt0 = cpu_ns()
+#define PROF_LAP(i) do { uint64_t pt1 = cpu_ns(); g_prof[i] += pt1 - pt0; pt0 = pt1; } while (0)
 // Band::create (banded.rs:1278-1367)
 void Band::create(const uint8_t* x, size_t m, const uint8_t* y, size_t n, size_t k, size_t w, const ClipScores& cs,
                   Workspace& ws) {
+    PROF_T0;
     reset(m, n);
     find_kmer_matches(x, m, y, n, k, ws.matches);
+    PROF_LAP(0);
     if (ws.matches.empty()) {  // banded.rs:1309-1313
         std::fill(start.begin(), start.end(), 0u);
         std::fill(end.begin(), end.end(), (uint32_t)rows);
@@ -297,6 +315,7 @@ void Band::create(const uint8_t* x, size_t m, const uint8_t* y, size_t n, size_t
     }
     const uint32_t reward = (uint32_t)(cs.match_scores_some ? cs.match_score : 2);  // banded.rs:105,1315-1318
     sdpkpp_path(ws.matches, k, reward, cs.gap_open, cs.gap_extend, ws.path);
+    PROF_LAP(1);
     const std::vector<Match>& mm = ws.matches;
     set_boundaries(mm[ws.path.front()], mm[ws.path.back()], k, w, cs);
     bool have = false;
@@ -312,6 +331,7 @@ void Band::create(const uint8_t* x, size_t m, const uint8_t* y, size_t n, size_t
         prev = cur;
         have = true;
     }
+    PROF_LAP(2);
 }
 
 }  // namespace bgband

@@ -7,12 +7,17 @@
 #include <thread>
 
 #include "band_host.h"
+#include <sched.h>
+
+#include <chrono>
+
 #include "banded_kernels.h"
 
 using namespace bgband_dev;
 
 int bg_compact_matrix(const int32_t* matrix, std::vector<uint8_t>& code_map, std::vector<int32_t>& table);
 
+namespace bgband { extern std::atomic<uint64_t> g_prof[4]; }
 namespace {
 
 constexpr uint64_t kMaxCells = 5000000;  // banded.rs:104
@@ -21,10 +26,23 @@ struct HostPair {
     uint32_t m = 0, n = 0, flags = BP_OK;
     uint32_t start_0 = 0, end_0 = 0, start_n = 0, end_n = 0;
     uint64_t cells = 0;
-    std::vector<int2> rowc;         // per row {cf, cl}
-    std::vector<uint32_t> row_off;  // per row traceback byte offset
     uint64_t tb_bytes = 0;
 };
+
+unsigned host_threads() {
+    // the smaller of the affinity mask and the cgroup CPU quota: threads beyond the quota only get throttled
+    unsigned nt = std::max(1u, std::thread::hardware_concurrency());
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof(set), &set) == 0 && CPU_COUNT(&set) > 0) nt = (unsigned)CPU_COUNT(&set);
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        long long quota = 0, period = 0;
+        if (fscanf(f, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0)
+            nt = std::min<unsigned>(nt, (unsigned)std::max<long long>(1, (quota + period - 1) / period));
+        fclose(f);
+    }
+    return nt;
+}
 
 bgband::ClipScores clip_scores(const bg_scoring_t* sc, int mode) {
     bgband::ClipScores c;
@@ -46,27 +64,31 @@ bgband::ClipScores clip_scores(const bg_scoring_t* sc, int mode) {
     return c;
 }
 
-// per-column row ranges -> per-row column ranges (one interval per row for a monotone band)
-void rows_from_columns(const bgband::Band& b, HostPair& hp) {
+// Per-column row ranges -> per-row column ranges, written straight into the pinned staging arrays.
+// For a monotone band (Band::monotone) the columns containing row i form one interval: its first
+// column is the first one whose range reaches down to i, its last the last one starting at or above
+// i — two O(m + n) sweeps instead of visiting every band cell.
+void rows_from_columns(const bgband::Band& b, HostPair& hp, int2* rowc, uint32_t* row_off) {
     const uint32_t m = hp.m, n = hp.n;
-    hp.rowc.assign((size_t)m + 1, make_int2(1, 0));
+    for (uint32_t i = 0; i <= m; i++) rowc[i] = make_int2(1, 0);
+    uint32_t done = 0;  // rows < done were inside an earlier column
     for (uint32_t j = 0; j <= n; j++) {
         if (b.end[j] <= b.start[j]) continue;
-        for (uint32_t i = b.start[j]; i < b.end[j] && i <= m; i++) {
-            int2& rc = hp.rowc[i];
-            if (rc.y < rc.x) {
-                rc.x = (int)j;
-                rc.y = (int)j;
-            } else {
-                rc.y = (int)j;
-            }
-        }
+        const uint32_t e = std::min<uint32_t>(b.end[j], m + 1);
+        for (uint32_t i = std::max(b.start[j], done); i < e; i++) rowc[i].x = (int)j;
+        done = std::max(done, e);
     }
-    hp.row_off.assign((size_t)m + 1, 0);
+    uint32_t lim = m + 1;  // rows >= lim are inside a later column
+    for (uint32_t j = n + 1; j-- > 0;) {
+        if (b.end[j] <= b.start[j]) continue;
+        const uint32_t e = std::min<uint32_t>(std::min<uint32_t>(b.end[j], m + 1), lim);
+        for (uint32_t i = b.start[j]; i < e; i++) rowc[i].y = (int)j;
+        lim = std::min(lim, b.start[j]);
+    }
     uint64_t off = 0, covered = 0;
     for (uint32_t i = 0; i <= m; i++) {
-        hp.row_off[i] = (uint32_t)off;
-        const int2 rc = hp.rowc[i];
+        row_off[i] = (uint32_t)off;
+        const int2 rc = rowc[i];
         if (rc.y >= rc.x) {
             covered += (uint64_t)(rc.y - rc.x + 1);
             // row 0 is a closed form, not stored; rows start dword-aligned (K3 stores four cells at a time)
@@ -79,10 +101,11 @@ void rows_from_columns(const bgband::Band& b, HostPair& hp) {
 }
 
 void build_pair(const bgband::ClipScores& cs, uint32_t k, uint32_t w, const uint8_t* x, uint32_t m, const uint8_t* y,
-                uint32_t n, bgband::Band& band, bgband::Workspace& ws, HostPair& hp, bool want_rows) {
+                uint32_t n, bgband::Band& band, bgband::Workspace& ws, HostPair& hp, int2* rowc, uint32_t* row_off) {
     hp.m = m;
     hp.n = n;
     hp.flags = BP_OK;
+    hp.tb_bytes = 0;
     band.create(x, m, y, n, k, w, cs, ws);
     hp.cells = band.num_cells();
     hp.start_0 = band.start[0];
@@ -91,21 +114,80 @@ void build_pair(const bgband::ClipScores& cs, uint32_t k, uint32_t w, const uint
     hp.end_n = band.end[n];
     if (hp.cells > kMaxCells) {
         hp.flags = BP_TOO_MANY_CELLS;
-        return;
-    }
-    if (n == 0 || !band.monotone()) {
+    } else if (n == 0 || !band.monotone()) {
         // with an empty y the reference's own traceback does not terminate in most modes;
         // non-monotone bands never come out of Band::create
         hp.flags = BP_UNSUPPORTED;
-        return;
+    } else {
+        rows_from_columns(band, hp, rowc, row_off);
     }
-    if (want_rows) rows_from_columns(band, hp);
+    if (hp.flags != BP_OK) {
+        for (uint32_t i = 0; i <= m; i++) {
+            rowc[i] = make_int2(1, 0);
+            row_off[i] = 0;
+        }
+        hp.tb_bytes = 0;
+    }
 }
 
+// grow-only pinned host buffer
+int pinned_reserve(void** p, size_t* cur, size_t need) {
+    if (need <= *cur) return BG_OK;
+    if (*p) {
+        hipHostFree(*p);
+        *p = nullptr;
+        *cur = 0;
+    }
+    need = (need + 4095) & ~(size_t)4095;
+    BG_HIP(hipHostMalloc(p, need, hipHostMallocDefault));
+    *cur = need;
+    return BG_OK;
+}
+
+}  // namespace
+
+// Scratch that survives between calls (bg_ctx::band): two sets, so that the traceback of one
+// sub-batch (K4, latency bound, a handful of wavefronts) overlaps the fill of the next one (K3) and
+// the host threads that build the following band.
+struct bg_band_scratch {
+    struct Set {
+        // pinned staging
+        void *h_pairs = nullptr, *h_rowc = nullptr, *h_roff = nullptr;
+        size_t hc_pairs = 0, hc_rowc = 0, hc_roff = 0;
+        // device
+        void *d_pairs = nullptr, *d_rowc = nullptr, *d_roff = nullptr, *d_tb = nullptr, *d_aux = nullptr;
+        size_t dc_pairs = 0, dc_rowc = 0, dc_roff = 0, dc_tb = 0, dc_aux = 0;
+        hipEvent_t copied = nullptr, filled = nullptr, traced = nullptr;
+        bool busy = false;
+    } set[2];
+    void* io[6] = {};  // x, y, x_off, y_off, out, ops on the device
+    size_t io_cap[6] = {};
+    void* h_ops = nullptr;  // pinned landing zone of the operations
+    size_t h_ops_cap = 0;
+    hipStream_t tb_stream = nullptr;
+};
+
+void bg_band_scratch_free(bg_band_scratch* b) {
+    if (!b) return;
+    for (auto& s : b->set) {
+        hipHostFree(s.h_pairs); hipHostFree(s.h_rowc); hipHostFree(s.h_roff);
+        hipFree(s.d_pairs); hipFree(s.d_rowc); hipFree(s.d_roff); hipFree(s.d_tb); hipFree(s.d_aux);
+        if (s.copied) hipEventDestroy(s.copied);
+        if (s.filled) hipEventDestroy(s.filled);
+        if (s.traced) hipEventDestroy(s.traced);
+    }
+    for (void* p : b->io) hipFree(p);
+    hipHostFree(b->h_ops);
+    if (b->tb_stream) hipStreamDestroy(b->tb_stream);
+    delete b;
+}
+
+namespace {
+
 template <typename F>
-void parallel_for(uint64_t n, F&& fn) {
-    unsigned nt = std::max(1u, std::thread::hardware_concurrency());
-    nt = (unsigned)std::min<uint64_t>(nt, std::max<uint64_t>(1, n / 4));
+void parallel_for(uint64_t n, uint64_t grain, F&& fn) {
+    unsigned nt = host_threads();
+    nt = (unsigned)std::min<uint64_t>(nt, std::max<uint64_t>(1, n / grain));
     if (nt <= 1) {
         fn(0, 0, n);
         return;
@@ -115,9 +197,9 @@ void parallel_for(uint64_t n, F&& fn) {
     for (unsigned t = 0; t < nt; t++)
         th.emplace_back([&, t] {
             for (;;) {
-                const uint64_t lo = next.fetch_add(16);
+                const uint64_t lo = next.fetch_add(grain);
                 if (lo >= n) break;
-                fn(t, lo, std::min<uint64_t>(n, lo + 16));
+                fn(t, lo, std::min<uint64_t>(n, lo + grain));
             }
         });
     for (auto& t : th) t.join();
@@ -141,7 +223,7 @@ extern "C" int bg_band_create_batch(const bg_scoring_t* sc, int mode, uint32_t k
     int rc = check_scoring(sc);
     if (rc) return rc;
     const bgband::ClipScores cs = clip_scores(sc, mode);
-    parallel_for(n_pairs, [&](unsigned, uint64_t lo, uint64_t hi) {
+    parallel_for(n_pairs, 4, [&](unsigned, uint64_t lo, uint64_t hi) {
         bgband::Band band;
         bgband::Workspace ws;
         for (uint64_t p = lo; p < hi; p++) {
@@ -152,6 +234,7 @@ extern "C" int bg_band_create_batch(const bg_scoring_t* sc, int mode, uint32_t k
             if (band_cells) band_cells[p] = band.num_cells();
         }
     });
+    if (getenv("BG_TRACE")) fprintf(stderr, "[bg banded] cpu-ms: kmers %.1f sdp %.1f band %.1f (threads %u)\n", bgband::g_prof[0] / 1e6, bgband::g_prof[1] / 1e6, bgband::g_prof[2] / 1e6, host_threads());
     return BG_OK;
 }
 
@@ -167,6 +250,17 @@ extern "C" int bg_align_banded_batch(bg_ctx* ctx, const bg_scoring_t* sc, int mo
     if (!x_off || !y_off || !out) return BG_ERR_INVALID_ARG;
     BG_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
+    if (!ctx->band) {
+        ctx->band = new bg_band_scratch;
+        BG_HIP(hipStreamCreateWithFlags(&ctx->band->tb_stream, hipStreamNonBlocking));
+        for (auto& s : ctx->band->set) {
+            BG_HIP(hipEventCreateWithFlags(&s.copied, hipEventDisableTiming));
+            BG_HIP(hipEventCreateWithFlags(&s.filled, hipEventDisableTiming));
+            BG_HIP(hipEventCreateWithFlags(&s.traced, hipEventDisableTiming));
+        }
+    }
+    bg_band_scratch& B = *ctx->band;
+    hipStream_t st_tb = B.tb_stream;
 
     const bgband::ClipScores cs = clip_scores(sc, mode);
     uint64_t max_x = 0, max_y = 0;
@@ -199,147 +293,152 @@ extern "C" int bg_align_banded_batch(bg_ctx* ctx, const bg_scoring_t* sc, int mo
     }
     band_fill_fn fill = get_band_fill(sm);
 
-    // sequences and outputs of the whole batch live on the device; band data goes chunk by chunk
-    const uint64_t xb = x_off[n_pairs], yb = y_off[n_pairs];
-    uint8_t *d_x = nullptr, *d_y = nullptr, *d_ops = nullptr;
-    uint64_t *d_xo = nullptr, *d_yo = nullptr;
-    bg_alignment_t* d_out = nullptr;
-    void *d_pairs = nullptr, *d_rowc = nullptr, *d_roff = nullptr, *d_tb = nullptr, *d_aux = nullptr;
-    size_t cap_pairs = 0, cap_rowc = 0, cap_roff = 0, cap_tb = 0, cap_aux = 0;
-    std::vector<uint8_t> h_ops;
-    auto cleanup = [&]() {
-        hipFree(d_x); hipFree(d_y); hipFree(d_ops); hipFree(d_xo); hipFree(d_yo); hipFree(d_out);
-        hipFree(d_pairs); hipFree(d_rowc); hipFree(d_roff); hipFree(d_tb); hipFree(d_aux);
+    const bool trace = getenv("BG_TRACE") != nullptr;
+    auto now = []() { return std::chrono::steady_clock::now(); };
+    auto t_last = now();
+    auto lap = [&](const char* what) {
+        if (!trace) return;
+        const auto t1 = now();
+        fprintf(stderr, "[bg banded] %-18s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t_last).count());
+        t_last = t1;
     };
-    auto run = [&]() -> int {
-        BG_HIP(hipMalloc((void**)&d_x, std::max<uint64_t>(xb, 16)));
-        BG_HIP(hipMalloc((void**)&d_y, std::max<uint64_t>(yb, 16)));
-        BG_HIP(hipMalloc((void**)&d_xo, (n_pairs + 1) * 8));
-        BG_HIP(hipMalloc((void**)&d_yo, (n_pairs + 1) * 8));
-        BG_HIP(hipMalloc((void**)&d_out, n_pairs * sizeof(bg_alignment_t)));
-        if (ops_buf) BG_HIP(hipMalloc((void**)&d_ops, n_pairs * stride));
-        if (xb) BG_HIP(hipMemcpyAsync(d_x, x, xb, hipMemcpyHostToDevice, st));
-        if (yb) BG_HIP(hipMemcpyAsync(d_y, y, yb, hipMemcpyHostToDevice, st));
-        BG_HIP(hipMemcpyAsync(d_xo, x_off, (n_pairs + 1) * 8, hipMemcpyHostToDevice, st));
-        BG_HIP(hipMemcpyAsync(d_yo, y_off, (n_pairs + 1) * 8, hipMemcpyHostToDevice, st));
-        a.x = d_x;
-        a.x_off = d_xo;
-        a.y = d_y;
-        a.y_off = d_yo;
-        a.out = d_out;
-        a.ops = d_ops;
 
-        const uint64_t chunk_pairs = ctx->chunk_pairs > 0 ? (uint64_t)ctx->chunk_pairs : 4096;
-        const uint64_t budget = 32ull << 30;
-        std::vector<HostPair> hp;
-        std::vector<BandPair> dp;
-        std::vector<int2> rowc_all;
-        std::vector<uint32_t> roff_all;
-        for (uint64_t p0 = 0; p0 < n_pairs;) {
-            const uint64_t want = std::min<uint64_t>(chunk_pairs, n_pairs - p0);
-            hp.assign(want, HostPair());
-            parallel_for(want, [&](unsigned, uint64_t lo, uint64_t hi) {
-                bgband::Band band;
-                bgband::Workspace ws;
-                for (uint64_t q = lo; q < hi; q++) {
-                    const uint64_t p = p0 + q;
-                    build_pair(cs, k, w, x + x_off[p], (uint32_t)(x_off[p + 1] - x_off[p]), y + y_off[p],
-                               (uint32_t)(y_off[p + 1] - y_off[p]), band, ws, hp[q], true);
-                }
-            });
-            // take as many pairs as fit the scratch budget
-            uint64_t take = 0, rows = 0, tbb = 0, auxw = 0;
-            for (; take < want; take++) {
-                const HostPair& h = hp[take];
-                const uint64_t r2 = rows + h.m + 1, t2 = tbb + (h.flags == BP_OK ? h.tb_bytes : 0);
-                const uint64_t a2 = auxw + ((BandAux(h.m, h.n).words() + 3) & ~3ull);
-                if (take > 0 && t2 + a2 * 4 + r2 * 12 > budget) break;
-                rows = r2;
-                tbb = t2;
-                auxw = a2;
-            }
-            dp.assign(take, BandPair());
-            rowc_all.resize(rows);
-            roff_all.resize(rows);
-            uint64_t ro = 0, to = 0, ao = 0;
-            for (uint64_t q = 0; q < take; q++) {
-                const HostPair& h = hp[q];
-                BandPair& d = dp[q];
-                d.rowc_off = ro;
-                d.tb_off = to;
-                d.aux_off = ao;
-                d.start_0 = h.start_0;
-                d.end_0 = h.end_0;
-                d.start_n = h.start_n;
-                d.end_n = h.end_n;
-                d.flags = h.flags;
-                if (h.flags == BP_OK) {
-                    memcpy(&rowc_all[ro], h.rowc.data(), (size_t)(h.m + 1) * sizeof(int2));
-                    memcpy(&roff_all[ro], h.row_off.data(), (size_t)(h.m + 1) * 4);
-                    to += h.tb_bytes;
-                } else {
-                    for (uint32_t i = 0; i <= h.m; i++) {
-                        rowc_all[ro + i] = make_int2(1, 0);
-                        roff_all[ro + i] = 0;
-                    }
-                }
-                ro += h.m + 1;
-                ao += (BandAux(h.m, h.n).words() + 3) & ~3ull;
-                if (band_cells) band_cells[p0 + q] = h.cells;
-            }
-            int r2;
-            if ((r2 = bg_reserve(&d_pairs, &cap_pairs, take * sizeof(BandPair)))) return r2;
-            if ((r2 = bg_reserve(&d_rowc, &cap_rowc, std::max<size_t>(rows * sizeof(int2), 64)))) return r2;
-            if ((r2 = bg_reserve(&d_roff, &cap_roff, std::max<size_t>(rows * 4, 64)))) return r2;
-            if ((r2 = bg_reserve(&d_tb, &cap_tb, std::max<size_t>(to, 64)))) return r2;
-            if ((r2 = bg_reserve(&d_aux, &cap_aux, std::max<size_t>(ao * 4, 64)))) return r2;
-            BG_HIP(hipMemcpyAsync(d_pairs, dp.data(), take * sizeof(BandPair), hipMemcpyHostToDevice, st));
-            BG_HIP(hipMemcpyAsync(d_rowc, rowc_all.data(), rows * sizeof(int2), hipMemcpyHostToDevice, st));
-            BG_HIP(hipMemcpyAsync(d_roff, roff_all.data(), rows * 4, hipMemcpyHostToDevice, st));
-            BG_HIP(hipMemsetAsync(d_aux, 0, ao * 4, st));
-            a.pairs = (const BandPair*)d_pairs;
-            a.rowc = (const int2*)d_rowc;
-            a.row_off = (const uint32_t*)d_roff;
-            a.tb = (uint8_t*)d_tb;
-            a.aux = (int32_t*)d_aux;
-            a.pair0 = p0;
-            a.n_pairs = (uint32_t)take;
-            if (ctx->timing) BG_HIP(hipEventRecord(ctx->ev[0], st));
-            fill<<<dim3((unsigned)((take + 3) / 4)), dim3(256), 0, st>>>(a);
-            BG_HIP(hipGetLastError());
-            if (ctx->timing) {
-                BG_HIP(hipEventRecord(ctx->ev[1], st));
-                BG_HIP(hipEventSynchronize(ctx->ev[1]));
-                float ms = 0;
-                BG_HIP(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
-                ctx->last.fill_ms += ms;
-                ctx->last.fill_launches += 1;
-                BG_HIP(hipEventRecord(ctx->ev[0], st));
-            }
-            launch_band_traceback(a, st);
-            BG_HIP(hipGetLastError());
-            if (ctx->timing) {
-                BG_HIP(hipEventRecord(ctx->ev[1], st));
-                BG_HIP(hipEventSynchronize(ctx->ev[1]));
-                float ms = 0;
-                BG_HIP(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
-                ctx->last.traceback_ms += ms;
-                ctx->last.traceback_launches += 1;
-            }
-            BG_HIP(hipStreamSynchronize(st));  // the host vectors of this chunk are reused
-            p0 += take;
+    // sequences and result records of the whole batch live on the device; band data goes in sub-batches
+    const uint64_t xb = x_off[n_pairs], yb = y_off[n_pairs];
+    const size_t io_need[6] = {std::max<uint64_t>(xb, 16), std::max<uint64_t>(yb, 16), (n_pairs + 1) * 8, (n_pairs + 1) * 8,
+                               n_pairs * sizeof(bg_alignment_t), ops_buf ? n_pairs * stride : 16};
+    for (int i = 0; i < 6; i++)
+        if ((rc = bg_reserve(&B.io[i], &B.io_cap[i], io_need[i]))) return rc;
+    uint8_t *d_x = (uint8_t*)B.io[0], *d_y = (uint8_t*)B.io[1], *d_ops = ops_buf ? (uint8_t*)B.io[5] : nullptr;
+    uint64_t *d_xo = (uint64_t*)B.io[2], *d_yo = (uint64_t*)B.io[3];
+    bg_alignment_t* d_out = (bg_alignment_t*)B.io[4];
+    if (xb) BG_HIP(hipMemcpyAsync(d_x, x, xb, hipMemcpyHostToDevice, st));
+    if (yb) BG_HIP(hipMemcpyAsync(d_y, y, yb, hipMemcpyHostToDevice, st));
+    BG_HIP(hipMemcpyAsync(d_xo, x_off, (n_pairs + 1) * 8, hipMemcpyHostToDevice, st));
+    BG_HIP(hipMemcpyAsync(d_yo, y_off, (n_pairs + 1) * 8, hipMemcpyHostToDevice, st));
+    a.x = d_x;
+    a.x_off = d_xo;
+    a.y = d_y;
+    a.y_off = d_yo;
+    a.out = d_out;
+    a.ops = d_ops;
+    lap("h2d sequences");
+
+    // sub-batch size: enough wavefronts to fill the chip, small enough that a large batch pipelines
+    const uint64_t chunk_pairs = ctx->chunk_pairs > 0 ? (uint64_t)ctx->chunk_pairs : 4096;
+    const uint64_t budget = 16ull << 30;  // per scratch set
+    const uint64_t grain = std::max<uint64_t>(1, std::min<uint64_t>(64, 65536 / (max_x + max_y + 1)));
+    std::vector<HostPair> hp;
+    std::vector<uint64_t> row0;
+    uint64_t n_chunk = 0;
+    for (uint64_t p0 = 0; p0 < n_pairs; n_chunk++) {
+        bg_band_scratch::Set& S = B.set[n_chunk & 1];
+        if (S.busy) {  // its staging and device buffers were last used two sub-batches ago
+            BG_HIP(hipEventSynchronize(S.traced));
+            S.busy = false;
         }
-        BG_HIP(hipMemcpyAsync(out, d_out, n_pairs * sizeof(bg_alignment_t), hipMemcpyDeviceToHost, st));
-        if (ops_buf) {
-            h_ops.resize(n_pairs * stride);
-            BG_HIP(hipMemcpyAsync(h_ops.data(), d_ops, n_pairs * stride, hipMemcpyDeviceToHost, st));
+        const uint64_t want = std::min<uint64_t>(chunk_pairs, n_pairs - p0);
+        hp.assign(want, HostPair());
+        row0.resize(want + 1);
+        row0[0] = 0;
+        for (uint64_t q = 0; q < want; q++) row0[q + 1] = row0[q] + (x_off[p0 + q + 1] - x_off[p0 + q]) + 1;
+        if ((rc = pinned_reserve(&S.h_rowc, &S.hc_rowc, std::max<size_t>(row0[want] * sizeof(int2), 64)))) return rc;
+        if ((rc = pinned_reserve(&S.h_roff, &S.hc_roff, std::max<size_t>(row0[want] * 4, 64)))) return rc;
+        if ((rc = pinned_reserve(&S.h_pairs, &S.hc_pairs, want * sizeof(BandPair)))) return rc;
+        int2* h_rowc = (int2*)S.h_rowc;
+        uint32_t* h_roff = (uint32_t*)S.h_roff;
+        BandPair* dp = (BandPair*)S.h_pairs;
+        parallel_for(want, grain, [&](unsigned, uint64_t lo, uint64_t hi) {
+            bgband::Band band;
+            bgband::Workspace ws;
+            for (uint64_t q = lo; q < hi; q++) {
+                const uint64_t p = p0 + q;
+                build_pair(cs, k, w, x + x_off[p], (uint32_t)(x_off[p + 1] - x_off[p]), y + y_off[p],
+                           (uint32_t)(y_off[p + 1] - y_off[p]), band, ws, hp[q], h_rowc + row0[q], h_roff + row0[q]);
+            }
+        });
+        lap("band build");
+        if (trace) { fprintf(stderr, "[bg banded] cpu-ms: kmers %.1f sdp %.1f band %.1f (threads %u)\n", bgband::g_prof[0] / 1e6, bgband::g_prof[1] / 1e6, bgband::g_prof[2] / 1e6, host_threads()); }
+        // take as many pairs as fit the scratch budget (the rest is rebuilt with the next sub-batch)
+        uint64_t take = 0, tbb = 0, auxw = 0;
+        for (; take < want; take++) {
+            const HostPair& h = hp[take];
+            const uint64_t t2 = tbb + h.tb_bytes, a2 = auxw + ((BandAux(h.m, h.n).words() + 3) & ~3ull);
+            if (take > 0 && t2 + a2 * 4 > budget) break;
+            BandPair& d = dp[take];
+            d.rowc_off = row0[take];
+            d.tb_off = tbb;
+            d.aux_off = auxw;
+            d.start_0 = h.start_0;
+            d.end_0 = h.end_0;
+            d.start_n = h.start_n;
+            d.end_n = h.end_n;
+            d.flags = h.flags;
+            d._pad = 0;
+            if (band_cells) band_cells[p0 + take] = h.cells;
+            tbb = t2;
+            auxw = a2;
         }
-        BG_HIP(hipStreamSynchronize(st));
-        return BG_OK;
-    };
-    rc = run();
-    cleanup();
-    if (rc) return rc;
+        const uint64_t rows = row0[take];
+        if ((rc = bg_reserve(&S.d_pairs, &S.dc_pairs, take * sizeof(BandPair)))) return rc;
+        if ((rc = bg_reserve(&S.d_rowc, &S.dc_rowc, std::max<size_t>(rows * sizeof(int2), 64)))) return rc;
+        if ((rc = bg_reserve(&S.d_roff, &S.dc_roff, std::max<size_t>(rows * 4, 64)))) return rc;
+        if ((rc = bg_reserve(&S.d_tb, &S.dc_tb, std::max<size_t>(tbb, 64)))) return rc;
+        if ((rc = bg_reserve(&S.d_aux, &S.dc_aux, std::max<size_t>(auxw * 4, 64)))) return rc;
+        BG_HIP(hipMemcpyAsync(S.d_pairs, dp, take * sizeof(BandPair), hipMemcpyHostToDevice, st));
+        BG_HIP(hipMemcpyAsync(S.d_rowc, h_rowc, rows * sizeof(int2), hipMemcpyHostToDevice, st));
+        BG_HIP(hipMemcpyAsync(S.d_roff, h_roff, rows * 4, hipMemcpyHostToDevice, st));
+        BG_HIP(hipEventRecord(S.copied, st));
+        BG_HIP(hipMemsetAsync(S.d_aux, 0, auxw * 4, st));
+        a.pairs = (const BandPair*)S.d_pairs;
+        a.rowc = (const int2*)S.d_rowc;
+        a.row_off = (const uint32_t*)S.d_roff;
+        a.tb = (uint8_t*)S.d_tb;
+        a.aux = (int32_t*)S.d_aux;
+        a.pair0 = p0;
+        a.n_pairs = (uint32_t)take;
+        if (ctx->timing) BG_HIP(hipEventRecord(ctx->ev[0], st));
+        fill<<<dim3((unsigned)((take + 3) / 4)), dim3(256), 0, st>>>(a);
+        BG_HIP(hipGetLastError());
+        if (ctx->timing) {
+            BG_HIP(hipEventRecord(ctx->ev[1], st));
+            BG_HIP(hipEventSynchronize(ctx->ev[1]));
+            float ms = 0;
+            BG_HIP(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+            ctx->last.fill_ms += ms;
+            ctx->last.fill_launches += 1;
+        }
+        BG_HIP(hipEventRecord(S.filled, st));
+        // K4 on its own stream: it overlaps the next sub-batch's K3
+        BG_HIP(hipStreamWaitEvent(st_tb, S.filled, 0));
+        if (ctx->timing) BG_HIP(hipEventRecord(ctx->ev[0], st_tb));
+        launch_band_traceback(a, st_tb);
+        BG_HIP(hipGetLastError());
+        if (ctx->timing) {
+            BG_HIP(hipEventRecord(ctx->ev[1], st_tb));
+            BG_HIP(hipEventSynchronize(ctx->ev[1]));
+            float ms = 0;
+            BG_HIP(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+            ctx->last.traceback_ms += ms;
+            ctx->last.traceback_launches += 1;
+        }
+        BG_HIP(hipEventRecord(S.traced, st_tb));
+        S.busy = true;
+        lap("enqueue");
+        p0 += take;
+    }
+    // results: records and (pinned) operations come back on the traceback stream
+    BG_HIP(hipMemcpyAsync(out, d_out, n_pairs * sizeof(bg_alignment_t), hipMemcpyDeviceToHost, st_tb));
+    if (ops_buf) {
+        if ((rc = pinned_reserve(&B.h_ops, &B.h_ops_cap, n_pairs * stride))) return rc;
+        BG_HIP(hipMemcpyAsync(B.h_ops, d_ops, n_pairs * stride, hipMemcpyDeviceToHost, st_tb));
+    }
+    BG_HIP(hipStreamSynchronize(st_tb));
+    BG_HIP(hipStreamSynchronize(st));
+    for (auto& s : B.set) s.busy = false;
+    lap("drain + d2h");
+
+    const uint8_t* h_ops = (const uint8_t*)B.h_ops;
     uint64_t used = 0;
     int status = BG_OK;
     for (uint64_t p = 0; p < n_pairs; p++) {
@@ -348,12 +447,13 @@ extern "C" int bg_align_banded_batch(bg_ctx* ctx, const bg_scoring_t* sc, int mo
         out[p].ops_off = used;
         if (ops_buf && out[p].status == BG_OK) {
             if (used + out[p].n_ops <= ops_cap)
-                memcpy(ops_buf + used, h_ops.data() + src, out[p].n_ops);
+                memcpy(ops_buf + used, h_ops + src, out[p].n_ops);
             else if (status == BG_OK)
                 status = BG_ERR_OPS_CAP;
         }
         used += out[p].n_ops;
     }
     if (ops_used) *ops_used = used;
+    lap("compact ops");
     return status;
 }

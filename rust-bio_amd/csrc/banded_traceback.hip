@@ -1,4 +1,8 @@
-// K4 — banded_traceback_kernel: one lane per pair.  Border passes
+// K4 — banded_traceback_kernel: one wavefront per pair.  The walk is serial, so all 64 lanes follow it
+// redundantly (uniform control flow, broadcast loads) — except along diagonals: whenever the current
+// move is MATCH/SUBST, lane t looks at cell (i-t, j-t), a ballot finds how far the path stays on the
+// diagonal and the whole run is emitted at once (one pair of dependent loads per run instead of per
+// cell; runs are ~25 cells long on 10 % divergent reads).  Border passes
 // (/root/reference/src/alignment/pairwise/banded.rs:725-765), traceback (767-831) and the
 // "ended outside the band" fix-up (833-855).  Design notes: banded_kernels.h.
 #include "banded_kernels.h"
@@ -6,8 +10,9 @@
 namespace bgband_dev {
 
 __global__ __launch_bounds__(256) void banded_traceback_kernel(const BandArgs a) {
-    const uint32_t pair = blockIdx.x * blockDim.x + threadIdx.x;
-    if (pair >= a.n_pairs) return;
+    const uint32_t pair = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63;
+    if (pair >= a.n_pairs) return;  // wave-uniform
     const BandPair bp = a.pairs[pair];
     const SwScoring sc = a.sc;
     const uint64_t xo = a.x_off[a.pair0 + pair], yo = a.y_off[a.pair0 + pair];
@@ -22,7 +27,7 @@ __global__ __launch_bounds__(256) void banded_traceback_kernel(const BandArgs a)
         // banded.rs:407-420: band above MAX_CELLS -> {score: MIN_SCORE, everything else zero, no ops}
         rec.score = BG_MIN_SCORE;
         rec.status = bp.flags == BP_TOO_MANY_CELLS ? (int8_t)BG_OK : (int8_t)BG_ERR_UNSUPPORTED;
-        a.out[a.pair0 + pair] = rec;
+        if (lane == 0) a.out[a.pair0 + pair] = rec;
         return;
     }
     const int2* rowc = a.rowc + bp.rowc_off;
@@ -153,7 +158,13 @@ __global__ __launch_bounds__(256) void banded_traceback_kernel(const BandArgs a)
     int status = BG_OK;
     auto push = [&](uint32_t op) {
         ++n_ops;
-        if (ops_end && n_ops <= a.ops_stride) ops_end[-(int64_t)n_ops] = (uint8_t)op;
+        if (lane == 0 && ops_end && n_ops <= a.ops_stride) ops_end[-(int64_t)n_ops] = (uint8_t)op;
+    };
+    auto push_many = [&](uint32_t op, uint32_t count) {  // all lanes share the stores
+        if (ops_end)
+            for (uint32_t t = lane; t < count; t += 64)
+                if (n_ops + t + 1 <= a.ops_stride) ops_end[-(int64_t)(n_ops + t + 1)] = (uint8_t)op;
+        n_ops += count;
     };
     auto push_clip = [&](uint32_t op, uint32_t len) {
         if (a.filter_clips) return;
@@ -171,6 +182,29 @@ __global__ __launch_bounds__(256) void banded_traceback_kernel(const BandArgs a)
         if (steps > guard) {
             status = BG_ERR_TRACEBACK;
             break;
+        }
+        if ((layer == TB_MATCH || layer == TB_SUBST) && i >= 1 && j >= 1) {
+            // ---- diagonal run: lane t inspects (i-t, j-t); interior cells only (row < m, 1 <= column < n)
+            bool ok = false;
+            uint32_t st = layer;
+            if (lane >= 1 && i > lane && j > lane) {
+                const uint32_t ii = i - lane, jj = j - lane;
+                const int2 rc = rowc[ii];
+                if (rc.y >= rc.x && (int)jj >= rc.x && (int)jj <= rc.y) {
+                    st = s_nibble_of_code((uint32_t)tb[roff[ii] + jj - (uint32_t)rc.x] & 7u);
+                    ok = st == TB_MATCH || st == TB_SUBST;
+                }
+            }
+            const uint64_t mask = __ballot(ok) >> 1;          // bit t-1: lane t continues the run
+            const uint32_t r = mask == ~0ull >> 1 ? 63u : (uint32_t)__ffsll((unsigned long long)~mask) - 1u;
+            if (lane <= r && ops_end && n_ops + lane + 1 <= a.ops_stride)
+                ops_end[-(int64_t)(n_ops + lane + 1)] = (uint8_t)(st == TB_MATCH ? BG_OP_MATCH : BG_OP_SUBST);
+            n_ops += r + 1;
+            i -= r + 1;
+            j -= r + 1;
+            steps += r;
+            layer = s_nib(i, j);
+            continue;
         }
         uint32_t next = TB_START;
         bool bad = false;
@@ -240,7 +274,7 @@ __global__ __launch_bounds__(256) void banded_traceback_kernel(const BandArgs a)
         if (i != 0) {
             const int32_t i_score = sc.go + sc.ge * ((int32_t)i - 1);
             if (i_score > sc.xp) {
-                for (uint32_t t = 0; t < i; t++) push(BG_OP_INS);
+                push_many(BG_OP_INS, i);
                 xstart = 0;
             } else {
                 push_clip(BG_OP_XCLIP, i);
@@ -250,7 +284,7 @@ __global__ __launch_bounds__(256) void banded_traceback_kernel(const BandArgs a)
         if (j != 0) {
             const int32_t d_score = sc.go + sc.ge * ((int32_t)j - 1);
             if (d_score > sc.yp) {
-                for (uint32_t t = 0; t < j; t++) push(BG_OP_DEL);
+                push_many(BG_OP_DEL, j);
                 ystart = 0;
             } else {
                 push_clip(BG_OP_YCLIP, j);
@@ -274,11 +308,11 @@ __global__ __launch_bounds__(256) void banded_traceback_kernel(const BandArgs a)
     rec.n_clips = (uint8_t)nc;
     rec.mode = (uint8_t)a.mode;
     rec.status = (int8_t)status;
-    a.out[a.pair0 + pair] = rec;
+    if (lane == 0) a.out[a.pair0 + pair] = rec;
 }
 
 void launch_band_traceback(const BandArgs& a, hipStream_t st) {
-    banded_traceback_kernel<<<dim3((a.n_pairs + 255) / 256), dim3(256), 0, st>>>(a);
+    banded_traceback_kernel<<<dim3((a.n_pairs + 3) / 4), dim3(256), 0, st>>>(a);
 }
 
 }  // namespace bgband_dev

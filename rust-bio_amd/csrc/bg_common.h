@@ -22,6 +22,9 @@ extern thread_local std::string bg_tls_error;
         }                                                                                \
     } while (0)
 
+struct bg_band_scratch;  // banded_api.hip
+void bg_band_scratch_free(bg_band_scratch*);
+
 struct bg_ctx {
     int device = 0;
     hipStream_t stream = nullptr;  // internal stream of the host-buffer API
@@ -34,6 +37,7 @@ struct bg_ctx {
     size_t bnd_bytes = 0;
     void* table = nullptr;  // compacted scoring table + code map
     size_t table_bytes = 0;
+    bg_band_scratch* band = nullptr;  // persistent scratch of the banded pipeline
     int64_t chunk_pairs = 0;  // 0 = default
     bool force_wide = false;  // tests: disable the NARROW (28-bit key) kernels
     // timing

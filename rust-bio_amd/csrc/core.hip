@@ -54,6 +54,7 @@ extern "C" int bg_free(bg_ctx* ctx) {
     hipFree(ctx->aux);
     hipFree(ctx->bnd);
     hipFree(ctx->table);
+    bg_band_scratch_free(ctx->band);
     if (ctx->ev[0]) hipEventDestroy(ctx->ev[0]);
     if (ctx->ev[1]) hipEventDestroy(ctx->ev[1]);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
