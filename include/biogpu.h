@@ -97,6 +97,40 @@ int bg_fm_backward_search_batch_dev(bg_fm* fm, uint64_t n_q, const uint8_t* d_pa
                                     const uint64_t* d_pat_off, uint8_t* d_tag, uint64_t* d_lower,
                                     uint64_t* d_upper, uint32_t* d_matched_len, void* stream);
 
+/* ---- suffix-array lookups for FM-index hits (kernel K6) ------------------------------------
+ * Attach the suffix array the FM index was built from, then resolve rows to text positions.
+ * The index handle must come from bg_fm_build over the same text (n rows). */
+#define BG_SA_NONE 0xFFFFFFFFFFFFFFFFull  /* SuffixArray::get -> None (row >= len) */
+#define BG_SA_PANIC 0xFFFFFFFFFFFFFFFEull /* the reference would panic (missing extra row / non-alphabet byte) */
+
+/* RawSuffixArray (suffix_array.rs:25, get 134-141): the full SA, n entries */
+int bg_fm_set_suffix_array(bg_fm* fm, const uint64_t* sa, uint64_t n);
+/* SampledSuffixArray as RawSuffixArray::sample builds it (suffix_array.rs:86-120): sample[i] =
+ * SA[i * sampling_rate], n_sample = ceil(n / rate); sentinel = last byte of the text; the rows
+ * whose BWT byte is the sentinel and that are not sampled, sorted by row, with their positions
+ * (`extra_rows`, a hash map in the reference). */
+int bg_fm_set_sampled_suffix_array(bg_fm* fm, const uint64_t* sample, uint64_t n_sample,
+                                   uint32_t sampling_rate, uint8_t sentinel,
+                                   const uint64_t* extra_rows, const uint64_t* extra_pos,
+                                   uint64_t n_extra);
+/* SuffixArray::get for a batch of rows (suffix_array.rs:134-141 raw, 157-184 sampled):
+ * pos[i] = SA[index[i]], BG_SA_NONE if index[i] >= n.  Returns BG_ERR_OUT_OF_ALPHABET if any
+ * row hit BG_SA_PANIC. */
+int bg_sa_get_batch(bg_fm* fm, uint64_t n_idx, const uint64_t* index, uint64_t* pos);
+int bg_sa_get_batch_dev(bg_fm* fm, uint64_t n_idx, const uint64_t* d_index, uint64_t* d_pos,
+                        void* stream);
+/* Interval::occ for a batch (fmindex.rs:75-79): positions of interval v are written to
+ * pos[out_off[v] .. out_off[v+1]) in row order; out_off (n_iv + 1 entries) is filled by the call.
+ * BG_ERR_INVALID_ARG if an interval exceeds the suffix array (the reference's expect() panic),
+ * BG_ERR_OPS_CAP if pos_cap is too small (out_off is still filled). */
+int bg_interval_occ_batch(bg_fm* fm, uint64_t n_iv, const uint64_t* lower, const uint64_t* upper,
+                          uint64_t* out_off, uint64_t* pos, uint64_t pos_cap);
+/* Device flavour: the caller supplies the prefix offsets (exclusive scan of upper - lower) and
+ * their total; asynchronous on `stream`. */
+int bg_interval_occ_batch_dev(bg_fm* fm, uint64_t n_iv, const uint64_t* d_lower,
+                              const uint64_t* d_out_off, uint64_t total, uint64_t* d_pos,
+                              void* stream);
+
 /* ------------------------------------------------------------------ pairwise alignment */
 
 /* Scoring<F> (pairwise/mod.rs:238-247) as the *effective* values `custom` sees.  match_fn is

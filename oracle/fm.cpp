@@ -274,3 +274,64 @@ extern "C" void orc_backward_search_batch(const uint8_t* bwt, uint64_t n, const 
     for (int t = 0; t < threads; t++) th.emplace_back(work, t);
     for (auto& t : th) t.join();
 }
+
+// ---- SampledSuffixArray (suffix_array.rs:86-184) -------------------------------------------
+// `sample` (86-120): every s-th SA entry is kept; rows whose BWT character is the sentinel (the last
+// byte of the text, suffix_array.rs `sentinel()`) are kept as extra rows unless already sampled.
+struct orc_sampled_sa {
+    std::vector<uint64_t> sample;
+    std::vector<std::pair<uint64_t, uint64_t>> extra;  // (row, position), sorted by row (HashMap in the reference)
+    uint64_t s = 1;
+    uint8_t sentinel = 0;
+};
+
+extern "C" orc_sampled_sa* orc_sa_sample(const uint64_t* sa, uint64_t n, const uint8_t* text, const uint8_t* bwt,
+                                         uint64_t sampling_rate) {
+    orc_sampled_sa* h = new orc_sampled_sa;
+    h->s = sampling_rate;
+    h->sentinel = n ? text[n - 1] : 0;
+    for (uint64_t i = 0; i < n; i++) {  // suffix_array.rs:100-111
+        if (i % sampling_rate == 0)
+            h->sample.push_back(sa[i]);
+        else if (bwt[i] == h->sentinel)
+            h->extra.push_back({i, sa[i]});
+    }
+    return h;
+}
+extern "C" void orc_sa_sample_free(orc_sampled_sa* h) { delete h; }
+extern "C" uint64_t orc_sa_sample_counts(const orc_sampled_sa* h, uint64_t* n_extra) {
+    if (n_extra) *n_extra = h->extra.size();
+    return h->sample.size();
+}
+extern "C" void orc_sa_sample_export(const orc_sampled_sa* h, uint64_t* sample, uint64_t* extra_row, uint64_t* extra_pos) {
+    std::copy(h->sample.begin(), h->sample.end(), sample);
+    for (size_t i = 0; i < h->extra.size(); i++) {
+        extra_row[i] = h->extra[i].first;
+        extra_pos[i] = h->extra[i].second;
+    }
+}
+
+// SampledSuffixArray::get (suffix_array.rs:157-184).  Returns -1 for None (index >= len) and -2 where the
+// reference would panic (Occ::get on a byte outside the alphabet).
+extern "C" int orc_sampled_sa_get(const orc_sampled_sa* h, const uint8_t* bwt, uint64_t n, const uint64_t* less,
+                                  uint64_t less_len, const orc_occ* occ, uint64_t index, uint64_t* out) {
+    if (index >= n) return -1;
+    uint64_t pos = index, offset = 0;
+    for (;;) {
+        if (pos % h->s == 0) {  // 162-164
+            *out = h->sample[pos / h->s] + offset;
+            return 0;
+        }
+        const uint8_t c = bwt[pos];
+        if (c == h->sentinel) {  // 168-175
+            auto it = std::lower_bound(h->extra.begin(), h->extra.end(), std::make_pair(pos, (uint64_t)0));
+            if (it == h->extra.end() || it->first != pos) return -2;
+            *out = it->second + offset;
+            return 0;
+        }
+        uint64_t o = 0;
+        if ((uint64_t)c >= less_len || orc_occ_get(occ, bwt, n, pos - 1, c, &o) != 0) return -2;
+        pos = less[c] + o;  // 177-178
+        offset += 1;
+    }
+}

@@ -116,6 +116,18 @@ void orc_backward_search_batch(const uint8_t* bwt, uint64_t n, const uint64_t* l
                                uint64_t* lower, uint64_t* upper, uint64_t* matched_len,
                                int threads);
 
+
+/* SampledSuffixArray (suffix_array.rs:86-184): sample() and get().  orc_sampled_sa_get returns 0,
+ * -1 for None (index out of range) or -2 where the reference would panic. */
+typedef struct orc_sampled_sa orc_sampled_sa;
+orc_sampled_sa* orc_sa_sample(const uint64_t* sa, uint64_t n, const uint8_t* text, const uint8_t* bwt,
+                              uint64_t sampling_rate);
+void orc_sa_sample_free(orc_sampled_sa*);
+uint64_t orc_sa_sample_counts(const orc_sampled_sa*, uint64_t* n_extra);
+void orc_sa_sample_export(const orc_sampled_sa*, uint64_t* sample, uint64_t* extra_row, uint64_t* extra_pos);
+int orc_sampled_sa_get(const orc_sampled_sa*, const uint8_t* bwt, uint64_t n, const uint64_t* less,
+                       uint64_t less_len, const orc_occ* occ, uint64_t index, uint64_t* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -101,6 +101,12 @@ def lib():
               C.c_uint64, u32p]),
             ("orc_lcskpp", C.c_uint64,
              [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint64, u32p]),
+            ("orc_sa_sample", C.c_void_p, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64]),
+            ("orc_sa_sample_free", None, [C.c_void_p]),
+            ("orc_sa_sample_counts", C.c_uint64, [C.c_void_p, u64p]),
+            ("orc_sa_sample_export", None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+            ("orc_sampled_sa_get", C.c_int,
+             [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, u64p]),
         ]:
             if hasattr(L, name):
                 f = getattr(L, name)
@@ -341,3 +347,49 @@ def backward_search_batch(bwt_arr, less_arr, occ, pat, pat_off, threads=1):
                                     p.ctypes.data, off.ctypes.data, tag.ctypes.data,
                                     lo.ctypes.data, hi.ctypes.data, ml.ctypes.data, threads)
     return tag, lo, hi, ml
+
+
+class SampledSuffixArray:
+    """RawSuffixArray::sample + SampledSuffixArray::get (suffix_array.rs:86-184)."""
+
+    def __init__(self, sa, text, bwt_arr, less_arr, occ, sampling_rate):
+        self.sa = np.ascontiguousarray(sa, dtype=np.uint64)
+        self.text = np.frombuffer(_buf(text), dtype=np.uint8)
+        self.bwt = np.ascontiguousarray(bwt_arr, dtype=np.uint8)
+        self.less = np.ascontiguousarray(less_arr, dtype=np.uint64)
+        self.occ = occ
+        self.s = int(sampling_rate)
+        self.h = lib().orc_sa_sample(self.sa.ctypes.data, len(self.sa), self.text.ctypes.data,
+                                     self.bwt.ctypes.data, self.s)
+
+    def arrays(self):
+        ne = C.c_uint64(0)
+        ns = lib().orc_sa_sample_counts(self.h, C.byref(ne))
+        sample = np.zeros(ns, dtype=np.uint64)
+        erow = np.zeros(ne.value, dtype=np.uint64)
+        epos = np.zeros(ne.value, dtype=np.uint64)
+        lib().orc_sa_sample_export(self.h, sample.ctypes.data, erow.ctypes.data, epos.ctypes.data)
+        return sample, erow, epos
+
+    def get(self, index):
+        out = C.c_uint64(0)
+        rc = lib().orc_sampled_sa_get(self.h, self.bwt.ctypes.data, len(self.bwt), self.less.ctypes.data,
+                                      len(self.less), self.occ.h, int(index), C.byref(out))
+        if rc == -1:
+            return None
+        if rc != 0:
+            raise IndexError("the reference panics here (byte outside the alphabet)")
+        return int(out.value)
+
+    def __del__(self):
+        try:
+            lib().orc_sa_sample_free(self.h)
+        except Exception:
+            pass
+
+
+def interval_occ(lower, upper, sa):
+    """Interval::occ (fmindex.rs:75-79); `sa` is a raw array or a SampledSuffixArray."""
+    if isinstance(sa, SampledSuffixArray):
+        return [sa.get(i) for i in range(lower, upper)]
+    return [int(sa[i]) for i in range(lower, upper)]

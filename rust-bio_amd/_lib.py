@@ -70,6 +70,8 @@ assert ALN_DTYPE.itemsize == 64, ALN_DTYPE.itemsize
 SYMBOLS = ["bg_device_count", "bg_init", "bg_free", "bg_strerror", "bg_last_error",
            "bg_set_option", "bg_suffix_array", "bg_bwt", "bg_less", "bg_fm_build", "bg_fm_free",
            "bg_fm_device_bytes", "bg_fm_backward_search_batch", "bg_fm_backward_search_batch_dev",
+           "bg_fm_set_suffix_array", "bg_fm_set_sampled_suffix_array", "bg_sa_get_batch", "bg_sa_get_batch_dev",
+           "bg_interval_occ_batch", "bg_interval_occ_batch_dev",
            "bg_align_batch", "bg_align_batch_dev", "bg_align_banded_batch", "bg_band_create_batch", "bg_get_timing",
            "bg_enable_timing"]
 
@@ -110,6 +112,12 @@ def lib():
         L.bg_fm_device_bytes.argtypes = [vp]
         L.bg_fm_backward_search_batch.argtypes = [vp, u64, vp, vp, vp, vp, vp, vp]
         L.bg_fm_backward_search_batch_dev.argtypes = [vp, u64, vp, vp, vp, vp, vp, vp, vp]
+        L.bg_fm_set_suffix_array.argtypes = [vp, vp, u64]
+        L.bg_fm_set_sampled_suffix_array.argtypes = [vp, vp, u64, u32, C.c_uint8, vp, vp, u64]
+        L.bg_sa_get_batch.argtypes = [vp, u64, vp, vp]
+        L.bg_sa_get_batch_dev.argtypes = [vp, u64, vp, vp, vp]
+        L.bg_interval_occ_batch.argtypes = [vp, u64, vp, vp, vp, vp, u64]
+        L.bg_interval_occ_batch_dev.argtypes = [vp, u64, vp, vp, u64, vp, vp]
         L.bg_align_batch.argtypes = [vp, C.POINTER(ScoringC), i32, u64, vp, vp, vp, vp, vp, vp,
                                      u64, C.POINTER(u64)]
         L.bg_align_batch_dev.argtypes = [vp, C.POINTER(ScoringC), i32, u64, vp, vp, vp, vp, u32,

@@ -22,63 +22,11 @@
 #include <algorithm>
 #include <numeric>
 
-#include "bg_common.h"
+#include "fm_kernels.h"
+
+using namespace bgfm;
 
 namespace {
-
-constexpr uint32_t kSymPerBlock = 192;
-constexpr uint32_t kMaxExcLds = 1024;   // exception positions staged in LDS
-constexpr uint32_t kMaxExcSyms = 32;    // distinct exception byte values supported
-constexpr uint8_t kClsZero = 4;         // in alphabet, never occurs in the BWT
-constexpr uint8_t kClsExc = 8;          // kClsExc + e : exception symbol e
-constexpr uint8_t kClsPanic = 255;      // not in the alphabet: the reference panics
-
-struct FmDev {
-    const uint4* blocks;
-    const uint32_t* exc_pos;      // all exception positions, sorted
-    const uint32_t* exc_sym_pos;  // per exception symbol, sorted, concatenated
-    const uint8_t* sym_class;     // [256]
-    const uint32_t* less;         // [256]
-    uint32_t exc_sym_off[kMaxExcSyms + 1];
-    uint32_t n;
-    uint32_t n_exc;
-};
-
-// number of entries <= r in a sorted array
-template <typename P>
-__device__ __forceinline__ uint32_t count_le(P arr, uint32_t lo, uint32_t hi, uint32_t r) {
-    while (lo < hi) {
-        uint32_t mid = (lo + hi) >> 1;
-        if (arr[mid] <= r)
-            lo = mid + 1;
-        else
-            hi = mid;
-    }
-    return lo;
-}
-
-// this lane's share of rank(code c) inside one block: lane t==0 holds the counters,
-// lanes 1..3 hold 64 symbols each
-__device__ __forceinline__ uint32_t block_part(const uint4 v, uint32_t t, uint32_t o, uint32_t c) {
-    if (t == 0) {
-        uint32_t lo = (c & 1) ? v.y : v.x;
-        uint32_t hi = (c & 1) ? v.w : v.z;
-        return (c & 2) ? hi : lo;
-    }
-    const int have = (int)o + 1 - (int)(t - 1) * 64;  // symbols of this lane inside [0, o]
-    if (have <= 0) return 0;
-    const uint64_t pat = (uint64_t)c * 0x5555555555555555ull;
-    uint64_t w0 = ((uint64_t)v.y << 32) | v.x;
-    uint64_t w1 = ((uint64_t)v.w << 32) | v.z;
-    uint64_t e0 = ~(w0 ^ pat), e1 = ~(w1 ^ pat);
-    e0 = e0 & (e0 >> 1) & 0x5555555555555555ull;
-    e1 = e1 & (e1 >> 1) & 0x5555555555555555ull;
-    const int t0 = have >= 32 ? 32 : have;
-    const int t1 = have >= 64 ? 32 : (have > 32 ? have - 32 : 0);
-    const uint64_t m0 = t0 == 32 ? ~0ull : ((1ull << (2 * t0)) - 1);
-    const uint64_t m1 = t1 == 32 ? ~0ull : ((1ull << (2 * t1)) - 1);
-    return (uint32_t)(__popcll(e0 & m0) + __popcll(e1 & m1));
-}
 
 __global__ __launch_bounds__(256) void fm_backward_search_kernel(
     FmDev fm, uint64_t n_q, const uint8_t* __restrict__ pat, const uint64_t* __restrict__ pat_off,
@@ -210,17 +158,6 @@ __global__ __launch_bounds__(256) void fm_backward_search_kernel(
 
 }  // namespace
 
-struct bg_fm {
-    bg_ctx* ctx = nullptr;
-    FmDev dev = {};
-    void* d_blocks = nullptr;
-    void* d_exc_pos = nullptr;
-    void* d_exc_sym_pos = nullptr;
-    void* d_class = nullptr;
-    void* d_less = nullptr;
-    uint64_t bytes = 0;
-};
-
 extern "C" int bg_fm_build(bg_ctx* ctx, const uint8_t* bwt, uint64_t n, const uint64_t* less,
                            uint32_t less_len, uint32_t occ_k, const uint8_t* alphabet,
                            uint32_t n_sym, bg_fm** out) {
@@ -298,8 +235,12 @@ extern "C" int bg_fm_build(bg_ctx* ctx, const uint8_t* bwt, uint64_t n, const ui
         }
     }
     std::vector<uint32_t> exc_sym_pos;
+    std::vector<uint8_t> exc_byte(exc_pos.size());
+    for (size_t e = 0; e < exc_pos.size(); e++) exc_byte[e] = bwt[exc_pos[e]];
     bg_fm* fm = new bg_fm;
     fm->ctx = ctx;
+    for (int c = 0; c < 256; c++)
+        if (code_of[c] >= 0) fm->code_byte[code_of[c]] = (uint8_t)c;
     fm->dev.exc_sym_off[0] = 0;
     for (size_t e = 0; e < exc_by_sym.size(); e++) {
         exc_sym_pos.insert(exc_sym_pos.end(), exc_by_sym[e].begin(), exc_by_sym[e].end());
@@ -327,6 +268,7 @@ extern "C" int bg_fm_build(bg_ctx* ctx, const uint8_t* bwt, uint64_t n, const ui
     if ((rc = upload(&fm->d_exc_pos, exc_pos.data(), exc_pos.size() * 4))) return fail(rc);
     if ((rc = upload(&fm->d_exc_sym_pos, exc_sym_pos.data(), exc_sym_pos.size() * 4)))
         return fail(rc);
+    if ((rc = upload(&fm->d_exc_byte, exc_byte.data(), exc_byte.size()))) return fail(rc);
     if ((rc = upload(&fm->d_class, cls, 256))) return fail(rc);
     if ((rc = upload(&fm->d_less, less32, sizeof(less32)))) return fail(rc);
     fm->dev.blocks = (const uint4*)fm->d_blocks;
@@ -347,6 +289,10 @@ extern "C" int bg_fm_free(bg_fm* fm) {
     hipFree(fm->d_exc_sym_pos);
     hipFree(fm->d_class);
     hipFree(fm->d_less);
+    hipFree(fm->d_exc_byte);
+    hipFree(fm->d_sa);
+    hipFree(fm->d_extra_row);
+    hipFree(fm->d_extra_pos);
     delete fm;
     return BG_OK;
 }

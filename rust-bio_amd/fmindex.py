@@ -15,6 +15,9 @@ class Interval:  # fmindex.rs:69-80
     upper: int
 
     def occ(self, sa):
+        """Interval::occ (fmindex.rs:75-79); `sa` is a device-attached Raw/SampledSuffixArray or a host array."""
+        if hasattr(sa, "fm"):
+            return [int(v) for v in sa.fm.interval_occ_arrays([self.lower], [self.upper])[1]]
         return [int(sa[p]) for p in range(self.lower, self.upper)]
 
 
@@ -86,6 +89,22 @@ class FMIndex:
         _lib.check(_lib.lib().bg_fm_backward_search_batch_dev(self.h, n_q, d_pat, d_off, d_tag,
                                                               d_lo, d_hi, d_ml, stream),
                    "backward_search_dev")
+
+    def interval_occ_arrays(self, lower, upper):
+        """Interval::occ for a batch: returns (out_off, positions); needs an attached suffix array."""
+        lo = np.ascontiguousarray(lower, dtype=np.uint64)
+        hi = np.ascontiguousarray(upper, dtype=np.uint64)
+        n = len(lo)
+        off = np.zeros(n + 1, dtype=np.uint64)
+        total = int(np.maximum(hi.astype(np.int64) - lo.astype(np.int64), 0).sum())
+        pos = np.zeros(max(total, 1), dtype=np.uint64)
+        _lib.check(_lib.lib().bg_interval_occ_batch(self.h, n, lo.ctypes.data, hi.ctypes.data, off.ctypes.data,
+                                                    pos.ctypes.data, total), "Interval::occ")
+        return off, pos[:total]
+
+    def interval_occ_dev(self, n_iv, d_lower, d_out_off, total, d_pos, stream=0):
+        _lib.check(_lib.lib().bg_interval_occ_batch_dev(self.h, n_iv, d_lower, d_out_off, total, d_pos, stream),
+                   "Interval::occ (dev)")
 
     def close(self):
         if self.h:
