@@ -144,3 +144,19 @@ def _umod(z, m):
     hi = _lsr(z, 32) % m
     lo = (z & 0xFFFFFFFF) % m
     return ((hi * ((1 << 32) % m)) % m + lo) % m
+
+
+def reads_from_genome(text, n_reads, length, seed, sub=0.05, ins=0.01, dele=0.01, chunk=1 << 16):
+    """cfg 5 reads: windows of the genome at SplitMix64 positions, mutated like cfg 2 (mutate_fixed).
+    Returns (reads uint8[n_reads * length], starts int64[n_reads])."""
+    dev = text.device
+    n = text.numel() - 1
+    starts = (_lsr(splitmix64(seed, n_reads, dev), 1) % (n - length)).to(torch.int64)
+    ar = torch.arange(length, dtype=torch.int64, device=dev)
+    out = []
+    for c0 in range(0, n_reads, chunk):
+        s = starts[c0:c0 + chunk]
+        refs = text[(s[:, None] + ar[None, :]).reshape(-1)].view(-1, length)
+        x, _ = mutate_fixed(refs, seed + 1000003 + 7919 * (c0 // chunk), sub, ins, dele)
+        out.append(x.reshape(-1))
+    return torch.cat(out), starts
