@@ -1,0 +1,131 @@
+// The reference's known-answer tests, written against the C++ host mirror (include/biogpu.hpp) the way
+// the reference writes them against its Rust API — plus the panics the reference asserts on.
+// Needs a gfx950 device (the engine has no CPU fallback).  Usage: run_kats [filter-substring]
+#include <cstdio>
+#include <cstring>
+#include <sstream>
+
+#include "biogpu.hpp"
+
+using namespace bio;
+using namespace bio::alignment;
+using namespace bio::alignment::pairwise;
+using namespace bio::data_structures;
+
+static int g_failed = 0;
+static const char* g_current = "";
+#define CHECK(cond)                                                                     \
+    do {                                                                                \
+        if (!(cond)) {                                                                  \
+            std::fprintf(stderr, "FAIL %s: %s (%s:%d)\n", g_current, #cond, __FILE__, __LINE__); \
+            g_failed++;                                                                 \
+        }                                                                               \
+    } while (0)
+#define CHECK_EQ(a, b)                                                                  \
+    do {                                                                                \
+        const auto va = (a);                                                            \
+        const auto vb = (b);                                                            \
+        if (!(va == vb)) {                                                              \
+            std::ostringstream os;                                                      \
+            os << va << " != " << vb;                                                   \
+            std::fprintf(stderr, "FAIL %s: %s == %s: %s (%s:%d)\n", g_current, #a, #b, os.str().c_str(), __FILE__, __LINE__); \
+            g_failed++;                                                                 \
+        }                                                                               \
+    } while (0)
+static std::string ops_str(const std::vector<AlignmentOperation>& v) {
+    static const char* n[] = {"M", "S", "D", "I", "X", "Y"};
+    std::string s;
+    for (auto& o : v) {
+        s += n[o.kind];
+        if (o.kind >= AlignmentOperation::Xclip) s += std::to_string(o.len);
+        s += ' ';
+    }
+    return s;
+}
+#define CHECK_OPS(a, b)                                                                 \
+    do {                                                                                \
+        if (!((a) == (b))) {                                                            \
+            std::fprintf(stderr, "FAIL %s: operations [%s] != [%s] (%s:%d)\n", g_current, ops_str(a).c_str(), ops_str(b).c_str(), __FILE__, __LINE__); \
+            g_failed++;                                                                 \
+        }                                                                               \
+    } while (0)
+template <typename F>
+static bool panics(F&& f) {
+    try {
+        f();
+    } catch (const Panic&) {
+        return true;
+    }
+    return false;
+}
+
+static int32_t blosum62(uint8_t a, uint8_t b);
+#include "kats_generated.inc"
+
+// scores::blosum62 (src/scores/blosum62.rs) through the pairs the golden fixture holds
+static int32_t blosum62(uint8_t a, uint8_t b) {
+    static int8_t tab[256][256];
+    static bool init = false;
+    if (!init) {
+        std::memset(tab, 0, sizeof(tab));
+        for (auto& p : kBlosum62Pairs) tab[(uint8_t)p.a][(uint8_t)p.b] = p.v;
+        init = true;
+    }
+    return tab[a][b];
+}
+
+// ---- the reference's asserts (mod.rs:265-266, 322 ff.; suffix_array.rs:431-437; fmindex.rs:229)
+static void kat_panics() {
+    CHECK(panics([] { Scoring::from_scores(1, -1, 1, -1); }));   // gap_open can't be positive
+    CHECK(panics([] { Scoring::from_scores(-5, 1, 1, -1); }));   // gap_extend can't be positive
+    CHECK(panics([] { Scoring::from_scores(-5, -1, 1, -1).xclip(1); }));
+    CHECK(panics([] { suffix_array::suffix_array(text("ACGT")); }));   // no sentinel
+    CHECK(panics([] { suffix_array::suffix_array(text("AC#GT$")); }));  // '#' < '$'
+    CHECK(panics([] {  // pattern byte outside the alphabet reaches Occ::get
+        const Text t = text("GCCTTAACATTATTACGCCTA$");
+        const auto alphabet = alphabets::dna::n_alphabet();
+        const auto sa = suffix_array::suffix_array(t);
+        const auto b = bwt::bwt(t, sa);
+        fmindex::FMIndex fm(b, bwt::less(b, alphabet), bwt::Occ(b, 3, alphabet));
+        fm.backward_search(text("TT~"));
+    }));
+    CHECK(panics([] {  // Interval out of range of suffix array (fmindex.rs:77)
+        const Text t = text("GCCTTAACATTATTACGCCTA$");
+        const auto sa = suffix_array::suffix_array(t);
+        fmindex::Interval{0, sa.size() + 1}.occ(sa);
+    }));
+}
+
+// ---- batch entry points: a batch equals its single calls
+static void kat_batches_equal_single_calls() {
+    auto aligner = pairwise::Aligner::with_scoring(Scoring::from_scores(-5, -1, 1, -1));
+    std::vector<std::pair<Text, Text>> pairs = {{text("ACCGTGGAT"), text("AAAAACCGTTGAT")},
+                                                {text("ACGTACGT"), text("ACGGTACGT")},
+                                                {text(""), text("ACGT")},
+                                                {text("TTTT"), text("")}};
+    const auto batch = aligner.align_batch(AlignmentMode::Local, pairs);
+    for (size_t p = 0; p < pairs.size(); p++) CHECK(batch[p] == aligner.local(pairs[p].first, pairs[p].second));
+}
+
+int main(int argc, char** argv) {
+    const char* filter = argc > 1 ? argv[1] : "";
+    int ran = 0;
+    auto run = [&](const char* name, void (*fn)()) {
+        if (*filter && !std::strstr(name, filter)) return;
+        g_current = name;
+        const int before = g_failed;
+        try {
+            fn();
+        } catch (const std::exception& e) {
+            std::fprintf(stderr, "FAIL %s: unexpected panic: %s\n", name, e.what());
+            g_failed++;
+        }
+        ran++;
+        if (g_failed != before) std::fprintf(stderr, "  ^ in %s\n", name);
+    };
+    for (auto& k : kKats) run(k.name, k.fn);
+    run("kat_panics", kat_panics);
+    run("kat_batches_equal_single_calls", kat_batches_equal_single_calls);
+    std::printf("%d tests, %d failed\n", ran, g_failed);
+    return g_failed ? 1 : 0;
+}
