@@ -159,9 +159,11 @@ def main():
                 "note": "VALU-bound integer DP; HBM fraction reported as required, see DESIGN.md"}
 
     # parity of a sample against the oracle + CPU baseline on the same sample (rank 0)
-    parity = {} if (rank == 0 and not args.skip_cpu) else None
+    # the CPU legs (oracle parity sample + cpu_baseline) run on rank 0 of the single-GPU run only
+    do_cpu = rank == 0 and world == 1 and not args.skip_cpu
+    parity = {} if do_cpu else None
     cpu_baseline = None
-    if rank == 0 and not args.skip_cpu:
+    if do_cpu:
         import oracle_py as orc
         threads = args.cpu_threads or host_cores()
         # bounded sample: ~10-60 CPU-seconds of work spread over all host cores
@@ -210,7 +212,7 @@ def main():
                                      "affine-gap (-5,-1,+1,-1), score+coords+traceback ops (BASELINE configs[1])",
                          "pairs_per_gpu": n_pairs, "read_len": L, "parallelism": f"shard{world}"},
               "roofline": roofline}
-    if rank == 0 and not args.skip_cpu:
+    if do_cpu:
         result["host_api"] = {"value": round(host_api_gcups, 2), "unit": "GCUPS", "pairs": nh,
                               "note": "bg_align_batch with pageable host buffers in and out (PCIe-inclusive)"}
     del x, y, d_ops, d_out
@@ -264,7 +266,7 @@ def main():
                                "traffic": pmc_traffic("fm_backward_search_kernel", "fm_queries_per_launch", n_q),
                                "launch_ms": round(fm_ms, 4), "queries_per_launch": n_q,
                                "alg_bytes_per_query": round(alg_bytes / n_q, 1)}}
-        if rank == 0 and not args.skip_cpu:
+        if do_cpu:
             import oracle_py as orc
             nsq = min(n_q, 400_000)
             threads = args.cpu_threads or host_cores()
@@ -364,7 +366,7 @@ def main():
                                "traffic": pmc_traffic("banded_fill_kernel", "banded_pairs_per_launch", Pb_launch),
                                "alg_bytes_per_pair": round(balg / Pb, 1)},
                   "pairs_per_launch": Pb_launch}
-        if rank == 0 and not args.skip_cpu:
+        if do_cpu:
             import oracle_py as orc
             nsb = min(Pb, max(8, (args.cpu_threads or host_cores()) // 2))
             threads = min(nsb, args.cpu_threads or host_cores())

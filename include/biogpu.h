@@ -204,6 +204,49 @@ int bg_band_create_batch(const bg_scoring_t* sc, int mode, uint32_t k, uint32_t 
                          const uint8_t* x, const uint64_t* x_off, const uint8_t* y, const uint64_t* y_off,
                          const uint64_t* band_off, uint32_t* start, uint32_t* end, uint64_t* band_cells);
 
+/* compute_alignment (banded.rs:406-869) over caller-supplied bands — the common tail of
+ * custom_with_prehash / custom_with_matches / custom_with_expanded_matches / custom_with_match_path
+ * / semiglobal_with_prehash (banded.rs:294-401, 938-970) once their band exists.  Pair p's band is
+ * the n_p + 1 half-open row ranges band_start/band_end[band_off[p] ..]; `mode` applies the same
+ * clip overrides as bg_align_banded_batch.  A band whose column ranges are not monotone gets
+ * status BG_ERR_UNSUPPORTED for that pair. */
+int bg_align_banded_bands_batch(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint64_t n_pairs,
+                                const uint8_t* x, const uint64_t* x_off, const uint8_t* y,
+                                const uint64_t* y_off, const uint64_t* band_off,
+                                const uint32_t* band_start, const uint32_t* band_end,
+                                bg_alignment_t* out, uint8_t* ops_buf, uint64_t ops_cap,
+                                uint64_t* ops_used, uint64_t* band_cells);
+
+/* Band::create_with_matches (banded.rs:1301-1328; path == NULL) or Band::create_from_match_path
+ * (banded.rs:1330-1367) for a batch, on host threads.  Matches are (x, y) uint32 pairs, sorted;
+ * pair p owns matches_xy[2*match_off[p] .. 2*match_off[p+1]) and, if given, path[path_off[p] ..
+ * path_off[p+1]) (indices into its matches).  BG_ERR_INVALID_ARG where the reference asserts
+ * (unsorted matches) or indexes out of bounds. */
+int bg_band_from_matches_batch(const bg_scoring_t* sc, int mode, uint32_t k, uint32_t w,
+                               uint64_t n_pairs, const uint64_t* x_off, const uint64_t* y_off,
+                               const uint32_t* matches_xy, const uint64_t* match_off,
+                               const uint32_t* path, const uint64_t* path_off,
+                               const uint64_t* band_off, uint32_t* start, uint32_t* end,
+                               uint64_t* band_cells);
+
+/* sparse.rs on the host: find_kmer_matches (337-348), sdpkpp path (188-295), lcskpp path + score
+ * (67-143), sdpkpp_union_lcskpp_path (297-329), expand_kmer_matches (404-500).  Each returns the
+ * length of its result (call again with a larger buffer if it exceeds `cap`), or UINT64_MAX where
+ * the reference asserts ("incoming matches must be sorted"). */
+uint64_t bg_sparse_find_kmer_matches(const uint8_t* x, uint64_t m, const uint8_t* y, uint64_t n,
+                                     uint32_t k, uint32_t* out_xy, uint64_t cap);
+uint64_t bg_sparse_sdpkpp(const uint32_t* matches_xy, uint64_t n_matches, uint32_t k,
+                          uint32_t match_score, int32_t gap_open, int32_t gap_extend,
+                          uint32_t* path, uint64_t cap);
+uint64_t bg_sparse_lcskpp(const uint32_t* matches_xy, uint64_t n_matches, uint32_t k, uint32_t* path,
+                          uint64_t cap, uint32_t* score);
+uint64_t bg_sparse_sdpkpp_union_lcskpp_path(const uint32_t* matches_xy, uint64_t n_matches, uint32_t k,
+                                            uint32_t match_score, int32_t gap_open,
+                                            int32_t gap_extend, uint32_t* path, uint64_t cap);
+uint64_t bg_sparse_expand_kmer_matches(const uint8_t* x, uint64_t m, const uint8_t* y, uint64_t n,
+                                       uint32_t k, const uint32_t* matches_xy, uint64_t n_matches,
+                                       uint32_t allowed_mismatches, uint32_t* out_xy, uint64_t cap);
+
 /* Timing of the last *_dev / batch call's kernels on this ctx, measured with HIP events on
  * the stream the kernels ran on (used by bench.py for the roofline line). */
 typedef struct {

@@ -92,6 +92,64 @@ struct Alignment {
     }
 };
 
+// alignment::sparse (sparse.rs): the pieces the banded aligner's entry points take or produce
+namespace sparse {
+using Match = std::pair<uint32_t, uint32_t>;  // (x position, y position)
+namespace detail {
+inline std::vector<uint32_t> flat(const std::vector<Match>& mm) {
+    std::vector<uint32_t> v;
+    for (auto& m : mm) {
+        v.push_back(m.first);
+        v.push_back(m.second);
+    }
+    return v;
+}
+inline std::vector<Match> pairs(const std::vector<uint32_t>& v, uint64_t n) {
+    std::vector<Match> mm(n);
+    for (uint64_t i = 0; i < n; i++) mm[i] = {v[2 * i], v[2 * i + 1]};
+    return mm;
+}
+}  // namespace detail
+// hash_kmers (sparse.rs:350-359): only the identity of the indexed sequence matters to the engine
+struct KmerHash {
+    Text seq;
+    size_t k;
+};
+inline KmerHash hash_kmers(const Text& seq, size_t k) { return {seq, k}; }
+inline std::vector<Match> find_kmer_matches(const Text& a, const Text& b, size_t k) {  // sparse.rs:337-348
+    const uint64_t n = bg_sparse_find_kmer_matches(a.data(), a.size(), b.data(), b.size(), (uint32_t)k, nullptr, 0);
+    std::vector<uint32_t> v(2 * n + 2);
+    bg_sparse_find_kmer_matches(a.data(), a.size(), b.data(), b.size(), (uint32_t)k, v.data(), n);
+    return detail::pairs(v, n);
+}
+inline std::vector<Match> find_kmer_matches_seq2_hashed(const Text& a, const KmerHash& h, size_t k) {  // sparse.rs:383-402
+    if (h.k != k) throw Panic("k-mer hash built with a different k");
+    return find_kmer_matches(a, h.seq, k);
+}
+inline std::vector<size_t> sdpkpp_union_lcskpp_path(const std::vector<Match>& mm, size_t k, uint32_t match_score,
+                                                    int32_t gap_open, int32_t gap_extend) {  // sparse.rs:297-329
+    const auto f = detail::flat(mm);
+    std::vector<uint32_t> p(2 * mm.size() + 2);
+    const uint64_t n = bg_sparse_sdpkpp_union_lcskpp_path(f.data(), mm.size(), (uint32_t)k, match_score, gap_open, gap_extend,
+                                                          p.data(), p.size());
+    if (n == UINT64_MAX) throw Panic("incoming matches must be sorted");
+    return std::vector<size_t>(p.begin(), p.begin() + n);
+}
+inline std::vector<Match> expand_kmer_matches(const Text& a, const Text& b, size_t k, const std::vector<Match>& sorted_matches,
+                                              size_t allowed_mismatches) {  // sparse.rs:404-500
+    const auto f = detail::flat(sorted_matches);
+    uint64_t cap = sorted_matches.size() + a.size() + b.size() + 8;
+    for (;;) {
+        std::vector<uint32_t> v(2 * cap);
+        const uint64_t n = bg_sparse_expand_kmer_matches(a.data(), a.size(), b.data(), b.size(), (uint32_t)k, f.data(),
+                                                         sorted_matches.size(), (uint32_t)allowed_mismatches, v.data(), cap);
+        if (n == UINT64_MAX) throw Panic("incoming matches must be sorted");
+        if (n <= cap) return detail::pairs(v, n);
+        cap = n;
+    }
+}
+}  // namespace sparse
+
 namespace pairwise {
 
 constexpr int32_t MIN_SCORE = BG_MIN_SCORE;  // mod.rs:174
@@ -295,6 +353,29 @@ public:
         return res;
     }
 
+    // ---- entry points that take matches / chains / a prehash from the caller (banded.rs:294-401, 938-970)
+    Alignment custom_with_matches(const Text& x, const Text& y, const std::vector<sparse::Match>& matches) {
+        return with_matches(AlignmentMode::Custom, x, y, matches, nullptr);
+    }
+    Alignment custom_with_match_path(const Text& x, const Text& y, const std::vector<sparse::Match>& matches,
+                                     const std::vector<size_t>& path) {
+        return with_matches(AlignmentMode::Custom, x, y, matches, &path);
+    }
+    Alignment custom_with_expanded_matches(const Text& x, const Text& y, std::vector<sparse::Match> matches,
+                                           std::optional<size_t> allowed_mismatches, bool use_lcskpp_union) {
+        if (allowed_mismatches) matches = sparse::expand_kmer_matches(x, y, k_, matches, *allowed_mismatches);
+        if (!use_lcskpp_union) return with_matches(AlignmentMode::Custom, x, y, matches, nullptr);
+        const int32_t ms = scoring.match_scores ? scoring.match_scores->first : 2;  // DEFAULT_MATCH_SCORE, banded.rs:105
+        const auto path = sparse::sdpkpp_union_lcskpp_path(matches, k_, (uint32_t)ms, scoring.gap_open, scoring.gap_extend);
+        return with_matches(AlignmentMode::Custom, x, y, matches, &path);
+    }
+    Alignment custom_with_prehash(const Text& x, const Text& y, const sparse::KmerHash& y_kmer_hash) {
+        return with_matches(AlignmentMode::Custom, x, y, sparse::find_kmer_matches_seq2_hashed(x, y_kmer_hash, k_), nullptr);
+    }
+    Alignment semiglobal_with_prehash(const Text& x, const Text& y, const sparse::KmerHash& y_kmer_hash) {
+        return with_matches(AlignmentMode::Semiglobal, x, y, sparse::find_kmer_matches_seq2_hashed(x, y_kmer_hash, k_), nullptr);
+    }
+
     Scoring scoring;
     std::vector<uint64_t> band_cells;  // Band::num_cells of the last batch
 
@@ -302,6 +383,34 @@ private:
     Aligner(Scoring s, size_t k, size_t w, std::shared_ptr<Context> ctx)
         : scoring(std::move(s)), k_(k), w_(w), ctx_(ctx ? std::move(ctx) : Context::shared_default()) {}
     Alignment one(AlignmentMode m, const Text& x, const Text& y) { return align_batch(m, {{x, y}})[0]; }
+    // the band from the caller's matches (host), then compute_alignment on the device
+    Alignment with_matches(AlignmentMode mode, const Text& x, const Text& y, const std::vector<sparse::Match>& matches,
+                           const std::vector<size_t>* path) {
+        std::vector<int32_t> table;
+        const bg_scoring_t sc = scoring.to_c(table);
+        const uint64_t x_off[2] = {0, x.size()}, y_off[2] = {0, y.size()}, m_off[2] = {0, matches.size()}, b_off[2] = {0, y.size() + 1};
+        const auto flat = sparse::detail::flat(matches);
+        std::vector<uint32_t> p32;
+        uint64_t p_off[2] = {0, 0};
+        if (path) {
+            p32.assign(path->begin(), path->end());
+            p_off[1] = p32.size();
+        }
+        std::vector<uint32_t> start(y.size() + 1), end(y.size() + 1);
+        band_cells.assign(1, 0);
+        const int rc = bg_band_from_matches_batch(&sc, (int)mode, (uint32_t)k_, (uint32_t)w_, 1, x_off, y_off, flat.data(), m_off,
+                                                  path ? p32.data() : nullptr, path ? p_off : nullptr, b_off, start.data(),
+                                                  end.data(), band_cells.data());
+        if (rc == BG_ERR_INVALID_ARG) throw Panic("incoming matches must be sorted / path index out of bounds");
+        check(rc, "Band::create_with_matches");
+        bg_alignment_t out;
+        std::vector<uint8_t> ops(x.size() + y.size() + 16);
+        uint64_t used = 0;
+        check(bg_align_banded_bands_batch(ctx_->raw(), &sc, (int)mode, 1, x.data(), x_off, y.data(), y_off, b_off, start.data(),
+                                          end.data(), &out, ops.data(), ops.size(), &used, band_cells.data()),
+              "banded::Aligner");
+        return detail::to_alignment(out, ops.data());
+    }
     size_t k_, w_;
     std::shared_ptr<Context> ctx_;
 };

@@ -199,6 +199,12 @@ struct BandedAligner {
     Band band;
     size_t k, w;
     BandedAligner(const Scoring& s, size_t k_, size_t w_) : scoring(s), k(k_), w(w_) {}
+    // how the band of the next run() is made (the custom_with_* entry points)
+    int variant = 0;
+    std::vector<Match> v_matches;
+    std::vector<size_t> v_path;
+    int v_allowed_mismatches = -1;
+    bool v_use_lcskpp_union = false;
 
     // banded.rs:406-869
     Alignment compute_alignment(const uint8_t* x, size_t m, const uint8_t* y, size_t n) {
@@ -599,7 +605,26 @@ struct BandedAligner {
             scoring.xclip_prefix = scoring.xclip_suffix = scoring.yclip_prefix = scoring.yclip_suffix = 0;
             filter = true;
         }
-        band = Band::create(x, m, y, n, k, w, scoring);
+        // variant: 0 create (282-285), 1 custom_with_matches (313-321), 2 custom_with_match_path (391-401),
+        //          3 custom_with_expanded_matches (338-389)
+        if (variant == 0) {
+            band = Band::create(x, m, y, n, k, w, scoring);
+        } else if (variant == 1) {
+            band = Band::create_with_matches(m, n, k, w, scoring, v_matches);
+        } else if (variant == 2) {
+            band = Band::create_from_match_path(m, n, k, w, scoring, v_path, v_matches);
+        } else {
+            const std::vector<Match> expanded =
+                v_allowed_mismatches >= 0 ? expand_kmer_matches(x, m, y, n, k, v_matches, (size_t)v_allowed_mismatches) : v_matches;
+            if (v_use_lcskpp_union) {
+                const int32_t match_score = scoring.match_scores_some ? scoring.match_score : DEFAULT_MATCH_SCORE;
+                const std::vector<size_t> path =
+                    sdpkpp_union_lcskpp_path(expanded, k, (uint32_t)match_score, scoring.gap_open, scoring.gap_extend);
+                band = Band::create_from_match_path(m, n, k, w, scoring, path, expanded);
+            } else {
+                band = Band::create_with_matches(m, n, k, w, scoring, expanded);
+            }
+        }
         if (cells) *cells = band.num_cells();
         Alignment a = compute_alignment(x, m, y, n);
         if (mode != ORC_MODE_CUSTOM) a.mode = mode;
@@ -685,5 +710,33 @@ extern "C" void orc_band_apply(uint64_t m, uint64_t n, const uint32_t* ops, uint
     for (uint64_t j = 0; j <= n; j++) {
         start[j] = (uint32_t)b.start[j];
         end[j] = (uint32_t)b.end[j];
+    }
+}
+
+// custom_with_matches / custom_with_match_path / custom_with_expanded_matches (banded.rs:313-401), any mode.
+// Optionally exports the band (n + 1 half-open row ranges).
+extern "C" int orc_banded_align_with(const orc_scoring_t* sc, int mode, uint32_t k, uint32_t w, const uint8_t* x,
+                                     uint64_t m, const uint8_t* y, uint64_t n, int variant, const uint32_t* matches_xy,
+                                     uint64_t n_matches, const uint32_t* path, uint64_t n_path, int allowed_mismatches,
+                                     int use_lcskpp_union, orc_alignment_t* out, uint64_t* ops, uint64_t ops_cap,
+                                     uint64_t* band_cells, uint32_t* band_start, uint32_t* band_end) {
+    try {
+        orc::BandedAligner al(orc::scoring_from_c(sc), k, w);
+        al.variant = variant;
+        for (uint64_t i = 0; i < n_matches; i++) al.v_matches.emplace_back(matches_xy[2 * i], matches_xy[2 * i + 1]);
+        for (uint64_t i = 0; i < n_path; i++) al.v_path.push_back(path[i]);
+        al.v_allowed_mismatches = allowed_mismatches;
+        al.v_use_lcskpp_union = use_lcskpp_union != 0;
+        size_t cells = 0;
+        orc::Alignment a = al.run(mode, x, m, y, n, &cells);
+        if (band_cells) *band_cells = cells;
+        if (band_start && band_end)
+            for (uint64_t j = 0; j <= n; j++) {
+                band_start[j] = (uint32_t)al.band.start[j];
+                band_end[j] = (uint32_t)al.band.end[j];
+            }
+        return orc::export_alignment(a, out, ops, ops_cap);
+    } catch (const std::exception&) {
+        return -2;
     }
 }

@@ -101,6 +101,15 @@ def lib():
               C.c_uint64, u32p]),
             ("orc_lcskpp", C.c_uint64,
              [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint64, u32p]),
+            ("orc_sdpkpp_union_lcskpp_path", C.c_uint64,
+             [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32, C.c_void_p, C.c_uint64]),
+            ("orc_expand_kmer_matches", C.c_uint64,
+             [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint64, C.c_uint32,
+              C.c_void_p, C.c_uint64]),
+            ("orc_banded_align_with", C.c_int,
+             [C.POINTER(Scoring), C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
+              C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.POINTER(AlignmentRec),
+              C.c_void_p, C.c_uint64, u64p, C.c_void_p, C.c_void_p]),
             ("orc_sa_sample", C.c_void_p, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64]),
             ("orc_sa_sample_free", None, [C.c_void_p]),
             ("orc_sa_sample_counts", C.c_uint64, [C.c_void_p, u64p]),
@@ -393,3 +402,59 @@ def interval_occ(lower, upper, sa):
     if isinstance(sa, SampledSuffixArray):
         return [sa.get(i) for i in range(lower, upper)]
     return [int(sa[i]) for i in range(lower, upper)]
+
+
+def _matches_xy(matches):
+    return np.ascontiguousarray(np.asarray(matches, dtype=np.uint32).reshape(-1, 2))
+
+
+def sdpkpp_union_lcskpp_path(matches, k, match_score, gap_open, gap_extend):
+    """sparse.rs:297-329"""
+    mm = _matches_xy(matches)
+    path = np.zeros(2 * len(mm) + 1, dtype=np.uint32)
+    n = lib().orc_sdpkpp_union_lcskpp_path(mm.ctypes.data, len(mm), k, match_score, gap_open, gap_extend,
+                                           path.ctypes.data, len(path))
+    return [int(v) for v in path[:n]]
+
+
+def expand_kmer_matches(x, y, k, matches, allowed_mismatches):
+    """sparse.rs:404-500"""
+    xb, yb = _buf(x), _buf(y)
+    mm = _matches_xy(matches)
+    cap = len(mm) + len(xb) + len(yb) + 8
+    while True:
+        out = np.zeros((cap, 2), dtype=np.uint32)
+        n = lib().orc_expand_kmer_matches(xb.ctypes.data, len(xb), yb.ctypes.data, len(yb), k, mm.ctypes.data, len(mm),
+                                          allowed_mismatches, out.ctypes.data, cap)
+        if n <= cap:
+            return [(int(a), int(b)) for a, b in out[:n]]
+        cap = n
+
+
+def banded_align_with(scoring, mode, k, w, x, y, matches, path=None, expanded=False, allowed_mismatches=None,
+                      use_lcskpp_union=False, want_band=False):
+    """custom_with_matches / custom_with_match_path / custom_with_expanded_matches (banded.rs:313-401), in any
+    mode.  Returns the alignment dict (+ 'band_cells', and 'band' = (start, end) when want_band)."""
+    sc = scoring[0] if isinstance(scoring, tuple) else scoring
+    xb, yb = _buf(x), _buf(y)
+    mm = _matches_xy(matches)
+    variant = 3 if expanded else (2 if path is not None else 1)
+    pp = np.ascontiguousarray(path if path is not None else [], dtype=np.uint32)
+    rec = AlignmentRec()
+    cap = len(xb) + len(yb) + 8
+    ops = np.zeros(cap, dtype=np.uint64)
+    cells = C.c_uint64(0)
+    bs = np.zeros(len(yb) + 1, dtype=np.uint32)
+    be = np.zeros(len(yb) + 1, dtype=np.uint32)
+    rc = lib().orc_banded_align_with(C.byref(sc), MODES[mode] if isinstance(mode, str) else mode, k, w, xb.ctypes.data,
+                                     len(xb), yb.ctypes.data, len(yb), variant, mm.ctypes.data, len(mm), pp.ctypes.data,
+                                     len(pp), -1 if allowed_mismatches is None else int(allowed_mismatches),
+                                     1 if use_lcskpp_union else 0, C.byref(rec), ops.ctypes.data, cap, C.byref(cells),
+                                     bs.ctypes.data, be.ctypes.data)
+    if rc:
+        raise RuntimeError(f"oracle banded_align_with failed rc={rc}")
+    d = _rec_to_dict(rec, decode_ops(ops[:rec.n_ops]))
+    d["band_cells"] = int(cells.value)
+    if want_band:
+        d["band"] = (bs, be)
+    return d

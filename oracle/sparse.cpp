@@ -210,6 +210,80 @@ std::vector<Match> find_kmer_matches(const uint8_t* seq1, size_t n1, const uint8
     return matches;
 }
 
+// sparse.rs:297-329
+std::vector<size_t> sdpkpp_union_lcskpp_path(const std::vector<Match>& matches, size_t k, uint32_t match_score,
+                                             int32_t gap_open, int32_t gap_extend) {
+    if (matches.empty()) return {};
+    const SparseResult lcs = lcskpp(matches, k);
+    const SparseResult sdp = sdpkpp(matches, k, match_score, gap_open, gap_extend);
+    // binary_search(..).unwrap_or(0) / Ok(ind) => ind + 1, Err(_) => len
+    auto bsearch = [&](size_t key, size_t* idx) {
+        auto it = std::lower_bound(lcs.path.begin(), lcs.path.end(), key);
+        if (it != lcs.path.end() && *it == key) {
+            *idx = (size_t)(it - lcs.path.begin());
+            return true;
+        }
+        return false;
+    };
+    size_t pre = 0, post = lcs.path.size(), t;
+    if (bsearch(sdp.path[0], &t)) pre = t;
+    if (bsearch(sdp.path.back(), &t)) post = t + 1;
+    std::vector<size_t> u;
+    for (size_t i = 0; i < pre; i++) u.push_back(lcs.path[i]);
+    for (size_t i = 0; i < sdp.path.size(); i++) u.push_back(sdp.path[i]);
+    for (size_t i = post; i < lcs.path.size(); i++) u.push_back(lcs.path[i]);
+    return u;
+}
+
+// sparse.rs:404-500
+std::vector<Match> expand_kmer_matches(const uint8_t* seq1, size_t n1, const uint8_t* seq2, size_t n2, size_t k,
+                                       const std::vector<Match>& sorted_matches, size_t allowed_mismatches) {
+    check_sorted(sorted_matches);
+    typedef std::pair<int32_t, int32_t> P;
+    std::map<int32_t, P> last_match_along_diagonal;  // HashMapFx in the reference (lookups only)
+    std::vector<Match> left(sorted_matches);
+    for (const Match& tm : sorted_matches) {
+        const int32_t diag = (int32_t)tm.first - (int32_t)tm.second;
+        const int32_t min_xy = (int32_t)std::min(tm.first, tm.second);
+        const P dflt((int32_t)tm.first - min_xy - 1, (int32_t)tm.second - min_xy - 1);
+        auto it = last_match_along_diagonal.find(diag);
+        const P last_match = it != last_match_along_diagonal.end() ? it->second : dflt;
+        size_t n_mismatches = 0;
+        P curr((int32_t)tm.first - 1, (int32_t)tm.second - 1);
+        for (;;) {
+            if (last_match >= curr) break;
+            n_mismatches += seq1[curr.first] == seq2[curr.second] ? 0 : 1;
+            if (n_mismatches > allowed_mismatches) break;
+            left.emplace_back((uint32_t)curr.first, (uint32_t)curr.second);
+            curr = P(curr.first - 1, curr.second - 1);
+        }
+        last_match_along_diagonal[diag] = P((int32_t)tm.first, (int32_t)tm.second);
+    }
+    std::sort(left.begin(), left.end());
+    std::vector<Match> expanded(left);
+    std::reverse(left.begin(), left.end());
+    std::map<int32_t, Match> next_match_along_diagonal;
+    for (const Match& tm : left) {
+        const int32_t diag = (int32_t)tm.first - (int32_t)tm.second;
+        const uint32_t room = std::min((uint32_t)n1 - tm.first, (uint32_t)n2 - tm.second);
+        const uint32_t max_inc = room > (uint32_t)k - 1 ? room - ((uint32_t)k - 1) : 0;  // saturating_sub
+        auto it = next_match_along_diagonal.find(diag);
+        const Match next_match = it != next_match_along_diagonal.end() ? it->second : Match(tm.first + max_inc, tm.second + max_inc);
+        size_t n_mismatches = 0;
+        Match curr(tm.first + 1, tm.second + 1);
+        for (;;) {
+            if (curr >= next_match) break;
+            n_mismatches += seq1[curr.first + k - 1] == seq2[curr.second + k - 1] ? 0 : 1;
+            if (n_mismatches > allowed_mismatches) break;
+            expanded.push_back(curr);
+            curr = Match(curr.first + 1, curr.second + 1);
+        }
+        next_match_along_diagonal[diag] = tm;
+    }
+    std::sort(expanded.begin(), expanded.end());
+    return expanded;
+}
+
 }  // namespace orc
 
 extern "C" uint64_t orc_find_kmer_matches(const uint8_t* x, uint64_t m, const uint8_t* y, uint64_t n,
@@ -243,4 +317,23 @@ extern "C" uint64_t orc_lcskpp(const uint32_t* matches_xy, uint64_t n_matches, u
     for (uint64_t i = 0; i < r.path.size() && i < cap; i++) path[i] = (uint32_t)r.path[i];
     *score = r.score;
     return r.path.size();
+}
+
+extern "C" uint64_t orc_sdpkpp_union_lcskpp_path(const uint32_t* matches_xy, uint64_t n_matches, uint32_t k,
+                                                 uint32_t match_score, int32_t gap_open, int32_t gap_extend,
+                                                 uint32_t* path, uint64_t cap) {
+    auto r = orc::sdpkpp_union_lcskpp_path(to_matches(matches_xy, n_matches), k, match_score, gap_open, gap_extend);
+    for (uint64_t i = 0; i < r.size() && i < cap; i++) path[i] = (uint32_t)r[i];
+    return r.size();
+}
+
+extern "C" uint64_t orc_expand_kmer_matches(const uint8_t* x, uint64_t m, const uint8_t* y, uint64_t n, uint32_t k,
+                                            const uint32_t* matches_xy, uint64_t n_matches, uint32_t allowed_mismatches,
+                                            uint32_t* out_xy, uint64_t cap) {
+    auto r = orc::expand_kmer_matches(x, m, y, n, k, to_matches(matches_xy, n_matches), allowed_mismatches);
+    for (uint64_t i = 0; i < r.size() && i < cap; i++) {
+        out_xy[2 * i] = r[i].first;
+        out_xy[2 * i + 1] = r[i].second;
+    }
+    return r.size();
 }

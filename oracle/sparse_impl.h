@@ -17,6 +17,10 @@ struct SparseResult {                          // sparse.rs:40-47
 SparseResult lcskpp(const std::vector<Match>& matches, size_t k);
 SparseResult sdpkpp(const std::vector<Match>& matches, size_t k, uint32_t match_score, int32_t gap_open,
                     int32_t gap_extend);
+std::vector<size_t> sdpkpp_union_lcskpp_path(const std::vector<Match>& matches, size_t k, uint32_t match_score,
+                                             int32_t gap_open, int32_t gap_extend);
+std::vector<Match> expand_kmer_matches(const uint8_t* seq1, size_t n1, const uint8_t* seq2, size_t n2, size_t k,
+                                       const std::vector<Match>& sorted_matches, size_t allowed_mismatches);
 std::vector<Match> find_kmer_matches(const uint8_t* seq1, size_t n1, const uint8_t* seq2, size_t n2, size_t k);
 }  // namespace orc
 #endif

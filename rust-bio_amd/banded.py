@@ -1,10 +1,11 @@
 """pairwise::banded::Aligner — host mirror of /root/reference/src/alignment/pairwise/banded.rs:122-1004
-on top of the C ABI (bg_align_banded_batch, bg_band_create_batch)."""
+on top of the C ABI (bg_align_banded_batch, bg_band_create_batch, bg_band_from_matches_batch,
+bg_align_banded_bands_batch)."""
 import ctypes as C
 
 import numpy as np
 
-from . import _lib
+from . import _lib, sparse
 from .pairwise import (MODE_CUSTOM, MODE_GLOBAL, MODE_LOCAL, MODE_SEMIGLOBAL, Scoring, to_alignment)
 
 MAX_CELLS = 5_000_000  # banded.rs:104
@@ -87,6 +88,89 @@ class Aligner:
         y, yo = _lib.concat(ys)
         out, ops = self.align_arrays(mode, x, xo, y, yo)
         return [to_alignment(out[p], ops) for p in range(len(xs))]
+
+    # ---- entry points that take the k-mer matches / the chain from the caller (banded.rs:294-401, 938-970):
+    # the band is built on the host from what they pass, then compute_alignment runs on the device
+    def bands_from_matches(self, mode, x_off, y_off, matches, match_off, path=None, path_off=None):
+        """Band::create_with_matches / create_from_match_path for a batch -> (band_off, start, end, cells)."""
+        xo = np.ascontiguousarray(x_off, dtype=np.uint64)
+        yo = np.ascontiguousarray(y_off, dtype=np.uint64)
+        n = len(xo) - 1
+        mm = np.ascontiguousarray(np.asarray(matches, dtype=np.uint32).reshape(-1, 2))
+        mo = np.ascontiguousarray(match_off, dtype=np.uint64)
+        boff = np.zeros(n + 1, dtype=np.uint64)
+        boff[1:] = np.cumsum(np.diff(yo).astype(np.uint64) + np.uint64(1))
+        start = np.zeros(int(boff[-1]), dtype=np.uint32)
+        end = np.zeros(int(boff[-1]), dtype=np.uint32)
+        cells = np.zeros(n, dtype=np.uint64)
+        pp = po = None
+        if path is not None:
+            pp = np.ascontiguousarray(path, dtype=np.uint32)
+            po = np.ascontiguousarray(path_off, dtype=np.uint64)
+        sc = self.scoring.to_c()
+        rc = _lib.lib().bg_band_from_matches_batch(C.byref(sc), mode, self.k, self.w, n, xo.ctypes.data, yo.ctypes.data,
+                                                   mm.ctypes.data, mo.ctypes.data,
+                                                   pp.ctypes.data if pp is not None else None,
+                                                   po.ctypes.data if po is not None else None, boff.ctypes.data,
+                                                   start.ctypes.data, end.ctypes.data, cells.ctypes.data)
+        assert rc != -1, "incoming matches must be sorted / path index out of bounds"  # the reference's panics
+        _lib.check(rc, "bg_band_from_matches_batch")
+        return boff, start, end, cells
+
+    def align_bands_arrays(self, mode, x, x_off, y, y_off, band_off, band_start, band_end, want_ops=True):
+        """compute_alignment (banded.rs:406-869) over explicit bands."""
+        xb, yb = _lib.as_u8(x), _lib.as_u8(y)
+        xo = np.ascontiguousarray(x_off, dtype=np.uint64)
+        yo = np.ascontiguousarray(y_off, dtype=np.uint64)
+        bo = np.ascontiguousarray(band_off, dtype=np.uint64)
+        bs = np.ascontiguousarray(band_start, dtype=np.uint32)
+        be = np.ascontiguousarray(band_end, dtype=np.uint32)
+        n = len(xo) - 1
+        out = np.zeros(n, dtype=_lib.ALN_DTYPE)
+        cap = int(xo[-1] + yo[-1]) + 4 * n + 8 if want_ops else 0
+        ops = np.zeros(max(cap, 1), dtype=np.uint8) if want_ops else None
+        used = C.c_uint64(0)
+        cells = np.zeros(n, dtype=np.uint64)
+        sc = self.scoring.to_c()
+        rc = _lib.lib().bg_align_banded_bands_batch(self.ctx.h, C.byref(sc), mode, n, xb.ctypes.data, xo.ctypes.data,
+                                                    yb.ctypes.data, yo.ctypes.data, bo.ctypes.data, bs.ctypes.data,
+                                                    be.ctypes.data, out.ctypes.data,
+                                                    ops.ctypes.data if want_ops else None, cap, C.byref(used),
+                                                    cells.ctypes.data)
+        self.last_cells = cells
+        _lib.check(rc, "bg_align_banded_bands_batch")
+        return out, ops
+
+    def _with_matches(self, mode, x, y, matches, path=None):
+        xb, yb = bytes(x), bytes(y)
+        xo, yo = np.array([0, len(xb)], dtype=np.uint64), np.array([0, len(yb)], dtype=np.uint64)
+        mm = np.asarray(matches, dtype=np.uint32).reshape(-1, 2)
+        bo, bs, be, _ = self.bands_from_matches(mode, xo, yo, mm, [0, len(mm)],
+                                                None if path is None else list(path),
+                                                None if path is None else [0, len(path)])
+        out, ops = self.align_bands_arrays(mode, xb, xo, yb, yo, bo, bs, be)
+        return to_alignment(out[0], ops)
+
+    def custom_with_matches(self, x, y, matches):  # banded.rs:313-321
+        return self._with_matches(MODE_CUSTOM, x, y, matches)
+
+    def custom_with_match_path(self, x, y, matches, path):  # banded.rs:391-401
+        return self._with_matches(MODE_CUSTOM, x, y, matches, path)
+
+    def custom_with_expanded_matches(self, x, y, matches, allowed_mismatches, use_lcskpp_union):  # banded.rs:338-389
+        expanded = (sparse.expand_kmer_matches(x, y, self.k, matches, allowed_mismatches)
+                    if allowed_mismatches is not None else list(matches))
+        if use_lcskpp_union:
+            ms = self.scoring.match_scores[0] if self.scoring.match_scores is not None else 2  # banded.rs:105
+            path = sparse.sdpkpp_union_lcskpp_path(expanded, self.k, ms, self.scoring.gap_open, self.scoring.gap_extend)
+            return self._with_matches(MODE_CUSTOM, x, y, expanded, path)
+        return self._with_matches(MODE_CUSTOM, x, y, expanded)
+
+    def custom_with_prehash(self, x, y, y_kmer_hash):  # banded.rs:294-302
+        return self._with_matches(MODE_CUSTOM, x, y, sparse.find_kmer_matches_seq2_hashed(x, y_kmer_hash, self.k))
+
+    def semiglobal_with_prehash(self, x, y, y_kmer_hash):  # banded.rs:938-970
+        return self._with_matches(MODE_SEMIGLOBAL, x, y, sparse.find_kmer_matches_seq2_hashed(x, y_kmer_hash, self.k))
 
     def custom(self, x, y): return self.align_batch(MODE_CUSTOM, [x], [y])[0]          # banded.rs:282
     def global_(self, x, y): return self.align_batch(MODE_GLOBAL, [x], [y])[0]         # banded.rs:872

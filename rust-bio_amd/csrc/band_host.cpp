@@ -181,6 +181,143 @@ bool sdpkpp_path(const std::vector<Match>& matches, size_t k_, uint32_t match_sc
     return true;
 }
 
+// lcskpp (sparse.rs:67-143): best chain of k-mer matches by covered bases.  dp values are the tuples
+// (score, predecessor index); the Fenwick tree holds (score, match index) with the tuple order.
+bool lcskpp_path(const std::vector<Match>& matches, size_t k_, std::vector<uint32_t>& path, uint32_t* score_out) {
+    path.clear();
+    if (score_out) *score_out = 0;
+    const uint32_t nm = (uint32_t)matches.size();
+    if (nm == 0) return true;
+    for (uint32_t i = 1; i < nm; i++)
+        if (!(matches[i - 1] < matches[i])) return false;
+    const uint32_t k = (uint32_t)k_;
+    std::vector<Event> ev;
+    ev.reserve(2 * (size_t)nm);
+    uint32_t span = 0;
+    for (uint32_t i = 0; i < nm; i++) {
+        ev.push_back({matches[i].x, matches[i].y, i + nm});
+        ev.push_back({matches[i].x + k, matches[i].y + k, i});
+        span = std::max(span, std::max(matches[i].x + k, matches[i].y + k));
+    }
+    std::sort(ev.begin(), ev.end());
+    std::vector<uint64_t> tree((size_t)span + 1, 0);  // score << 32 | index
+    std::vector<uint32_t> score(nm, 0);
+    std::vector<int32_t> back(nm, 0);
+    auto better = [](uint32_t s1, int32_t i1, uint32_t s2, int32_t i2) { return s1 > s2 || (s1 == s2 && i1 > i2); };
+    uint32_t best_score = k;
+    int32_t best_idx = 0;
+    for (const Event& e : ev) {
+        const uint32_t p = e.tag % nm;
+        if (e.tag >= nm) {
+            score[p] = k;
+            back[p] = -1;
+            uint64_t bp = 0;
+            for (size_t i = (size_t)e.y + 1; i > 0; i -= i & (~i + 1)) bp = std::max(bp, tree[i]);
+            if ((uint32_t)(bp >> 32) > 0) {
+                score[p] = k + (uint32_t)(bp >> 32);
+                back[p] = (int32_t)(uint32_t)bp;
+                if (better(score[p], (int32_t)p, best_score, best_idx)) {
+                    best_score = score[p];
+                    best_idx = (int32_t)p;
+                }
+            }
+        } else {
+            if (e.x > k && e.y > k) {
+                const Match key{e.x - k - 1, e.y - k - 1};
+                auto it = std::lower_bound(matches.begin(), matches.end(), key);
+                if (it != matches.end() && it->x == key.x && it->y == key.y) {
+                    const int32_t c = (int32_t)(it - matches.begin());
+                    if (better(score[c] + 1, c, score[p], back[p])) {
+                        score[p] = score[c] + 1;
+                        back[p] = c;
+                    }
+                    if (better(score[p], (int32_t)p, best_score, best_idx)) {
+                        best_score = score[p];
+                        best_idx = (int32_t)p;
+                    }
+                }
+            }
+            const uint64_t f = (uint64_t)score[p] << 32 | p;
+            for (size_t i = (size_t)e.y + 1; i < tree.size(); i += i & (~i + 1)) tree[i] = std::max(tree[i], f);
+        }
+    }
+    for (int32_t q = best_idx; q >= 0; q = back[q]) path.push_back((uint32_t)q);
+    std::reverse(path.begin(), path.end());
+    if (score_out) *score_out = best_score;
+    return true;
+}
+
+// sdpkpp_union_lcskpp_path (sparse.rs:297-329): lcskpp prefix + the sdpkpp path + lcskpp suffix
+bool sdpkpp_union_lcskpp_path(const std::vector<Match>& matches, size_t k, uint32_t match_score, int32_t gap_open,
+                              int32_t gap_extend, std::vector<uint32_t>& out) {
+    out.clear();
+    if (matches.empty()) return true;
+    std::vector<uint32_t> lcs, sdp;
+    if (!lcskpp_path(matches, k, lcs, nullptr) || !sdpkpp_path(matches, k, match_score, gap_open, gap_extend, sdp)) return false;
+    size_t pre = 0, post = lcs.size();
+    auto it = std::lower_bound(lcs.begin(), lcs.end(), sdp.front());
+    if (it != lcs.end() && *it == sdp.front()) pre = (size_t)(it - lcs.begin());
+    it = std::lower_bound(lcs.begin(), lcs.end(), sdp.back());
+    if (it != lcs.end() && *it == sdp.back()) post = (size_t)(it - lcs.begin()) + 1;
+    out.insert(out.end(), lcs.begin(), lcs.begin() + pre);
+    out.insert(out.end(), sdp.begin(), sdp.end());
+    out.insert(out.end(), lcs.begin() + post, lcs.end());
+    return true;
+}
+
+// expand_kmer_matches (sparse.rs:404-500): grow every match along its diagonal, to the left until the
+// previous match of the diagonal and then to the right until the next one, tolerating
+// `allowed_mismatches` mismatching bases per run.  The reference keeps "last/next match of a diagonal"
+// in hash maps; here the matches are bucketed by diagonal, which visits them in the same order.
+bool expand_kmer_matches(const uint8_t* x, size_t m, const uint8_t* y, size_t n, size_t k, const std::vector<Match>& sorted,
+                         size_t allowed_mismatches, std::vector<Match>& out) {
+    out.clear();
+    for (size_t i = 1; i < sorted.size(); i++)
+        if (!(sorted[i - 1] < sorted[i])) return false;
+    std::vector<Match> left(sorted);
+    {
+        // matches of one diagonal appear in increasing x in the sorted order
+        std::vector<std::pair<int64_t, uint32_t>> by_diag;  // (diagonal, index)
+        for (uint32_t i = 0; i < sorted.size(); i++) by_diag.push_back({(int64_t)sorted[i].x - (int64_t)sorted[i].y, i});
+        std::stable_sort(by_diag.begin(), by_diag.end(), [](auto& a, auto& b) { return a.first < b.first; });
+        for (size_t t = 0; t < by_diag.size(); t++) {
+            const Match cur = sorted[by_diag[t].second];
+            const bool has_prev = t > 0 && by_diag[t - 1].first == by_diag[t].first;
+            const int64_t mn = std::min(cur.x, cur.y);
+            // exclusive lower end of the walk: the previous match of the diagonal, or one before the diagonal's start
+            const int64_t stop_x = has_prev ? (int64_t)sorted[by_diag[t - 1].second].x : (int64_t)cur.x - mn - 1;
+            size_t miss = 0;
+            for (int64_t cx = (int64_t)cur.x - 1, cy = (int64_t)cur.y - 1; cx > stop_x; cx--, cy--) {
+                miss += x[cx] == y[cy] ? 0 : 1;
+                if (miss > allowed_mismatches) break;
+                left.push_back({(uint32_t)cx, (uint32_t)cy});
+            }
+        }
+    }
+    std::sort(left.begin(), left.end());
+    out = left;
+    {
+        std::vector<std::pair<int64_t, uint32_t>> by_diag;
+        for (uint32_t i = 0; i < left.size(); i++) by_diag.push_back({(int64_t)left[i].x - (int64_t)left[i].y, i});
+        std::stable_sort(by_diag.begin(), by_diag.end(), [](auto& a, auto& b) { return a.first < b.first; });
+        for (size_t t = 0; t < by_diag.size(); t++) {
+            const Match cur = left[by_diag[t].second];
+            const bool has_next = t + 1 < by_diag.size() && by_diag[t + 1].first == by_diag[t].first;
+            const uint32_t room = std::min((uint32_t)m - cur.x, (uint32_t)n - cur.y);
+            const uint32_t max_inc = room > (uint32_t)k - 1 ? room - ((uint32_t)k - 1) : 0;
+            const uint32_t stop_x = has_next ? left[by_diag[t + 1].second].x : cur.x + max_inc;  // exclusive
+            size_t miss = 0;
+            for (uint32_t cx = cur.x + 1, cy = cur.y + 1; cx < stop_x; cx++, cy++) {
+                miss += x[cx + k - 1] == y[cy + k - 1] ? 0 : 1;
+                if (miss > allowed_mismatches) break;
+                out.push_back({cx, cy});
+            }
+        }
+    }
+    std::sort(out.begin(), out.end());
+    return true;
+}
+
 // ---------------------------------------------------------------------------------- Band
 void Band::reset(size_t m, size_t n) {
     rows = m + 1;
@@ -301,26 +438,19 @@ std::atomic<uint64_t> g_prof[4];
 static inline uint64_t cpu_ns() { timespec ts; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts); return (uint64_t)ts.tv_sec * 1000000000ull + ts.tv_nsec; }
 #define PROF_T0 uint64_t pt0 = cpu_ns()
 #define PROF_LAP(i) do { uint64_t pt1 = cpu_ns(); g_prof[i] += pt1 - pt0; pt0 = pt1; } while (0)
-// Band::create (banded.rs:1278-1367)
-void Band::create(const uint8_t* x, size_t m, const uint8_t* y, size_t n, size_t k, size_t w, const ClipScores& cs,
-                  Workspace& ws) {
-    PROF_T0;
+// Band::create_from_match_path (banded.rs:1330-1367)
+void Band::create_from_match_path(size_t m, size_t n, size_t k, size_t w, const ClipScores& cs,
+                                  const std::vector<uint32_t>& path, const std::vector<Match>& mm) {
     reset(m, n);
-    find_kmer_matches(x, m, y, n, k, ws.matches);
-    PROF_LAP(0);
-    if (ws.matches.empty()) {  // banded.rs:1309-1313
+    if (mm.empty() || path.empty()) {  // banded.rs:1341-1344 (an empty path with matches panics in the reference)
         std::fill(start.begin(), start.end(), 0u);
         std::fill(end.begin(), end.end(), (uint32_t)rows);
         return;
     }
-    const uint32_t reward = (uint32_t)(cs.match_scores_some ? cs.match_score : 2);  // banded.rs:105,1315-1318
-    sdpkpp_path(ws.matches, k, reward, cs.gap_open, cs.gap_extend, ws.path);
-    PROF_LAP(1);
-    const std::vector<Match>& mm = ws.matches;
-    set_boundaries(mm[ws.path.front()], mm[ws.path.back()], k, w, cs);
+    set_boundaries(mm[path.front()], mm[path.back()], k, w, cs);
     bool have = false;
     Match prev{0, 0};
-    for (uint32_t idx : ws.path) {
+    for (uint32_t idx : path) {
         const Match cur = mm[idx];
         if (have && cur.x == prev.x + 1 && cur.y == prev.y + 1) {
             add_entry(prev.x + (uint32_t)k, prev.y + (uint32_t)k, w);
@@ -331,7 +461,35 @@ void Band::create(const uint8_t* x, size_t m, const uint8_t* y, size_t n, size_t
         prev = cur;
         have = true;
     }
+}
+
+// Band::create_with_matches (banded.rs:1301-1328); false if the matches are not sorted (sparse.rs:212-217)
+bool Band::create_with_matches(size_t m, size_t n, size_t k, size_t w, const ClipScores& cs, const std::vector<Match>& mm,
+                               Workspace& ws) {
+    if (mm.empty()) {  // banded.rs:1309-1313
+        reset(m, n);
+        std::fill(start.begin(), start.end(), 0u);
+        std::fill(end.begin(), end.end(), (uint32_t)rows);
+        return true;
+    }
+    for (size_t i = 1; i < mm.size(); i++)
+        if (!(mm[i - 1] < mm[i])) return false;
+    const uint32_t reward = (uint32_t)(cs.match_scores_some ? cs.match_score : 2);  // banded.rs:105,1315-1318
+    PROF_T0;
+    sdpkpp_path(mm, k, reward, cs.gap_open, cs.gap_extend, ws.path);
+    PROF_LAP(1);
+    create_from_match_path(m, n, k, w, cs, ws.path, mm);
     PROF_LAP(2);
+    return true;
+}
+
+// Band::create (banded.rs:1278-1287)
+void Band::create(const uint8_t* x, size_t m, const uint8_t* y, size_t n, size_t k, size_t w, const ClipScores& cs,
+                  Workspace& ws) {
+    PROF_T0;
+    find_kmer_matches(x, m, y, n, k, ws.matches);
+    PROF_LAP(0);
+    create_with_matches(m, n, k, w, cs, ws.matches, ws);
 }
 
 }  // namespace bgband

@@ -25,8 +25,14 @@ struct Workspace {
 };
 
 void find_kmer_matches(const uint8_t* x, size_t m, const uint8_t* y, size_t n, size_t k, std::vector<Match>& out);
+// sparse.rs:188-295 / 67-143 / 297-329 / 404-500; `false` = the matches are not sorted (the reference asserts)
 bool sdpkpp_path(const std::vector<Match>& matches, size_t k, uint32_t match_score, int32_t gap_open,
                  int32_t gap_extend, std::vector<uint32_t>& path);
+bool lcskpp_path(const std::vector<Match>& matches, size_t k, std::vector<uint32_t>& path, uint32_t* score);
+bool sdpkpp_union_lcskpp_path(const std::vector<Match>& matches, size_t k, uint32_t match_score, int32_t gap_open,
+                              int32_t gap_extend, std::vector<uint32_t>& path);
+bool expand_kmer_matches(const uint8_t* x, size_t m, const uint8_t* y, size_t n, size_t k, const std::vector<Match>& sorted,
+                         size_t allowed_mismatches, std::vector<Match>& out);
 
 struct Band {
     size_t rows = 0, cols = 0;
@@ -38,6 +44,10 @@ struct Band {
     void set_boundaries(Match first, Match last, size_t k, size_t w, const ClipScores& cs);
     void create(const uint8_t* x, size_t m, const uint8_t* y, size_t n, size_t k, size_t w, const ClipScores& cs,
                 Workspace& ws);
+    bool create_with_matches(size_t m, size_t n, size_t k, size_t w, const ClipScores& cs, const std::vector<Match>& matches,
+                             Workspace& ws);
+    void create_from_match_path(size_t m, size_t n, size_t k, size_t w, const ClipScores& cs,
+                                const std::vector<uint32_t>& path, const std::vector<Match>& matches);
     uint64_t num_cells() const;
     bool monotone() const;  // starts and ends of non-empty columns never decrease
 };

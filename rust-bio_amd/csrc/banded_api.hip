@@ -4,6 +4,7 @@
 // MAX_CELLS early-out (banded.rs:104,407-420), then K3 + K4 over sub-batches.
 #include <algorithm>
 #include <atomic>
+#include <functional>
 #include <thread>
 
 #include "band_host.h"
@@ -100,13 +101,12 @@ void rows_from_columns(const bgband::Band& b, HostPair& hp, int2* rowc, uint32_t
     if (covered != hp.cells || off > 0xFFFFFFF0ull) hp.flags = BP_UNSUPPORTED;
 }
 
-void build_pair(const bgband::ClipScores& cs, uint32_t k, uint32_t w, const uint8_t* x, uint32_t m, const uint8_t* y,
-                uint32_t n, bgband::Band& band, bgband::Workspace& ws, HostPair& hp, int2* rowc, uint32_t* row_off) {
+// everything the device needs to know about one pair's band (the band itself is already in `band`)
+void build_pair(uint32_t m, uint32_t n, const bgband::Band& band, HostPair& hp, int2* rowc, uint32_t* row_off) {
     hp.m = m;
     hp.n = n;
     hp.flags = BP_OK;
     hp.tb_bytes = 0;
-    band.create(x, m, y, n, k, w, cs, ws);
     hp.cells = band.num_cells();
     hp.start_0 = band.start[0];
     hp.end_0 = band.end[0];
@@ -238,10 +238,13 @@ extern "C" int bg_band_create_batch(const bg_scoring_t* sc, int mode, uint32_t k
     return BG_OK;
 }
 
-extern "C" int bg_align_banded_batch(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint32_t k, uint32_t w,
-                                     uint64_t n_pairs, const uint8_t* x, const uint64_t* x_off, const uint8_t* y,
-                                     const uint64_t* y_off, bg_alignment_t* out, uint8_t* ops_buf, uint64_t ops_cap,
-                                     uint64_t* ops_used, uint64_t* band_cells) {
+// `make_band(p, band, ws)` fills the band of pair p (called from host threads); false = invalid input
+using BandMaker = std::function<bool(uint64_t, bgband::Band&, bgband::Workspace&)>;
+
+static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint64_t n_pairs, const uint8_t* x,
+                             const uint64_t* x_off, const uint8_t* y, const uint64_t* y_off, bg_alignment_t* out,
+                             uint8_t* ops_buf, uint64_t ops_cap, uint64_t* ops_used, uint64_t* band_cells,
+                             const BandMaker& make_band) {
     if (!ctx || !sc || mode < BG_MODE_CUSTOM || mode > BG_MODE_LOCAL) return BG_ERR_INVALID_ARG;
     int rc = check_scoring(sc);
     if (rc) return rc;
@@ -348,15 +351,21 @@ extern "C" int bg_align_banded_batch(bg_ctx* ctx, const bg_scoring_t* sc, int mo
         int2* h_rowc = (int2*)S.h_rowc;
         uint32_t* h_roff = (uint32_t*)S.h_roff;
         BandPair* dp = (BandPair*)S.h_pairs;
+        std::atomic<bool> bad_input{false};
         parallel_for(want, grain, [&](unsigned, uint64_t lo, uint64_t hi) {
             bgband::Band band;
             bgband::Workspace ws;
             for (uint64_t q = lo; q < hi; q++) {
                 const uint64_t p = p0 + q;
-                build_pair(cs, k, w, x + x_off[p], (uint32_t)(x_off[p + 1] - x_off[p]), y + y_off[p],
-                           (uint32_t)(y_off[p + 1] - y_off[p]), band, ws, hp[q], h_rowc + row0[q], h_roff + row0[q]);
+                const uint32_t m = (uint32_t)(x_off[p + 1] - x_off[p]), n = (uint32_t)(y_off[p + 1] - y_off[p]);
+                if (!make_band(p, band, ws) || band.start.size() != (size_t)n + 1) {
+                    bad_input = true;
+                    band.reset(m, n);
+                }
+                build_pair(m, n, band, hp[q], h_rowc + row0[q], h_roff + row0[q]);
             }
         });
+        if (bad_input) return BG_ERR_INVALID_ARG;
         lap("band build");
         if (trace) { fprintf(stderr, "[bg banded] cpu-ms: kmers %.1f sdp %.1f band %.1f (threads %u)\n", bgband::g_prof[0] / 1e6, bgband::g_prof[1] / 1e6, bgband::g_prof[2] / 1e6, host_threads()); }
         // take as many pairs as fit the scratch budget (the rest is rebuilt with the next sub-batch)
@@ -456,4 +465,142 @@ extern "C" int bg_align_banded_batch(bg_ctx* ctx, const bg_scoring_t* sc, int mo
     if (ops_used) *ops_used = used;
     lap("compact ops");
     return status;
+}
+
+extern "C" int bg_align_banded_batch(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint32_t k, uint32_t w,
+                                     uint64_t n_pairs, const uint8_t* x, const uint64_t* x_off, const uint8_t* y,
+                                     const uint64_t* y_off, bg_alignment_t* out, uint8_t* ops_buf, uint64_t ops_cap,
+                                     uint64_t* ops_used, uint64_t* band_cells) {
+    if (!sc || mode < BG_MODE_CUSTOM || mode > BG_MODE_LOCAL) return BG_ERR_INVALID_ARG;
+    const bgband::ClipScores cs = clip_scores(sc, mode);
+    return banded_batch_impl(ctx, sc, mode, n_pairs, x, x_off, y, y_off, out, ops_buf, ops_cap, ops_used, band_cells,
+                             [&](uint64_t p, bgband::Band& band, bgband::Workspace& ws) {
+                                 band.create(x + x_off[p], (size_t)(x_off[p + 1] - x_off[p]), y + y_off[p],
+                                             (size_t)(y_off[p + 1] - y_off[p]), k, w, cs, ws);
+                                 return true;
+                             });
+}
+
+// compute_alignment (banded.rs:406-869) over caller-supplied bands: n + 1 half-open row ranges per pair at
+// band_off[p] — what custom_with_matches / custom_with_match_path / custom_with_expanded_matches /
+// *_with_prehash (banded.rs:294-401, 938-970) reach after building their band on the host.
+extern "C" int bg_align_banded_bands_batch(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint64_t n_pairs, const uint8_t* x,
+                                           const uint64_t* x_off, const uint8_t* y, const uint64_t* y_off,
+                                           const uint64_t* band_off, const uint32_t* band_start, const uint32_t* band_end,
+                                           bg_alignment_t* out, uint8_t* ops_buf, uint64_t ops_cap, uint64_t* ops_used,
+                                           uint64_t* band_cells) {
+    if (n_pairs && (!band_off || !band_start || !band_end)) return BG_ERR_INVALID_ARG;
+    return banded_batch_impl(ctx, sc, mode, n_pairs, x, x_off, y, y_off, out, ops_buf, ops_cap, ops_used, band_cells,
+                             [&](uint64_t p, bgband::Band& band, bgband::Workspace&) {
+                                 const size_t m = (size_t)(x_off[p + 1] - x_off[p]), n = (size_t)(y_off[p + 1] - y_off[p]);
+                                 band.reset(m, n);
+                                 for (size_t j = 0; j <= n; j++) {
+                                     band.start[j] = band_start[band_off[p] + j];
+                                     band.end[j] = band_end[band_off[p] + j];
+                                     if (band.end[j] > m + 1 && band.end[j] > band.start[j]) return false;
+                                 }
+                                 return true;
+                             });
+}
+
+namespace {
+std::vector<bgband::Match> to_matches(const uint32_t* xy, uint64_t n) {
+    std::vector<bgband::Match> v(n);
+    for (uint64_t i = 0; i < n; i++) v[i] = {xy[2 * i], xy[2 * i + 1]};
+    return v;
+}
+}  // namespace
+
+// Band::create_with_matches (banded.rs:1301-1328; path == NULL) or Band::create_from_match_path
+// (1330-1367) for a batch; matches of pair p are matches_xy[2*match_off[p] .. 2*match_off[p+1]).
+extern "C" int bg_band_from_matches_batch(const bg_scoring_t* sc, int mode, uint32_t k, uint32_t w, uint64_t n_pairs,
+                                          const uint64_t* x_off, const uint64_t* y_off, const uint32_t* matches_xy,
+                                          const uint64_t* match_off, const uint32_t* path, const uint64_t* path_off,
+                                          const uint64_t* band_off, uint32_t* start, uint32_t* end, uint64_t* band_cells) {
+    if (!sc || !x_off || !y_off || !match_off || (n_pairs && (!band_off || !start || !end))) return BG_ERR_INVALID_ARG;
+    if (path && !path_off) return BG_ERR_INVALID_ARG;
+    int rc = check_scoring(sc);
+    if (rc) return rc;
+    const bgband::ClipScores cs = clip_scores(sc, mode);
+    std::atomic<bool> bad{false};
+    parallel_for(n_pairs, 4, [&](unsigned, uint64_t lo, uint64_t hi) {
+        bgband::Band band;
+        bgband::Workspace ws;
+        for (uint64_t p = lo; p < hi; p++) {
+            const uint32_t m = (uint32_t)(x_off[p + 1] - x_off[p]), n = (uint32_t)(y_off[p + 1] - y_off[p]);
+            const std::vector<bgband::Match> mm = to_matches(matches_xy + 2 * match_off[p], match_off[p + 1] - match_off[p]);
+            bool ok = true;
+            if (path) {
+                std::vector<uint32_t> pp(path + path_off[p], path + path_off[p + 1]);
+                for (uint32_t idx : pp) ok = ok && idx < mm.size();
+                if (!mm.empty() && pp.empty()) ok = false;  // path[0] panics in the reference
+                if (ok) band.create_from_match_path(m, n, k, w, cs, pp, mm);
+            } else {
+                ok = band.create_with_matches(m, n, k, w, cs, mm, ws);
+            }
+            if (!ok) {
+                bad = true;
+                continue;
+            }
+            memcpy(start + band_off[p], band.start.data(), (size_t)(n + 1) * 4);
+            memcpy(end + band_off[p], band.end.data(), (size_t)(n + 1) * 4);
+            if (band_cells) band_cells[p] = band.num_cells();
+        }
+    });
+    return bad ? BG_ERR_INVALID_ARG : BG_OK;
+}
+
+// ---- sparse.rs helpers on the host (callers of custom_with_matches / _expanded_matches need them) ----
+// All take matches as (x, y) uint32 pairs; return the number of entries the result has (which may exceed
+// `cap`: call again with a larger buffer), or UINT64_MAX when the reference would assert (unsorted matches).
+extern "C" uint64_t bg_sparse_find_kmer_matches(const uint8_t* x, uint64_t m, const uint8_t* y, uint64_t n, uint32_t k,
+                                                uint32_t* out_xy, uint64_t cap) {
+    std::vector<bgband::Match> mm;
+    bgband::find_kmer_matches(x, m, y, n, k, mm);
+    for (uint64_t i = 0; i < mm.size() && i < cap; i++) {
+        out_xy[2 * i] = mm[i].x;
+        out_xy[2 * i + 1] = mm[i].y;
+    }
+    return mm.size();
+}
+
+extern "C" uint64_t bg_sparse_sdpkpp(const uint32_t* matches_xy, uint64_t n_matches, uint32_t k, uint32_t match_score,
+                                     int32_t gap_open, int32_t gap_extend, uint32_t* path, uint64_t cap) {
+    std::vector<uint32_t> pp;
+    const auto mm = to_matches(matches_xy, n_matches);
+    for (size_t i = 1; i < mm.size(); i++)
+        if (!(mm[i - 1] < mm[i])) return UINT64_MAX;
+    if (!bgband::sdpkpp_path(mm, k, match_score, gap_open, gap_extend, pp)) return UINT64_MAX;
+    for (uint64_t i = 0; i < pp.size() && i < cap; i++) path[i] = pp[i];
+    return pp.size();
+}
+
+extern "C" uint64_t bg_sparse_lcskpp(const uint32_t* matches_xy, uint64_t n_matches, uint32_t k, uint32_t* path, uint64_t cap,
+                                     uint32_t* score) {
+    std::vector<uint32_t> pp;
+    if (!bgband::lcskpp_path(to_matches(matches_xy, n_matches), k, pp, score)) return UINT64_MAX;
+    for (uint64_t i = 0; i < pp.size() && i < cap; i++) path[i] = pp[i];
+    return pp.size();
+}
+
+extern "C" uint64_t bg_sparse_sdpkpp_union_lcskpp_path(const uint32_t* matches_xy, uint64_t n_matches, uint32_t k,
+                                                       uint32_t match_score, int32_t gap_open, int32_t gap_extend,
+                                                       uint32_t* path, uint64_t cap) {
+    std::vector<uint32_t> pp;
+    if (!bgband::sdpkpp_union_lcskpp_path(to_matches(matches_xy, n_matches), k, match_score, gap_open, gap_extend, pp))
+        return UINT64_MAX;
+    for (uint64_t i = 0; i < pp.size() && i < cap; i++) path[i] = pp[i];
+    return pp.size();
+}
+
+extern "C" uint64_t bg_sparse_expand_kmer_matches(const uint8_t* x, uint64_t m, const uint8_t* y, uint64_t n, uint32_t k,
+                                                  const uint32_t* matches_xy, uint64_t n_matches, uint32_t allowed_mismatches,
+                                                  uint32_t* out_xy, uint64_t cap) {
+    std::vector<bgband::Match> out;
+    if (!bgband::expand_kmer_matches(x, m, y, n, k, to_matches(matches_xy, n_matches), allowed_mismatches, out)) return UINT64_MAX;
+    for (uint64_t i = 0; i < out.size() && i < cap; i++) {
+        out_xy[2 * i] = out[i].x;
+        out_xy[2 * i + 1] = out[i].y;
+    }
+    return out.size();
 }

@@ -4,7 +4,7 @@ windows -> best hit per read.  The reference has no such function; callers compo
 same three calls (/root/reference/src/lib.rs:129-165, benches/fmindex.rs:20-38).  Everything
 between the calls is index arithmetic on device tensors (torch), nothing leaves HBM.
 
-Definition used here (tests/test_gpu_pipeline.py restates it with the CPU oracle):
+Definition used here (tests/test_gpu_pipeline.py restates it on the CPU):
   * seeds: the windows read[o : o + seed_len] for o = 0, stride, 2*stride, ... (whole windows only);
   * a seed votes when its search is Complete and its interval holds at most `max_occ` rows;
   * each hit position p of a seed at offset o proposes the read start s = p - o; proposals that

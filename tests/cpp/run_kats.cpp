@@ -107,6 +107,26 @@ static void kat_batches_equal_single_calls() {
     for (size_t p = 0; p < pairs.size(); p++) CHECK(batch[p] == aligner.local(pairs[p].first, pairs[p].second));
 }
 
+// ---- banded entry points that take matches / a prehash (banded.rs:294-401; doctest banded.rs:46-54, test 1464-1466)
+static void kat_banded_with_matches_and_prehash() {
+    const Text x = text("AGCACACGTGTGCGCTATACAGTAAGTAGTAGTACACGTGTCACAGTTGTACTAGCATGAC");
+    const Text y = text("AGCACACGTGTGCGCTATACAGTACACGTGTCACAGTTGTACTAGCATGAC");
+    auto score = [](uint8_t a, uint8_t b) { return a == b ? 1 : -1; };
+    const size_t k = 8, w = 6;
+    auto aligner = pairwise::banded::Aligner::new_(-5, -1, score, k, w);
+    const auto y_kmers_hash = sparse::hash_kmers(y, k);
+    CHECK(aligner.semiglobal_with_prehash(x, y, y_kmers_hash) == aligner.semiglobal(x, y));
+    CHECK(aligner.custom_with_prehash(x, y, y_kmers_hash) == aligner.custom(x, y));
+    const auto matches = sparse::find_kmer_matches(x, y, k);
+    CHECK(aligner.custom_with_matches(x, y, matches) == aligner.custom(x, y));
+    // no matches -> the full matrix (banded.rs:1309-1313; what the fuzz target compares against)
+    auto full = pairwise::Aligner::new_(-5, -1, score);
+    CHECK(aligner.custom_with_matches(x, y, {}) == full.custom(x, y));
+    CHECK(aligner.custom_with_expanded_matches(x, y, matches, std::optional<size_t>(1), true).score ==
+          aligner.custom_with_expanded_matches(x, y, matches, std::nullopt, false).score);
+    CHECK(panics([&] { aligner.custom_with_matches(x, y, {{5, 5}, {1, 1}}); }));  // unsorted
+}
+
 int main(int argc, char** argv) {
     const char* filter = argc > 1 ? argv[1] : "";
     int ran = 0;
@@ -126,6 +146,7 @@ int main(int argc, char** argv) {
     for (auto& k : kKats) run(k.name, k.fn);
     run("kat_panics", kat_panics);
     run("kat_batches_equal_single_calls", kat_batches_equal_single_calls);
+    run("kat_banded_with_matches_and_prehash", kat_banded_with_matches_and_prehash);
     std::printf("%d tests, %d failed\n", ran, g_failed);
     return g_failed ? 1 : 0;
 }

@@ -160,3 +160,66 @@ def test_blosum62_banded():
               yclip_prefix=MIN_SCORE, yclip_suffix=MIN_SCORE)
     for mode in ("local", "semiglobal"):
         differential(kw, False, mode, 4, 6, xs, ys)
+
+
+# ---- the entry points that take matches / chains / prehashes from the caller (banded.rs:294-401, 938-970)
+def _rand_pair2(rng, n=400, nsub=30):
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    y = acgt[rng.integers(0, 4, size=n)]
+    x = y.copy()
+    x[rng.integers(0, n, size=nsub)] = acgt[rng.integers(0, 4, size=nsub)]
+    cut = int(rng.integers(0, n // 4))
+    return np.delete(x, np.arange(cut, cut + int(rng.integers(0, 8)))).tobytes(), y.tobytes()
+
+
+def ops_tokens(al):
+    return list(al.operations)
+
+
+def test_custom_with_matches_family_vs_oracle():
+    from rust_bio_amd import sparse
+    from rust_bio_amd.banded import Aligner as BAligner
+    rng = np.random.default_rng(41)
+    sc = Scoring.from_scores(-5, -1, 1, -1).xclip(-6).yclip(-2)
+    osc = orc.make_scoring(-5, -1, 1, -1, xclip_prefix=-6, xclip_suffix=-6, yclip_prefix=-2, yclip_suffix=-2)
+    k, w = 7, 5
+    al = BAligner.with_scoring(sc, k, w)
+    for it in range(12):
+        x, y = _rand_pair2(rng)
+        mm = sparse.find_kmer_matches(x, y, k)
+        # custom_with_matches == custom; [] == the full matrix (the fuzz target's reference run)
+        a = al.custom_with_matches(x, y, mm)
+        r = orc.banded_align_with(osc, "custom", k, w, x, y, mm)
+        assert a.score == r["score"] and ops_tokens(a) == r["ops"]
+        assert a.score == al.custom(x, y).score and ops_tokens(a) == ops_tokens(al.custom(x, y))
+        e = al.custom_with_matches(x, y, [])
+        rf = orc.align(osc, "custom", x, y)
+        assert e.score == rf["score"] and ops_tokens(e) == rf["ops"]
+        if not mm:
+            continue
+        # custom_with_match_path with the lcskpp chain
+        path, _ = sparse.lcskpp(mm, k)
+        a = al.custom_with_match_path(x, y, mm, path)
+        r = orc.banded_align_with(osc, "custom", k, w, x, y, mm, path=path)
+        assert a.score == r["score"] and ops_tokens(a) == r["ops"]
+        # custom_with_expanded_matches, all four flag combinations
+        for allowed in (None, 1):
+            for union in (False, True):
+                a = al.custom_with_expanded_matches(x, y, mm, allowed, union)
+                r = orc.banded_align_with(osc, "custom", k, w, x, y, mm, expanded=True, allowed_mismatches=allowed,
+                                          use_lcskpp_union=union)
+                assert a.score == r["score"] and ops_tokens(a) == r["ops"], (it, allowed, union)
+
+
+def test_with_prehash_equals_plain_calls():
+    # banded.rs:53,89 (doctest) and 1464-1466: *_with_prehash(x, y, hash_kmers(y, k)) == the plain call
+    from rust_bio_amd import sparse
+    from rust_bio_amd.banded import Aligner as BAligner
+    x = b"AGCACACGTGTGCGCTATACAGTAAGTAGTAGTACACGTGTCACAGTTGTACTAGCATGAC"
+    y = b"AGCACACGTGTGCGCTATACAGTACACGTGTCACAGTTGTACTAGCATGAC"
+    al = BAligner.new(-5, -1, lambda a, b: 1 if a == b else -1, 8, 6)
+    h = sparse.hash_kmers(y, 8)
+    s1, s2 = al.semiglobal(x, y), al.semiglobal_with_prehash(x, y, h)
+    assert s1.score == s2.score and ops_tokens(s1) == ops_tokens(s2) and s2.mode == s1.mode
+    c1, c2 = al.custom(x, y), al.custom_with_prehash(x, y, h)
+    assert c1.score == c2.score and ops_tokens(c1) == ops_tokens(c2)

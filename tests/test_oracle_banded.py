@@ -154,3 +154,54 @@ def test_band_monotone_on_random_inputs():
         st, en, cells = orc.band_create(sc, k, w, xs[0], ys[0])
         ne = [(int(s), int(e)) for s, e in zip(st, en) if e > s]
         assert all(a[0] <= b[0] and a[1] <= b[1] for a, b in zip(ne, ne[1:])), (trial, k, w)
+
+
+# ---- sparse.rs helpers behind custom_with_expanded_matches (banded.rs:338-389)
+def test_expand_kmer_matches_kat():
+    g = load("sparse_kats.json")["expand_kmer_matches"]
+    for c in g["cases"]:
+        x, y = c["x"].encode(), c["y"].encode()
+        assert orc.find_kmer_matches(x, y, g["k"]).tolist() == c["matches"]
+        got = orc.expand_kmer_matches(x, y, g["k"], c["matches"], g["allowed_mismatches"])
+        assert got == [tuple(m) for m in c["expanded"]], c
+
+
+def test_union_path_contains_sdpkpp_path():
+    import numpy as np
+    rng = np.random.default_rng(8)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    for _ in range(30):
+        y = acgt[rng.integers(0, 4, size=300)]
+        x = y.copy()
+        x[rng.integers(0, 300, size=20)] = acgt[rng.integers(0, 4, size=20)]
+        mm = orc.find_kmer_matches(x.tobytes(), y.tobytes(), 6)
+        if not len(mm):
+            continue
+        sdp = orc.sdpkpp(mm, 6, 1, -5, -1)[0]
+        lcs = orc.lcskpp(mm, 6)[0]
+        uni = orc.sdpkpp_union_lcskpp_path(mm, 6, 1, -5, -1)
+        # sparse.rs:297-329: lcskpp prefix + whole sdpkpp path + lcskpp suffix
+        i = uni.index(sdp[0])
+        assert uni[i:i + len(sdp)] == sdp
+        assert uni[:i] == lcs[:i] and set(uni[i + len(sdp):]) <= set(lcs)
+
+
+def test_custom_with_matches_equals_custom():
+    # banded.rs:313-321 with matches = find_kmer_matches(x, y, k) is `custom` (282-285)
+    import numpy as np
+    rng = np.random.default_rng(9)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    sc = orc.make_scoring(-5, -1, 1, -1, xclip_prefix=-3, yclip_suffix=-2)
+    for _ in range(20):
+        y = acgt[rng.integers(0, 4, size=200)].tobytes()
+        xa = np.frombuffer(y, dtype=np.uint8).copy()
+        xa[rng.integers(0, 200, size=12)] = acgt[rng.integers(0, 4, size=12)]
+        x = xa.tobytes()
+        mm = orc.find_kmer_matches(x, y, 8)
+        a = orc.banded_align(sc, "custom", 8, 6, x, y)
+        b = orc.banded_align_with(sc, "custom", 8, 6, x, y, mm)
+        assert (a["score"], a["ops"]) == (b["score"], b["ops"])
+        # an empty match list is the full matrix (banded.rs:1309-1313; the fuzz target's reference run)
+        full = orc.align(sc, "custom", x, y)
+        c = orc.banded_align_with(sc, "custom", 8, 6, x, y, [])
+        assert (c["score"], c["ops"]) == (full["score"], full["ops"])
