@@ -1,0 +1,717 @@
+// Band construction on the device — `Band::create` (/root/reference/src/alignment/pairwise/banded.rs:1278-1367)
+// for a sub-batch of pairs, so that the banded pipeline no longer waits for host threads:
+//
+//   B1 kmer_match_kernel   sparse::find_kmer_matches (sparse.rs:337-402): all exact k-mer matches of a pair,
+//                          sorted by (x, y).  One block per pair: a chained hash table of y's k-mers in
+//                          global scratch, every x position probes it, counts -> block scan -> fill.
+//   B2 chain_kernel        sparse::sdpkpp (sparse.rs:188-295): the best chain under the affine gap
+//                          penalty, with the reference's tie-breaking (derived Ord of PrevPtr and of the
+//                          (score, index) dp tuples).  One wavefront per pair; the prefix-max Fenwick tree
+//                          lives in LDS over rank-compressed y coordinates, its log(n) nodes are read /
+//                          updated by different lanes at once, the event order is a two-pointer merge.
+//   B3 band_kernel         Band::create_from_match_path (banded.rs:1330-1367) with set_boundaries /
+//                          add_kmer / add_gap / add_entry.  Every one of them only lowers start[j] or
+//                          raises end[j], so the order does not matter: lanes take path elements and
+//                          apply them with atomicMin / atomicMax.
+//   B4 band_rows_kernel    column ranges -> per-row column ranges, traceback offsets, cell count, flags
+//                          (what banded_api.hip computes on the host for host-built bands).
+//
+// Pairs the device path does not cover (more matches than the LDS tree holds, overlong hash chains)
+// are flagged and rebuilt by the host builder (band_host.cpp); results are identical either way —
+// tests/test_gpu_banded.py compares the two builders band by band.
+#include "banded_kernels.h"
+#include "band_device.h"
+
+namespace bgband_dev {
+
+namespace {
+
+constexpr uint32_t kNone = 0xFFFFFFFFu;
+
+__device__ __forceinline__ uint64_t kmer_hash(const uint8_t* s, uint32_t k) {
+    uint64_t h = 0xCBF29CE484222325ull;
+    for (uint32_t t = 0; t < k; t++) h = (h ^ s[t]) * 0x100000001B3ull + 0x9E3779B97F4A7C15ull;
+    return h;
+}
+__device__ __forceinline__ bool kmer_equal(const uint8_t* a, const uint8_t* b, uint32_t k) {
+    for (uint32_t t = 0; t < k; t++)
+        if (a[t] != b[t]) return false;
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------- B1
+__global__ __launch_bounds__(256) void kmer_match_kernel(const BandDevArgs a) {
+    const uint32_t pair = blockIdx.x;
+    const uint64_t xo = a.x_off[a.pair0 + pair], yo = a.y_off[a.pair0 + pair];
+    const uint32_t m = (uint32_t)(a.x_off[a.pair0 + pair + 1] - xo), n = (uint32_t)(a.y_off[a.pair0 + pair + 1] - yo);
+    const uint8_t* x = a.x + xo;
+    const uint8_t* y = a.y + yo;
+    const uint32_t k = a.k;
+    BandDevPair* st = a.state + pair;
+    uint32_t* head = a.head + (size_t)pair * a.table_size;
+    uint32_t* next = a.next + (size_t)pair * a.max_n;
+    uint64_t* hy = a.hy + (size_t)pair * a.max_n;
+    uint32_t* cnt = a.cnt + (size_t)pair * (a.max_m + 1);
+    uint32_t* mx = a.mx + (size_t)pair * a.cap_matches;
+    uint32_t* my = a.my + (size_t)pair * a.cap_matches;
+    __shared__ uint32_t s_part[256];
+    __shared__ uint32_t s_flag;
+    if (threadIdx.x == 0) s_flag = 0;
+    const uint32_t nky = n >= k && k ? n - k + 1 : 0, nkx = m >= k && k ? m - k + 1 : 0;
+    for (uint32_t i = threadIdx.x; i < a.table_size; i += blockDim.x) head[i] = kNone;
+    __syncthreads();
+    const uint32_t shift = 64 - a.table_bits;
+    for (uint32_t i = threadIdx.x; i < nky; i += blockDim.x) {
+        const uint64_t h = kmer_hash(y + i, k);
+        hy[i] = h;
+        next[i] = atomicExch(&head[(h * 0xD6E8FEB86659FD93ull) >> shift], i);
+    }
+    __syncthreads();
+    // every thread owns a contiguous range of x positions (the same in both passes)
+    const uint32_t per = (nkx + blockDim.x - 1) / blockDim.x;
+    const uint32_t p0 = min(nkx, threadIdx.x * per), p1 = min(nkx, p0 + per);
+    uint32_t mine = 0;
+    for (uint32_t p = p0; p < p1; p++) {
+        const uint64_t h = kmer_hash(x + p, k);
+        uint32_t c = 0;
+        for (uint32_t i = head[(h * 0xD6E8FEB86659FD93ull) >> shift]; i != kNone; i = next[i])
+            if (hy[i] == h && kmer_equal(y + i, x + p, k)) c++;
+        cnt[p] = c;
+        mine += c;
+        if (c > kMaxMatchesPerKmer) s_flag = 1;  // the in-place sort below is quadratic: leave it to the host
+    }
+    s_part[threadIdx.x] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (uint32_t t = 0; t < blockDim.x; t++) {
+            const uint32_t v = s_part[t];
+            s_part[t] = run;
+            run += v;
+        }
+        st->n_matches = run;
+        st->flags = (run > a.cap_matches || run > kMaxChainMatches || s_flag || k == 0 || m + k >= (1u << 20)) ? BP_HOST_FALLBACK : BP_OK;
+    }
+    __syncthreads();
+    if (st->flags != BP_OK) return;
+    uint32_t off = s_part[threadIdx.x];
+    for (uint32_t p = p0; p < p1; p++) {
+        const uint32_t c = cnt[p];
+        if (!c) continue;
+        const uint64_t h = kmer_hash(x + p, k);
+        uint32_t w = 0;
+        for (uint32_t i = head[(h * 0xD6E8FEB86659FD93ull) >> shift]; i != kNone; i = next[i])
+            if (hy[i] == h && kmer_equal(y + i, x + p, k)) {  // insertion sort by y (chains are in arbitrary order)
+                uint32_t t = w++;
+                while (t > 0 && my[off + t - 1] > i) {
+                    my[off + t] = my[off + t - 1];
+                    t--;
+                }
+                my[off + t] = i;
+            }
+        for (uint32_t t = 0; t < c; t++) mx[off + t] = p;
+        off += c;
+    }
+}
+
+// ------------------------------------------------------------------------------------------- B2
+// Fenwick node: the reference's PrevPtr order (plane, score, d, id[, x, y]) as two 64-bit keys.
+//   hi = plane << 32 | score        lo = d << 32 | id << 20 | x_end      (id decides before x is looked at)
+struct Frag {
+    uint64_t hi, lo;
+};
+__device__ __forceinline__ bool frag_less(const Frag& p, const Frag& q) { return p.hi < q.hi || (p.hi == q.hi && p.lo < q.lo); }
+
+__global__ __launch_bounds__(64) void chain_kernel(const BandDevArgs a) {
+    extern __shared__ __align__(16) uint8_t s_raw[];
+    const uint32_t pair = blockIdx.x;
+    const uint32_t lane = threadIdx.x;
+    BandDevPair* st = a.state + pair;
+    if (st->flags != BP_OK) return;
+    const uint32_t nm = st->n_matches;
+    uint32_t* path = a.path + (size_t)pair * a.cap_matches;
+    if (nm == 0) {
+        if (lane == 0) st->n_path = 0;
+        return;
+    }
+    const uint32_t* mx = a.mx + (size_t)pair * a.cap_matches;
+    const uint32_t* my = a.my + (size_t)pair * a.cap_matches;
+    uint32_t* qpos = a.qpos + (size_t)pair * a.cap_matches;  // tree position a start event queries
+    uint32_t* upos = a.upos + (size_t)pair * a.cap_matches;  // tree position an end event raises
+    int32_t* cont = a.cont + (size_t)pair * a.cap_matches;   // the match one diagonal step earlier, or -1
+    const uint32_t k = a.k;
+    uint32_t np2 = 64;
+    while (np2 < nm) np2 <<= 1;
+    if (nm < a.chain_min || nm > a.chain_cap) return;  // another launch (LDS size class) owns this pair
+    // LDS carve-up for chain_cap matches: tree | score | back.  The sort buffer of the end-y values
+    // aliases the tree, which is only zeroed once the tree positions have been computed.
+    Frag* tree = (Frag*)s_raw;                                       // [nm + 1], 1-based
+    uint32_t* ye = (uint32_t*)s_raw;                                 // sorted end-y values, [np2 <= chain_cap + 1]
+    uint32_t* score = (uint32_t*)(s_raw + 16 * (size_t)(a.chain_cap + 1));  // [nm]
+    int16_t* back = (int16_t*)(score + a.chain_cap);                 // [nm], indices < 4096
+    for (uint32_t i = lane; i < np2; i += 64) ye[i] = i < nm ? my[i] + k : kNone;
+    for (uint32_t i = lane; i < nm; i += 64) {
+        int32_t c = -1;
+        const uint32_t cx = mx[i], cy = my[i];
+        if (cx > 0 && cy > 0) {  // sparse.rs:265-267: binary search for (x - 1, y - 1)
+            uint32_t lo = 0, hi = nm;
+            const uint32_t kx = cx - 1, ky = cy - 1;
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                const uint32_t vx = mx[mid], vy = my[mid];
+                if (vx < kx || (vx == kx && vy < ky))
+                    lo = mid + 1;
+                else
+                    hi = mid;
+            }
+            if (lo < nm && mx[lo] == kx && my[lo] == ky) c = (int32_t)lo;
+        }
+        cont[i] = c;
+    }
+    __syncthreads();
+    // bitonic sort of the end-y values: rank compression of the tree's coordinate
+    for (uint32_t size = 2; size <= np2; size <<= 1)
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            for (uint32_t t = lane; t < (np2 >> 1); t += 64) {
+                const uint32_t i = 2 * t - (t & (stride - 1)), j = i + stride;
+                const bool up = (i & size) == 0;
+                const uint32_t vi = ye[i], vj = ye[j];
+                if ((vi > vj) == up) {
+                    ye[i] = vj;
+                    ye[j] = vi;
+                }
+            }
+            __syncthreads();
+        }
+    // tree position of a coordinate v = number of end-y values <= v (equal values share a node)
+    auto pos_of = [&](uint32_t v) -> uint32_t {
+        uint32_t lo = 0, hi = nm;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (ye[mid] <= v)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        return lo;
+    };
+    for (uint32_t i = lane; i < nm; i += 64) {
+        qpos[i] = pos_of(my[i]);
+        upos[i] = pos_of(my[i] + k);
+    }
+    __syncthreads();
+    for (uint32_t i = lane; i <= nm; i += 64) tree[i] = Frag{0, 0};
+    __syncthreads();
+
+    const uint32_t ms = a.match_score;
+    const uint32_t go = (uint32_t)(-(int64_t)a.gap_open), ge = (uint32_t)(-(int64_t)a.gap_extend);
+    uint32_t best_score = k;  // (k, 0): sparse.rs:234
+    int32_t best_idx = 0;
+    auto better = [](uint32_t s1, int32_t i1, uint32_t s2, int32_t i2) { return s1 > s2 || (s1 == s2 && i1 > i2); };
+    // Events in (x, y, tag) order: ends (tag = index) before starts (tag = index + nm) at equal
+    // coordinates.  Both lists are sorted already, so the order is a merge of two cursors.  Each lane
+    // keeps one record of the current 64-record window of either list; the current record is read
+    // with a wave-uniform lane index, a window is reloaded every 64 events of its kind.
+    uint32_t s = 0, e = 0;
+    uint32_t ws_x = 0, ws_y = 0, ws_q = 0, we_x = 0, we_y = 0, we_u = 0;
+    int32_t we_c = -1;
+    auto load_s = [&](uint32_t base) {
+        const uint32_t i = base + lane;
+        if (i < nm) {
+            ws_x = mx[i];
+            ws_y = my[i];
+            ws_q = qpos[i];
+        }
+    };
+    auto load_e = [&](uint32_t base) {
+        const uint32_t i = base + lane;
+        if (i < nm) {
+            we_x = mx[i] + k;
+            we_y = my[i] + k;
+            we_u = upos[i];
+            we_c = cont[i];
+        }
+    };
+    auto pick = [](uint32_t v, uint32_t idx) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)idx); };
+    // maximum of the 128-bit keys of lanes 0..15, in every lane: four row_shr steps, then lane 15 is read
+    auto row_max = [&](Frag v) -> Frag {
+#define BG_SHR(x, ctl) (uint32_t) __builtin_amdgcn_update_dpp(0, (int)(x), ctl, 0xf, 0xf, true)
+        uint32_t h1 = (uint32_t)(v.hi >> 32), h0 = (uint32_t)v.hi, l1 = (uint32_t)(v.lo >> 32), l0 = (uint32_t)v.lo;
+#define BG_STEP(ctl)                                                                                   \
+        {                                                                                                  \
+            const uint32_t q1 = BG_SHR(h1, ctl), q0 = BG_SHR(h0, ctl), r1 = BG_SHR(l1, ctl), r0 = BG_SHR(l0, ctl); \
+            const uint64_t qh = (uint64_t)q1 << 32 | q0, ql = (uint64_t)r1 << 32 | r0;                         \
+            const uint64_t vh = (uint64_t)h1 << 32 | h0, vl = (uint64_t)l1 << 32 | l0;                         \
+            if (vh < qh || (vh == qh && vl < ql)) {                                                            \
+                h1 = q1;                                                                                       \
+                h0 = q0;                                                                                       \
+                l1 = r1;                                                                                       \
+                l0 = r0;                                                                                       \
+            }                                                                                                  \
+        }
+        BG_STEP(0x111) BG_STEP(0x112) BG_STEP(0x114) BG_STEP(0x118)
+#undef BG_STEP
+#undef BG_SHR
+        Frag r;
+        r.hi = (uint64_t)pick(h1, 15) << 32 | pick(h0, 15);
+        r.lo = (uint64_t)pick(l1, 15) << 32 | pick(l0, 15);
+        return r;
+    };
+    load_s(0);
+    load_e(0);
+    while (e < nm) {
+        const uint32_t ex = pick(we_x, e & 63), ey = pick(we_y, e & 63);
+        bool take_start = false;
+        uint32_t sx = 0, sy = 0;
+        if (s < nm) {
+            sx = pick(ws_x, s & 63);
+            sy = pick(ws_y, s & 63);
+            take_start = sx < ex || (sx == ex && sy < ey);
+        }
+        if (take_start) {
+            const uint32_t p = s;
+            uint32_t sc = k * ms;
+            int32_t bk = -1;
+            // prefix maximum over tree[1 .. pos]: the chain pos, pos - lowbit(pos), ... has one node per set
+            // bit b of pos, pos with the bits below b cleared; lane b reads it (pos < 4096: lanes 0..11)
+            const uint32_t i = pick(ws_q, s & 63);
+            Frag bp{0, 0};
+            if (lane < 13 && ((i >> lane) & 1u)) bp = tree[i & ~((1u << lane) - 1u)];
+            bp = row_max(bp);
+            const uint32_t bscore = (uint32_t)bp.hi;
+            if (bscore > 0) {
+                const uint32_t bid = ((uint32_t)bp.lo >> 20) & 0xFFFu, d = (uint32_t)(bp.lo >> 32);
+                const uint32_t bx = (uint32_t)bp.lo & 0xFFFFFu, by = d - bx;
+                const uint32_t gap = max(sx - bx, sy - by);
+                const uint32_t pen = gap > 0 ? go + gap * ge : 0;
+                const uint32_t sum = bscore + k * ms;
+                const uint32_t ns = sum > pen ? sum - pen : 0;
+                if (better(ns, (int32_t)bid, sc, bk)) {
+                    sc = ns;
+                    bk = (int32_t)bid;
+                }
+                if (better(sc, (int32_t)p, best_score, best_idx)) {
+                    best_score = sc;
+                    best_idx = (int32_t)p;
+                }
+            }
+            if (lane == 0) {
+                score[p] = sc;
+                back[p] = (int16_t)bk;
+            }
+            s++;
+            if ((s & 63) == 0) load_s(s);
+        } else {
+            const uint32_t p = e;
+            uint32_t sc = score[p];
+            int32_t bk = back[p];
+            const int32_t c = (int32_t)pick((uint32_t)we_c, e & 63);
+            if (c >= 0) {
+                const uint32_t cs = score[c] + ms;
+                if (better(cs, c, sc, bk)) {
+                    sc = cs;
+                    bk = c;
+                }
+                if (better(sc, (int32_t)p, best_score, best_idx)) {
+                    best_score = sc;
+                    best_idx = (int32_t)p;
+                }
+                if (lane == 0) {
+                    score[p] = sc;
+                    back[p] = (int16_t)bk;
+                }
+            }
+            const uint32_t d = ex + ey;
+            Frag f;
+            f.hi = (uint64_t)(uint32_t)(sc + d * ge) << 32 | sc;
+            f.lo = (uint64_t)d << 32 | (uint64_t)p << 20 | ex;
+            // raise tree[pos], tree[pos + lowbit(pos)], ...: the chain is the set of distinct round-ups of pos
+            // to multiples of 2^b; lane b takes the one for b if it differs from the one for b - 1
+            const uint32_t i = pick(we_u, e & 63);
+            if (lane < 13) {
+                const uint32_t cb = ((i - 1) | ((1u << lane) - 1u)) + 1u;
+                const uint32_t cp = lane ? ((i - 1) | ((1u << (lane - 1)) - 1u)) + 1u : 0u;
+                if (cb != cp && cb <= nm && frag_less(tree[cb], f)) tree[cb] = f;
+            }
+            e++;
+            if ((e & 63) == 0) load_e(e);
+        }
+        __builtin_amdgcn_wave_barrier();  // one wavefront, LDS is in order: nothing to wait for, only keep the order
+    }
+    __syncthreads();
+    // the chain, last element first, then reversed in place
+    if (lane == 0) {
+        uint32_t len = 0;
+        for (int32_t q = best_idx; q >= 0; q = back[q]) path[len++] = (uint32_t)q;
+        st->n_path = len;
+    }
+    __syncthreads();
+    const uint32_t len = st->n_path;
+    for (uint32_t t = lane; t < len / 2; t += 64) {
+        const uint32_t u = path[t];
+        path[t] = path[len - 1 - t];
+        path[len - 1 - t] = u;
+    }
+}
+
+// ------------------------------------------------------------------------------------------- B3
+// One tile of the per-column ranges in LDS: columns [j0, j0 + kBandTile).  Every operation only
+// lowers start[j] or raises end[j]; columns outside the tile are skipped (another pass owns them).
+constexpr uint32_t kBandTile = 8192;
+struct BandCols {
+    uint32_t* start;  // LDS, indexed by j - j0
+    uint32_t* end;
+    uint32_t rows, cols;  // m + 1, n + 1
+    uint32_t j0, j1;      // tile: [j0, j1)
+};
+__device__ __forceinline__ uint32_t ssub(uint32_t p, uint32_t q) { return p > q ? p - q : 0; }
+
+// banded.rs:1111-1120
+__device__ void add_entry(const BandCols& b, uint32_t r, uint32_t c, uint32_t w) {
+    const uint32_t lo = ssub(r, w), hi = (uint32_t)min((uint64_t)r + w + 1, (uint64_t)b.rows);
+    for (uint64_t j = max((uint64_t)ssub(c, w), (uint64_t)b.j0), je = min(min((uint64_t)c + w + 1, (uint64_t)b.cols), (uint64_t)b.j1); j < je; j++) {
+        atomicMin(&b.start[j - b.j0], lo);
+        atomicMax(&b.end[j - b.j0], hi);
+    }
+}
+// banded.rs:1071-1107.  (tid, nth): the loops are shared by nth cooperating threads — every step only
+// lowers a start or raises an end, so any split works.
+__device__ void add_kmer(const BandCols& b, uint32_t r_, uint32_t c_, uint32_t k, uint32_t w, uint32_t tid = 0, uint32_t nth = 1) {
+    if (k == 0) return;
+    const uint64_t r = r_, c = c_, rows = b.rows, cols = b.cols;
+    const uint64_t t0 = b.j0, t1 = b.j1;
+    auto lower = [&](uint64_t j, uint32_t v) {
+        if (j >= t0 && j < t1) atomicMin(&b.start[j - t0], v);
+    };
+    auto raise = [&](uint64_t j, uint32_t v) {
+        if (j >= t0 && j < t1) atomicMax(&b.end[j - t0], v);
+    };
+    const uint64_t i0 = ssub(r_, w);
+    for (uint64_t j = (uint64_t)ssub(c_, w) + tid, je = min(c + w + 1, cols); j < je; j += nth) lower(j, (uint32_t)i0);
+    const uint64_t ja = min(c + w, cols);
+    for (uint64_t j = ja + tid, je = min(c + k + w, cols); j < je; j += nth) lower(j, (uint32_t)(i0 + (j - ja)));
+    const uint64_t jl = c + k - 1 > w ? c + k - 1 - w : 0, jf = c > w ? c - w : 0;
+    for (uint64_t s = 1 + tid; s <= jl - min(jl, jf); s += nth)  // j = jl - s, i = r + w + k - s
+        raise(jl - s, (uint32_t)min(r + w + k - s, rows));
+    const uint32_t e = (uint32_t)min(r + w + k, rows);
+    for (uint64_t j = jl + tid, je = min(c + k + w, cols); j < je; j += nth) raise(j, e);
+}
+// banded.rs:1123-1137 (u32 arithmetic like the reference's release build)
+__device__ void add_gap(const BandCols& b, uint32_t r0, uint32_t c0, uint32_t r1, uint32_t c1, uint32_t w, uint32_t tid = 0, uint32_t nth = 1) {
+    const uint32_t nr = r1 - r0, nc = c1 - c0;
+    if (nr > nc) {
+        for (uint64_t r = (uint64_t)r0 + tid; r < r1; r += nth)
+            add_entry(b, (uint32_t)r, c0 + (c1 - c0) * ((uint32_t)r - r0) / (r1 - r0), w);
+    } else {
+        // only the columns whose +-w box can touch the tile
+        const uint32_t ca = max(c0, ssub(b.j0, w)), cb = (uint32_t)min((uint64_t)c1, (uint64_t)b.j1 + w);
+        for (uint64_t c = (uint64_t)ca + tid; c < cb; c += nth)
+            add_entry(b, r0 + (r1 - r0) * ((uint32_t)c - c0) / (c1 - c0), (uint32_t)c, w);
+    }
+}
+// banded.rs:1150-1276
+// (all threads of the block call this with the same arguments and share the loops)
+__device__ void set_boundaries(const BandCols& b, uint32_t fx, uint32_t fy, uint32_t lx, uint32_t ly, uint32_t k, uint32_t w,
+                               const BandDevArgs& a, uint32_t tid, uint32_t nth) {
+    const uint64_t lazy = 2ull * k, rows = b.rows, cols = b.cols;
+    {
+        const uint64_t r = fx, c = fy;
+        if (r != 0 || c != 0) {
+            const int32_t to_start = (r > 0 ? a.xclip_prefix : 0) + (c > 0 ? a.yclip_prefix : 0);
+            if (to_start == 0) {
+                const uint64_t d = min(lazy, min(r, c));
+                add_kmer(b, (uint32_t)(r - d), (uint32_t)(c - d), (uint32_t)d, w, tid, nth);
+                add_gap(b, (uint32_t)(r > lazy ? r - lazy : 0), (uint32_t)(c > lazy ? c - lazy : 0), (uint32_t)(r - d), (uint32_t)(c - d), w, tid, nth);
+            } else {
+                const int32_t diag = r > c ? a.xclip_prefix : (r < c ? a.yclip_prefix : 0);
+                if (diag == 0) {
+                    const uint64_t d = min(r, c);
+                    add_kmer(b, (uint32_t)(r - d), (uint32_t)(c - d), (uint32_t)d, w, tid, nth);
+                    const uint32_t sr = (uint32_t)(r > lazy ? r - lazy : 0), sc = (uint32_t)(c > lazy ? c - lazy : 0);
+                    const uint32_t er = (uint32_t)(r - d), ec = (uint32_t)(c - d);
+                    if (sr <= er && sc <= ec) add_gap(b, sr, sc, er, ec, w, tid, nth);
+                } else {
+                    add_gap(b, 0, 0, fx, fy, w, tid, nth);
+                }
+            }
+        }
+    }
+    {
+        const uint64_t r = (uint64_t)lx + k, c = (uint64_t)ly + k;
+        if (!(r == rows && c == cols)) {
+            const int32_t from_end = (r == rows ? 0 : a.xclip_suffix) + (c == cols ? 0 : a.yclip_suffix);
+            const uint64_t dr = rows - r, dc = cols - c;
+            bool diagonal = false;
+            uint64_t d = 0;
+            if (from_end == 0) {
+                d = min(lazy, min(dr, dc));
+                diagonal = true;
+            } else {
+                const int32_t diag = dr > dc ? a.xclip_suffix : (dr < dc ? a.yclip_suffix : 0);
+                if (diag == 0) {
+                    d = min(dr, dc);
+                    diagonal = true;
+                }
+            }
+            if (diagonal) {
+                add_kmer(b, (uint32_t)r, (uint32_t)c, (uint32_t)d, w, tid, nth);
+                const uint64_t r1 = min(rows, r + d) - 1, c1 = min(cols, c + d) - 1;
+                const uint64_t r2 = min(rows, r + lazy), c2 = min(cols, c + lazy);
+                if (r1 <= r2 && c1 <= c2) add_gap(b, (uint32_t)r1, (uint32_t)c1, (uint32_t)r2, (uint32_t)c2, w, tid, nth);
+            } else {
+                add_gap(b, (uint32_t)r, (uint32_t)c, (uint32_t)rows, (uint32_t)cols, w, tid, nth);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void band_kernel(const BandDevArgs a) {
+    __shared__ uint32_t s_start[kBandTile], s_end[kBandTile];
+    const uint32_t pair = blockIdx.x;
+    const BandDevPair* st = a.state + pair;
+    if (st->flags != BP_OK) return;
+    const uint64_t xo = a.x_off[a.pair0 + pair], yo = a.y_off[a.pair0 + pair];
+    const uint32_t m = (uint32_t)(a.x_off[a.pair0 + pair + 1] - xo), n = (uint32_t)(a.y_off[a.pair0 + pair + 1] - yo);
+    uint32_t* g_start = a.col_start + (size_t)pair * (a.max_n + 1);
+    uint32_t* g_end = a.col_end + (size_t)pair * (a.max_n + 1);
+    const bool full = st->n_matches == 0;  // banded.rs:1309-1313: no matches -> the full matrix
+    const uint32_t* mx = a.mx + (size_t)pair * a.cap_matches;
+    const uint32_t* my = a.my + (size_t)pair * a.cap_matches;
+    const uint32_t* path = a.path + (size_t)pair * a.cap_matches;
+    const uint32_t len = st->n_path, k = a.k, w = a.w;
+    for (uint32_t j0 = 0; j0 <= n; j0 += kBandTile) {
+        BandCols b;
+        b.start = s_start;
+        b.end = s_end;
+        b.rows = m + 1;
+        b.cols = n + 1;
+        b.j0 = j0;
+        b.j1 = min(n + 1, j0 + kBandTile);
+        for (uint32_t j = threadIdx.x; j < b.j1 - j0; j += blockDim.x) {
+            s_start[j] = full ? 0u : m + 1;  // empty range m+1..0 (banded.rs:1061-1067)
+            s_end[j] = full ? m + 1 : 0u;
+        }
+        __syncthreads();
+        if (!full) {
+            set_boundaries(b, mx[path[0]], my[path[0]], mx[path[len - 1]], my[path[len - 1]], k, w, a, threadIdx.x, blockDim.x);
+            for (uint32_t t = threadIdx.x; t < len; t += blockDim.x) {  // banded.rs:1352-1365
+                const uint32_t cx = mx[path[t]], cy = my[path[t]];
+                if ((uint64_t)cy + k + w < j0) continue;  // entirely left of the tile
+                if (t > 0) {
+                    const uint32_t px = mx[path[t - 1]], py = my[path[t - 1]];
+                    if (ssub(py + k - 1, w) >= b.j1) continue;  // entirely right of it
+                    if (cx == px + 1 && cy == py + 1) {
+                        add_entry(b, px + k, py + k, w);
+                        continue;
+                    }
+                    add_gap(b, px + (k - 1), py + (k - 1), cx, cy, w);
+                } else if (ssub(cy, w) >= b.j1) {
+                    continue;
+                }
+                add_kmer(b, cx, cy, k, w);
+            }
+        }
+        __syncthreads();
+        for (uint32_t j = threadIdx.x; j < b.j1 - j0; j += blockDim.x) {
+            g_start[j0 + j] = s_start[j];
+            g_end[j0 + j] = s_end[j];
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------- B4
+// Block-wide inclusive scan helpers over 256 threads
+__device__ __forceinline__ uint64_t block_sum(uint64_t v, uint64_t* s_tmp) {
+    s_tmp[threadIdx.x] = v;
+    __syncthreads();
+    for (uint32_t o = blockDim.x >> 1; o; o >>= 1) {
+        if (threadIdx.x < o) s_tmp[threadIdx.x] += s_tmp[threadIdx.x + o];
+        __syncthreads();
+    }
+    const uint64_t r = s_tmp[0];
+    __syncthreads();
+    return r;
+}
+
+__global__ __launch_bounds__(256) void band_rows_kernel(const BandDevArgs a) {
+    const uint32_t pair = blockIdx.x;
+    BandDevPair* st = a.state + pair;
+    if (st->flags == BP_HOST_FALLBACK) return;
+    const uint64_t xo = a.x_off[a.pair0 + pair], yo = a.y_off[a.pair0 + pair];
+    const uint32_t m = (uint32_t)(a.x_off[a.pair0 + pair + 1] - xo), n = (uint32_t)(a.y_off[a.pair0 + pair + 1] - yo);
+    const uint32_t* start = a.col_start + (size_t)pair * (a.max_n + 1);
+    const uint32_t* end = a.col_end + (size_t)pair * (a.max_n + 1);
+    int2* rowc = a.rowc + a.row0[pair];
+    uint32_t* roff = a.row_off + a.row0[pair];
+    __shared__ uint64_t s_tmp[256];
+    __shared__ uint32_t s_bad;
+    if (threadIdx.x == 0) s_bad = 0;
+    // Band::num_cells (banded.rs:1374-1380)
+    uint64_t cells = 0;
+    for (uint32_t j = threadIdx.x; j <= n; j += blockDim.x) cells += end[j] > start[j] ? end[j] - start[j] : 0;
+    cells = block_sum(cells, s_tmp);
+    uint32_t flags = BP_OK;
+    if (cells > 5000000ull)
+        flags = BP_TOO_MANY_CELLS;  // banded.rs:104, 407-420
+    else if (n == 0)
+        flags = BP_UNSUPPORTED;
+    for (uint32_t i = threadIdx.x; i <= m; i += blockDim.x) {
+        rowc[i] = make_int2(1, 0);
+        roff[i] = 0;
+    }
+    __syncthreads();
+    if (flags == BP_OK) {
+        // per-column work needs the nearest non-empty column on either side: a running maximum of `end`
+        // to the left (rows < it were inside an earlier column) and a running minimum of `start` to the
+        // right.  Both are scans; columns are few enough for one thread per chunk + a serial pass of 256.
+        const uint32_t per = (n + 1 + blockDim.x - 1) / blockDim.x;
+        const uint32_t j0 = min(n + 1, threadIdx.x * per), j1 = min(n + 1, j0 + per);
+        // monotonicity of the non-empty columns + the left prefix maximum of end
+        uint32_t loc_max_end = 0, loc_last_s = 0, loc_last_e = 0, loc_first_s = 0, loc_first_e = 0;
+        bool loc_any = false, loc_ok = true;
+        for (uint32_t j = j0; j < j1; j++) {
+            if (end[j] <= start[j]) continue;
+            if (loc_any && (start[j] < loc_last_s || end[j] < loc_last_e)) loc_ok = false;
+            if (!loc_any) {
+                loc_first_s = start[j];
+                loc_first_e = end[j];
+            }
+            loc_last_s = start[j];
+            loc_last_e = end[j];
+            loc_max_end = max(loc_max_end, min(end[j], m + 1));
+            loc_any = true;
+        }
+        __shared__ uint32_t s_any[256], s_fs[256], s_fe[256], s_ls[256], s_le[256], s_pre_end[256], s_suf_start[256];
+        s_any[threadIdx.x] = loc_any;
+        s_fs[threadIdx.x] = loc_first_s;
+        s_fe[threadIdx.x] = loc_first_e;
+        s_ls[threadIdx.x] = loc_last_s;
+        s_le[threadIdx.x] = loc_last_e;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            bool any = false;
+            uint32_t ps = 0, pe = 0, run = 0;
+            for (uint32_t t = 0; t < blockDim.x; t++) {
+                s_pre_end[t] = run;  // max end (clamped) over the columns of earlier chunks
+                if (!s_any[t]) continue;
+                if (any && (s_fs[t] < ps || s_fe[t] < pe)) s_bad = 1;
+                ps = s_ls[t];
+                pe = s_le[t];
+                any = true;
+                run = max(run, min(pe, m + 1));
+            }
+            uint32_t lim = m + 1;
+            for (uint32_t t = blockDim.x; t-- > 0;) {
+                s_suf_start[t] = lim;  // min start over the columns of later chunks
+                if (s_any[t]) lim = min(lim, s_fs[t]);
+            }
+        }
+        __syncthreads();
+        if (!loc_ok) s_bad = 1;
+        __syncthreads();
+        if (s_bad) {
+            flags = BP_UNSUPPORTED;  // not monotone: cannot come out of Band::create
+        } else {
+            // first column of every row: rows [max(start_j, done), end_j) with done = max end to the left
+            uint32_t done = s_pre_end[threadIdx.x];
+            for (uint32_t j = j0; j < j1; j++) {
+                if (end[j] <= start[j]) continue;
+                const uint32_t e = min(end[j], m + 1);
+                for (uint32_t i = max(start[j], done); i < e; i++) rowc[i].x = (int)j;
+                done = max(done, e);
+            }
+            // last column: rows [start_j, min(end_j, lim)) with lim = min start to the right
+            uint32_t lim = s_suf_start[threadIdx.x];
+            for (uint32_t j = j1; j-- > j0;) {
+                if (end[j] <= start[j]) continue;
+                const uint32_t e = min(min(end[j], m + 1), lim);
+                for (uint32_t i = start[j]; i < e; i++) rowc[i].y = (int)j;
+                lim = min(lim, start[j]);
+            }
+        }
+        __syncthreads();
+    }
+    uint64_t tb_bytes = 0;
+    if (flags == BP_OK) {
+        // traceback offsets: exclusive scan of the dword-padded row widths (row 0 is not stored)
+        const uint32_t per = (m + 1 + blockDim.x - 1) / blockDim.x;
+        const uint32_t i0 = min(m + 1, threadIdx.x * per), i1 = min(m + 1, i0 + per);
+        uint64_t loc = 0, covered = 0;
+        for (uint32_t i = i0; i < i1; i++) {
+            const int2 rc = rowc[i];
+            if (rc.y >= rc.x) {
+                covered += (uint64_t)(rc.y - rc.x + 1);
+                if (i >= 1) loc += ((uint64_t)(rc.y - rc.x + 1) + 3) & ~3ull;
+            }
+        }
+        s_tmp[threadIdx.x] = loc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint64_t run = 0;
+            for (uint32_t t = 0; t < blockDim.x; t++) {
+                const uint64_t v = s_tmp[t];
+                s_tmp[t] = run;
+                run += v;
+            }
+        }
+        __syncthreads();
+        uint64_t off = s_tmp[threadIdx.x];
+        __syncthreads();
+        for (uint32_t i = i0; i < i1; i++) {
+            roff[i] = (uint32_t)off;
+            const int2 rc = rowc[i];
+            if (rc.y >= rc.x && i >= 1) off += ((uint64_t)(rc.y - rc.x + 1) + 3) & ~3ull;
+        }
+        const uint64_t total = block_sum(loc, s_tmp);
+        const uint64_t cov = block_sum(covered, s_tmp);
+        tb_bytes = (total + 15) & ~15ull;
+        if (cov != cells || total > 0xFFFFFFF0ull) flags = BP_UNSUPPORTED;  // holes: not one interval per row
+    }
+    if (flags != BP_OK) {
+        for (uint32_t i = threadIdx.x; i <= m; i += blockDim.x) {
+            rowc[i] = make_int2(1, 0);
+            roff[i] = 0;
+        }
+        tb_bytes = 0;
+    }
+    if (threadIdx.x == 0) {
+        st->flags = flags;
+        st->cells = cells;
+        st->tb_bytes = tb_bytes;
+        st->start_0 = start[0];
+        st->end_0 = end[0];
+        st->start_n = start[n];
+        st->end_n = end[n];
+    }
+}
+
+}  // namespace
+
+static size_t chain_lds_bytes(uint32_t cap) { return 16 * (size_t)(cap + 1) + 6 * (size_t)cap + 16; }
+
+int launch_band_match(const BandDevArgs& a, hipStream_t st) {
+    kmer_match_kernel<<<dim3(a.n_pairs), dim3(256), 0, st>>>(a);
+    return hipGetLastError() == hipSuccess ? BG_OK : BG_ERR_HIP;
+}
+
+int launch_band_chain_and_raster(const BandDevArgs& a, hipStream_t st) {
+    // two LDS size classes: most pairs of a long-read batch sit just around 2k matches
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)chain_lds_bytes(kMaxChainMatches));
+        attr_set = true;
+    }
+    BandDevArgs c = a;
+    c.chain_min = 0;
+    c.chain_cap = kSmallChainMatches;
+    chain_kernel<<<dim3(a.n_pairs), dim3(64), chain_lds_bytes(c.chain_cap), st>>>(c);
+    c.chain_min = kSmallChainMatches + 1;
+    c.chain_cap = kMaxChainMatches;
+    chain_kernel<<<dim3(a.n_pairs), dim3(64), chain_lds_bytes(c.chain_cap), st>>>(c);
+    band_kernel<<<dim3(a.n_pairs), dim3(256), 0, st>>>(a);
+    band_rows_kernel<<<dim3(a.n_pairs), dim3(256), 0, st>>>(a);
+    return hipGetLastError() == hipSuccess ? BG_OK : BG_ERR_HIP;
+}
+
+}  // namespace bgband_dev

@@ -12,6 +12,7 @@
 
 #include <chrono>
 
+#include "band_device.h"
 #include "banded_kernels.h"
 
 using namespace bgband_dev;
@@ -160,6 +161,11 @@ struct bg_band_scratch {
         hipEvent_t copied = nullptr, filled = nullptr, traced = nullptr;
         bool busy = false;
     } set[2];
+    // device band builder (band_device.hip): scratch slices per pair + its per-pair state
+    void* db[14] = {};
+    size_t db_cap[14] = {};
+    void* h_state = nullptr;  // pinned copy of the builder's BandDevPair array
+    size_t h_state_cap = 0;
     void* io[6] = {};  // x, y, x_off, y_off, out, ops on the device
     size_t io_cap[6] = {};
     void* h_ops = nullptr;  // pinned landing zone of the operations
@@ -177,6 +183,8 @@ void bg_band_scratch_free(bg_band_scratch* b) {
         if (s.traced) hipEventDestroy(s.traced);
     }
     for (void* p : b->io) hipFree(p);
+    for (void* p : b->db) hipFree(p);
+    hipHostFree(b->h_state);
     hipHostFree(b->h_ops);
     if (b->tb_stream) hipStreamDestroy(b->tb_stream);
     delete b;
@@ -244,7 +252,7 @@ using BandMaker = std::function<bool(uint64_t, bgband::Band&, bgband::Workspace&
 static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint64_t n_pairs, const uint8_t* x,
                              const uint64_t* x_off, const uint8_t* y, const uint64_t* y_off, bg_alignment_t* out,
                              uint8_t* ops_buf, uint64_t ops_cap, uint64_t* ops_used, uint64_t* band_cells,
-                             const BandMaker& make_band) {
+                             const BandMaker& make_band, const uint32_t* dev_kw = nullptr) {
     if (!ctx || !sc || mode < BG_MODE_CUSTOM || mode > BG_MODE_LOCAL) return BG_ERR_INVALID_ARG;
     int rc = check_scoring(sc);
     if (rc) return rc;
@@ -351,23 +359,121 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
         int2* h_rowc = (int2*)S.h_rowc;
         uint32_t* h_roff = (uint32_t*)S.h_roff;
         BandPair* dp = (BandPair*)S.h_pairs;
-        std::atomic<bool> bad_input{false};
-        parallel_for(want, grain, [&](unsigned, uint64_t lo, uint64_t hi) {
-            bgband::Band band;
-            bgband::Workspace ws;
-            for (uint64_t q = lo; q < hi; q++) {
-                const uint64_t p = p0 + q;
-                const uint32_t m = (uint32_t)(x_off[p + 1] - x_off[p]), n = (uint32_t)(y_off[p + 1] - y_off[p]);
-                if (!make_band(p, band, ws) || band.start.size() != (size_t)n + 1) {
-                    bad_input = true;
-                    band.reset(m, n);
-                }
-                build_pair(m, n, band, hp[q], h_rowc + row0[q], h_roff + row0[q]);
+        const bool on_device = dev_kw != nullptr && !ctx->band_on_host;
+        if (on_device) {
+            // ---- Band::create on the device (band_device.hip); the few pairs it hands back are built below
+            uint32_t max_m = 0, max_n = 0;
+            for (uint64_t q = 0; q < want; q++) {
+                max_m = std::max<uint32_t>(max_m, (uint32_t)(x_off[p0 + q + 1] - x_off[p0 + q]));
+                max_n = std::max<uint32_t>(max_n, (uint32_t)(y_off[p0 + q + 1] - y_off[p0 + q]));
             }
-        });
-        if (bad_input) return BG_ERR_INVALID_ARG;
-        lap("band build");
-        if (trace) { fprintf(stderr, "[bg banded] cpu-ms: kmers %.1f sdp %.1f band %.1f (threads %u)\n", bgband::g_prof[0] / 1e6, bgband::g_prof[1] / 1e6, bgband::g_prof[2] / 1e6, host_threads()); }
+            BandDevArgs d = {};
+            d.x = d_x;
+            d.x_off = d_xo;
+            d.y = d_y;
+            d.y_off = d_yo;
+            d.pair0 = p0;
+            d.n_pairs = (uint32_t)want;
+            d.k = dev_kw[0];
+            d.w = dev_kw[1];
+            d.gap_open = cs.gap_open;
+            d.gap_extend = cs.gap_extend;
+            d.xclip_prefix = cs.xclip_prefix;
+            d.xclip_suffix = cs.xclip_suffix;
+            d.yclip_prefix = cs.yclip_prefix;
+            d.yclip_suffix = cs.yclip_suffix;
+            d.match_score = (uint32_t)(cs.match_scores_some ? cs.match_score : 2);  // banded.rs:105,1315-1318
+            d.max_m = max_m;
+            d.max_n = std::max<uint32_t>(max_n, 1);
+            d.table_bits = 4;
+            while ((1u << d.table_bits) < 2 * d.max_n) d.table_bits++;
+            d.table_size = 1u << d.table_bits;
+            d.cap_matches = kMaxChainMatches + 1;
+            d.debug = getenv("BG_DEBUG") ? (uint32_t)atoi(getenv("BG_DEBUG")) : 0;
+            const size_t need[14] = {(size_t)want * d.table_size * 4, (size_t)want * d.max_n * 4, (size_t)want * d.max_n * 8,
+                                     (size_t)want * (d.max_m + 1) * 4, (size_t)want * d.cap_matches * 4,
+                                     (size_t)want * d.cap_matches * 4, (size_t)want * d.cap_matches * 4,
+                                     (size_t)want * d.cap_matches * 4, (size_t)want * d.cap_matches * 4,
+                                     (size_t)want * d.cap_matches * 4, (size_t)want * (d.max_n + 1) * 4,
+                                     (size_t)want * (d.max_n + 1) * 4, (size_t)want * sizeof(BandDevPair), (size_t)(want + 1) * 8};
+            for (int i = 0; i < 14; i++)
+                if ((rc = bg_reserve(&B.db[i], &B.db_cap[i], std::max<size_t>(need[i], 64)))) return rc;
+            d.head = (uint32_t*)B.db[0];
+            d.next = (uint32_t*)B.db[1];
+            d.hy = (uint64_t*)B.db[2];
+            d.cnt = (uint32_t*)B.db[3];
+            d.mx = (uint32_t*)B.db[4];
+            d.my = (uint32_t*)B.db[5];
+            d.path = (uint32_t*)B.db[6];
+            d.qpos = (uint32_t*)B.db[7];
+            d.upos = (uint32_t*)B.db[8];
+            d.cont = (int32_t*)B.db[9];
+            d.col_start = (uint32_t*)B.db[10];
+            d.col_end = (uint32_t*)B.db[11];
+            d.state = (BandDevPair*)B.db[12];
+            d.row0 = (const uint64_t*)B.db[13];
+            if ((rc = bg_reserve(&S.d_rowc, &S.dc_rowc, std::max<size_t>(row0[want] * sizeof(int2), 64)))) return rc;
+            if ((rc = bg_reserve(&S.d_roff, &S.dc_roff, std::max<size_t>(row0[want] * 4, 64)))) return rc;
+            d.rowc = (int2*)S.d_rowc;
+            d.row_off = (uint32_t*)S.d_roff;
+            if ((rc = pinned_reserve(&B.h_state, &B.h_state_cap, want * sizeof(BandDevPair)))) return rc;
+            BG_HIP(hipMemcpyAsync(B.db[13], row0.data(), (want + 1) * 8, hipMemcpyHostToDevice, st));
+            if ((rc = launch_band_match(d, st))) return rc;
+            if ((rc = launch_band_chain_and_raster(d, st))) return rc;
+            BG_HIP(hipMemcpyAsync(B.h_state, d.state, want * sizeof(BandDevPair), hipMemcpyDeviceToHost, st));
+            BG_HIP(hipStreamSynchronize(st));
+            lap("band build (device)");
+            const BandDevPair* hs = (const BandDevPair*)B.h_state;
+            std::vector<uint64_t> redo;
+            for (uint64_t q = 0; q < want; q++) {
+                HostPair& h = hp[q];
+                h.m = (uint32_t)(x_off[p0 + q + 1] - x_off[p0 + q]);
+                h.n = (uint32_t)(y_off[p0 + q + 1] - y_off[p0 + q]);
+                h.flags = hs[q].flags;
+                h.cells = hs[q].cells;
+                h.tb_bytes = hs[q].tb_bytes;
+                h.start_0 = hs[q].start_0;
+                h.end_0 = hs[q].end_0;
+                h.start_n = hs[q].start_n;
+                h.end_n = hs[q].end_n;
+                if (h.flags == BP_HOST_FALLBACK) redo.push_back(q);
+            }
+            if (!redo.empty()) {
+                parallel_for(redo.size(), 1, [&](unsigned, uint64_t lo, uint64_t hi) {
+                    bgband::Band band;
+                    bgband::Workspace ws;
+                    for (uint64_t t = lo; t < hi; t++) {
+                        const uint64_t q = redo[t], p = p0 + q;
+                        make_band(p, band, ws);
+                        build_pair(hp[q].m, hp[q].n, band, hp[q], h_rowc + row0[q], h_roff + row0[q]);
+                    }
+                });
+                for (uint64_t q : redo) {
+                    const size_t nr = (size_t)hp[q].m + 1;
+                    BG_HIP(hipMemcpyAsync((int2*)S.d_rowc + row0[q], h_rowc + row0[q], nr * sizeof(int2), hipMemcpyHostToDevice, st));
+                    BG_HIP(hipMemcpyAsync((uint32_t*)S.d_roff + row0[q], h_roff + row0[q], nr * 4, hipMemcpyHostToDevice, st));
+                }
+                if (trace) fprintf(stderr, "[bg banded] %zu of %llu pairs rebuilt on the host\n", redo.size(), (unsigned long long)want);
+            }
+        } else {
+        std::atomic<bool> bad_input{false};
+            parallel_for(want, grain, [&](unsigned, uint64_t lo, uint64_t hi) {
+                bgband::Band band;
+                bgband::Workspace ws;
+                for (uint64_t q = lo; q < hi; q++) {
+                    const uint64_t p = p0 + q;
+                    const uint32_t m = (uint32_t)(x_off[p + 1] - x_off[p]), n = (uint32_t)(y_off[p + 1] - y_off[p]);
+                    if (!make_band(p, band, ws) || band.start.size() != (size_t)n + 1) {
+                        bad_input = true;
+                        band.reset(m, n);
+                    }
+                    build_pair(m, n, band, hp[q], h_rowc + row0[q], h_roff + row0[q]);
+                }
+            });
+            if (bad_input) return BG_ERR_INVALID_ARG;
+            lap("band build");
+            if (trace) { fprintf(stderr, "[bg banded] cpu-ms: kmers %.1f sdp %.1f band %.1f (threads %u)\n", bgband::g_prof[0] / 1e6, bgband::g_prof[1] / 1e6, bgband::g_prof[2] / 1e6, host_threads()); }
+        }
         // take as many pairs as fit the scratch budget (the rest is rebuilt with the next sub-batch)
         uint64_t take = 0, tbb = 0, auxw = 0;
         for (; take < want; take++) {
@@ -395,8 +501,10 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
         if ((rc = bg_reserve(&S.d_tb, &S.dc_tb, std::max<size_t>(tbb, 64)))) return rc;
         if ((rc = bg_reserve(&S.d_aux, &S.dc_aux, std::max<size_t>(auxw * 4, 64)))) return rc;
         BG_HIP(hipMemcpyAsync(S.d_pairs, dp, take * sizeof(BandPair), hipMemcpyHostToDevice, st));
-        BG_HIP(hipMemcpyAsync(S.d_rowc, h_rowc, rows * sizeof(int2), hipMemcpyHostToDevice, st));
-        BG_HIP(hipMemcpyAsync(S.d_roff, h_roff, rows * 4, hipMemcpyHostToDevice, st));
+        if (!on_device) {
+            BG_HIP(hipMemcpyAsync(S.d_rowc, h_rowc, rows * sizeof(int2), hipMemcpyHostToDevice, st));
+            BG_HIP(hipMemcpyAsync(S.d_roff, h_roff, rows * 4, hipMemcpyHostToDevice, st));
+        }
         BG_HIP(hipEventRecord(S.copied, st));
         BG_HIP(hipMemsetAsync(S.d_aux, 0, auxw * 4, st));
         a.pairs = (const BandPair*)S.d_pairs;
@@ -473,12 +581,14 @@ extern "C" int bg_align_banded_batch(bg_ctx* ctx, const bg_scoring_t* sc, int mo
                                      uint64_t* ops_used, uint64_t* band_cells) {
     if (!sc || mode < BG_MODE_CUSTOM || mode > BG_MODE_LOCAL) return BG_ERR_INVALID_ARG;
     const bgband::ClipScores cs = clip_scores(sc, mode);
+    const uint32_t kw[2] = {k, w};
     return banded_batch_impl(ctx, sc, mode, n_pairs, x, x_off, y, y_off, out, ops_buf, ops_cap, ops_used, band_cells,
                              [&](uint64_t p, bgband::Band& band, bgband::Workspace& ws) {
                                  band.create(x + x_off[p], (size_t)(x_off[p + 1] - x_off[p]), y + y_off[p],
                                              (size_t)(y_off[p + 1] - y_off[p]), k, w, cs, ws);
                                  return true;
-                             });
+                             },
+                             kw);
 }
 
 // compute_alignment (banded.rs:406-869) over caller-supplied bands: n + 1 half-open row ranges per pair at

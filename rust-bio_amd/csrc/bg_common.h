@@ -40,6 +40,7 @@ struct bg_ctx {
     bg_band_scratch* band = nullptr;  // persistent scratch of the banded pipeline
     int64_t chunk_pairs = 0;  // 0 = default
     bool force_wide = false;  // tests: disable the NARROW (28-bit key) kernels
+    bool band_on_host = false;  // build bands with the host builder (band_host.cpp) instead of band_device.hip
     // timing
     bool timing = false;
     hipEvent_t ev[2] = {nullptr, nullptr};

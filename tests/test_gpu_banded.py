@@ -223,3 +223,53 @@ def test_with_prehash_equals_plain_calls():
     assert s1.score == s2.score and ops_tokens(s1) == ops_tokens(s2) and s2.mode == s1.mode
     c1, c2 = al.custom(x, y), al.custom_with_prehash(x, y, h)
     assert c1.score == c2.score and ops_tokens(c1) == ops_tokens(c2)
+
+
+def test_device_band_builder_equals_host_builder():
+    """Band::create on the device (band_device.hip) vs on host threads (band_host.cpp): same bands (cell
+    counts), same alignments — including pairs the device path hands back to the host (repeats)."""
+    from rust_bio_amd.banded import Aligner as BAligner
+    rng = np.random.default_rng(77)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    xs, ys = [], []
+    for it in range(96):
+        n = int(rng.integers(50, 3000))
+        y = acgt[rng.integers(0, 4, size=n)]
+        if it % 7 == 0:  # a tandem repeat: many matches per k-mer
+            unit = acgt[rng.integers(0, 4, size=int(rng.integers(2, 9)))]
+            y[n // 3:n // 3 + 300] = np.resize(unit, 300)[:len(y[n // 3:n // 3 + 300])]
+        x = y.copy()
+        nsub = max(1, n // 15)
+        x[rng.integers(0, n, size=nsub)] = acgt[rng.integers(0, 4, size=nsub)]
+        cut = int(rng.integers(0, max(1, n - 20)))
+        x = np.delete(x, np.arange(cut, cut + int(rng.integers(0, 12))))
+        if it % 5 == 0:
+            x = x[int(rng.integers(0, 30)):]
+        if it % 11 == 0:
+            x = acgt[rng.integers(0, 4, size=int(rng.integers(5, 200)))]  # unrelated: few or no matches
+        xs.append(x.tobytes())
+        ys.append(y.tobytes())
+    for mode, sc in [(2, Scoring.from_scores(-5, -1, 1, -1)), (3, Scoring.from_scores(-4, -2, 2, -3)),
+                     (0, Scoring.from_scores(-5, -1, 1, -1).xclip(-7).yclip_prefix_(-3).yclip_suffix_(0)),
+                     (1, Scoring.new(-6, -1, lambda a, b: 2 if a == b else -2))]:
+        for k, w in [(8, 6), (11, 20), (5, 3)]:
+            al = BAligner.with_scoring(sc, k, w)
+            x, xo = _lib.concat(xs)
+            y, yo = _lib.concat(ys)
+            al.ctx.set_option("band_on_host", 1)
+            try:
+                out_h, ops_h = al.align_arrays(mode, x, xo, y, yo)
+                cells_h = al.last_cells.copy()
+            except Exception as e:  # noqa: BLE001 - statuses are compared below
+                out_h, ops_h, cells_h = al.last_out.copy(), al.last_ops.copy(), al.last_cells.copy()
+            al.ctx.set_option("band_on_host", 0)
+            try:
+                out_d, ops_d = al.align_arrays(mode, x, xo, y, yo)
+            except Exception as e:  # noqa: BLE001
+                out_d, ops_d = al.last_out, al.last_ops
+            assert (al.last_cells == cells_h).all(), (mode, k, w)
+            for f in ("score", "xstart", "xend", "ystart", "yend", "n_ops", "status"):
+                assert (out_d[f] == out_h[f]).all(), (mode, k, w, f)
+            for p in range(len(xs)):
+                if out_h["status"][p] == 0:
+                    assert decode_ops(out_d[p], ops_d) == decode_ops(out_h[p], ops_h), (mode, k, w, p)
