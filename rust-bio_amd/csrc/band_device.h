@@ -9,6 +9,7 @@ enum : uint32_t { BP_HOST_FALLBACK = 3 };  // continues BP_OK / BP_TOO_MANY_CELL
 
 constexpr uint32_t kMaxChainMatches = 4095;    // matches per pair the LDS Fenwick tree of chain_kernel holds
 constexpr uint32_t kSmallChainMatches = 2047;  // ... in its small LDS size class (two wavefronts per CU more)
+constexpr uint32_t kChainGlobalMinPairs = 1024;  // from this many pairs per launch the chain tree goes to global scratch
 constexpr uint32_t kMaxMatchesPerKmer = 32;   // matches of one x k-mer sorted in place by kmer_match_kernel
 
 // what the builder leaves per pair (read back by the host: 48 bytes per pair)
@@ -34,7 +35,7 @@ struct BandDevArgs {
     uint32_t max_m, max_n;  // longest x / y of the sub-batch (scratch strides)
     uint32_t table_size, table_bits, cap_matches;
     uint32_t chain_min, chain_cap;
-    uint32_t debug;  // chain_kernel: the range of match counts this launch handles
+    int32_t chain_global;  // 1 / 0: force the global / LDS tree variant of chain_kernel, -1: by batch size  // chain_kernel: the range of match counts this launch handles
     // scratch, one slice per pair
     uint32_t* head;   // [table_size]
     uint32_t* next;   // [max_n]
@@ -42,6 +43,9 @@ struct BandDevArgs {
     uint32_t* cnt;    // [max_m + 1]
     uint32_t *mx, *my, *path, *qpos, *upos;  // [cap_matches]
     int32_t* cont;                           // [cap_matches]
+    void* g_tree;       // [cap_matches + 1] x 16 B: chain_kernel<false>
+    uint32_t* g_score;  // [cap_matches]
+    int16_t* g_back;    // [cap_matches]
     uint32_t *col_start, *col_end;           // [max_n + 1]
     BandDevPair* state;                      // [n_pairs]
     // outputs in the layout K3 / K4 read

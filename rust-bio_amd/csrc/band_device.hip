@@ -122,6 +122,10 @@ struct Frag {
 };
 __device__ __forceinline__ bool frag_less(const Frag& p, const Frag& q) { return p.hi < q.hi || (p.hi == q.hi && p.lo < q.lo); }
 
+// LDS_TREE: tree / score / back live in LDS (lowest latency per event, but LDS limits a CU to one to three
+// pairs); otherwise in global scratch (L2-resident; every event costs a memory round trip, but tens of
+// wavefronts per CU hide it).  Only the sort buffer of the end-y values is always in LDS.
+template <bool LDS_TREE>
 __global__ __launch_bounds__(64) void chain_kernel(const BandDevArgs a) {
     extern __shared__ __align__(16) uint8_t s_raw[];
     const uint32_t pair = blockIdx.x;
@@ -145,10 +149,19 @@ __global__ __launch_bounds__(64) void chain_kernel(const BandDevArgs a) {
     if (nm < a.chain_min || nm > a.chain_cap) return;  // another launch (LDS size class) owns this pair
     // LDS carve-up for chain_cap matches: tree | score | back.  The sort buffer of the end-y values
     // aliases the tree, which is only zeroed once the tree positions have been computed.
-    Frag* tree = (Frag*)s_raw;                                       // [nm + 1], 1-based
     uint32_t* ye = (uint32_t*)s_raw;                                 // sorted end-y values, [np2 <= chain_cap + 1]
-    uint32_t* score = (uint32_t*)(s_raw + 16 * (size_t)(a.chain_cap + 1));  // [nm]
-    int16_t* back = (int16_t*)(score + a.chain_cap);                 // [nm], indices < 4096
+    Frag* tree;       // [nm + 1], 1-based
+    uint32_t* score;  // [nm]
+    int16_t* back;    // [nm], indices < 4096
+    if (LDS_TREE) {
+        tree = (Frag*)s_raw;
+        score = (uint32_t*)(s_raw + 16 * (size_t)(a.chain_cap + 1));
+        back = (int16_t*)(score + a.chain_cap);
+    } else {
+        tree = (Frag*)a.g_tree + (size_t)pair * (a.cap_matches + 1);
+        score = a.g_score + (size_t)pair * a.cap_matches;
+        back = a.g_back + (size_t)pair * a.cap_matches;
+    }
     for (uint32_t i = lane; i < np2; i += 64) ye[i] = i < nm ? my[i] + k : kNone;
     for (uint32_t i = lane; i < nm; i += 64) {
         int32_t c = -1;
@@ -697,18 +710,26 @@ int launch_band_match(const BandDevArgs& a, hipStream_t st) {
 
 int launch_band_chain_and_raster(const BandDevArgs& a, hipStream_t st) {
     // two LDS size classes: most pairs of a long-read batch sit just around 2k matches
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute((const void*)chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)chain_lds_bytes(kMaxChainMatches));
-        attr_set = true;
-    }
     BandDevArgs c = a;
     c.chain_min = 0;
-    c.chain_cap = kSmallChainMatches;
-    chain_kernel<<<dim3(a.n_pairs), dim3(64), chain_lds_bytes(c.chain_cap), st>>>(c);
-    c.chain_min = kSmallChainMatches + 1;
     c.chain_cap = kMaxChainMatches;
-    chain_kernel<<<dim3(a.n_pairs), dim3(64), chain_lds_bytes(c.chain_cap), st>>>(c);
+    if (a.chain_global > 0 || (a.chain_global < 0 && a.n_pairs >= kChainGlobalMinPairs)) {
+        // enough pairs to hide memory latency with occupancy: tree in global scratch, 16 KB of LDS per pair
+        chain_kernel<false><<<dim3(a.n_pairs), dim3(64), 4 * (size_t)(kMaxChainMatches + 1), st>>>(c);
+    } else {
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipFuncSetAttribute((const void*)chain_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)chain_lds_bytes(kMaxChainMatches));
+            attr_set = true;
+        }
+        // two LDS size classes: most pairs of a long-read batch sit just around 2k matches
+        c.chain_cap = kSmallChainMatches;
+        chain_kernel<true><<<dim3(a.n_pairs), dim3(64), chain_lds_bytes(c.chain_cap), st>>>(c);
+        c.chain_min = kSmallChainMatches + 1;
+        c.chain_cap = kMaxChainMatches;
+        chain_kernel<true><<<dim3(a.n_pairs), dim3(64), chain_lds_bytes(c.chain_cap), st>>>(c);
+    }
     band_kernel<<<dim3(a.n_pairs), dim3(256), 0, st>>>(a);
     band_rows_kernel<<<dim3(a.n_pairs), dim3(256), 0, st>>>(a);
     return hipGetLastError() == hipSuccess ? BG_OK : BG_ERR_HIP;

@@ -158,12 +158,14 @@ struct bg_band_scratch {
         // device
         void *d_pairs = nullptr, *d_rowc = nullptr, *d_roff = nullptr, *d_tb = nullptr, *d_aux = nullptr;
         size_t dc_pairs = 0, dc_rowc = 0, dc_roff = 0, dc_tb = 0, dc_aux = 0;
-        hipEvent_t copied = nullptr, filled = nullptr, traced = nullptr;
+        hipEvent_t copied = nullptr, filled = nullptr, traced = nullptr, built = nullptr;
         bool busy = false;
     } set[2];
     // device band builder (band_device.hip): scratch slices per pair + its per-pair state
-    void* db[14] = {};
-    size_t db_cap[14] = {};
+    void* db[17] = {};
+    size_t db_cap[17] = {};
+    hipStream_t build_stream = nullptr;
+    hipEvent_t seq_ready = nullptr;
     void* h_state = nullptr;  // pinned copy of the builder's BandDevPair array
     size_t h_state_cap = 0;
     void* io[6] = {};  // x, y, x_off, y_off, out, ops on the device
@@ -181,12 +183,15 @@ void bg_band_scratch_free(bg_band_scratch* b) {
         if (s.copied) hipEventDestroy(s.copied);
         if (s.filled) hipEventDestroy(s.filled);
         if (s.traced) hipEventDestroy(s.traced);
+        if (s.built) hipEventDestroy(s.built);
     }
     for (void* p : b->io) hipFree(p);
     for (void* p : b->db) hipFree(p);
     hipHostFree(b->h_state);
     hipHostFree(b->h_ops);
     if (b->tb_stream) hipStreamDestroy(b->tb_stream);
+    if (b->build_stream) hipStreamDestroy(b->build_stream);
+    if (b->seq_ready) hipEventDestroy(b->seq_ready);
     delete b;
 }
 
@@ -339,16 +344,36 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
     const uint64_t chunk_pairs = ctx->chunk_pairs > 0 ? (uint64_t)ctx->chunk_pairs : 4096;
     const uint64_t budget = 16ull << 30;  // per scratch set
     const uint64_t grain = std::max<uint64_t>(1, std::min<uint64_t>(64, 65536 / (max_x + max_y + 1)));
-    std::vector<HostPair> hp;
-    std::vector<uint64_t> row0;
-    uint64_t n_chunk = 0;
-    for (uint64_t p0 = 0; p0 < n_pairs; n_chunk++) {
+    // Two sub-batches are in flight: while K3/K4 of one run, the band of the next one is being built —
+    // by band_device.hip on its own stream, or by the host threads.
+    struct Plan {
+        uint64_t p0 = 0, want = 0;
+        bool on_device = false;
+        std::vector<HostPair> hp;
+        std::vector<uint64_t> row0;
+    } plan[2];
+    if (!B.build_stream) {
+        BG_HIP(hipStreamCreateWithFlags(&B.build_stream, hipStreamNonBlocking));
+        BG_HIP(hipEventCreateWithFlags(&B.seq_ready, hipEventDisableTiming));
+        for (auto& s : B.set) BG_HIP(hipEventCreateWithFlags(&s.built, hipEventDisableTiming));
+    }
+    hipStream_t st_build = B.build_stream;
+    BG_HIP(hipEventRecord(B.seq_ready, st));
+    BG_HIP(hipStreamWaitEvent(st_build, B.seq_ready, 0));
+
+    auto issue = [&](uint64_t p0, uint64_t n_chunk) -> int {
+        Plan& P = plan[n_chunk & 1];
+        std::vector<HostPair>& hp = P.hp;
+        std::vector<uint64_t>& row0 = P.row0;
+        int rc = BG_OK;
         bg_band_scratch::Set& S = B.set[n_chunk & 1];
+        P.p0 = p0;
         if (S.busy) {  // its staging and device buffers were last used two sub-batches ago
             BG_HIP(hipEventSynchronize(S.traced));
             S.busy = false;
         }
         const uint64_t want = std::min<uint64_t>(chunk_pairs, n_pairs - p0);
+        P.want = want;
         hp.assign(want, HostPair());
         row0.resize(want + 1);
         row0[0] = 0;
@@ -358,8 +383,9 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
         if ((rc = pinned_reserve(&S.h_pairs, &S.hc_pairs, want * sizeof(BandPair)))) return rc;
         int2* h_rowc = (int2*)S.h_rowc;
         uint32_t* h_roff = (uint32_t*)S.h_roff;
-        BandPair* dp = (BandPair*)S.h_pairs;
+        (void)S.h_pairs;
         const bool on_device = dev_kw != nullptr && !ctx->band_on_host;
+        P.on_device = on_device;
         if (on_device) {
             // ---- Band::create on the device (band_device.hip); the few pairs it hands back are built below
             uint32_t max_m = 0, max_n = 0;
@@ -389,14 +415,15 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
             while ((1u << d.table_bits) < 2 * d.max_n) d.table_bits++;
             d.table_size = 1u << d.table_bits;
             d.cap_matches = kMaxChainMatches + 1;
-            d.debug = getenv("BG_DEBUG") ? (uint32_t)atoi(getenv("BG_DEBUG")) : 0;
-            const size_t need[14] = {(size_t)want * d.table_size * 4, (size_t)want * d.max_n * 4, (size_t)want * d.max_n * 8,
+            d.chain_global = ctx->band_chain_global;
+            const size_t need[17] = {(size_t)want * d.table_size * 4, (size_t)want * d.max_n * 4, (size_t)want * d.max_n * 8,
                                      (size_t)want * (d.max_m + 1) * 4, (size_t)want * d.cap_matches * 4,
                                      (size_t)want * d.cap_matches * 4, (size_t)want * d.cap_matches * 4,
                                      (size_t)want * d.cap_matches * 4, (size_t)want * d.cap_matches * 4,
                                      (size_t)want * d.cap_matches * 4, (size_t)want * (d.max_n + 1) * 4,
-                                     (size_t)want * (d.max_n + 1) * 4, (size_t)want * sizeof(BandDevPair), (size_t)(want + 1) * 8};
-            for (int i = 0; i < 14; i++)
+                                     (size_t)want * (d.max_n + 1) * 4, (size_t)want * sizeof(BandDevPair), (size_t)(want + 1) * 8,
+                                     (size_t)want * (d.cap_matches + 1) * 16, (size_t)want * d.cap_matches * 4, (size_t)want * d.cap_matches * 2};
+            for (int i = 0; i < 17; i++)
                 if ((rc = bg_reserve(&B.db[i], &B.db_cap[i], std::max<size_t>(need[i], 64)))) return rc;
             d.head = (uint32_t*)B.db[0];
             d.next = (uint32_t*)B.db[1];
@@ -412,16 +439,54 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
             d.col_end = (uint32_t*)B.db[11];
             d.state = (BandDevPair*)B.db[12];
             d.row0 = (const uint64_t*)B.db[13];
+            d.g_tree = B.db[14];
+            d.g_score = (uint32_t*)B.db[15];
+            d.g_back = (int16_t*)B.db[16];
             if ((rc = bg_reserve(&S.d_rowc, &S.dc_rowc, std::max<size_t>(row0[want] * sizeof(int2), 64)))) return rc;
             if ((rc = bg_reserve(&S.d_roff, &S.dc_roff, std::max<size_t>(row0[want] * 4, 64)))) return rc;
             d.rowc = (int2*)S.d_rowc;
             d.row_off = (uint32_t*)S.d_roff;
             if ((rc = pinned_reserve(&B.h_state, &B.h_state_cap, want * sizeof(BandDevPair)))) return rc;
-            BG_HIP(hipMemcpyAsync(B.db[13], row0.data(), (want + 1) * 8, hipMemcpyHostToDevice, st));
-            if ((rc = launch_band_match(d, st))) return rc;
-            if ((rc = launch_band_chain_and_raster(d, st))) return rc;
-            BG_HIP(hipMemcpyAsync(B.h_state, d.state, want * sizeof(BandDevPair), hipMemcpyDeviceToHost, st));
-            BG_HIP(hipStreamSynchronize(st));
+            BG_HIP(hipMemcpyAsync(B.db[13], row0.data(), (want + 1) * 8, hipMemcpyHostToDevice, st_build));
+            if ((rc = launch_band_match(d, st_build))) return rc;
+            if ((rc = launch_band_chain_and_raster(d, st_build))) return rc;
+            BG_HIP(hipMemcpyAsync(B.h_state, d.state, want * sizeof(BandDevPair), hipMemcpyDeviceToHost, st_build));
+            BG_HIP(hipEventRecord(S.built, st_build));
+        } else {
+        std::atomic<bool> bad_input{false};
+            parallel_for(want, grain, [&](unsigned, uint64_t lo, uint64_t hi) {
+                bgband::Band band;
+                bgband::Workspace ws;
+                for (uint64_t q = lo; q < hi; q++) {
+                    const uint64_t p = p0 + q;
+                    const uint32_t m = (uint32_t)(x_off[p + 1] - x_off[p]), n = (uint32_t)(y_off[p + 1] - y_off[p]);
+                    if (!make_band(p, band, ws) || band.start.size() != (size_t)n + 1) {
+                        bad_input = true;
+                        band.reset(m, n);
+                    }
+                    build_pair(m, n, band, hp[q], h_rowc + row0[q], h_roff + row0[q]);
+                }
+            });
+            if (bad_input) return BG_ERR_INVALID_ARG;
+            lap("band build");
+            if (trace) { fprintf(stderr, "[bg banded] cpu-ms: kmers %.1f sdp %.1f band %.1f (threads %u)\n", bgband::g_prof[0] / 1e6, bgband::g_prof[1] / 1e6, bgband::g_prof[2] / 1e6, host_threads()); }
+        }
+        return BG_OK;
+    };
+
+    auto finish = [&](uint64_t n_chunk, uint64_t* take_out) -> int {
+        Plan& P = plan[n_chunk & 1];
+        std::vector<HostPair>& hp = P.hp;
+        std::vector<uint64_t>& row0 = P.row0;
+        bg_band_scratch::Set& S = B.set[n_chunk & 1];
+        const uint64_t p0 = P.p0, want = P.want;
+        const bool on_device = P.on_device;
+        int2* h_rowc = (int2*)S.h_rowc;
+        uint32_t* h_roff = (uint32_t*)S.h_roff;
+        BandPair* dp = (BandPair*)S.h_pairs;
+        int rc = BG_OK;
+        if (on_device) {
+            BG_HIP(hipEventSynchronize(S.built));
             lap("band build (device)");
             const BandDevPair* hs = (const BandDevPair*)B.h_state;
             std::vector<uint64_t> redo;
@@ -455,24 +520,6 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
                 }
                 if (trace) fprintf(stderr, "[bg banded] %zu of %llu pairs rebuilt on the host\n", redo.size(), (unsigned long long)want);
             }
-        } else {
-        std::atomic<bool> bad_input{false};
-            parallel_for(want, grain, [&](unsigned, uint64_t lo, uint64_t hi) {
-                bgband::Band band;
-                bgband::Workspace ws;
-                for (uint64_t q = lo; q < hi; q++) {
-                    const uint64_t p = p0 + q;
-                    const uint32_t m = (uint32_t)(x_off[p + 1] - x_off[p]), n = (uint32_t)(y_off[p + 1] - y_off[p]);
-                    if (!make_band(p, band, ws) || band.start.size() != (size_t)n + 1) {
-                        bad_input = true;
-                        band.reset(m, n);
-                    }
-                    build_pair(m, n, band, hp[q], h_rowc + row0[q], h_roff + row0[q]);
-                }
-            });
-            if (bad_input) return BG_ERR_INVALID_ARG;
-            lap("band build");
-            if (trace) { fprintf(stderr, "[bg banded] cpu-ms: kmers %.1f sdp %.1f band %.1f (threads %u)\n", bgband::g_prof[0] / 1e6, bgband::g_prof[1] / 1e6, bgband::g_prof[2] / 1e6, host_threads()); }
         }
         // take as many pairs as fit the scratch budget (the rest is rebuilt with the next sub-batch)
         uint64_t take = 0, tbb = 0, auxw = 0;
@@ -514,6 +561,7 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
         a.aux = (int32_t*)S.d_aux;
         a.pair0 = p0;
         a.n_pairs = (uint32_t)take;
+        if (on_device) BG_HIP(hipStreamWaitEvent(st, S.built, 0));
         if (ctx->timing) BG_HIP(hipEventRecord(ctx->ev[0], st));
         fill<<<dim3((unsigned)((take + 3) / 4)), dim3(256), 0, st>>>(a);
         BG_HIP(hipGetLastError());
@@ -542,7 +590,21 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
         BG_HIP(hipEventRecord(S.traced, st_tb));
         S.busy = true;
         lap("enqueue");
-        p0 += take;
+        *take_out = take;
+        return BG_OK;
+    };
+
+    {
+        uint64_t p0 = 0, n_chunk = 0;
+        if ((rc = issue(0, 0))) return rc;
+        for (;;) {
+            uint64_t take = 0;
+            if ((rc = finish(n_chunk, &take))) return rc;
+            p0 += take;
+            if (p0 >= n_pairs) break;
+            n_chunk++;
+            if ((rc = issue(p0, n_chunk))) return rc;
+        }
     }
     // results: records and (pinned) operations come back on the traceback stream
     BG_HIP(hipMemcpyAsync(out, d_out, n_pairs * sizeof(bg_alignment_t), hipMemcpyDeviceToHost, st_tb));

@@ -263,13 +263,34 @@ def test_device_band_builder_equals_host_builder():
             except Exception as e:  # noqa: BLE001 - statuses are compared below
                 out_h, ops_h, cells_h = al.last_out.copy(), al.last_ops.copy(), al.last_cells.copy()
             al.ctx.set_option("band_on_host", 0)
-            try:
-                out_d, ops_d = al.align_arrays(mode, x, xo, y, yo)
-            except Exception as e:  # noqa: BLE001
-                out_d, ops_d = al.last_out, al.last_ops
-            assert (al.last_cells == cells_h).all(), (mode, k, w)
-            for f in ("score", "xstart", "xend", "ystart", "yend", "n_ops", "status"):
-                assert (out_d[f] == out_h[f]).all(), (mode, k, w, f)
-            for p in range(len(xs)):
-                if out_h["status"][p] == 0:
-                    assert decode_ops(out_d[p], ops_d) == decode_ops(out_h[p], ops_h), (mode, k, w, p)
+            for chain_global in (0, 1):  # both placements of the chaining kernel's tree
+                al.ctx.set_option("band_chain_global", chain_global)
+                try:
+                    out_d, ops_d = al.align_arrays(mode, x, xo, y, yo)
+                except Exception as e:  # noqa: BLE001
+                    out_d, ops_d = al.last_out, al.last_ops
+                assert (al.last_cells == cells_h).all(), (mode, k, w, chain_global)
+                for f in ("score", "xstart", "xend", "ystart", "yend", "n_ops", "status"):
+                    assert (out_d[f] == out_h[f]).all(), (mode, k, w, f, chain_global)
+                for p in range(len(xs)):
+                    if out_h["status"][p] == 0:
+                        assert decode_ops(out_d[p], ops_d) == decode_ops(out_h[p], ops_h), (mode, k, w, p, chain_global)
+            al.ctx.set_option("band_chain_global", -1)
+
+
+def test_device_band_builder_large_batch_10kb():
+    """The configuration bench.py runs (10 kb pairs, k-mer 16, w 32, sub-batches above the global-tree
+    threshold): device-built bands vs host-built ones on 1536 pairs, every field and every operation."""
+    from rust_bio_amd.banded import Aligner as BAligner
+    P, L = 1536, 10_000
+    x, off, y, _ = synth.sw_pairs(P, L, seed=91, sub=0.06, ins=0.02, dele=0.02)
+    al = BAligner.with_scoring(Scoring.from_scores(-5, -1, 1, -1), 16, 32)
+    al.ctx.set_option("band_on_host", 1)
+    out_h, ops_h = al.align_arrays(2, x, off, y, off)
+    cells_h = al.last_cells.copy()
+    al.ctx.set_option("band_on_host", 0)
+    out_d, ops_d = al.align_arrays(2, x, off, y, off)
+    assert (al.last_cells == cells_h).all()
+    for f in ("score", "xstart", "xend", "ystart", "yend", "n_ops", "status", "ops_off"):
+        assert (out_d[f] == out_h[f]).all(), f
+    assert (ops_d[:int(out_d["n_ops"].sum())] == ops_h[:int(out_h["n_ops"].sum())]).all()
