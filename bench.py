@@ -97,7 +97,7 @@ def main():
     ap.add_argument("--pattern-len", type=int, default=100)
     ap.add_argument("--skip-fm", action="store_true")
     ap.add_argument("--skip-banded", action="store_true")
-    ap.add_argument("--banded-pairs", type=int, default=8192, help="banded leg: 10 kb pairs per GPU (configs[3] is 100k over 8 GPUs)")
+    ap.add_argument("--banded-pairs", type=int, default=32768, help="banded leg: 10 kb pairs per GPU (configs[3] is 100k over 8 GPUs)")
     ap.add_argument("--skip-pipeline", action="store_true")
     ap.add_argument("--pipeline-reads", type=int, default=1_000_000, help="seed-and-extend leg: reads per GPU")
     ap.add_argument("--skip-cpu", action="store_true")

@@ -341,8 +341,8 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
     lap("h2d sequences");
 
     // sub-batch size: enough wavefronts to fill the chip, small enough that a large batch pipelines
-    const uint64_t chunk_pairs = ctx->chunk_pairs > 0 ? (uint64_t)ctx->chunk_pairs : 4096;
-    const uint64_t budget = 16ull << 30;  // per scratch set
+    const uint64_t chunk_pairs = ctx->chunk_pairs > 0 ? (uint64_t)ctx->chunk_pairs : 16384;
+    const uint64_t budget = 28ull << 30;  // traceback + aux per scratch set (two sets, of 288 GB HBM)
     const uint64_t grain = std::max<uint64_t>(1, std::min<uint64_t>(64, 65536 / (max_x + max_y + 1)));
     // Two sub-batches are in flight: while K3/K4 of one run, the band of the next one is being built —
     // by band_device.hip on its own stream, or by the host threads.
@@ -563,7 +563,10 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
         a.n_pairs = (uint32_t)take;
         if (on_device) BG_HIP(hipStreamWaitEvent(st, S.built, 0));
         if (ctx->timing) BG_HIP(hipEventRecord(ctx->ev[0], st));
-        fill<<<dim3((unsigned)((take + 3) / 4)), dim3(256), 0, st>>>(a);
+        if (sm == SCORE_PARAMS && !ctx->band_fill_v1)
+            launch_band_fill2(a, (uint32_t)max_x, st);  // K3v2: four pairs per wavefront + separate epilogue
+        else
+            fill<<<dim3((unsigned)((take + 3) / 4)), dim3(256), 0, st>>>(a);
         BG_HIP(hipGetLastError());
         if (ctx->timing) {
             BG_HIP(hipEventRecord(ctx->ev[1], st));

@@ -49,7 +49,11 @@ struct BandAux {
     __host__ __device__ uint64_t off_Sn() const { return off_V() + (n + 1); }
     __host__ __device__ uint64_t off_bits() const { return off_Sn() + (m + 1); }
     __host__ __device__ uint64_t off_bnd() const { return (off_bits() + (m + 4) / 4 + 3) & ~3ull; }
-    __host__ __device__ uint64_t words() const { return off_bnd() + 4ull * (n + 1); }
+    // K3v2 only: what the rows inside the band of column n looked like when the fill left them
+    //   int2 {S(i,n), I(i,n)} [m+1], then bytes (cell | I case << 5) [m+1]
+    __host__ __device__ uint64_t off_endv() const { return off_bnd() + 4ull * (n + 1); }
+    __host__ __device__ uint64_t off_endc() const { return off_endv() + 2ull * (m + 1); }
+    __host__ __device__ uint64_t words() const { return off_endc() + (m + 4) / 4; }
 };
 
 struct BandArgs {
@@ -76,6 +80,9 @@ struct BandArgs {
 
 typedef void (*band_fill_fn)(const BandArgs);
 band_fill_fn get_band_fill(int sm);
+// K3v2 (banded_fill2.hip): LP lanes per pair, R rows per lane, MatchParams scoring; the last-column
+// epilogue runs in its own kernel.  Returns false if the geometry is not instantiated.
+bool launch_band_fill2(const BandArgs& a, uint32_t max_m, hipStream_t st);
 void launch_band_traceback(const BandArgs& a, hipStream_t st);
 
 }  // namespace bgband_dev
