@@ -27,3 +27,5 @@ if [ -x "$R/tools/pmc_calib" ]; then
   done
 fi
 python "$R/tools/pmc_summary.py" "$OUT" "$TAG"
+# the raw traces are bulky (every torch kernel of the run): keep the summaries only
+rm -rf "$OUT"/kt "$OUT"/pmc_FETCH_SIZE "$OUT"/pmc_WRITE_SIZE "$OUT"/cal_FETCH_SIZE "$OUT"/cal_WRITE_SIZE
