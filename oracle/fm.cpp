@@ -335,3 +335,188 @@ extern "C" int orc_sampled_sa_get(const orc_sampled_sa* h, const uint8_t* bwt, u
         offset += 1;
     }
 }
+
+// ---- FMDIndex (fmindex.rs:250-576): bi-directional search and supermaximal exact matches ----------
+namespace {
+
+struct BiInterval {  // fmindex.rs:254-259
+    uint64_t lower = 0, lower_rev = 0, size = 0, match_size = 0;
+    BiInterval swapped() const { return BiInterval{lower_rev, lower, size, match_size}; }  // 275-282
+};
+
+struct Panic {};
+
+// dna::complement (alphabets/dna.rs:37-69): IUPAC table, identity elsewhere, case preserved
+uint8_t dna_complement(uint8_t a) {
+    static uint8_t comp[256];
+    static bool init = false;
+    if (!init) {
+        for (int v = 0; v < 256; v++) comp[v] = (uint8_t)v;
+        const char* from = "AGCTYRWSKMDVHBN";
+        const char* to = "TCGARYWSMKHBDVN";
+        for (int i = 0; from[i]; i++) {
+            comp[(uint8_t)from[i]] = (uint8_t)to[i];
+            comp[(uint8_t)from[i] + 32] = (uint8_t)(to[i] + 32);
+        }
+        init = true;
+    }
+    return comp[a];
+}
+
+struct Fmd {
+    const uint8_t* bwt;
+    uint64_t n;
+    const uint64_t* less;
+    uint64_t less_len;
+    const orc_occ* occ;
+    uint64_t less_of(uint64_t a) const {  // fmindex.rs:228-230: index out of bounds panics
+        if (a >= less_len) throw Panic();
+        return less[a];
+    }
+    uint64_t occ_of(uint64_t r, uint8_t a) const {
+        uint64_t o = 0;
+        if (r >= n || orc_occ_get(occ, bwt, n, r, a, &o) != 0) throw Panic();
+        return o;
+    }
+    // fmindex.rs:504-514
+    BiInterval init_interval_with(uint8_t a) const {
+        const uint8_t comp_a = dna_complement(a);
+        const uint64_t lower = less_of(a);
+        return BiInterval{lower, less_of(comp_a), less_of((uint64_t)a + 1) - lower, 1};
+    }
+    // fmindex.rs:517-524
+    BiInterval init_interval() const { return BiInterval{0, 0, n, 0}; }
+    // fmindex.rs:527-558
+    BiInterval backward_ext(const BiInterval& interval, uint8_t a) const {
+        uint64_t s = 0, o = 0, l = interval.lower_rev;
+        for (const char* p = "$TGCNAtgcna"; *p; p++) {
+            const uint8_t b = (uint8_t)*p;
+            l += s;
+            o = interval.lower == 0 ? 0 : occ_of(interval.lower - 1, b);
+            if (interval.lower + interval.size == 0) throw Panic();  // usize underflow
+            s = occ_of(interval.lower + interval.size - 1, b) - o;
+            if (b == a) break;
+        }
+        const uint64_t k = less_of(a) + o;
+        return BiInterval{k, l, s, interval.match_size + 1};
+    }
+    // fmindex.rs:560-564
+    BiInterval forward_ext(const BiInterval& interval, uint8_t a) const {
+        return backward_ext(interval.swapped(), dna_complement(a)).swapped();
+    }
+    struct Smem {
+        BiInterval iv;
+        uint64_t pos, len;
+    };
+    // fmindex.rs:363-434
+    std::vector<Smem> smems(const uint8_t* pattern, uint64_t plen, uint64_t i, uint64_t l) const {
+        std::vector<std::pair<BiInterval, uint64_t>> curr, prev;
+        std::vector<Smem> matches;
+        if (i >= plen) throw Panic();  // pattern[i]
+        uint64_t match_len = 0;
+        BiInterval interval = init_interval_with(pattern[i]);
+        if (interval.size != 0) match_len += 1;
+        for (uint64_t t = i + 1; t < plen; t++) {
+            const BiInterval fwd = forward_ext(interval, pattern[t]);
+            if (interval.size != fwd.size) curr.push_back({interval, match_len});
+            if (fwd.size == 0) break;
+            interval = fwd;
+            match_len += 1;
+        }
+        curr.push_back({interval, match_len});
+        std::reverse(curr.begin(), curr.end());
+        std::swap(curr, prev);
+        int64_t j = (int64_t)plen;
+        for (int64_t k = (int64_t)i - 1; k >= -1; k--) {
+            const uint8_t a = k == -1 ? (uint8_t)'$' : pattern[k];
+            curr.clear();
+            int64_t last_size = -1;
+            for (const auto& e : prev) {
+                const BiInterval fwd = backward_ext(e.first, a);
+                if ((fwd.size == 0 || k == -1) && curr.empty() && k < j && e.second >= l) {
+                    j = k;
+                    matches.push_back({e.first, (uint64_t)(k + 1), e.second});
+                }
+                if (fwd.size != 0 && (int64_t)fwd.size != last_size) {
+                    last_size = (int64_t)fwd.size;
+                    curr.push_back({fwd, e.second + 1});
+                }
+            }
+            if (curr.empty()) break;
+            std::swap(curr, prev);
+        }
+        return matches;
+    }
+    // fmindex.rs:479-501
+    std::vector<Smem> all_smems(const uint8_t* pattern, uint64_t plen, uint64_t l) const {
+        std::vector<Smem> out;
+        uint64_t i0 = 0;
+        while (i0 < plen) {
+            std::vector<Smem> cur = smems(pattern, plen, i0, l);
+            uint64_t next_i0 = i0 + 1;
+            for (const Smem& s : cur)
+                if (s.pos + s.len > next_i0) next_i0 = s.pos + s.len;
+            i0 = next_i0;
+            out.insert(out.end(), cur.begin(), cur.end());
+        }
+        return out;
+    }
+};
+
+}  // namespace
+
+// FMDIndex::from (fmindex.rs:311-329): 1 if the BWT is a word over n_alphabet + '$'
+extern "C" int orc_fmd_check(const uint8_t* bwt, uint64_t n) {
+    for (uint64_t i = 0; i < n; i++)
+        if (!strchr("ACGTNacgtn$", bwt[i]) || bwt[i] == 0) return 0;
+    return 1;
+}
+
+// smems (all == 0: overlapping position i) / all_smems (all != 0).  Records of 6 uint64:
+// lower, lower_rev, size, match_size, pattern position, length.  Returns the number of records
+// (may exceed cap), or -1 where the reference would panic.
+extern "C" int64_t orc_fmd_smems(const uint8_t* bwt, uint64_t n, const uint64_t* less, uint64_t less_len,
+                                 const orc_occ* occ, const uint8_t* pattern, uint64_t plen, uint64_t i, uint64_t l,
+                                 int all, uint64_t* out, uint64_t cap) {
+    const Fmd f{bwt, n, less, less_len, occ};
+    try {
+        const std::vector<Fmd::Smem> r = all ? f.all_smems(pattern, plen, l) : f.smems(pattern, plen, i, l);
+        for (size_t t = 0; t < r.size() && t < cap; t++) {
+            uint64_t* o = out + 6 * t;
+            o[0] = r[t].iv.lower;
+            o[1] = r[t].iv.lower_rev;
+            o[2] = r[t].iv.size;
+            o[3] = r[t].iv.match_size;
+            o[4] = r[t].pos;
+            o[5] = r[t].len;
+        }
+        return (int64_t)r.size();
+    } catch (const Panic&) {
+        return -1;
+    }
+}
+
+// init_interval (op 0), init_interval_with(a) (op 1), backward_ext (op 2), forward_ext (op 3); iv = 4 uint64
+extern "C" int orc_fmd_interval(const uint8_t* bwt, uint64_t n, const uint64_t* less, uint64_t less_len,
+                                const orc_occ* occ, int op, const uint64_t* iv, uint8_t a, uint64_t* out) {
+    const Fmd f{bwt, n, less, less_len, occ};
+    try {
+        BiInterval r;
+        const BiInterval in = iv ? BiInterval{iv[0], iv[1], iv[2], iv[3]} : BiInterval{};
+        if (op == 0)
+            r = f.init_interval();
+        else if (op == 1)
+            r = f.init_interval_with(a);
+        else if (op == 2)
+            r = f.backward_ext(in, a);
+        else
+            r = f.forward_ext(in, a);
+        out[0] = r.lower;
+        out[1] = r.lower_rev;
+        out[2] = r.size;
+        out[3] = r.match_size;
+        return 0;
+    } catch (const Panic&) {
+        return -1;
+    }
+}

@@ -128,6 +128,18 @@ void orc_sa_sample_export(const orc_sampled_sa*, uint64_t* sample, uint64_t* ext
 int orc_sampled_sa_get(const orc_sampled_sa*, const uint8_t* bwt, uint64_t n, const uint64_t* less,
                        uint64_t less_len, const orc_occ* occ, uint64_t index, uint64_t* out);
 
+
+/* FMDIndex (fmindex.rs:250-576).  orc_fmd_check: FMDIndex::from's assert (BWT over n_alphabet + '$').
+ * orc_fmd_smems: smems(pattern, i, l) (all == 0) or all_smems(pattern, l); records of 6 uint64
+ * {lower, lower_rev, size, match_size, pattern position, length}; returns their number or -1 (panic).
+ * orc_fmd_interval: op 0 init_interval, 1 init_interval_with(a), 2 backward_ext(iv, a), 3 forward_ext. */
+int orc_fmd_check(const uint8_t* bwt, uint64_t n);
+int64_t orc_fmd_smems(const uint8_t* bwt, uint64_t n, const uint64_t* less, uint64_t less_len,
+                      const orc_occ* occ, const uint8_t* pattern, uint64_t plen, uint64_t i, uint64_t l,
+                      int all, uint64_t* out, uint64_t cap);
+int orc_fmd_interval(const uint8_t* bwt, uint64_t n, const uint64_t* less, uint64_t less_len,
+                     const orc_occ* occ, int op, const uint64_t* iv, uint8_t a, uint64_t* out);
+
 #ifdef __cplusplus
 }
 #endif

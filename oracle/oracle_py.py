@@ -110,6 +110,12 @@ def lib():
              [C.POINTER(Scoring), C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
               C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.POINTER(AlignmentRec),
               C.c_void_p, C.c_uint64, u64p, C.c_void_p, C.c_void_p]),
+            ("orc_fmd_check", C.c_int, [C.c_void_p, C.c_uint64]),
+            ("orc_fmd_smems", C.c_int64,
+             [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64,
+              C.c_uint64, C.c_int, C.c_void_p, C.c_uint64]),
+            ("orc_fmd_interval", C.c_int,
+             [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int, C.c_void_p, C.c_uint8, C.c_void_p]),
             ("orc_sa_sample", C.c_void_p, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64]),
             ("orc_sa_sample_free", None, [C.c_void_p]),
             ("orc_sa_sample_counts", C.c_uint64, [C.c_void_p, u64p]),
@@ -458,3 +464,44 @@ def banded_align_with(scoring, mode, k, w, x, y, matches, path=None, expanded=Fa
     if want_band:
         d["band"] = (bs, be)
     return d
+
+
+class FMDIndex:
+    """FMDIndex (fmindex.rs:250-576) over the oracle's FM index parts; intervals are tuples
+    (lower, lower_rev, size, match_size); smems are (interval, pattern position, length)."""
+
+    def __init__(self, bwt_arr, less_arr, occ):
+        self.bwt = np.ascontiguousarray(np.frombuffer(_buf(bwt_arr), dtype=np.uint8))
+        self.less = np.ascontiguousarray(less_arr, dtype=np.uint64)
+        self.occ = occ
+        assert lib().orc_fmd_check(self.bwt.ctypes.data, len(self.bwt)), \
+            "Expecting BWT over the DNA alphabet (including N) with the sentinel $."
+
+    def _interval(self, op, iv=None, a=0):
+        out = np.zeros(4, dtype=np.uint64)
+        ivp = np.ascontiguousarray(iv, dtype=np.uint64) if iv is not None else None
+        rc = lib().orc_fmd_interval(self.bwt.ctypes.data, len(self.bwt), self.less.ctypes.data, len(self.less),
+                                    self.occ.h, op, ivp.ctypes.data if ivp is not None else None, a, out.ctypes.data)
+        if rc:
+            raise IndexError("the reference panics here")
+        return tuple(int(v) for v in out)
+
+    def init_interval(self): return self._interval(0)
+    def init_interval_with(self, a): return self._interval(1, None, a)
+    def backward_ext(self, iv, a): return self._interval(2, iv, a)
+    def forward_ext(self, iv, a): return self._interval(3, iv, a)
+
+    def _smems(self, pattern, i, l, all_):
+        pb = np.frombuffer(_buf(pattern), dtype=np.uint8)
+        cap = 4 * len(pb) + 8
+        out = np.zeros(6 * cap, dtype=np.uint64)
+        n = lib().orc_fmd_smems(self.bwt.ctypes.data, len(self.bwt), self.less.ctypes.data, len(self.less), self.occ.h,
+                                pb.ctypes.data, len(pb), i, l, all_, out.ctypes.data, cap)
+        if n < 0:
+            raise IndexError("the reference panics here")
+        assert n <= cap
+        r = out[:6 * n].reshape(n, 6)
+        return [((int(v[0]), int(v[1]), int(v[2]), int(v[3])), int(v[4]), int(v[5])) for v in r]
+
+    def smems(self, pattern, i, l): return self._smems(pattern, i, l, 0)
+    def all_smems(self, pattern, l): return self._smems(pattern, 0, l, 1)
