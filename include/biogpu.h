@@ -131,6 +131,23 @@ int bg_interval_occ_batch_dev(bg_fm* fm, uint64_t n_iv, const uint64_t* d_lower,
                               const uint64_t* d_out_off, uint64_t total, uint64_t* d_pos,
                               void* stream);
 
+/* ---- FMD index: supermaximal exact matches (kernel K7) ---------------------------------------
+ * FMDIndex::smems(pattern, i, l) (fmindex.rs:363-434; all == 0, i_pos[q] = i) or
+ * FMDIndex::all_smems(pattern, l) (479-501; all != 0, i_pos may be NULL) for a batch of patterns.
+ * The index must have been built (bg_fm_build) over T$R$-style text whose BWT is a word over
+ * dna::n_alphabet() + '$' — FMDIndex::from's assert (323-327), else BG_ERR_UNSUPPORTED.
+ * Pattern q's matches are the records out[(q*cap + t)*6 ..], t < min(count[q], cap), six uint32:
+ * BiInterval {lower, lower_rev, size, match_size}, position on the pattern, SMEM length — in the
+ * order the reference pushes them.  count[q] == 0xFFFFFFFF where the reference would panic
+ * (BG_ERR_OUT_OF_ALPHABET); BG_ERR_OPS_CAP if some count exceeds cap. */
+int bg_fmd_smems_batch(bg_fm* fm, int all, uint64_t n_p, const uint8_t* pat, const uint64_t* pat_off,
+                       const uint32_t* i_pos, uint32_t min_len, uint32_t cap, uint32_t* count,
+                       uint32_t* out);
+int bg_fmd_smems_batch_dev(bg_fm* fm, int all, uint64_t n_p, const uint8_t* d_pat,
+                           const uint64_t* d_pat_off, const uint32_t* d_i_pos, uint32_t min_len,
+                           uint32_t max_pattern_len, uint32_t cap, uint32_t* d_count, uint32_t* d_out,
+                           void* stream);
+
 /* ------------------------------------------------------------------ pairwise alignment */
 
 /* Scoring<F> (pairwise/mod.rs:238-247) as the *effective* values `custom` sees.  match_fn is

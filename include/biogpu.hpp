@@ -579,6 +579,66 @@ private:
 
 inline std::vector<size_t> Interval::occ(const FMIndex& fm) const { return fm.occ_batch({*this})[0]; }
 
+// BiInterval (fmindex.rs:250-283)
+struct BiInterval {
+    size_t lower = 0, lower_rev = 0, size = 0, match_size = 0;
+    Interval forward() const { return {lower, lower + size}; }
+    Interval revcomp() const { return {lower_rev, lower_rev + size}; }
+    bool operator==(const BiInterval& o) const {
+        return lower == o.lower && lower_rev == o.lower_rev && size == o.size && match_size == o.match_size;
+    }
+};
+
+// FMDIndex::from(fmindex) (fmindex.rs:311-329); smems / all_smems (363-501) run on the device
+class FMDIndex {
+public:
+    struct Smem {  // the reference's tuple (BiInterval, position on the pattern, SMEM length)
+        BiInterval interval;
+        size_t position, length;
+    };
+    explicit FMDIndex(const FMIndex& fm, const bwt::BWT& b) : fm_(&fm) {
+        for (uint8_t c : b)
+            if (!c || !std::char_traits<char>::find("ACGTNacgtn$", 11, (char)c))
+                throw Panic("Expecting BWT over the DNA alphabet (including N) with the sentinel $.");
+    }
+    std::vector<Smem> smems(const Text& pattern, size_t i, size_t l) const { return run({pattern}, {(uint32_t)i}, l, false)[0]; }
+    std::vector<Smem> all_smems(const Text& pattern, size_t l) const { return run({pattern}, {}, l, true)[0]; }
+    std::vector<std::vector<Smem>> smems_batch(const std::vector<Text>& patterns, const std::vector<uint32_t>& positions,
+                                               size_t l) const {
+        return run(patterns, positions, l, false);
+    }
+    std::vector<std::vector<Smem>> all_smems_batch(const std::vector<Text>& patterns, size_t l) const {
+        return run(patterns, {}, l, true);
+    }
+
+private:
+    std::vector<std::vector<Smem>> run(const std::vector<Text>& patterns, const std::vector<uint32_t>& positions, size_t l,
+                                       bool all) const {
+        Text pat;
+        std::vector<uint64_t> off{0};
+        size_t cap = 1;
+        for (auto& p : patterns) {
+            pat.insert(pat.end(), p.begin(), p.end());
+            off.push_back(pat.size());
+            cap = std::max(cap, p.size() + 1);
+        }
+        const size_t n = patterns.size();
+        std::vector<uint32_t> count(n), out(n * cap * 6);
+        const int rc = bg_fmd_smems_batch(fm_->raw(), all ? 1 : 0, n, pat.data(), off.data(), all ? nullptr : positions.data(),
+                                          (uint32_t)l, (uint32_t)cap, count.data(), out.data());
+        if (rc == BG_ERR_OUT_OF_ALPHABET) throw Panic("index out of bounds");
+        check(rc, "FMDIndex::smems");
+        std::vector<std::vector<Smem>> res(n);
+        for (size_t q = 0; q < n; q++)
+            for (uint32_t t = 0; t < count[q]; t++) {
+                const uint32_t* r = &out[(q * cap + t) * 6];
+                res[q].push_back({{r[0], r[1], r[2], r[3]}, r[4], r[5]});
+            }
+        return res;
+    }
+    const FMIndex* fm_;
+};
+
 }  // namespace fmindex
 
 namespace suffix_array {

@@ -239,6 +239,10 @@ extern "C" int bg_fm_build(bg_ctx* ctx, const uint8_t* bwt, uint64_t n, const ui
     for (size_t e = 0; e < exc_pos.size(); e++) exc_byte[e] = bwt[exc_pos[e]];
     bg_fm* fm = new bg_fm;
     fm->ctx = ctx;
+    fm->less_len = less_len;
+    fm->fmd_ok = true;
+    for (int c = 0; c < 256; c++)
+        if (hist[c] && (c == 0 || !strchr("ACGTNacgtn$", c))) fm->fmd_ok = false;
     for (int c = 0; c < 256; c++)
         if (code_of[c] >= 0) fm->code_byte[code_of[c]] = (uint8_t)c;
     fm->dev.exc_sym_off[0] = 0;

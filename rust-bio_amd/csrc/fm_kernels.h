@@ -81,6 +81,8 @@ struct bg_fm {
     uint32_t sa_rate = 0;
     uint8_t sa_sentinel = 0;
     uint8_t code_byte[4] = {0, 0, 0, 0};  // byte value of each 2-bit code
+    uint32_t less_len = 0;
+    bool fmd_ok = false;  // the BWT is a word over dna::n_alphabet() + '$' (FMDIndex::from, fmindex.rs:323-327)
 };
 
 #endif

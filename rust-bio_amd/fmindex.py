@@ -116,3 +116,63 @@ class FMIndex:
             self.close()
         except Exception:
             pass
+
+
+@dataclass(frozen=True)
+class BiInterval:  # fmindex.rs:250-283
+    lower: int
+    lower_rev: int
+    size: int
+    match_size: int
+
+    def forward(self):
+        return Interval(self.lower, self.lower + self.size)
+
+    def revcomp(self):
+        return Interval(self.lower_rev, self.lower_rev + self.size)
+
+
+class FMDIndex:
+    """FMDIndex::from(fmindex) (fmindex.rs:311-329): bi-directional search over an FM index of T$R$...
+    `smems` / `all_smems` (363-501) run on the device; results are (BiInterval, position, length)."""
+
+    def __init__(self, fmindex):
+        b = fmindex.bwt()
+        ok = np.isin(b, np.frombuffer(b"ACGTNacgtn$", dtype=np.uint8)).all()
+        assert ok, "Expecting BWT over the DNA alphabet (including N) with the sentinel $."
+        self.fm = fmindex
+
+    def smems_arrays(self, pat, pat_off, i_pos, l, all_=False, cap=None):
+        p = _lib.as_u8(pat)
+        off = np.ascontiguousarray(pat_off, dtype=np.uint64)
+        n = len(off) - 1
+        if cap is None:
+            cap = int(np.diff(off).max()) + 1 if n else 1
+        ip = np.ascontiguousarray(i_pos, dtype=np.uint32) if i_pos is not None else None
+        cnt = np.zeros(n, dtype=np.uint32)
+        out = np.zeros((n, cap, 6), dtype=np.uint32)
+        rc = _lib.lib().bg_fmd_smems_batch(self.fm.h, 1 if all_ else 0, n, p.ctypes.data, off.ctypes.data,
+                                           ip.ctypes.data if ip is not None else None, l, cap, cnt.ctypes.data,
+                                           out.ctypes.data)
+        _lib.check(rc, "FMDIndex::smems")
+        return cnt, out
+
+    @staticmethod
+    def _decode(cnt, out, q):
+        return [(BiInterval(int(r[0]), int(r[1]), int(r[2]), int(r[3])), int(r[4]), int(r[5])) for r in out[q, :cnt[q]]]
+
+    def smems_batch(self, patterns, positions, l):
+        buf, off = _lib.concat(patterns)
+        cnt, out = self.smems_arrays(buf, off, positions, l)
+        return [self._decode(cnt, out, q) for q in range(len(patterns))]
+
+    def all_smems_batch(self, patterns, l):
+        buf, off = _lib.concat(patterns)
+        cnt, out = self.smems_arrays(buf, off, None, l, all_=True)
+        return [self._decode(cnt, out, q) for q in range(len(patterns))]
+
+    def smems(self, pattern, i, l):  # fmindex.rs:363
+        return self.smems_batch([bytes(pattern)], [i], l)[0]
+
+    def all_smems(self, pattern, l):  # fmindex.rs:479
+        return self.all_smems_batch([bytes(pattern)], l)[0]

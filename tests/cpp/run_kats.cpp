@@ -127,6 +127,50 @@ static void kat_banded_with_matches_and_prehash() {
     CHECK(panics([&] { aligner.custom_with_matches(x, y, {{5, 5}, {1, 1}}); }));  // unsorted
 }
 
+// ---- FMDIndex (fmindex.rs:704-780: test_smems, test_all_smems)
+static void kat_fmdindex_smems() {
+    const Text orig = text("GCCTTAACAT"), t = text("GCCTTAACAT$ATGTTAAGGC$");
+    const auto alphabet = alphabets::dna::n_alphabet();
+    const auto sa = suffix_array::suffix_array(t);
+    const auto b = bwt::bwt(t, sa);
+    const auto less = bwt::less(b, alphabet);
+    const bwt::Occ occ(b, 3, alphabet);
+    fmindex::FMIndex fmindex(b, less, occ);
+    fmindex::FMDIndex fmdindex(fmindex, b);
+    {
+        const auto intervals = fmdindex.smems(text("AA"), 0, 0);
+        CHECK(intervals[0].interval.forward().occ(sa) == (std::vector<size_t>{5, 16}));
+        CHECK(intervals[0].interval.revcomp().occ(sa) == (std::vector<size_t>{3, 14}));
+        CHECK_EQ(intervals[0].position, (size_t)0);
+        CHECK_EQ(intervals[0].length, (size_t)2);
+    }
+    {
+        const auto intervals = fmdindex.smems(text("CTTAA"), 1, 0);
+        CHECK(intervals[0].interval.forward().occ(sa) == (std::vector<size_t>{2}));
+        CHECK(intervals[0].interval.revcomp().occ(sa) == (std::vector<size_t>{14}));
+        CHECK_EQ(intervals[0].position, (size_t)0);
+        CHECK_EQ(intervals[0].length, (size_t)5);
+        CHECK_EQ(intervals[0].interval.match_size, (size_t)5);
+    }
+    CHECK(fmdindex.smems(text("CTTAA"), 1, 7).empty());
+    {
+        const Text t2 = text("ATTCGGGG$CCCCGAAT$");
+        const auto sa2 = suffix_array::suffix_array(t2);
+        const auto b2 = bwt::bwt(t2, sa2);
+        fmindex::FMIndex fm2(b2, bwt::less(b2, alphabet), bwt::Occ(b2, 3, alphabet));
+        fmindex::FMDIndex fmd2(fm2, b2);
+        const auto intervals = fmd2.all_smems(text("ATTGGGG"), 0);
+        CHECK_EQ(intervals.size(), (size_t)2);
+        const size_t solutions[2][4] = {{0, 14, 0, 3}, {4, 9, 3, 4}};
+        for (size_t i = 0; i < intervals.size() && i < 2; i++) {
+            CHECK_EQ(intervals[i].interval.forward().occ(sa2)[0], solutions[i][0]);
+            CHECK_EQ(intervals[i].interval.revcomp().occ(sa2)[0], solutions[i][1]);
+            CHECK_EQ(intervals[i].position, solutions[i][2]);
+            CHECK_EQ(intervals[i].length, solutions[i][3]);
+        }
+    }
+}
+
 int main(int argc, char** argv) {
     const char* filter = argc > 1 ? argv[1] : "";
     int ran = 0;
@@ -147,6 +191,7 @@ int main(int argc, char** argv) {
     run("kat_panics", kat_panics);
     run("kat_batches_equal_single_calls", kat_batches_equal_single_calls);
     run("kat_banded_with_matches_and_prehash", kat_banded_with_matches_and_prehash);
+    run("kat_fmdindex_smems", kat_fmdindex_smems);
     std::printf("%d tests, %d failed\n", ran, g_failed);
     return g_failed ? 1 : 0;
 }
