@@ -51,10 +51,8 @@ __global__ __launch_bounds__(256) void kmer_match_kernel(const BandDevArgs a) {
     uint32_t* head = a.head + (size_t)pair * a.table_size;
     uint32_t* next = a.next + (size_t)pair * a.max_n;
     uint64_t* hy = a.hy + (size_t)pair * a.max_n;
-    uint32_t* cnt = a.cnt + (size_t)pair * (a.max_m + 1);
     uint32_t* mx = a.mx + (size_t)pair * a.cap_matches;
     uint32_t* my = a.my + (size_t)pair * a.cap_matches;
-    __shared__ uint32_t s_part[256];
     __shared__ uint32_t s_flag;
     if (threadIdx.x == 0) s_flag = 0;
     const uint32_t nky = n >= k && k ? n - k + 1 : 0, nkx = m >= k && k ? m - k + 1 : 0;
@@ -67,50 +65,54 @@ __global__ __launch_bounds__(256) void kmer_match_kernel(const BandDevArgs a) {
         next[i] = atomicExch(&head[(h * 0xD6E8FEB86659FD93ull) >> shift], i);
     }
     __syncthreads();
-    // every thread owns a contiguous range of x positions (the same in both passes)
-    const uint32_t per = (nkx + blockDim.x - 1) / blockDim.x;
-    const uint32_t p0 = min(nkx, threadIdx.x * per), p1 = min(nkx, p0 + per);
-    uint32_t mine = 0;
-    for (uint32_t p = p0; p < p1; p++) {
-        const uint64_t h = kmer_hash(x + p, k);
+    // x positions in tiles of 256 (thread t probes position tile + t: coalesced, and the matches come out
+    // in x order): count -> exclusive scan inside the tile -> fill at the running offset
+    __shared__ uint32_t s_scan[256];
+    uint32_t run = 0;
+    bool over = (k == 0 || m + k >= (1u << 20));
+    for (uint32_t p0 = 0; p0 < nkx && !over; p0 += blockDim.x) {
+        const uint32_t p = p0 + threadIdx.x;
+        uint64_t h = 0;
         uint32_t c = 0;
-        for (uint32_t i = head[(h * 0xD6E8FEB86659FD93ull) >> shift]; i != kNone; i = next[i])
-            if (hy[i] == h && kmer_equal(y + i, x + p, k)) c++;
-        cnt[p] = c;
-        mine += c;
-        if (c > kMaxMatchesPerKmer) s_flag = 1;  // the in-place sort below is quadratic: leave it to the host
-    }
-    s_part[threadIdx.x] = mine;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t run = 0;
-        for (uint32_t t = 0; t < blockDim.x; t++) {
-            const uint32_t v = s_part[t];
-            s_part[t] = run;
-            run += v;
+        if (p < nkx) {
+            h = kmer_hash(x + p, k);
+            for (uint32_t i = head[(h * 0xD6E8FEB86659FD93ull) >> shift]; i != kNone; i = next[i])
+                if (hy[i] == h && kmer_equal(y + i, x + p, k)) c++;
         }
-        st->n_matches = run;
-        st->flags = (run > a.cap_matches || run > kMaxChainMatches || s_flag || k == 0 || m + k >= (1u << 20)) ? BP_HOST_FALLBACK : BP_OK;
-    }
-    __syncthreads();
-    if (st->flags != BP_OK) return;
-    uint32_t off = s_part[threadIdx.x];
-    for (uint32_t p = p0; p < p1; p++) {
-        const uint32_t c = cnt[p];
-        if (!c) continue;
-        const uint64_t h = kmer_hash(x + p, k);
-        uint32_t w = 0;
-        for (uint32_t i = head[(h * 0xD6E8FEB86659FD93ull) >> shift]; i != kNone; i = next[i])
-            if (hy[i] == h && kmer_equal(y + i, x + p, k)) {  // insertion sort by y (chains are in arbitrary order)
-                uint32_t t = w++;
-                while (t > 0 && my[off + t - 1] > i) {
-                    my[off + t] = my[off + t - 1];
-                    t--;
+        s_scan[threadIdx.x] = c;
+        __syncthreads();
+        for (uint32_t o = 1; o < blockDim.x; o <<= 1) {
+            const uint32_t v = threadIdx.x >= o ? s_scan[threadIdx.x - o] : 0;
+            __syncthreads();
+            s_scan[threadIdx.x] += v;
+            __syncthreads();
+        }
+        const uint32_t off = run + s_scan[threadIdx.x] - c;
+        const uint32_t tile_total = s_scan[blockDim.x - 1];
+        // the in-place sort below is quadratic in c, and the chain kernel holds kMaxChainMatches
+        if (c > kMaxMatchesPerKmer) s_flag = 1;
+        __syncthreads();
+        if (run + tile_total > a.cap_matches || run + tile_total > kMaxChainMatches || s_flag) {
+            over = true;  // block-uniform: s_flag and the totals are read after the barrier
+        } else if (c) {
+            uint32_t w = 0;
+            for (uint32_t i = head[(h * 0xD6E8FEB86659FD93ull) >> shift]; i != kNone; i = next[i])
+                if (hy[i] == h && kmer_equal(y + i, x + p, k)) {  // insertion sort by y (chains are in arbitrary order)
+                    uint32_t t = w++;
+                    while (t > 0 && my[off + t - 1] > i) {
+                        my[off + t] = my[off + t - 1];
+                        t--;
+                    }
+                    my[off + t] = i;
                 }
-                my[off + t] = i;
-            }
-        for (uint32_t t = 0; t < c; t++) mx[off + t] = p;
-        off += c;
+            for (uint32_t t = 0; t < c; t++) mx[off + t] = p;
+        }
+        run += tile_total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        st->n_matches = over ? 0 : run;
+        st->flags = over ? BP_HOST_FALLBACK : BP_OK;
     }
 }
 
@@ -534,7 +536,6 @@ __global__ __launch_bounds__(256) void band_kernel(const BandDevArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------- B4
-// Block-wide inclusive scan helpers over 256 threads
 __device__ __forceinline__ uint64_t block_sum(uint64_t v, uint64_t* s_tmp) {
     s_tmp[threadIdx.x] = v;
     __syncthreads();
@@ -547,6 +548,11 @@ __device__ __forceinline__ uint64_t block_sum(uint64_t v, uint64_t* s_tmp) {
     return r;
 }
 
+// Column ranges -> per-row column ranges.  The band Band::create rasterises has no empty column between
+// its first and last one, and starts / ends never decrease: then the first column of row i is the first
+// one whose end exceeds i, its last column the last one whose start does not — two binary searches per
+// row, rows spread over the threads (coalesced), instead of a sequential sweep.  Anything else goes back
+// to the host builder.
 __global__ __launch_bounds__(256) void band_rows_kernel(const BandDevArgs a) {
     const uint32_t pair = blockIdx.x;
     BandDevPair* st = a.state + pair;
@@ -558,128 +564,96 @@ __global__ __launch_bounds__(256) void band_rows_kernel(const BandDevArgs a) {
     int2* rowc = a.rowc + a.row0[pair];
     uint32_t* roff = a.row_off + a.row0[pair];
     __shared__ uint64_t s_tmp[256];
-    __shared__ uint32_t s_bad;
-    if (threadIdx.x == 0) s_bad = 0;
-    // Band::num_cells (banded.rs:1374-1380)
+    __shared__ uint32_t s_scan[256];
+    __shared__ uint32_t s_first, s_last, s_bad;
+    if (threadIdx.x == 0) {
+        s_first = 0xFFFFFFFFu;
+        s_last = 0;
+        s_bad = 0;
+    }
+    __syncthreads();
+    // Band::num_cells (banded.rs:1374-1380), first / last non-empty column
     uint64_t cells = 0;
-    for (uint32_t j = threadIdx.x; j <= n; j += blockDim.x) cells += end[j] > start[j] ? end[j] - start[j] : 0;
+    uint32_t jf = 0xFFFFFFFFu, jl = 0;
+    bool any = false;
+    for (uint32_t j = threadIdx.x; j <= n; j += blockDim.x)
+        if (end[j] > start[j]) {
+            cells += end[j] - start[j];
+            jf = min(jf, j);
+            jl = max(jl, j);
+            any = true;
+        }
+    if (any) {
+        atomicMin(&s_first, jf);
+        atomicMax(&s_last, jl);
+    }
     cells = block_sum(cells, s_tmp);
+    const uint32_t j_first = s_first, j_last = s_last;
     uint32_t flags = BP_OK;
     if (cells > 5000000ull)
         flags = BP_TOO_MANY_CELLS;  // banded.rs:104, 407-420
-    else if (n == 0)
+    else if (n == 0 || j_first == 0xFFFFFFFFu)
         flags = BP_UNSUPPORTED;
-    for (uint32_t i = threadIdx.x; i <= m; i += blockDim.x) {
-        rowc[i] = make_int2(1, 0);
-        roff[i] = 0;
-    }
-    __syncthreads();
     if (flags == BP_OK) {
-        // per-column work needs the nearest non-empty column on either side: a running maximum of `end`
-        // to the left (rows < it were inside an earlier column) and a running minimum of `start` to the
-        // right.  Both are scans; columns are few enough for one thread per chunk + a serial pass of 256.
-        const uint32_t per = (n + 1 + blockDim.x - 1) / blockDim.x;
-        const uint32_t j0 = min(n + 1, threadIdx.x * per), j1 = min(n + 1, j0 + per);
-        // monotonicity of the non-empty columns + the left prefix maximum of end
-        uint32_t loc_max_end = 0, loc_last_s = 0, loc_last_e = 0, loc_first_s = 0, loc_first_e = 0;
-        bool loc_any = false, loc_ok = true;
-        for (uint32_t j = j0; j < j1; j++) {
-            if (end[j] <= start[j]) continue;
-            if (loc_any && (start[j] < loc_last_s || end[j] < loc_last_e)) loc_ok = false;
-            if (!loc_any) {
-                loc_first_s = start[j];
-                loc_first_e = end[j];
-            }
-            loc_last_s = start[j];
-            loc_last_e = end[j];
-            loc_max_end = max(loc_max_end, min(end[j], m + 1));
-            loc_any = true;
-        }
-        __shared__ uint32_t s_any[256], s_fs[256], s_fe[256], s_ls[256], s_le[256], s_pre_end[256], s_suf_start[256];
-        s_any[threadIdx.x] = loc_any;
-        s_fs[threadIdx.x] = loc_first_s;
-        s_fe[threadIdx.x] = loc_first_e;
-        s_ls[threadIdx.x] = loc_last_s;
-        s_le[threadIdx.x] = loc_last_e;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            bool any = false;
-            uint32_t ps = 0, pe = 0, run = 0;
-            for (uint32_t t = 0; t < blockDim.x; t++) {
-                s_pre_end[t] = run;  // max end (clamped) over the columns of earlier chunks
-                if (!s_any[t]) continue;
-                if (any && (s_fs[t] < ps || s_fe[t] < pe)) s_bad = 1;
-                ps = s_ls[t];
-                pe = s_le[t];
-                any = true;
-                run = max(run, min(pe, m + 1));
-            }
-            uint32_t lim = m + 1;
-            for (uint32_t t = blockDim.x; t-- > 0;) {
-                s_suf_start[t] = lim;  // min start over the columns of later chunks
-                if (s_any[t]) lim = min(lim, s_fs[t]);
-            }
+        for (uint32_t j = j_first + threadIdx.x; j <= j_last; j += blockDim.x) {
+            if (end[j] <= start[j]) s_bad = 1;  // a hole
+            if (j > j_first && (start[j] < start[j - 1] || end[j] < end[j - 1])) s_bad = 2;  // not monotone
         }
         __syncthreads();
-        if (!loc_ok) s_bad = 1;
-        __syncthreads();
-        if (s_bad) {
-            flags = BP_UNSUPPORTED;  // not monotone: cannot come out of Band::create
-        } else {
-            // first column of every row: rows [max(start_j, done), end_j) with done = max end to the left
-            uint32_t done = s_pre_end[threadIdx.x];
-            for (uint32_t j = j0; j < j1; j++) {
-                if (end[j] <= start[j]) continue;
-                const uint32_t e = min(end[j], m + 1);
-                for (uint32_t i = max(start[j], done); i < e; i++) rowc[i].x = (int)j;
-                done = max(done, e);
-            }
-            // last column: rows [start_j, min(end_j, lim)) with lim = min start to the right
-            uint32_t lim = s_suf_start[threadIdx.x];
-            for (uint32_t j = j1; j-- > j0;) {
-                if (end[j] <= start[j]) continue;
-                const uint32_t e = min(min(end[j], m + 1), lim);
-                for (uint32_t i = start[j]; i < e; i++) rowc[i].y = (int)j;
-                lim = min(lim, start[j]);
-            }
-        }
-        __syncthreads();
+        if (s_bad == 1) flags = BP_HOST_FALLBACK;  // the host sweep copes with holes
+        if (s_bad == 2) flags = BP_UNSUPPORTED;
     }
     uint64_t tb_bytes = 0;
     if (flags == BP_OK) {
-        // traceback offsets: exclusive scan of the dword-padded row widths (row 0 is not stored)
-        const uint32_t per = (m + 1 + blockDim.x - 1) / blockDim.x;
-        const uint32_t i0 = min(m + 1, threadIdx.x * per), i1 = min(m + 1, i0 + per);
-        uint64_t loc = 0, covered = 0;
-        for (uint32_t i = i0; i < i1; i++) {
-            const int2 rc = rowc[i];
-            if (rc.y >= rc.x) {
-                covered += (uint64_t)(rc.y - rc.x + 1);
-                if (i >= 1) loc += ((uint64_t)(rc.y - rc.x + 1) + 3) & ~3ull;
+        uint64_t covered = 0, run = 0;
+        for (uint32_t i0 = 0; i0 <= m; i0 += blockDim.x) {  // tiles of 256 rows
+            const uint32_t i = i0 + threadIdx.x;
+            uint32_t width = 0;
+            int2 rc = make_int2(1, 0);
+            if (i <= m) {
+                // first column whose end exceeds i
+                uint32_t lo = j_first, hi = j_last + 1;
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (min(end[mid], m + 1) > i)
+                        hi = mid;
+                    else
+                        lo = mid + 1;
+                }
+                const uint32_t cf = lo;
+                // last column whose start is at most i
+                lo = j_first;
+                hi = j_last + 1;
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (start[mid] <= i)
+                        lo = mid + 1;
+                    else
+                        hi = mid;
+                }
+                if (cf <= j_last && lo > j_first && cf <= lo - 1) {
+                    rc = make_int2((int)cf, (int)(lo - 1));
+                    covered += (uint64_t)(rc.y - rc.x + 1);
+                    if (i >= 1) width = ((uint32_t)(rc.y - rc.x + 1) + 3u) & ~3u;  // row 0 is not stored
+                }
+                rowc[i] = rc;
             }
-        }
-        s_tmp[threadIdx.x] = loc;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            uint64_t run = 0;
-            for (uint32_t t = 0; t < blockDim.x; t++) {
-                const uint64_t v = s_tmp[t];
-                s_tmp[t] = run;
-                run += v;
+            // exclusive scan of the widths inside the tile
+            s_scan[threadIdx.x] = width;
+            __syncthreads();
+            for (uint32_t o = 1; o < blockDim.x; o <<= 1) {
+                const uint32_t v = threadIdx.x >= o ? s_scan[threadIdx.x - o] : 0;
+                __syncthreads();
+                s_scan[threadIdx.x] += v;
+                __syncthreads();
             }
+            if (i <= m) roff[i] = (uint32_t)(run + s_scan[threadIdx.x] - width);
+            run += s_scan[blockDim.x - 1];
+            __syncthreads();
         }
-        __syncthreads();
-        uint64_t off = s_tmp[threadIdx.x];
-        __syncthreads();
-        for (uint32_t i = i0; i < i1; i++) {
-            roff[i] = (uint32_t)off;
-            const int2 rc = rowc[i];
-            if (rc.y >= rc.x && i >= 1) off += ((uint64_t)(rc.y - rc.x + 1) + 3) & ~3ull;
-        }
-        const uint64_t total = block_sum(loc, s_tmp);
         const uint64_t cov = block_sum(covered, s_tmp);
-        tb_bytes = (total + 15) & ~15ull;
-        if (cov != cells || total > 0xFFFFFFF0ull) flags = BP_UNSUPPORTED;  // holes: not one interval per row
+        tb_bytes = (run + 15) & ~15ull;
+        if (cov != cells || run > 0xFFFFFFF0ull) flags = BP_UNSUPPORTED;  // not one interval per row
     }
     if (flags != BP_OK) {
         for (uint32_t i = threadIdx.x; i <= m; i += blockDim.x) {
