@@ -308,6 +308,12 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
         a.alpha = A;
     }
     band_fill_fn fill = get_band_fill(sm);
+    // every reachable score within 24 bits: the scaled-key variant of K3v2 applies (same bound as sw_api.hip)
+    const int64_t mag = std::max<int64_t>({std::abs((int64_t)cs.gap_open), std::abs((int64_t)cs.gap_extend),
+                                           std::abs((int64_t)sc->match_score), std::abs((int64_t)sc->mismatch_score), 1});
+    auto clip_ok = [](int32_t c) { return c <= BG_MIN_SCORE / 2 || c >= -(1 << 22); };  // 'minus infinity' or small
+    const bool narrow = !ctx->force_wide && mag * ((int64_t)max_x + (int64_t)max_y + 8) < (1 << 24) && clip_ok(cs.xclip_prefix) &&
+                        clip_ok(cs.xclip_suffix) && clip_ok(cs.yclip_prefix) && clip_ok(cs.yclip_suffix);
 
     const bool trace = getenv("BG_TRACE") != nullptr;
     auto now = []() { return std::chrono::steady_clock::now(); };
@@ -564,7 +570,7 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
         if (on_device) BG_HIP(hipStreamWaitEvent(st, S.built, 0));
         if (ctx->timing) BG_HIP(hipEventRecord(ctx->ev[0], st));
         if (sm == SCORE_PARAMS && !ctx->band_fill_v1)
-            launch_band_fill2(a, (uint32_t)max_x, st);  // K3v2: four pairs per wavefront + separate epilogue
+            launch_band_fill2(a, narrow, st);  // K3v2: four pairs per wavefront + separate epilogue
         else
             fill<<<dim3((unsigned)((take + 3) / 4)), dim3(256), 0, st>>>(a);
         BG_HIP(hipGetLastError());

@@ -9,6 +9,8 @@
 //     in banded_epilogue_kernel (one wavefront per pair) from what the fill stored per row.
 //
 // MatchParams scoring only (Scoring::from_scores); tabulated match functions keep using K3.
+#include <type_traits>
+
 #include "banded_kernels.h"
 
 namespace bgband_dev {
@@ -30,8 +32,24 @@ __device__ __forceinline__ void wave_scan_first_max(int lane, int64_t& v, uint32
     }
 }
 
-template <int R, int LP>
+// NARROW (every reachable score fits 24 bits; checked by the host): K1's key trick — DP values are kept
+// scaled by 16 with the candidate's priority in the low bits, so the reference's first-maximum selection
+// (banded.rs:609-642, strict '>') is one integer max, "open" gap candidates carry bit 3, and the cell
+// update is branch-free (cells outside the band are computed and discarded).  MIN_SCORE maps to
+// NEGS = -2^30 with offsets preserved, which is all the reference's arithmetic on it needs.
+template <int R, int LP, bool NARROW>
 __global__ __launch_bounds__(256) void banded_fill2_kernel(const BandArgs a) {
+    constexpr int32_t NEGS = NARROW ? (kNarrowFloor * 16) : NEG;
+    // exact maps between the reference's integers and the scaled domain (identity for !NARROW)
+    auto to_s = [](int32_t v) -> int32_t {
+        if (!NARROW) return v;
+        if (v <= NEG / 2) return NEGS + (int32_t)((uint32_t)(max(v, NEG - (1 << 20)) - NEG) << 4);
+        return (int32_t)((uint32_t)v << 4);
+    };
+    auto from_s = [](int32_t v) -> int32_t {
+        if (!NARROW) return v;
+        return v < -(1 << 29) ? NEG + ((v - NEGS) >> 4) : (v >> 4);
+    };
     constexpr int PW = 64 / LP;
     constexpr int RS = LP * R;  // rows per strip
     const int lane = threadIdx.x & 63;
@@ -121,7 +139,7 @@ __global__ __launch_bounds__(256) void banded_fill2_kernel(const BandArgs a) {
     for (uint32_t strip = 0; strip < nstrips_w; strip++) {
         const uint32_t rb = (strip * LP + ll) * R;
         const int32_t mrow = (int32_t)m - (int32_t)rb - 1;
-        int32_t Sl[R], Dl[R], Il[R], Sn[R], cf[R], cl[R];
+        int32_t Sl[R], Dl[R], Il[R], Sn[R], cf[R], cl[R], ycl[R];
         uint32_t Ly[R], px[R], celln[R], icase[R], acc[R];
         uint32_t* tbr[R];  // dword stream of the row: cells cf..cl, four per word
         int jlo = 0x7fffffff, jhi = -1;
@@ -129,7 +147,8 @@ __global__ __launch_bounds__(256) void banded_fill2_kernel(const BandArgs a) {
         for (int r = 0; r < R; r++) {
             const uint32_t i = rb + r + 1;
             px[r] = 0;
-            Sl[r] = Dl[r] = Il[r] = Sn[r] = NEG;
+            Sl[r] = Dl[r] = Il[r] = Sn[r] = NEGS;
+            ycl[r] = NEGS;
             Ly[r] = 0;
             celln[r] = 0;
             icase[r] = IC_OPEN;
@@ -144,10 +163,11 @@ __global__ __launch_bounds__(256) void banded_fill2_kernel(const BandArgs a) {
                 if (rc.y >= rc.x) {
                     tbr[r] = (uint32_t*)(tb + roff[i]);
                     px[r] = x[i - 1];
+                    if (NARROW) ycl[r] = (int32_t)((uint32_t)to_s(sc.yp + sc.go + sc.ge * ((int32_t)i - 1)) | C_YP);
                     if (rc.x == 0) {  // (i, 0) is a band cell
                         const Col0 c = col0_cell(sc, i, m, fold0);
-                        Sl[r] = c.S;
-                        Il[r] = c.I;
+                        Sl[r] = to_s(c.S);
+                        Il[r] = to_s(c.I);
                         acc[r] = c.sbits | (c.ibits << 4);  // column 0 keeps whole nibbles
                         if (rc.y == 0) tbr[r][0] = acc[r];
                     }
@@ -175,32 +195,32 @@ __global__ __launch_bounds__(256) void banded_fill2_kernel(const BandArgs a) {
 
         // row above this lane's first row, for the first lane of the pair
         int2 rc_above = make_int2(1, 0);
-        int32_t Sn_above = NEG;
+        int32_t Sn_above = NEGS;
         if (live && ll == 0) {
             if (strip == 0) {
                 rc_above = rc0;
-                Sn_above = Sn0;
+                Sn_above = to_s(Sn0);
             } else if (rb <= m) {
                 rc_above = rowc[rb];
-                Sn_above = gSn[rb];
+                Sn_above = to_s(gSn[rb]);
             }
         }
         // S(rb, 0): the diagonal of this lane's first row at column 1
-        int32_t diag0 = NEG;
+        int32_t diag0 = NEGS;
         if (live) {
             int2 ra = rc_above;
             if (ll != 0 && rb <= m) ra = rowc[rb];
-            if (ra.y >= ra.x && ra.x == 0) diag0 = rb == 0 ? 0 : col0_cell(sc, rb, m, fold0).S;
+            if (ra.y >= ra.x && ra.x == 0) diag0 = rb == 0 ? 0 : to_s(col0_cell(sc, rb, m, fold0).S);
         }
         // the row below this lane's last one: while it is inside the band of a column, that lane (or the
         // next strip) publishes the column's fold instead of this one
         int2 rc_below = make_int2(1, 0);
         if (live && rb + R + 1 <= m) rc_below = rowc[rb + R + 1];
 
-        int32_t S_out = NEG, I_out = NEG, cm_out = NEG, Snl_out = NEG;
+        int32_t S_out = NEGS, I_out = NEGS, cm_out = NEGS, Snl_out = NEGS;
         int32_t ca_out = 0, q_out = 0;
         int32_t ychunk = 0, ychunk_nx = 0;
-        int4 bch = make_int4(NEG, NEG, NEG, 0), bch_nx = bch;
+        int4 bch = make_int4(NEGS, NEGS, NEGS, 0), bch_nx = bch;
         {
             const int jj = jlo + ll;  // column of chunk 0 for this lane
             if (jj <= jhi && jj >= 1) {
@@ -226,7 +246,7 @@ __global__ __launch_bounds__(256) void banded_fill2_kernel(const BandArgs a) {
                 q = ychunk;
                 Sn_prev = Sn_above;
                 const bool above_in = rc_above.y >= rc_above.x && j >= rc_above.x && j <= rc_above.y;
-                S_up = I_up = cm = NEG;
+                S_up = I_up = cm = NEGS;
                 ca = 0;
                 if (above_in) {
                     if (strip) {
@@ -235,7 +255,7 @@ __global__ __launch_bounds__(256) void banded_fill2_kernel(const BandArgs a) {
                         cm = bch.z;
                         ca = bch.w;
                     } else {
-                        S_up = row0_cell(sc, (uint32_t)j).S;  // banded.rs:518-546 (I[curr][0] = MIN)
+                        S_up = to_s(row0_cell(sc, (uint32_t)j).S);  // banded.rs:518-546 (I[curr][0] = MIN)
                     }
                 }
             }
@@ -251,8 +271,83 @@ __global__ __launch_bounds__(256) void banded_fill2_kernel(const BandArgs a) {
                 int32_t diag = diag0;
                 diag0 = S_up;
                 bool any_in = false;
-                int32_t v_best_m = NEG;
+                int32_t v_best_m = NEGS;
                 bool m_here = false;
+                if (NARROW) {
+                    const int32_t go_s = sc.go * 16, ge_s = sc.ge * 16, go_t = go_s + 8;  // open candidates carry bit 3
+                    const int32_t xs_s = to_s(sc.xs), ys_s = to_s(sc.ys);
+                    const int32_t match_k = (sc.match * 16) | (int32_t)C_MATCH, mismatch_k = (sc.mismatch * 16) | (int32_t)C_SUBST;
+                    const int32_t xkey_j = (int32_t)((uint32_t)to_s(xclip_j) | C_XP);
+                    const int32_t nmj = (int32_t)(n - (uint32_t)j);
+                    const int32_t ca_in = ca;
+                    int32_t cmk = cm | 15;  // fold key: clean running maximum | row priority (15 = an earlier lane)
+                    // LAST: some lane of the wavefront is at column n — only then the extra I candidate
+                    // Sn[i-1] + go (banded.rs:590-596) and the last-column records exist
+                    auto rows = [&](auto last_tag) {
+                        constexpr bool LAST = decltype(last_tag)::value;
+#pragma unroll
+                        for (int r = 0; r < R; r++) {
+                            const bool inb = j >= cf[r] && j <= cl[r];
+                            const bool is_m = (r == mrow);
+                            const int32_t left_S = Sl[r];
+                            const int32_t m_key = diag + (px[r] == (uint32_t)q ? match_k : mismatch_k);
+                            // banded.rs:580-607
+                            int32_t Iv_t = max(I_up + ge_s, S_up + go_t);
+                            uint32_t ic = IC_OPEN;
+                            if (LAST) {
+                                ic = (Iv_t & 8) ? IC_OPEN : IC_EXT;
+                                const int32_t clipk = Sn_prev + go_s;
+                                const bool ys = last_col && clipk > (Iv_t & ~15);
+                                Iv_t = ys ? clipk : Iv_t;
+                                ic = ys ? (uint32_t)IC_YS : ic;
+                            }
+                            const int32_t Dv_t = max(Dl[r] + ge_s, left_S + go_t);
+                            const int32_t Iv = Iv_t & ~15, Dv = Dv_t & ~15;
+                            // banded.rs:609-642: first maximum wins == max over (score | priority)
+                            const int32_t k_init = is_m ? (int32_t)(((uint32_t)cmk & ~15u) | C_XS) : (int32_t)((uint32_t)NEGS | C_XS);
+                            int32_t kb = max(max(k_init, m_key), (int32_t)((uint32_t)Iv | C_INS));
+                            kb = max(max(kb, (int32_t)((uint32_t)Dv | C_DEL)), xkey_j);
+                            kb = max(kb, ycl[r]);
+                            const int32_t best = kb & ~15;
+                            Sl[r] = inb ? best : NEGS;
+                            Dl[r] = inb ? Dv : NEGS;
+                            Il[r] = inb ? Iv : Il[r];
+                            S_up = inb ? best : NEGS;
+                            I_up = inb ? Iv : NEGS;
+                            // banded.rs:648-653 (a no-op at i == m)
+                            const int32_t fk = (int32_t)((uint32_t)(best + xs_s) | (uint32_t)(14 - r));
+                            cmk = max(cmk, (inb && !is_m) ? fk : (int32_t)0x80000000);
+                            // banded.rs:655-660
+                            const int32_t t1 = best + ys_s;
+                            const bool up = inb && t1 > Sn[r];
+                            Ly[r] = up ? (uint32_t)nmj : Ly[r];
+                            Sn[r] = up ? t1 : Sn[r];
+                            // traceback byte: four cells per store
+                            const uint32_t cell = (((uint32_t)kb & 7u) | (((uint32_t)Dv_t & 8u) << 1) | ((uint32_t)Iv_t & 8u)) ^ 24u;
+                            const uint32_t cj = (uint32_t)(j - cf[r]);
+                            const uint32_t sh = 8u * (cj & 3u);
+                            const uint32_t merged = sh ? (acc[r] | (cell << sh)) : cell;
+                            acc[r] = inb ? merged : acc[r];
+                            if (inb && ((cj & 3u) == 3u || j == cl[r])) tbr[r][cj >> 2] = merged;
+                            any_in = any_in || inb;
+                            m_here = m_here || (inb && is_m);
+                            v_best_m = (inb && is_m) ? best : v_best_m;
+                            if (LAST) {
+                                celln[r] = (inb && last_col) ? cell : celln[r];
+                                icase[r] = (inb && last_col) ? ic : icase[r];
+                            }
+                            diag = left_S;
+                            Sn_prev = Sn[r];
+                        }
+                    };
+                    if (__any(last_col))
+                        rows(std::true_type{});
+                    else
+                        rows(std::false_type{});
+                    const int32_t lo = cmk & 15;
+                    ca = lo == 15 ? ca_in : (mrow - 14 + lo);
+                    cm = cmk & ~15;
+                } else {
 #pragma unroll
                 for (int r = 0; r < R; r++) {
                     const bool inb = j >= cf[r] && j <= cl[r];
@@ -320,9 +415,10 @@ __global__ __launch_bounds__(256) void banded_fill2_kernel(const BandArgs a) {
                     diag = left_S;
                     Sn_prev = Sn[r];
                 }
+                }
                 // only the last band row of the column publishes (rows of a column's band are contiguous)
                 if (any_in && !(j >= rc_below.x && j <= rc_below.y)) {
-                    gV[j] = m_here ? v_best_m : cm;
+                    gV[j] = from_s(m_here ? v_best_m : cm);
                     gLx[j] = ca;
                 }
                 S_out = S_up;
@@ -338,10 +434,10 @@ __global__ __launch_bounds__(256) void banded_fill2_kernel(const BandArgs a) {
         for (int r = 0; r < R; r++) {
             const uint32_t i = rb + r + 1;
             if (live && i <= m && cl[r] >= cf[r]) {
-                gSn[i] = Sn[r];
+                gSn[i] = from_s(Sn[r]);
                 gLy[i] = (int32_t)Ly[r];
                 if (cl[r] == (int)n && cf[r] <= (int)n) {  // inside the band of the last column
-                    gEndV[i] = make_int2(Sl[r], Il[r]);
+                    gEndV[i] = make_int2(from_s(Sl[r]), from_s(Il[r]));
                     gEndC[i] = (uint8_t)(celln[r] | (icase[r] << 5));
                 }
             }
@@ -623,11 +719,13 @@ __global__ __launch_bounds__(256) void banded_epilogue_kernel(const BandArgs a) 
 
 }  // namespace
 
-bool launch_band_fill2(const BandArgs& a, uint32_t max_m, hipStream_t st) {
-    (void)max_m;
+bool launch_band_fill2(const BandArgs& a, bool narrow, hipStream_t st) {
     constexpr int LP = 16, R = 4, PW = 64 / LP;
     const uint32_t jobs = (a.n_pairs + PW - 1) / PW;
-    banded_fill2_kernel<R, LP><<<dim3((jobs + 3) / 4), dim3(256), 0, st>>>(a);
+    if (narrow)
+        banded_fill2_kernel<R, LP, true><<<dim3((jobs + 3) / 4), dim3(256), 0, st>>>(a);
+    else
+        banded_fill2_kernel<R, LP, false><<<dim3((jobs + 3) / 4), dim3(256), 0, st>>>(a);
     banded_epilogue_kernel<2><<<dim3((a.n_pairs + 3) / 4), dim3(256), 0, st>>>(a);
     return true;
 }

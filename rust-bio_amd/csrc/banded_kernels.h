@@ -82,7 +82,7 @@ typedef void (*band_fill_fn)(const BandArgs);
 band_fill_fn get_band_fill(int sm);
 // K3v2 (banded_fill2.hip): LP lanes per pair, R rows per lane, MatchParams scoring; the last-column
 // epilogue runs in its own kernel.  Returns false if the geometry is not instantiated.
-bool launch_band_fill2(const BandArgs& a, uint32_t max_m, hipStream_t st);
+bool launch_band_fill2(const BandArgs& a, bool narrow, hipStream_t st);
 void launch_band_traceback(const BandArgs& a, hipStream_t st);
 
 }  // namespace bgband_dev

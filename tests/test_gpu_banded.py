@@ -294,3 +294,48 @@ def test_device_band_builder_large_batch_10kb():
     for f in ("score", "xstart", "xend", "ystart", "yend", "n_ops", "status", "ops_off"):
         assert (out_d[f] == out_h[f]).all(), f
     assert (ops_d[:int(out_d["n_ops"].sum())] == ops_h[:int(out_h["n_ops"].sum())]).all()
+
+
+def test_fill_kernel_variants_agree():
+    """K3v2 with scaled keys (default), K3v2 with explicit compare chains (force_wide) and K3 with one pair
+    per wavefront (band_fill_v1) are three implementations of banded.rs:406-723: identical output."""
+    from rust_bio_amd.banded import Aligner as BAligner
+    rng = np.random.default_rng(5)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    xs, ys = [], []
+    for it in range(80):
+        n = int(rng.integers(30, 2500))
+        y = acgt[rng.integers(0, 4, size=n)]
+        x = y.copy()
+        nsub = max(1, n // 12)
+        x[rng.integers(0, n, size=nsub)] = acgt[rng.integers(0, 4, size=nsub)]
+        cut = int(rng.integers(0, max(1, n - 20)))
+        x = np.delete(x, np.arange(cut, cut + int(rng.integers(0, 15))))
+        if it % 4 == 0:
+            x = x[int(rng.integers(0, 40)):]
+        if it % 9 == 0:
+            y = y[:max(10, n - int(rng.integers(0, 60)))]
+        xs.append(x.tobytes())
+        ys.append(y.tobytes())
+    x, xo = _lib.concat(xs)
+    y, yo = _lib.concat(ys)
+    for mode, sc in [(0, Scoring.from_scores(-5, -1, 1, -1).xclip(-9).yclip(-4)), (1, Scoring.from_scores(-3, -2, 2, -2)),
+                     (2, Scoring.from_scores(-5, -1, 1, -1)), (3, Scoring.from_scores(-7, -1, 3, -4)),
+                     (0, Scoring.from_scores(-5, -1, 1, -1).xclip_prefix_(0).yclip_suffix_(-1))]:
+        al = BAligner.with_scoring(sc, 9, 7)
+        res = []
+        for opts in ({}, {"force_wide": 1}, {"band_fill_v1": 1}):
+            for k_, v_ in opts.items():
+                al.ctx.set_option(k_, v_)
+            try:
+                out, ops = al.align_arrays(mode, x, xo, y, yo)
+            except Exception:  # noqa: BLE001 - per-pair statuses are compared
+                out, ops = al.last_out, al.last_ops
+            res.append((out.copy(), ops.copy()))
+            for k_ in opts:
+                al.ctx.set_option(k_, 0)
+        for out, ops in res[1:]:
+            for f in ("score", "xstart", "xend", "ystart", "yend", "n_ops", "status", "ops_off"):
+                assert (out[f] == res[0][0][f]).all(), (mode, f)
+            nb = int(out["n_ops"].sum())
+            assert (ops[:nb] == res[0][1][:nb]).all(), mode
