@@ -5,6 +5,8 @@
 
 namespace bgsw {
 
+constexpr uint32_t kSegStride = 20;  // dwords per thread slot: 16 of data, padded against bank conflicts
+
 template <int NW>
 __global__ __launch_bounds__(256) void sw_traceback_kernel(const SwArgs a) {
     const uint32_t pair = blockIdx.x * blockDim.x + threadIdx.x;
@@ -27,11 +29,26 @@ __global__ __launch_bounds__(256) void sw_traceback_kernel(const SwArgs a) {
 
     const uint32_t job = pair / PW, grp = pair % PW;
     const uint32_t* tbj = (const uint32_t*)a.tb + (size_t)job * tb_job_words(geo.nstrips, geo.nsteps, NW);
+    // A diagonal step stays in the same lane's stream nine times out of ten (R = 10) and moves one step
+    // back in it: the 64 bytes a lane wrote for 16 / NW consecutive steps (one tile row, tb_word_off) are
+    // fetched once into this thread's LDS slot and the following cells are served from there — one global
+    // round trip per ~8 cells of the path instead of one per cell.
+    __shared__ __align__(16) uint32_t s_seg[256 * kSegStride];
+    uint32_t* seg = s_seg + threadIdx.x * kSegStride;
+    uint64_t seg_tag = ~0ull;
     // packed 5 bits of inner cell (1 <= i <= m, 1 <= j <= n)
     auto cell = [&](uint32_t i, uint32_t j) -> uint32_t {
         const uint32_t i1 = i - 1, lrow = i1 / R, rr = i1 - lrow * R;
         const uint32_t st = lrow / LP, llc = lrow - st * LP;
-        const uint32_t w = tbj[tb_word_off((uint64_t)st * geo.nsteps + (j - 1 + llc), grp * LP + llc, NW) + rr / 6];
+        const uint64_t g = (uint64_t)st * geo.nsteps + (j - 1 + llc);
+        constexpr uint32_t tsteps = 16 / NW;
+        const uint64_t base = (g / tsteps) * 1024ull + (grp * LP + llc) * 16u;
+        if (base != seg_tag) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) *(uint4*)&seg[4 * q] = *(const uint4*)&tbj[base + 4 * q];
+            seg_tag = base;
+        }
+        const uint32_t w = seg[(uint32_t)(g % tsteps) * NW + rr / 6];
         return (w >> (5 * (rr % 6))) & 31u;
     };
     // S nibble of cell (i,j), j < n (or the fill-time value for j == n, never requested)
