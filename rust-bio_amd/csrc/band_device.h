@@ -40,7 +40,6 @@ struct BandDevArgs {
     uint32_t* head;   // [table_size]
     uint32_t* next;   // [max_n]
     uint64_t* hy;     // [max_n]
-    uint32_t* cnt;    // [max_m + 1]
     uint32_t *mx, *my, *path, *qpos, *upos;  // [cap_matches]
     int32_t* cont;                           // [cap_matches]
     void* g_tree;       // [cap_matches + 1] x 16 B: chain_kernel<false>

@@ -434,7 +434,6 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
             d.head = (uint32_t*)B.db[0];
             d.next = (uint32_t*)B.db[1];
             d.hy = (uint64_t*)B.db[2];
-            d.cnt = (uint32_t*)B.db[3];
             d.mx = (uint32_t*)B.db[4];
             d.my = (uint32_t*)B.db[5];
             d.path = (uint32_t*)B.db[6];
