@@ -625,21 +625,24 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
     for (auto& s : B.set) s.busy = false;
     lap("drain + d2h");
 
+    // compact the operations: slots of `stride` bytes -> back to back (offsets serially, bytes on all threads)
     const uint8_t* h_ops = (const uint8_t*)B.h_ops;
     uint64_t used = 0;
     int status = BG_OK;
+    std::vector<uint64_t> src(n_pairs);
     for (uint64_t p = 0; p < n_pairs; p++) {
         if (out[p].status && status == BG_OK) status = out[p].status;
-        const uint64_t src = out[p].ops_off;
+        src[p] = out[p].ops_off;
         out[p].ops_off = used;
-        if (ops_buf && out[p].status == BG_OK) {
-            if (used + out[p].n_ops <= ops_cap)
-                memcpy(ops_buf + used, h_ops + src, out[p].n_ops);
-            else if (status == BG_OK)
-                status = BG_ERR_OPS_CAP;
-        }
+        if (ops_buf && out[p].status == BG_OK && used + out[p].n_ops > ops_cap && status == BG_OK) status = BG_ERR_OPS_CAP;
         used += out[p].n_ops;
     }
+    if (ops_buf)
+        parallel_for(n_pairs, 256, [&](unsigned, uint64_t lo, uint64_t hi) {
+            for (uint64_t p = lo; p < hi; p++)
+                if (out[p].status == BG_OK && out[p].ops_off + out[p].n_ops <= ops_cap)
+                    memcpy(ops_buf + out[p].ops_off, h_ops + src[p], out[p].n_ops);
+        });
     if (ops_used) *ops_used = used;
     lap("compact ops");
     return status;
