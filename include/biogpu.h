@@ -143,6 +143,11 @@ int bg_interval_occ_batch_dev(bg_fm* fm, uint64_t n_iv, const uint64_t* d_lower,
 int bg_fmd_smems_batch(bg_fm* fm, int all, uint64_t n_p, const uint8_t* pat, const uint64_t* pat_off,
                        const uint32_t* i_pos, uint32_t min_len, uint32_t cap, uint32_t* count,
                        uint32_t* out);
+/* Single bi-interval steps for a batch of requests: op[q] = 0 init_interval (fmindex.rs:517-524),
+ * 1 init_interval_with(sym[q]) (504-514), 2 backward_ext(iv_in[q], sym[q]) (527-558), 3 forward_ext
+ * (560-564).  Intervals are four uint32 {lower, lower_rev, size, match_size}. */
+int bg_fmd_interval_batch(bg_fm* fm, uint64_t n_req, const uint8_t* op, const uint32_t* iv_in,
+                          const uint8_t* sym, uint32_t* iv_out);
 int bg_fmd_smems_batch_dev(bg_fm* fm, int all, uint64_t n_p, const uint8_t* d_pat,
                            const uint64_t* d_pat_off, const uint32_t* d_i_pos, uint32_t min_len,
                            uint32_t max_pattern_len, uint32_t cap, uint32_t* d_count, uint32_t* d_out,

@@ -71,7 +71,7 @@ SYMBOLS = ["bg_device_count", "bg_init", "bg_free", "bg_strerror", "bg_last_erro
            "bg_set_option", "bg_suffix_array", "bg_bwt", "bg_less", "bg_fm_build", "bg_fm_free",
            "bg_fm_device_bytes", "bg_fm_backward_search_batch", "bg_fm_backward_search_batch_dev",
            "bg_fm_set_suffix_array", "bg_fm_set_sampled_suffix_array", "bg_sa_get_batch", "bg_sa_get_batch_dev",
-           "bg_interval_occ_batch", "bg_interval_occ_batch_dev", "bg_fmd_smems_batch", "bg_fmd_smems_batch_dev",
+           "bg_interval_occ_batch", "bg_interval_occ_batch_dev", "bg_fmd_smems_batch", "bg_fmd_smems_batch_dev", "bg_fmd_interval_batch",
            "bg_align_batch", "bg_align_batch_dev", "bg_align_banded_batch", "bg_band_create_batch",
            "bg_align_banded_bands_batch", "bg_band_from_matches_batch", "bg_sparse_find_kmer_matches", "bg_sparse_sdpkpp",
            "bg_sparse_lcskpp", "bg_sparse_sdpkpp_union_lcskpp_path", "bg_sparse_expand_kmer_matches", "bg_get_timing",
@@ -114,6 +114,7 @@ def lib():
         L.bg_fm_device_bytes.argtypes = [vp]
         L.bg_fm_backward_search_batch.argtypes = [vp, u64, vp, vp, vp, vp, vp, vp]
         L.bg_fm_backward_search_batch_dev.argtypes = [vp, u64, vp, vp, vp, vp, vp, vp, vp]
+        L.bg_fmd_interval_batch.argtypes = [vp, u64, vp, vp, vp, vp]
         L.bg_fmd_smems_batch.argtypes = [vp, i32, u64, vp, vp, vp, u32, u32, vp, vp]
         L.bg_fmd_smems_batch_dev.argtypes = [vp, i32, u64, vp, vp, vp, u32, u32, u32, vp, vp, vp]
         L.bg_fm_set_suffix_array.argtypes = [vp, vp, u64]

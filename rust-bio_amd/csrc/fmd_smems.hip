@@ -256,6 +256,51 @@ __global__ __launch_bounds__(256) void fmd_smems_kernel(const FmdArgs a) {
     }
 }
 
+// One request per quad: op 0 init_interval (fmindex.rs:517-524), 1 init_interval_with(a) (504-514),
+// 2 backward_ext(iv, a) (527-558), 3 forward_ext(iv, a) (560-564).  iv / out: lower, lower_rev, size, match_size.
+__global__ __launch_bounds__(256) void fmd_interval_kernel(FmdArgs a, uint64_t n_req, const uint8_t* op, const uint32_t* iv_in,
+                                                           const uint8_t* sym, uint32_t* iv_out, uint8_t* ok) {
+    __shared__ uint8_t s_class[256];
+    __shared__ uint32_t s_less[256];
+    __shared__ uint8_t s_comp[256];
+    __shared__ uint32_t s_exc[kMaxExcLds];
+    for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) {
+        s_class[i] = a.fm.sym_class[i];
+        s_less[i] = a.fm.less[i];
+        uint8_t c = (uint8_t)i;
+        const char* from = "AGCTYRWSKMDVHBN";
+        const char* to = "TCGARYWSMKHBDVN";
+        for (int k = 0; k < 15; k++) {
+            if (i == (uint32_t)from[k]) c = (uint8_t)to[k];
+            if (i == (uint32_t)from[k] + 32) c = (uint8_t)(to[k] + 32);
+        }
+        s_comp[i] = c;
+    }
+    const bool exc_in_lds = a.fm.n_exc <= kMaxExcLds;
+    if (exc_in_lds)
+        for (uint32_t i = threadIdx.x; i < a.fm.n_exc; i += blockDim.x) s_exc[i] = a.fm.exc_pos[i];
+    __syncthreads();
+    const uint32_t t = threadIdx.x & 3;
+    const uint64_t q = (uint64_t)blockIdx.x * (blockDim.x >> 2) + (threadIdx.x >> 2);
+    if (q >= n_req) return;  // quad-uniform
+    Ctx cx{a, s_class, s_less, s_comp, s_exc, exc_in_lds, t, false};
+    BiIv in{iv_in[4 * q], iv_in[4 * q + 1], iv_in[4 * q + 2], iv_in[4 * q + 3], 0};
+    BiIv r = in;
+    switch (op[q]) {
+        case 0: r = BiIv{0, 0, a.fm.n, 0, 0}; break;
+        case 1: r = cx.init_interval_with(sym[q]); break;
+        case 2: r = cx.backward_ext(in, sym[q]); break;
+        default: r = cx.forward_ext(in, sym[q]); break;
+    }
+    if (t == 0) {
+        iv_out[4 * q] = r.lower;
+        iv_out[4 * q + 1] = r.lower_rev;
+        iv_out[4 * q + 2] = r.size;
+        iv_out[4 * q + 3] = r.msz;
+        ok[q] = cx.panic ? 0 : 1;
+    }
+}
+
 }  // namespace
 
 extern "C" int bg_fmd_smems_batch_dev(bg_fm* fm, int all, uint64_t n_p, const uint8_t* d_pat, const uint64_t* d_pat_off,
@@ -335,4 +380,46 @@ extern "C" int bg_fmd_smems_batch(bg_fm* fm, int all, uint64_t n_p, const uint8_
             status = BG_ERR_OPS_CAP;
     }
     return status;
+}
+
+extern "C" int bg_fmd_interval_batch(bg_fm* fm, uint64_t n_req, const uint8_t* op, const uint32_t* iv_in, const uint8_t* sym,
+                                     uint32_t* iv_out) {
+    if (!fm || (n_req && (!op || !iv_in || !sym || !iv_out))) return BG_ERR_INVALID_ARG;
+    if (!fm->fmd_ok) return BG_ERR_UNSUPPORTED;
+    if (n_req == 0) return BG_OK;
+    bg_ctx* ctx = fm->ctx;
+    BG_HIP(hipSetDevice(ctx->device));
+    uint8_t *d_op = nullptr, *d_sym = nullptr, *d_ok = nullptr;
+    uint32_t *d_in = nullptr, *d_out = nullptr;
+    std::vector<uint8_t> okv(n_req);
+    auto run = [&]() -> int {
+        BG_HIP(hipMalloc((void**)&d_op, n_req));
+        BG_HIP(hipMalloc((void**)&d_sym, n_req));
+        BG_HIP(hipMalloc((void**)&d_ok, n_req));
+        BG_HIP(hipMalloc((void**)&d_in, n_req * 16));
+        BG_HIP(hipMalloc((void**)&d_out, n_req * 16));
+        hipStream_t st = ctx->stream;
+        BG_HIP(hipMemcpyAsync(d_op, op, n_req, hipMemcpyHostToDevice, st));
+        BG_HIP(hipMemcpyAsync(d_sym, sym, n_req, hipMemcpyHostToDevice, st));
+        BG_HIP(hipMemcpyAsync(d_in, iv_in, n_req * 16, hipMemcpyHostToDevice, st));
+        FmdArgs a = {};
+        a.fm = fm->dev;
+        a.less_len = fm->less_len;
+        fmd_interval_kernel<<<dim3((unsigned)((n_req + 63) / 64)), dim3(256), 0, st>>>(a, n_req, d_op, d_in, d_sym, d_out, d_ok);
+        BG_HIP(hipGetLastError());
+        BG_HIP(hipMemcpyAsync(iv_out, d_out, n_req * 16, hipMemcpyDeviceToHost, st));
+        BG_HIP(hipMemcpyAsync(okv.data(), d_ok, n_req, hipMemcpyDeviceToHost, st));
+        BG_HIP(hipStreamSynchronize(st));
+        return BG_OK;
+    };
+    int rc = run();
+    hipFree(d_op);
+    hipFree(d_sym);
+    hipFree(d_ok);
+    hipFree(d_in);
+    hipFree(d_out);
+    if (rc) return rc;
+    for (uint64_t q = 0; q < n_req; q++)
+        if (!okv[q]) return BG_ERR_OUT_OF_ALPHABET;
+    return BG_OK;
 }

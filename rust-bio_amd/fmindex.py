@@ -171,6 +171,25 @@ class FMDIndex:
         cnt, out = self.smems_arrays(buf, off, None, l, all_=True)
         return [self._decode(cnt, out, q) for q in range(len(patterns))]
 
+    def _interval(self, op, iv=None, a=0):
+        if iv is None:
+            ivn = np.zeros((1, 4), dtype=np.uint32)
+        elif isinstance(iv, BiInterval):
+            ivn = np.array([[iv.lower, iv.lower_rev, iv.size, iv.match_size]], dtype=np.uint32)
+        else:
+            ivn = np.array([list(iv)], dtype=np.uint32)
+        out = np.zeros((1, 4), dtype=np.uint32)
+        ops = np.array([op], dtype=np.uint8)
+        sym = np.array([a], dtype=np.uint8)
+        _lib.check(_lib.lib().bg_fmd_interval_batch(self.fm.h, 1, ops.ctypes.data, ivn.ctypes.data, sym.ctypes.data,
+                                                    out.ctypes.data), "FMDIndex interval")
+        return BiInterval(*(int(v) for v in out[0]))
+
+    def init_interval(self): return self._interval(0)                    # fmindex.rs:517
+    def init_interval_with(self, a): return self._interval(1, None, a)   # fmindex.rs:504
+    def backward_ext(self, iv, a): return self._interval(2, iv, a)       # fmindex.rs:527
+    def forward_ext(self, iv, a): return self._interval(3, iv, a)        # fmindex.rs:560
+
     def smems(self, pattern, i, l):  # fmindex.rs:363
         return self.smems_batch([bytes(pattern)], [i], l)[0]
 

@@ -96,3 +96,31 @@ def test_fmd_needs_dna_text():
     fm = FMIndex(b, less(b, b"ACGTXN"), Occ(b, 3, b"ACGTXN"))
     with pytest.raises(AssertionError):
         FMDIndex(fm)
+
+
+def test_init_interval_and_extensions():
+    # fmindex.rs:782-805 test_init_interval
+    c = G["init_interval"]
+    sa, b, ls, fmd = build(c["text"].encode())
+    iv = fmd.init_interval_with(ord(c["a"]))
+    assert iv.forward().occ(sa) == c["forward"] and iv.revcomp().occ(sa) == c["revcomp"]
+    empty = fmd.init_interval()
+    assert fmd.backward_ext(empty, ord(c["a"])) == iv
+    assert fmd.forward_ext(empty, ord(c["a"])) == iv
+    # random walks vs the oracle
+    rng = np.random.default_rng(3)
+    g = synth.random_dna(3000, seed=2).tobytes()
+    sa, b, ls, fmd = build(g + b"$" + revcomp(g) + b"$", k=8)
+    ofmd = orc.FMDIndex(b, ls, orc.Occ(b, 8, ALPHA))
+    for _ in range(60):
+        a0 = int(rng.choice(list(b"ACGT")))
+        iv, oiv = fmd.init_interval_with(a0), ofmd.init_interval_with(a0)
+        for _ in range(12):
+            assert (iv.lower, iv.lower_rev, iv.size, iv.match_size) == oiv
+            if iv.size == 0:
+                break
+            a1 = int(rng.choice(list(b"ACGTN$")))
+            if rng.random() < 0.5:
+                iv, oiv = fmd.backward_ext(iv, a1), ofmd.backward_ext(oiv, a1)
+            else:
+                iv, oiv = fmd.forward_ext(iv, a1), ofmd.forward_ext(oiv, a1)
