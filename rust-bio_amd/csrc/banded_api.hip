@@ -31,20 +31,7 @@ struct HostPair {
     uint64_t tb_bytes = 0;
 };
 
-unsigned host_threads() {
-    // the smaller of the affinity mask and the cgroup CPU quota: threads beyond the quota only get throttled
-    unsigned nt = std::max(1u, std::thread::hardware_concurrency());
-    cpu_set_t set;
-    CPU_ZERO(&set);
-    if (sched_getaffinity(0, sizeof(set), &set) == 0 && CPU_COUNT(&set) > 0) nt = (unsigned)CPU_COUNT(&set);
-    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
-        long long quota = 0, period = 0;
-        if (fscanf(f, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0)
-            nt = std::min<unsigned>(nt, (unsigned)std::max<long long>(1, (quota + period - 1) / period));
-        fclose(f);
-    }
-    return nt;
-}
+unsigned host_threads() { return bg_host_threads(); }
 
 bgband::ClipScores clip_scores(const bg_scoring_t* sc, int mode) {
     bgband::ClipScores c;

@@ -35,6 +35,10 @@ struct bg_ctx {
     size_t aux_bytes = 0;
     void* bnd = nullptr;
     size_t bnd_bytes = 0;
+    void* io[6] = {};       // host-buffer API: device copies of x, y, x_off, y_off, out, ops
+    size_t io_cap[6] = {};
+    void* h_ops = nullptr;  // ... and the pinned landing zone of the operations
+    size_t h_ops_cap = 0;
     void* table = nullptr;  // compacted scoring table + code map
     size_t table_bytes = 0;
     bg_band_scratch* band = nullptr;  // persistent scratch of the banded pipeline
@@ -51,6 +55,8 @@ struct bg_ctx {
 
 // grow-only device scratch
 int bg_reserve(void** p, size_t* cur, size_t need);
+// host threads this process may really use (affinity mask and cgroup CPU quota)
+unsigned bg_host_threads();
 
 // ---- device helpers -------------------------------------------------------------------
 // DPP cross-lane moves (gfx9 encodings): lane i <- lane i-1 / lane i+1 across the 64-lane wave.

@@ -1,4 +1,9 @@
 // Context management and shared utilities of libbiogpu.
+#include <sched.h>
+
+#include <algorithm>
+#include <thread>
+
 #include "bg_common.h"
 
 thread_local std::string bg_tls_error;
@@ -14,6 +19,20 @@ int bg_reserve(void** p, size_t* cur, size_t need) {
     BG_HIP(hipMalloc(p, need));
     *cur = need;
     return BG_OK;
+}
+
+unsigned bg_host_threads() {
+    unsigned nt = std::max(1u, std::thread::hardware_concurrency());
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof(set), &set) == 0 && CPU_COUNT(&set) > 0) nt = (unsigned)CPU_COUNT(&set);
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        long long quota = 0, period = 0;
+        if (fscanf(f, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0)
+            nt = std::min<unsigned>(nt, (unsigned)std::max<long long>(1, (quota + period - 1) / period));
+        fclose(f);
+    }
+    return nt;
 }
 
 extern "C" int bg_device_count(void) {
@@ -54,6 +73,8 @@ extern "C" int bg_free(bg_ctx* ctx) {
     hipFree(ctx->aux);
     hipFree(ctx->bnd);
     hipFree(ctx->table);
+    for (void* p : ctx->io) hipFree(p);
+    if (ctx->h_ops) hipHostFree(ctx->h_ops);
     bg_band_scratch_free(ctx->band);
     if (ctx->ev[0]) hipEventDestroy(ctx->ev[0]);
     if (ctx->ev[1]) hipEventDestroy(ctx->ev[1]);

@@ -7,6 +7,8 @@
 #include <map>
 #include <type_traits>
 
+#include <thread>
+
 #include "sw_kernels.h"
 
 namespace bgsw {
@@ -227,55 +229,52 @@ extern "C" int bg_align_batch(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uin
     const uint64_t xb = x_off[n_pairs], yb = y_off[n_pairs];
     const uint64_t stride = ops_buf ? max_x + max_y + 4 : 0;
     (void)max_sum;
-    uint8_t *d_x = nullptr, *d_y = nullptr, *d_ops = nullptr;
-    uint64_t *d_xo = nullptr, *d_yo = nullptr;
-    bg_alignment_t* d_out = nullptr;
-    std::vector<uint8_t> h_ops;
+    // device copies of the batch and the pinned landing zone of the operations persist in the ctx
+    const size_t need[6] = {std::max<uint64_t>(xb, 16), std::max<uint64_t>(yb, 16), (n_pairs + 1) * 8, (n_pairs + 1) * 8,
+                            n_pairs * sizeof(bg_alignment_t), std::max<uint64_t>(n_pairs * stride, 16)};
+    for (int i = 0; i < 6; i++)
+        if ((rc = bg_reserve(&ctx->io[i], &ctx->io_cap[i], need[i]))) return rc;
+    uint8_t *d_x = (uint8_t*)ctx->io[0], *d_y = (uint8_t*)ctx->io[1], *d_ops = stride ? (uint8_t*)ctx->io[5] : nullptr;
+    uint64_t *d_xo = (uint64_t*)ctx->io[2], *d_yo = (uint64_t*)ctx->io[3];
+    bg_alignment_t* d_out = (bg_alignment_t*)ctx->io[4];
+    if (stride && n_pairs * stride > ctx->h_ops_cap) {
+        if (ctx->h_ops) hipHostFree(ctx->h_ops);
+        ctx->h_ops = nullptr;
+        ctx->h_ops_cap = 0;
+        BG_HIP(hipHostMalloc(&ctx->h_ops, n_pairs * stride, hipHostMallocDefault));
+        ctx->h_ops_cap = n_pairs * stride;
+    }
     hipStream_t st = ctx->stream;
-    auto run = [&]() -> int {
-        BG_HIP(hipMalloc((void**)&d_x, std::max<uint64_t>(xb, 16)));
-        BG_HIP(hipMalloc((void**)&d_y, std::max<uint64_t>(yb, 16)));
-        BG_HIP(hipMalloc((void**)&d_xo, (n_pairs + 1) * 8));
-        BG_HIP(hipMalloc((void**)&d_yo, (n_pairs + 1) * 8));
-        BG_HIP(hipMalloc((void**)&d_out, n_pairs * sizeof(bg_alignment_t)));
-        if (stride) BG_HIP(hipMalloc((void**)&d_ops, n_pairs * stride));
-        if (xb) BG_HIP(hipMemcpyAsync(d_x, x, xb, hipMemcpyHostToDevice, st));
-        if (yb) BG_HIP(hipMemcpyAsync(d_y, y, yb, hipMemcpyHostToDevice, st));
-        BG_HIP(hipMemcpyAsync(d_xo, x_off, (n_pairs + 1) * 8, hipMemcpyHostToDevice, st));
-        BG_HIP(hipMemcpyAsync(d_yo, y_off, (n_pairs + 1) * 8, hipMemcpyHostToDevice, st));
-        int r2 = bg_align_batch_dev(ctx, sc, mode, n_pairs, d_x, d_xo, d_y, d_yo, (uint32_t)max_x,
-                                    (uint32_t)max_y, d_out, d_ops, stride, st);
-        if (r2) return r2;
-        BG_HIP(hipMemcpyAsync(out, d_out, n_pairs * sizeof(bg_alignment_t), hipMemcpyDeviceToHost, st));
-        if (stride) {
-            h_ops.resize(n_pairs * stride);
-            BG_HIP(hipMemcpyAsync(h_ops.data(), d_ops, n_pairs * stride, hipMemcpyDeviceToHost, st));
-        }
-        BG_HIP(hipStreamSynchronize(st));
-        return BG_OK;
-    };
-    rc = run();
-    hipFree(d_x);
-    hipFree(d_y);
-    hipFree(d_xo);
-    hipFree(d_yo);
-    hipFree(d_out);
-    hipFree(d_ops);
+    if (xb) BG_HIP(hipMemcpyAsync(d_x, x, xb, hipMemcpyHostToDevice, st));
+    if (yb) BG_HIP(hipMemcpyAsync(d_y, y, yb, hipMemcpyHostToDevice, st));
+    BG_HIP(hipMemcpyAsync(d_xo, x_off, (n_pairs + 1) * 8, hipMemcpyHostToDevice, st));
+    BG_HIP(hipMemcpyAsync(d_yo, y_off, (n_pairs + 1) * 8, hipMemcpyHostToDevice, st));
+    rc = bg_align_batch_dev(ctx, sc, mode, n_pairs, d_x, d_xo, d_y, d_yo, (uint32_t)max_x, (uint32_t)max_y, d_out, d_ops, stride, st);
     if (rc) return rc;
-    // compact the strided ops into the caller's buffer
+    BG_HIP(hipMemcpyAsync(out, d_out, n_pairs * sizeof(bg_alignment_t), hipMemcpyDeviceToHost, st));
+    if (stride) BG_HIP(hipMemcpyAsync(ctx->h_ops, d_ops, n_pairs * stride, hipMemcpyDeviceToHost, st));
+    BG_HIP(hipStreamSynchronize(st));
+    // compact the strided ops into the caller's buffer: offsets serially, bytes on all host threads
+    const uint8_t* h_ops = (const uint8_t*)ctx->h_ops;
     uint64_t used = 0;
     int status = BG_OK;
+    std::vector<uint64_t> src(n_pairs);
     for (uint64_t p = 0; p < n_pairs; p++) {
         if (out[p].status) status = out[p].status;
-        const uint64_t src = out[p].ops_off;
+        src[p] = out[p].ops_off;
         out[p].ops_off = used;
-        if (ops_buf) {
-            if (used + out[p].n_ops <= ops_cap)
-                memcpy(ops_buf + used, h_ops.data() + src, out[p].n_ops);
-            else if (status == BG_OK)
-                status = BG_ERR_OPS_CAP;
-        }
+        if (ops_buf && used + out[p].n_ops > ops_cap && status == BG_OK) status = BG_ERR_OPS_CAP;
         used += out[p].n_ops;
+    }
+    if (ops_buf) {
+        unsigned nt = std::max(1u, std::min(bg_host_threads(), (unsigned)(n_pairs / 4096 + 1)));
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; t++)
+            th.emplace_back([&, t] {
+                for (uint64_t p = n_pairs * t / nt, pe = n_pairs * (t + 1) / nt; p < pe; p++)
+                    if (out[p].ops_off + out[p].n_ops <= ops_cap) memcpy(ops_buf + out[p].ops_off, h_ops + src[p], out[p].n_ops);
+            });
+        for (auto& t : th) t.join();
     }
     if (ops_used) *ops_used = used;
     return status;
