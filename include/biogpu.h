@@ -84,6 +84,11 @@ uint64_t bg_fm_device_bytes(const bg_fm* fm);
 enum { BG_FM_COMPLETE = 0, BG_FM_PARTIAL = 1, BG_FM_ABSENT = 2,
        BG_FM_PANIC = 3 /* this query reached a byte outside the alphabet */ };
 
+/* Options of an index handle: "jump_min_queries" — batch size from which backward search builds (once,
+ * 256 MB) and uses a table of the search state after a pattern's last 12 symbols; < 0 disables it.
+ * Results do not depend on it. */
+int bg_fm_set_option(bg_fm* fm, const char* key, int64_t value);
+
 /* backward_search for n_q patterns (fmindex.rs:144-208).  Pattern q is
  * pat[pat_off[q] .. pat_off[q+1]).  Outputs per query: tag, Interval{lower,upper} (for
  * Partial: the interval of the maximal matching suffix), matched_len (Complete: |P|).

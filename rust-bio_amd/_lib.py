@@ -69,7 +69,7 @@ assert ALN_DTYPE.itemsize == 64, ALN_DTYPE.itemsize
 
 SYMBOLS = ["bg_device_count", "bg_init", "bg_free", "bg_strerror", "bg_last_error",
            "bg_set_option", "bg_suffix_array", "bg_bwt", "bg_less", "bg_fm_build", "bg_fm_free",
-           "bg_fm_device_bytes", "bg_fm_backward_search_batch", "bg_fm_backward_search_batch_dev",
+           "bg_fm_device_bytes", "bg_fm_set_option", "bg_fm_backward_search_batch", "bg_fm_backward_search_batch_dev",
            "bg_fm_set_suffix_array", "bg_fm_set_sampled_suffix_array", "bg_sa_get_batch", "bg_sa_get_batch_dev",
            "bg_interval_occ_batch", "bg_interval_occ_batch_dev", "bg_fmd_smems_batch", "bg_fmd_smems_batch_dev", "bg_fmd_interval_batch",
            "bg_align_batch", "bg_align_batch_dev", "bg_align_banded_batch", "bg_band_create_batch",
@@ -110,6 +110,7 @@ def lib():
         L.bg_less.argtypes = [vp, u64, vp, u32, vp, C.POINTER(u32)]
         L.bg_fm_build.argtypes = [vp, vp, u64, vp, u32, u32, vp, u32, C.POINTER(vp)]
         L.bg_fm_free.argtypes = [vp]
+        L.bg_fm_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
         L.bg_fm_device_bytes.restype = u64
         L.bg_fm_device_bytes.argtypes = [vp]
         L.bg_fm_backward_search_batch.argtypes = [vp, u64, vp, vp, vp, vp, vp, vp]

@@ -28,10 +28,15 @@ using namespace bgfm;
 
 namespace {
 
+// `jump` (optional): the state of the search after the LAST kJumpK symbols of a pattern, for every
+// kJumpK-mer over the four coded symbols — {l, r, depth}: depth < kJumpK means the search ends there
+// (the next symbol empties the interval).  A pattern whose last kJumpK symbols are all coded starts from
+// that entry: one table read instead of kJumpK LF steps (2 block reads each).  The table is filled by
+// this very kernel (run without it), so the results cannot differ.
 __global__ __launch_bounds__(256) void fm_backward_search_kernel(
     FmDev fm, uint64_t n_q, const uint8_t* __restrict__ pat, const uint64_t* __restrict__ pat_off,
     uint8_t* __restrict__ tag, uint64_t* __restrict__ lower, uint64_t* __restrict__ upper,
-    uint32_t* __restrict__ matched_len) {
+    uint32_t* __restrict__ matched_len, const uint4* __restrict__ jump) {
     __shared__ uint8_t s_class[256];
     __shared__ uint32_t s_less[256];
     __shared__ uint32_t s_exc[kMaxExcLds];
@@ -74,7 +79,36 @@ __global__ __launch_bounds__(256) void fm_backward_search_kernel(
                 l = 0;
                 r = fm.n - 1;  // fmindex.rs:148
                 matched = 0;
-                a_next = pat[off + len - 1];
+                if (jump && len >= kJumpK) {
+                    uint32_t idx = 0;
+                    bool coded = true;
+                    for (uint32_t u = 0; u < kJumpK; u++) {  // u-th symbol from the end
+                        const uint32_t c = s_class[pat[off + len - 1 - u]];
+                        coded = coded && c < 4;
+                        idx = idx << 2 | (c & 3u);
+                    }
+                    if (coded) {
+                        const uint4 e = jump[idx];
+                        l = e.x;
+                        r = e.y;
+                        matched = e.z;
+                        pos = len - e.z;
+                        if (e.z < kJumpK) {  // the search ends inside the last kJumpK symbols
+                            if (e.z)
+                                emit(BG_FM_PARTIAL, l, r + 1, e.z);
+                            else
+                                emit(BG_FM_ABSENT, 0, 0, 0);
+                            q += n_quads;
+                            continue;
+                        }
+                        if (pos == 0) {
+                            emit(BG_FM_COMPLETE, l, r + 1, matched);
+                            q += n_quads;
+                            continue;
+                        }
+                    }
+                }
+                a_next = pat[off + pos - 1];
                 active = true;
                 return;
             }
@@ -154,6 +188,26 @@ __global__ __launch_bounds__(256) void fm_backward_search_kernel(
             }
         }
     }
+}
+
+// jump-table construction: every kJumpK-mer over the four coded bytes as a pattern ...
+__global__ __launch_bounds__(256) void fm_jump_patterns_kernel(uint32_t code_byte, uint8_t* pat, uint64_t* pat_off) {
+    const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t n = 1ull << (2 * kJumpK);
+    if (idx > n) return;
+    pat_off[idx] = idx * kJumpK;
+    if (idx == n) return;
+    for (uint32_t j = 0; j < kJumpK; j++) pat[idx * kJumpK + j] = (uint8_t)(code_byte >> (8 * ((idx >> (2 * j)) & 3u)));
+}
+// ... and its search result as a table entry {l, r, depth, 0}
+__global__ __launch_bounds__(256) void fm_jump_pack_kernel(const uint8_t* tag, const uint64_t* lower, const uint64_t* upper,
+                                                           const uint32_t* matched, uint4* jump) {
+    const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (1ull << (2 * kJumpK))) return;
+    const uint32_t tg = tag[idx];
+    uint4 e = make_uint4(0, 0, 0, 0);
+    if (tg == BG_FM_COMPLETE || tg == BG_FM_PARTIAL) e = make_uint4((uint32_t)lower[idx], (uint32_t)upper[idx] - 1u, matched[idx], 0);
+    jump[idx] = e;
 }
 
 }  // namespace
@@ -245,6 +299,7 @@ extern "C" int bg_fm_build(bg_ctx* ctx, const uint8_t* bwt, uint64_t n, const ui
         if (hist[c] && (c == 0 || !strchr("ACGTNacgtn$", c))) fm->fmd_ok = false;
     for (int c = 0; c < 256; c++)
         if (code_of[c] >= 0) fm->code_byte[code_of[c]] = (uint8_t)c;
+    fm->n_codes = n_codes;
     fm->dev.exc_sym_off[0] = 0;
     for (size_t e = 0; e < exc_by_sym.size(); e++) {
         exc_sym_pos.insert(exc_sym_pos.end(), exc_by_sym[e].begin(), exc_by_sym[e].end());
@@ -294,6 +349,7 @@ extern "C" int bg_fm_free(bg_fm* fm) {
     hipFree(fm->d_class);
     hipFree(fm->d_less);
     hipFree(fm->d_exc_byte);
+    hipFree(fm->d_jump);
     hipFree(fm->d_sa);
     hipFree(fm->d_extra_row);
     hipFree(fm->d_extra_pos);
@@ -302,6 +358,20 @@ extern "C" int bg_fm_free(bg_fm* fm) {
 }
 
 extern "C" uint64_t bg_fm_device_bytes(const bg_fm* fm) { return fm ? fm->bytes : 0; }
+
+extern "C" int bg_fm_set_option(bg_fm* fm, const char* key, int64_t value) {
+    if (!fm || !key) return BG_ERR_INVALID_ARG;
+    if (!strcmp(key, "jump_min_queries")) {  // batch size from which K5 builds / uses its jump table; < 0: never
+        fm->no_jump = value < 0;
+        fm->jump_min_queries = value < 0 ? ~0ull : (uint64_t)value;
+        if (fm->no_jump && fm->d_jump) {
+            hipFree(fm->d_jump);
+            fm->d_jump = nullptr;
+        }
+        return BG_OK;
+    }
+    return BG_ERR_INVALID_ARG;
+}
 
 extern "C" int bg_fm_backward_search_batch_dev(bg_fm* fm, uint64_t n_q, const uint8_t* d_pat,
                                                const uint64_t* d_pat_off, uint8_t* d_tag,
@@ -315,9 +385,46 @@ extern "C" int bg_fm_backward_search_batch_dev(bg_fm* fm, uint64_t n_q, const ui
     const uint64_t quads_per_block = 64;
     uint64_t blocks = (n_q + quads_per_block - 1) / quads_per_block;
     blocks = std::min<uint64_t>(blocks, 256 * 8);  // 8 resident 256-thread blocks per CU
+    // the jump table pays off from a few million LF steps on; it is built once per index, by the search itself
+    if (!fm->d_jump && !fm->no_jump && n_q >= fm->jump_min_queries && fm->n_codes == 4) {
+        const uint64_t nk = 1ull << (2 * kJumpK);
+        uint8_t *t_pat = nullptr, *t_tag = nullptr;
+        uint64_t *t_off = nullptr, *t_lo = nullptr, *t_hi = nullptr;
+        uint32_t* t_ml = nullptr;
+        auto build = [&]() -> int {
+            BG_HIP(hipMalloc((void**)&t_pat, nk * kJumpK));
+            BG_HIP(hipMalloc((void**)&t_off, (nk + 1) * 8));
+            BG_HIP(hipMalloc((void**)&t_tag, nk));
+            BG_HIP(hipMalloc((void**)&t_lo, nk * 8));
+            BG_HIP(hipMalloc((void**)&t_hi, nk * 8));
+            BG_HIP(hipMalloc((void**)&t_ml, nk * 4));
+            BG_HIP(hipMalloc(&fm->d_jump, nk * sizeof(uint4)));
+            const uint32_t cb = (uint32_t)fm->code_byte[0] | (uint32_t)fm->code_byte[1] << 8 | (uint32_t)fm->code_byte[2] << 16 |
+                                (uint32_t)fm->code_byte[3] << 24;
+            fm_jump_patterns_kernel<<<dim3((unsigned)((nk + 256) / 256)), dim3(256), 0, st>>>(cb, t_pat, t_off);
+            fm_backward_search_kernel<<<dim3(256 * 8), dim3(256), 0, st>>>(fm->dev, nk, t_pat, t_off, t_tag, t_lo, t_hi, t_ml, nullptr);
+            fm_jump_pack_kernel<<<dim3((unsigned)(nk / 256)), dim3(256), 0, st>>>(t_tag, t_lo, t_hi, t_ml, (uint4*)fm->d_jump);
+            BG_HIP(hipGetLastError());
+            BG_HIP(hipStreamSynchronize(st));
+            fm->bytes += nk * sizeof(uint4);
+            return BG_OK;
+        };
+        const int rcj = build();
+        hipFree(t_pat);
+        hipFree(t_off);
+        hipFree(t_tag);
+        hipFree(t_lo);
+        hipFree(t_hi);
+        hipFree(t_ml);
+        if (rcj) {  // no memory for the table: search without it
+            hipFree(fm->d_jump);
+            fm->d_jump = nullptr;
+            fm->no_jump = true;
+        }
+    }
     if (ctx->timing) BG_HIP(hipEventRecord(ctx->ev[0], st));
     fm_backward_search_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(
-        fm->dev, n_q, d_pat, d_pat_off, d_tag, d_lower, d_upper, d_matched_len);
+        fm->dev, n_q, d_pat, d_pat_off, d_tag, d_lower, d_upper, d_matched_len, (const uint4*)fm->d_jump);
     BG_HIP(hipGetLastError());
     if (ctx->timing) {
         BG_HIP(hipEventRecord(ctx->ev[1], st));

@@ -11,6 +11,7 @@ constexpr uint32_t kMaxExcLds = 1024;   // exception positions staged in LDS
 constexpr uint32_t kMaxExcSyms = 32;    // distinct exception byte values supported
 constexpr uint8_t kClsZero = 4;         // in alphabet, never occurs in the BWT
 constexpr uint8_t kClsExc = 8;          // kClsExc + e : exception symbol e
+constexpr uint32_t kJumpK = 12;  // symbols covered by the jump table of K5 (4^12 entries x 16 bytes = 256 MB)
 constexpr uint8_t kClsPanic = 255;      // not in the alphabet: the reference panics
 
 struct FmDev {
@@ -81,6 +82,10 @@ struct bg_fm {
     uint32_t sa_rate = 0;
     uint8_t sa_sentinel = 0;
     uint8_t code_byte[4] = {0, 0, 0, 0};  // byte value of each 2-bit code
+    void* d_jump = nullptr;  // K5's jump table, built lazily by the first large batch
+    uint64_t jump_min_queries = 1u << 20;
+    bool no_jump = false;    // ... unless disabled (bg_fm_set_option) or out of memory
+    int n_codes = 0;         // distinct bytes with a 2-bit code (<= 4)
     uint32_t less_len = 0;
     bool fmd_ok = false;  // the BWT is a word over dna::n_alphabet() + '$' (FMDIndex::from, fmindex.rs:323-327)
 };

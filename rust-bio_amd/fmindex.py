@@ -55,6 +55,9 @@ class FMIndex:
     def bwt(self):
         return self._bwt
 
+    def set_option(self, key, value):
+        _lib.check(_lib.lib().bg_fm_set_option(self.h, key.encode(), int(value)), "bg_fm_set_option")
+
     def device_bytes(self):
         return int(_lib.lib().bg_fm_device_bytes(self.h))
 

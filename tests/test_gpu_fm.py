@@ -118,3 +118,33 @@ def test_genome_1m_sample_bit_exact():
         for r in range(int(lo[q]), int(hi[q])):
             s = int(sa[r])
             assert bytes(g[s:s + len(p)]) == p
+
+
+def test_jump_table_does_not_change_results():
+    """K5's table of the search state after the last 12 symbols (built by the search itself) against the
+    plain LF loop: patterns shorter than, equal to and longer than 12, with N's, partial and absent ones."""
+    g = synth.genome(300_000, 9)
+    sa, b, ls, fm = build(g, b"ACGTNacgtn", 64)
+    rng = np.random.default_rng(2)
+    pats = []
+    gb = g.tobytes()
+    for _ in range(30_000):
+        ln = int(rng.integers(1, 40))
+        s = int(rng.integers(0, len(gb) - 50))
+        p = bytearray(gb[s:s + ln])
+        r = rng.random()
+        if r < 0.3:
+            p[int(rng.integers(0, ln))] = b"ACGT"[int(rng.integers(0, 4))]
+        elif r < 0.35:
+            p[int(rng.integers(0, ln))] = ord("N")
+        elif r < 0.4:
+            p = bytearray(np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=ln)].tobytes())
+        pats.append(bytes(p))
+    buf, off = _lib.concat(pats)
+    fm.set_option("jump_min_queries", -1)
+    plain = fm.backward_search_arrays(buf, off)
+    fm.set_option("jump_min_queries", 0)
+    fast = fm.backward_search_arrays(buf, off)
+    assert fm.device_bytes() > 200_000_000  # the table exists
+    for a_, b_ in zip(plain, fast):
+        assert (a_ == b_).all()
