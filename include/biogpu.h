@@ -223,6 +223,15 @@ int bg_align_banded_batch(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint32_
                           uint8_t* ops_buf, uint64_t ops_cap, uint64_t* ops_used,
                           uint64_t* band_cells);
 
+/* Same with device pointers for the sequences, offsets, records and operation slots (bg_align_batch_dev
+ * conventions: record p keeps ops_off = (p + 1) * ops_stride - n_ops, its operations right-aligned in
+ * slot p; ops_stride >= longest x + longest y + 4).  The call is synchronous (it drives the engine's own
+ * streams); work queued on `stream` before it is waited for.  band_cells is a host array (optional). */
+int bg_align_banded_batch_dev(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint32_t k, uint32_t w,
+                              uint64_t n_pairs, const uint8_t* d_x, const uint64_t* d_x_off,
+                              const uint8_t* d_y, const uint64_t* d_y_off, bg_alignment_t* d_out,
+                              uint8_t* d_ops, uint64_t ops_stride, uint64_t* band_cells, void* stream);
+
 /* Band::create (banded.rs:1278-1367) for a batch, on host threads: k-mer matching, sparse DP
  * chaining (sparse.rs:188-295) and band rasterisation under the clip penalties `mode` implies.
  * Pair p's n_p+1 half-open row ranges [start, end) are written at band_off[p]; band_cells

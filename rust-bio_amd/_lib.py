@@ -72,7 +72,7 @@ SYMBOLS = ["bg_device_count", "bg_init", "bg_free", "bg_strerror", "bg_last_erro
            "bg_fm_device_bytes", "bg_fm_set_option", "bg_fm_backward_search_batch", "bg_fm_backward_search_batch_dev",
            "bg_fm_set_suffix_array", "bg_fm_set_sampled_suffix_array", "bg_sa_get_batch", "bg_sa_get_batch_dev",
            "bg_interval_occ_batch", "bg_interval_occ_batch_dev", "bg_fmd_smems_batch", "bg_fmd_smems_batch_dev", "bg_fmd_interval_batch",
-           "bg_align_batch", "bg_align_batch_dev", "bg_align_banded_batch", "bg_band_create_batch",
+           "bg_align_batch", "bg_align_batch_dev", "bg_align_banded_batch", "bg_align_banded_batch_dev", "bg_band_create_batch",
            "bg_align_banded_bands_batch", "bg_band_from_matches_batch", "bg_sparse_find_kmer_matches", "bg_sparse_sdpkpp",
            "bg_sparse_lcskpp", "bg_sparse_sdpkpp_union_lcskpp_path", "bg_sparse_expand_kmer_matches", "bg_get_timing",
            "bg_enable_timing"]
@@ -130,6 +130,7 @@ def lib():
                                          u32, vp, vp, u64, vp]
         L.bg_align_banded_batch.argtypes = [vp, C.POINTER(ScoringC), i32, u32, u32, u64, vp, vp,
                                             vp, vp, vp, vp, u64, C.POINTER(u64), vp]
+        L.bg_align_banded_batch_dev.argtypes = [vp, C.POINTER(ScoringC), i32, u32, u32, u64, vp, vp, vp, vp, vp, vp, u64, vp, vp]
         L.bg_band_create_batch.argtypes = [C.POINTER(ScoringC), i32, u32, u32, u64, vp, vp, vp, vp, vp, vp, vp, vp]
         L.bg_align_banded_bands_batch.argtypes = [vp, C.POINTER(ScoringC), i32, u64, vp, vp, vp, vp, vp, vp, vp, vp, vp,
                                                   u64, C.POINTER(u64), vp]

@@ -83,6 +83,17 @@ class Aligner:
         _lib.check(rc, "bg_align_banded_batch")
         return out, ops
 
+    def align_dev(self, mode, n_pairs, d_x, d_x_off, d_y, d_y_off, d_out, d_ops, ops_stride, stream=0, want_cells=False):
+        """Device-resident batch (pointers are ints): results stay in HBM; returns Band::num_cells per pair
+        when asked.  Synchronous."""
+        cells = np.zeros(n_pairs, dtype=np.uint64) if want_cells else None
+        sc = self.scoring.to_c()
+        _lib.check(_lib.lib().bg_align_banded_batch_dev(self.ctx.h, C.byref(sc), mode, self.k, self.w, n_pairs, d_x, d_x_off,
+                                                        d_y, d_y_off, d_out, d_ops, ops_stride,
+                                                        cells.ctypes.data if want_cells else None, stream),
+                   "bg_align_banded_batch_dev")
+        return cells
+
     def align_batch(self, mode, xs, ys):
         x, xo = _lib.concat(xs)
         y, yo = _lib.concat(ys)

@@ -241,16 +241,27 @@ extern "C" int bg_band_create_batch(const bg_scoring_t* sc, int mode, uint32_t k
 // `make_band(p, band, ws)` fills the band of pair p (called from host threads); false = invalid input
 using BandMaker = std::function<bool(uint64_t, bgband::Band&, bgband::Workspace&)>;
 
+// device-resident flavour: sequences, offsets, records and (strided) operation slots stay in HBM
+struct BandDevIO {
+    const uint8_t* d_x;
+    const uint64_t* d_xo;
+    const uint8_t* d_y;
+    const uint64_t* d_yo;
+    bg_alignment_t* d_out;
+    uint8_t* d_ops;       // may be null
+    uint64_t ops_stride;  // >= max_x + max_y + 4
+};
+
 static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint64_t n_pairs, const uint8_t* x,
                              const uint64_t* x_off, const uint8_t* y, const uint64_t* y_off, bg_alignment_t* out,
                              uint8_t* ops_buf, uint64_t ops_cap, uint64_t* ops_used, uint64_t* band_cells,
-                             const BandMaker& make_band, const uint32_t* dev_kw = nullptr) {
+                             const BandMaker& make_band, const uint32_t* dev_kw = nullptr, const BandDevIO* dio = nullptr) {
     if (!ctx || !sc || mode < BG_MODE_CUSTOM || mode > BG_MODE_LOCAL) return BG_ERR_INVALID_ARG;
     int rc = check_scoring(sc);
     if (rc) return rc;
     if (ops_used) *ops_used = 0;
     if (n_pairs == 0) return BG_OK;
-    if (!x_off || !y_off || !out) return BG_ERR_INVALID_ARG;
+    if (!x_off || !y_off || (!out && !dio)) return BG_ERR_INVALID_ARG;
     BG_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     if (!ctx->band) {
@@ -272,7 +283,8 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
         max_y = std::max(max_y, y_off[p + 1] - y_off[p]);
     }
     if (max_x > (1u << 24) || max_y > (1u << 24)) return BG_ERR_TOO_LARGE;
-    const uint64_t stride = (max_x + max_y + 4 + 3) & ~3ull;
+    const uint64_t stride = dio ? dio->ops_stride : ((max_x + max_y + 4 + 3) & ~3ull);
+    if (dio && dio->d_ops && stride < max_x + max_y + 4) return BG_ERR_OPS_CAP;
 
     BandArgs a = {};
     a.sc = {cs.gap_open, cs.gap_extend, cs.xclip_prefix, cs.xclip_suffix, cs.yclip_prefix, cs.yclip_suffix,
@@ -314,17 +326,33 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
 
     // sequences and result records of the whole batch live on the device; band data goes in sub-batches
     const uint64_t xb = x_off[n_pairs], yb = y_off[n_pairs];
-    const size_t io_need[6] = {std::max<uint64_t>(xb, 16), std::max<uint64_t>(yb, 16), (n_pairs + 1) * 8, (n_pairs + 1) * 8,
-                               n_pairs * sizeof(bg_alignment_t), ops_buf ? n_pairs * stride : 16};
-    for (int i = 0; i < 6; i++)
-        if ((rc = bg_reserve(&B.io[i], &B.io_cap[i], io_need[i]))) return rc;
-    uint8_t *d_x = (uint8_t*)B.io[0], *d_y = (uint8_t*)B.io[1], *d_ops = ops_buf ? (uint8_t*)B.io[5] : nullptr;
-    uint64_t *d_xo = (uint64_t*)B.io[2], *d_yo = (uint64_t*)B.io[3];
-    bg_alignment_t* d_out = (bg_alignment_t*)B.io[4];
-    if (xb) BG_HIP(hipMemcpyAsync(d_x, x, xb, hipMemcpyHostToDevice, st));
-    if (yb) BG_HIP(hipMemcpyAsync(d_y, y, yb, hipMemcpyHostToDevice, st));
-    BG_HIP(hipMemcpyAsync(d_xo, x_off, (n_pairs + 1) * 8, hipMemcpyHostToDevice, st));
-    BG_HIP(hipMemcpyAsync(d_yo, y_off, (n_pairs + 1) * 8, hipMemcpyHostToDevice, st));
+    const uint8_t *d_x, *d_y;
+    const uint64_t *d_xo, *d_yo;
+    uint8_t* d_ops;
+    bg_alignment_t* d_out;
+    if (dio) {
+        d_x = dio->d_x;
+        d_y = dio->d_y;
+        d_xo = dio->d_xo;
+        d_yo = dio->d_yo;
+        d_out = dio->d_out;
+        d_ops = dio->d_ops;
+    } else {
+        const size_t io_need[6] = {std::max<uint64_t>(xb, 16), std::max<uint64_t>(yb, 16), (n_pairs + 1) * 8, (n_pairs + 1) * 8,
+                                   n_pairs * sizeof(bg_alignment_t), ops_buf ? n_pairs * stride : 16};
+        for (int i = 0; i < 6; i++)
+            if ((rc = bg_reserve(&B.io[i], &B.io_cap[i], io_need[i]))) return rc;
+        d_x = (uint8_t*)B.io[0];
+        d_y = (uint8_t*)B.io[1];
+        d_ops = ops_buf ? (uint8_t*)B.io[5] : nullptr;
+        d_xo = (uint64_t*)B.io[2];
+        d_yo = (uint64_t*)B.io[3];
+        d_out = (bg_alignment_t*)B.io[4];
+        if (xb) BG_HIP(hipMemcpyAsync((void*)d_x, x, xb, hipMemcpyHostToDevice, st));
+        if (yb) BG_HIP(hipMemcpyAsync((void*)d_y, y, yb, hipMemcpyHostToDevice, st));
+        BG_HIP(hipMemcpyAsync((void*)d_xo, x_off, (n_pairs + 1) * 8, hipMemcpyHostToDevice, st));
+        BG_HIP(hipMemcpyAsync((void*)d_yo, y_off, (n_pairs + 1) * 8, hipMemcpyHostToDevice, st));
+    }
     a.x = d_x;
     a.x_off = d_xo;
     a.y = d_y;
@@ -601,6 +629,13 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
             if ((rc = issue(p0, n_chunk))) return rc;
         }
     }
+    if (dio) {  // everything stays in HBM; records keep the strided ops_off like bg_align_batch_dev
+        BG_HIP(hipStreamSynchronize(st_tb));
+        BG_HIP(hipStreamSynchronize(st));
+        for (auto& s : B.set) s.busy = false;
+        lap("drain");
+        return BG_OK;
+    }
     // results: records and (pinned) operations come back on the traceback stream
     BG_HIP(hipMemcpyAsync(out, d_out, n_pairs * sizeof(bg_alignment_t), hipMemcpyDeviceToHost, st_tb));
     if (ops_buf) {
@@ -649,6 +684,40 @@ extern "C" int bg_align_banded_batch(bg_ctx* ctx, const bg_scoring_t* sc, int mo
                                  return true;
                              },
                              kw);
+}
+
+// Device-resident flavour of bg_align_banded_batch: sequences, offsets, records and operation slots are
+// device pointers (records keep ops_off = (p + 1) * ops_stride - n_ops, operations right-aligned in their
+// slot, as bg_align_batch_dev leaves them).  Synchronous: it drives its own streams and returns when
+// the results are in place; work queued on `stream` before the call is waited for first.
+extern "C" int bg_align_banded_batch_dev(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint32_t k, uint32_t w,
+                                         uint64_t n_pairs, const uint8_t* d_x, const uint64_t* d_x_off, const uint8_t* d_y,
+                                         const uint64_t* d_y_off, bg_alignment_t* d_out, uint8_t* d_ops, uint64_t ops_stride,
+                                         uint64_t* band_cells, void* stream) {
+    if (!ctx || !sc || mode < BG_MODE_CUSTOM || mode > BG_MODE_LOCAL) return BG_ERR_INVALID_ARG;
+    if (n_pairs == 0) return BG_OK;
+    if (!d_x_off || !d_y_off || !d_out) return BG_ERR_INVALID_ARG;
+    BG_HIP(hipSetDevice(ctx->device));
+    BG_HIP(hipStreamSynchronize((hipStream_t)stream));
+    // the host side of the pipeline needs the lengths
+    std::vector<uint64_t> x_off(n_pairs + 1), y_off(n_pairs + 1);
+    BG_HIP(hipMemcpy(x_off.data(), d_x_off, (n_pairs + 1) * 8, hipMemcpyDeviceToHost));
+    BG_HIP(hipMemcpy(y_off.data(), d_y_off, (n_pairs + 1) * 8, hipMemcpyDeviceToHost));
+    const bgband::ClipScores cs = clip_scores(sc, mode);
+    const uint32_t kw[2] = {k, w};
+    const BandDevIO dio = {d_x, d_x_off, d_y, d_y_off, d_out, d_ops, ops_stride};
+    return banded_batch_impl(ctx, sc, mode, n_pairs, nullptr, x_off.data(), nullptr, y_off.data(), nullptr, nullptr, 0, nullptr,
+                             band_cells,
+                             [&](uint64_t p, bgband::Band& band, bgband::Workspace& ws) {
+                                 // a pair the device builder hands back: fetch its sequences for the host builder
+                                 const size_t m = (size_t)(x_off[p + 1] - x_off[p]), n = (size_t)(y_off[p + 1] - y_off[p]);
+                                 std::vector<uint8_t> hx(m + 1), hy(n + 1);
+                                 if (m && hipMemcpy(hx.data(), d_x + x_off[p], m, hipMemcpyDeviceToHost) != hipSuccess) return false;
+                                 if (n && hipMemcpy(hy.data(), d_y + y_off[p], n, hipMemcpyDeviceToHost) != hipSuccess) return false;
+                                 band.create(hx.data(), m, hy.data(), n, k, w, cs, ws);
+                                 return true;
+                             },
+                             kw, &dio);
 }
 
 // compute_alignment (banded.rs:406-869) over caller-supplied bands: n + 1 half-open row ranges per pair at

