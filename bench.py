@@ -261,9 +261,9 @@ def main():
                              "index_bytes": fm.device_bytes(), "index_build_s": round(build_s, 1)},
                   "tags": {"complete": int((d_tag == 0).sum().item()), "partial": int((d_tag == 1).sum().item()),
                            "absent": int((d_tag == 2).sum().item())},
-                  "roofline": {"bound": "hbm", "kernel": "fm_backward_search_kernel", "achieved": round(fm_ach, 2),
+                  "roofline": {"bound": "hbm", "kernel": "fm_backward_search_kernel<true>", "achieved": round(fm_ach, 2),
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(fm_ach / HBM_PEAK_GBS, 5),
-                               "traffic": pmc_traffic("fm_backward_search_kernel", "fm_queries_per_launch", n_q),
+                               "traffic": pmc_traffic("fm_backward_search_kernel<true>", "fm_queries_per_launch", n_q),
                                "launch_ms": round(fm_ms, 4), "queries_per_launch": n_q,
                                "alg_bytes_per_query": round(alg_bytes / n_q, 1)}}
         if do_cpu:

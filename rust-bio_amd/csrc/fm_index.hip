@@ -32,7 +32,9 @@ namespace {
 // kJumpK-mer over the four coded symbols — {l, r, depth}: depth < kJumpK means the search ends there
 // (the next symbol empties the interval).  A pattern whose last kJumpK symbols are all coded starts from
 // that entry: one table read instead of kJumpK LF steps (2 block reads each).  The table is filled by
-// this very kernel (run without it), so the results cannot differ.
+// this very kernel (run without it: JUMP == false, which also keeps the two apart in profiles), so the
+// results cannot differ.
+template <bool JUMP>
 __global__ __launch_bounds__(256) void fm_backward_search_kernel(
     FmDev fm, uint64_t n_q, const uint8_t* __restrict__ pat, const uint64_t* __restrict__ pat_off,
     uint8_t* __restrict__ tag, uint64_t* __restrict__ lower, uint64_t* __restrict__ upper,
@@ -79,7 +81,7 @@ __global__ __launch_bounds__(256) void fm_backward_search_kernel(
                 l = 0;
                 r = fm.n - 1;  // fmindex.rs:148
                 matched = 0;
-                if (jump && len >= kJumpK) {
+                if (JUMP && len >= kJumpK) {
                     uint32_t idx = 0;
                     bool coded = true;
                     for (uint32_t u = 0; u < kJumpK; u++) {  // u-th symbol from the end
@@ -402,7 +404,7 @@ extern "C" int bg_fm_backward_search_batch_dev(bg_fm* fm, uint64_t n_q, const ui
             const uint32_t cb = (uint32_t)fm->code_byte[0] | (uint32_t)fm->code_byte[1] << 8 | (uint32_t)fm->code_byte[2] << 16 |
                                 (uint32_t)fm->code_byte[3] << 24;
             fm_jump_patterns_kernel<<<dim3((unsigned)((nk + 256) / 256)), dim3(256), 0, st>>>(cb, t_pat, t_off);
-            fm_backward_search_kernel<<<dim3(256 * 8), dim3(256), 0, st>>>(fm->dev, nk, t_pat, t_off, t_tag, t_lo, t_hi, t_ml, nullptr);
+            fm_backward_search_kernel<false><<<dim3(256 * 8), dim3(256), 0, st>>>(fm->dev, nk, t_pat, t_off, t_tag, t_lo, t_hi, t_ml, nullptr);
             fm_jump_pack_kernel<<<dim3((unsigned)(nk / 256)), dim3(256), 0, st>>>(t_tag, t_lo, t_hi, t_ml, (uint4*)fm->d_jump);
             BG_HIP(hipGetLastError());
             BG_HIP(hipStreamSynchronize(st));
@@ -423,8 +425,12 @@ extern "C" int bg_fm_backward_search_batch_dev(bg_fm* fm, uint64_t n_q, const ui
         }
     }
     if (ctx->timing) BG_HIP(hipEventRecord(ctx->ev[0], st));
-    fm_backward_search_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(
-        fm->dev, n_q, d_pat, d_pat_off, d_tag, d_lower, d_upper, d_matched_len, (const uint4*)fm->d_jump);
+    if (fm->d_jump && n_q >= fm->jump_min_queries)
+        fm_backward_search_kernel<true><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(
+            fm->dev, n_q, d_pat, d_pat_off, d_tag, d_lower, d_upper, d_matched_len, (const uint4*)fm->d_jump);
+    else
+        fm_backward_search_kernel<false><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(
+            fm->dev, n_q, d_pat, d_pat_off, d_tag, d_lower, d_upper, d_matched_len, nullptr);
     BG_HIP(hipGetLastError());
     if (ctx->timing) {
         BG_HIP(hipEventRecord(ctx->ev[1], st));
