@@ -122,6 +122,10 @@ extern "C" int bg_set_option(bg_ctx* ctx, const char* key, int64_t value) {
         ctx->band_on_host = value != 0;
         return BG_OK;
     }
+    if (!strcmp(key, "no_pk16")) {
+        ctx->no_pk16 = value != 0;
+        return BG_OK;
+    }
     if (!strcmp(key, "force_wide")) {
         ctx->force_wide = value != 0;
         return BG_OK;

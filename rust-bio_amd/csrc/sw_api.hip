@@ -15,6 +15,7 @@ namespace bgsw {
 sw_fill_fn get_fill_params_narrow(int lp, int r, bool local);
 sw_fill_fn get_fill_params_wide(int lp, int r, bool local);
 sw_fill_fn get_fill_matrix(int lp, int r, int sm, bool narrow);
+sw_fill_fn get_fill_pk16(int lp, int r, bool fast);
 void launch_traceback(const SwArgs& a, int nw, hipStream_t st);
 
 struct Config {
@@ -129,7 +130,7 @@ extern "C" int bg_align_batch_dev(bg_ctx* ctx, const bg_scoring_t* sc, int mode,
         a.alpha = A;
     }
 
-    const Config cfg = pick_config(max_xlen, sm);
+    Config cfg = pick_config(max_xlen, sm);
     const bool all_zero_clips = a.sc.xp == 0 && a.sc.xs == 0 && a.sc.yp == 0 && a.sc.ys == 0;
     // NARROW kernels need every reachable score inside +-2^25 (sw_kernels.h): bound it by
     // (longest path) x (largest finite magnitude in the scoring)
@@ -146,6 +147,24 @@ extern "C" int bg_align_batch_dev(bg_ctx* ctx, const bg_scoring_t* sc, int mode,
                           ? (narrow ? get_fill_params_narrow(cfg.lp, cfg.r, all_zero_clips)
                                     : get_fill_params_wide(cfg.lp, cfg.r, all_zero_clips))
                           : get_fill_matrix(cfg.lp, cfg.r, sm, narrow);
+    // K1p: local alignment of short reads whose scores fit 12 bits (sw_fill_pk16.hip) — two pairs per lane.
+    // Bound: no real DP value, nor the epilogue's go * i terms, may leave +-2040.
+    const bool pk16 = !ctx->no_pk16 && sm == SCORE_PARAMS && all_zero_clips && cfg.lp == 16 && max_xlen >= 1 &&
+                      mag * ((int64_t)std::max(max_xlen, max_ylen) + 2) <= 2040;
+    sw_fill_fn fill_rest = nullptr;
+    if (pk16) {
+        // rows per lane: K1p's fast launch wants row m on the last row of a lane (m % R == 0); reads of a
+        // batch usually share one length, so prefer an R that divides the longest
+        for (int r = std::max(2, (int)((max_xlen + 15) / 16)); r <= 12; r++)
+            if (max_xlen % r == 0) {
+                cfg.r = r;
+                break;
+            }
+        fill = get_fill_pk16(cfg.lp, cfg.r, true);
+        fill_rest = get_fill_pk16(cfg.lp, cfg.r, false);
+        if (!fill || !fill_rest) return BG_ERR_UNSUPPORTED;
+        a.g.tb_fmt = 1;
+    }
     if (!fill) return BG_ERR_UNSUPPORTED;
     const int nw = tb_words(cfg.r);
     const uint32_t pw = 64 / cfg.lp;
@@ -181,10 +200,15 @@ extern "C" int bg_align_batch_dev(bg_ctx* ctx, const bg_scoring_t* sc, int mode,
         a.n_pairs = (uint32_t)std::min<uint64_t>(chunk, n_pairs - p0);
         const uint32_t njobs = (a.n_pairs + pw - 1) / pw;
         if (ctx->timing) BG_HIP(hipEventRecord(ctx->ev[0], st));
-        fill<<<dim3((njobs + 3) / 4), dim3(256), 0, st>>>(a);
+        const uint32_t nwaves = pk16 ? (njobs + 1) / 2 : njobs;  // a K1p wavefront takes two jobs
+        fill<<<dim3((nwaves + 3) / 4), dim3(256), 0, st>>>(a);
         BG_HIP(hipGetLastError());
+        if (ctx->timing) BG_HIP(hipEventRecord(ctx->ev[1], st));
+        if (fill_rest) {  // picks up what the fast launch skipped (other read lengths, unequal couples)
+            fill_rest<<<dim3((nwaves + 3) / 4), dim3(256), 0, st>>>(a);
+            BG_HIP(hipGetLastError());
+        }
         if (ctx->timing) {
-            BG_HIP(hipEventRecord(ctx->ev[1], st));
             BG_HIP(hipEventSynchronize(ctx->ev[1]));
             float ms = 0;
             BG_HIP(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));

@@ -61,6 +61,7 @@ struct SwScoring {
 //   Ly[m_cap+1]  Lx[n_cap+1]  colBits[m_cap+1 bytes]: (S nibble | I nibble << 4) of column n
 struct SwGeom {
     uint32_t lp, r, nsteps, nstrips, m_cap, n_cap, aux_stride;
+    uint32_t tb_fmt;  // 0: six 5-bit cells per word (K1); 1: three per 16-bit half (K1p, sw_fill_pk16.hip)
     __host__ __device__ uint32_t off_Ly() const { return 4; }
     __host__ __device__ uint32_t off_Lx() const { return 4 + (m_cap + 1); }
     __host__ __device__ uint32_t off_bits() const { return 4 + (m_cap + 1) + (n_cap + 1); }

@@ -49,7 +49,9 @@ __global__ __launch_bounds__(256) void sw_traceback_kernel(const SwArgs a) {
             seg_tag = base;
         }
         const uint32_t w = seg[(uint32_t)(g % tsteps) * NW + rr / 6];
-        return (w >> (5 * (rr % 6))) & 31u;
+        const uint32_t c = rr % 6;
+        // tb_fmt 1 (K1p): three cells per 16-bit half
+        return (w >> (geo.tb_fmt ? 5 * (c % 3) + 16 * (c / 3) : 5 * c)) & 31u;
     };
     // S nibble of cell (i,j), j < n (or the fill-time value for j == n, never requested)
     auto s_fill = [&](uint32_t i, uint32_t j) -> uint32_t {

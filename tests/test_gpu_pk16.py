@@ -1,0 +1,122 @@
+"""GPU parity of K1p (sw_fill_pk16.hip: Aligner::local on short reads, two pairs per lane in packed int16
+halves) against the CPU oracle and against the one-pair-per-lane K1 — scores, coordinates and operations."""
+import numpy as np
+import pytest
+
+import oracle_py as orc
+from rust_bio_amd import _lib, synth
+from rust_bio_amd.pairwise import MIN_SCORE, Aligner, Scoring, decode_ops
+
+pytestmark = pytest.mark.gpu
+CLIPS = dict(xclip_prefix=MIN_SCORE, xclip_suffix=MIN_SCORE, yclip_prefix=MIN_SCORE, yclip_suffix=MIN_SCORE)
+ALPHA = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+
+def related_pairs(rng, n_pairs, m_of, n_of, alpha=ALPHA):
+    """x is a mutated window of y (substitutions, one indel) or unrelated; lengths come from the callables"""
+    xs, ys = [], []
+    for p in range(n_pairs):
+        m, n = m_of(p), n_of(p)
+        y = alpha[rng.integers(0, len(alpha), size=n)]
+        if rng.random() < 0.7 and n >= 4 and m >= 4:
+            src = np.resize(y, m + 12)[int(rng.integers(0, 4)):]
+            x = src[:m + 8].copy()
+            k = int(rng.integers(0, max(1, m // 6)))
+            x[rng.integers(0, len(x), size=k)] = alpha[rng.integers(0, len(alpha), size=k)]
+            if rng.random() < 0.6:
+                c = int(rng.integers(0, len(x) - 1))
+                x = np.delete(x, np.arange(c, min(len(x), c + int(rng.integers(1, 6)))))
+            if rng.random() < 0.4:
+                c = int(rng.integers(0, len(x)))
+                x = np.insert(x, c, alpha[rng.integers(0, len(alpha), size=int(rng.integers(1, 5)))])
+            x = np.resize(x, m)
+        else:
+            x = alpha[rng.integers(0, len(alpha), size=m)]
+        xs.append(x.astype(np.uint8).tobytes())
+        ys.append(y.astype(np.uint8).tobytes())
+    return xs, ys
+
+
+def local_vs_oracle(kw, xs, ys):
+    al = Aligner.with_scoring(Scoring.from_scores(kw["gap_open"], kw["gap_extend"], kw["match"], kw["mismatch"]))
+    x, xo = _lib.concat(xs)
+    y, yo = _lib.concat(ys)
+    out, ops = al.align_arrays(3, x, xo, y, yo)
+    oout, oops, stride = orc.align_batch(orc.make_scoring(**kw, **CLIPS), "local", x, xo, y, yo, threads=8)
+    for f in ("score", "xstart", "xend", "ystart", "yend", "xlen", "ylen", "n_ops"):
+        bad = np.nonzero(out[f].astype(np.int64) != oout[f].astype(np.int64))[0]
+        assert len(bad) == 0, (f, kw, bad[:5], xs[bad[0]], ys[bad[0]], out[f][bad[0]], oout[f][bad[0]])
+    assert (out["status"] == 0).all()
+    for p in range(len(xs)):
+        want = orc.decode_ops(oops[p * stride:p * stride + int(oout["n_ops"][p])])
+        assert decode_ops(out[p], ops) == want, (kw, p, xs[p], ys[p])
+
+
+BASE = dict(gap_open=-5, gap_extend=-1, match=1, mismatch=-1)
+
+
+@pytest.mark.parametrize("m", [2, 8, 20, 33, 35, 37, 64, 96, 100, 121, 143, 150, 160, 176, 191, 192])
+def test_uniform_read_lengths_every_rows_per_lane(m):
+    # equal lengths take the fast launch when some R in 2..12 divides m (rows of m on a lane's last row),
+    # the second launch otherwise; 37 pairs leave a partial wavefront and a couple without a partner
+    rng = np.random.default_rng(m)
+    for n in sorted({m, m + 7, max(1, m // 2), 1, 211}):
+        xs, ys = related_pairs(rng, 37, lambda p: m, lambda p: n)
+        local_vs_oracle(BASE, xs, ys)
+
+
+def test_couples_with_different_lengths_take_two_passes():
+    rng = np.random.default_rng(5)
+    # pair p and pair p + 4 share lanes: make some couples agree and some not
+    lens = [150, 150, 150, 150, 150, 140, 150, 150, 120, 150, 150, 150, 150, 150, 150, 77, 150, 150, 150]
+    for n_pairs in (len(lens), 8, 5, 4, 3, 1):
+        xs, ys = related_pairs(rng, n_pairs, lambda p: lens[p], lambda p: lens[(p * 7) % len(lens)] + 3)
+        local_vs_oracle(BASE, xs, ys)
+    xs, ys = synth.ragged_pairs(400, 150, seed=77, min_len=1)
+    xs += [b"", b"ACGT", b"", b"A", b"C"]
+    ys += [b"", b"", b"ACGT", b"A", b"G"]
+    local_vs_oracle(BASE, xs, ys)
+
+
+def test_scorings_up_to_the_12_bit_bound_and_past_it():
+    rng = np.random.default_rng(9)
+    xs, ys = related_pairs(rng, 90, lambda p: 150, lambda p: 150)
+    xs2, ys2 = related_pairs(rng, 64, lambda p: 48 + (p % 3), lambda p: 60)
+    for kw in (dict(gap_open=0, gap_extend=0, match=1, mismatch=-1), dict(gap_open=-1, gap_extend=0, match=2, mismatch=0),
+               dict(gap_open=0, gap_extend=-1, match=1, mismatch=-3), dict(gap_open=-11, gap_extend=-4, match=13, mismatch=-12),
+               dict(gap_open=-13, gap_extend=-13, match=13, mismatch=-13),  # 13 * 152 = 1976: the last magnitude that fits
+               dict(gap_open=-14, gap_extend=-2, match=14, mismatch=-9),    # past the bound: K1 takes over
+               dict(gap_open=-3, gap_extend=-1, match=0, mismatch=-2), dict(gap_open=-2, gap_extend=-2, match=5, mismatch=0)):
+        local_vs_oracle(kw, xs, ys)
+        local_vs_oracle(kw, xs2, ys2)
+
+
+def test_other_alphabets_and_low_complexity():
+    rng = np.random.default_rng(10)
+    for alpha in (np.frombuffer(b"AC", dtype=np.uint8), np.frombuffer(b"A", dtype=np.uint8), np.arange(256, dtype=np.uint8)):
+        xs, ys = related_pairs(rng, 50, lambda p: 100, lambda p: 130, alpha=alpha)
+        local_vs_oracle(BASE, xs, ys)
+        local_vs_oracle(dict(gap_open=-2, gap_extend=-1, match=2, mismatch=-1), xs, ys)
+
+
+def test_same_answers_as_k1_at_scale():
+    # 200k x 150 bp: every byte of the result equals the one-pair-per-lane kernel's (which the oracle pins)
+    x, xo, y, yo = synth.sw_pairs(200_000, 150, seed=3)
+    al = Aligner.with_scoring(Scoring.from_scores(-5, -1, 1, -1))
+    out, ops = al.align_arrays(3, x, xo, y, yo)
+    al.ctx.set_option("no_pk16", 1)
+    out1, ops1 = al.align_arrays(3, x, xo, y, yo)
+    al.ctx.set_option("no_pk16", 0)
+    assert out.tobytes() == out1.tobytes()
+    assert (ops == ops1).all()
+    # a batch that is mostly uniform with stragglers: both launches and the second pass contribute
+    rng = np.random.default_rng(4)
+    xs, ys = related_pairs(rng, 30_000, lambda p: 150 if p % 97 else 149 - (p % 40), lambda p: 150 if p % 89 else 163)
+    x, xo = _lib.concat(xs)
+    y, yo = _lib.concat(ys)
+    out, ops = al.align_arrays(3, x, xo, y, yo)
+    al.ctx.set_option("no_pk16", 1)
+    out1, ops1 = al.align_arrays(3, x, xo, y, yo)
+    al.ctx.set_option("no_pk16", 0)
+    assert out.tobytes() == out1.tobytes()
+    assert (ops == ops1).all()
