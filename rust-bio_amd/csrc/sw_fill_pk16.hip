@@ -149,8 +149,10 @@ __global__ __launch_bounds__(256) void sw_fill_pk16_kernel(const SwArgs a) {
             const int32_t v = m ? (int32_t)col0_cell(sc, m, m, fold0).sbits : (int32_t)TB_START;
             aux0[0] = v;
             aux1[0] = v;
-            gLx0[0] = (int32_t)lx0;
-            gLx1[0] = (int32_t)lx0;
+            if (m == 0) {  // otherwise Lx[0] travels with the row-m lane's first packed store
+                *(uint8_t*)gLx0 = (uint8_t)lx0;
+                *(uint8_t*)gLx1 = (uint8_t)lx0;
+            }
         }
 
         const uint32_t rb = (uint32_t)ll * R;  // this lane owns rows rb+1 .. rb+R (single strip)
@@ -182,6 +184,14 @@ __global__ __launch_bounds__(256) void sw_fill_pk16_kernel(const SwArgs a) {
 #pragma unroll
         for (int k = 0; k < NH; k++) hwlast[k] = 0;
         pk lx_n = dup16((int32_t)lx0);
+        // VMEM store instructions are the scarce resource of this kernel (four per step cost 5 ms of 17 on
+        // 1M x 150 bp): traceback words leave as one 2*NW-dword store per TWO steps and pair, Lx[j] (<= m < 256)
+        // as bytes, four columns per dword store
+        pk wA[NW], wB[NW], pendA[NW], pendB[NW];
+#pragma unroll
+        for (int w = 0; w < NW; w++) wA[w] = wB[w] = pendA[w] = pendB[w] = 0;
+        bool prev_ok = false;
+        uint32_t lxaccA = lx0 << 24, lxaccB = lx0 << 24;  // Lx[0] ends up in byte 0 of the first dword
         if (pair_ok && (uint32_t)ll < n) ychunk_nx = (uint32_t)y0[ll] | ((uint32_t)y1[ll] << 16);
 
         // Sn[i]/Ly[i] (mod.rs:799-802, "first maximum of the row") per block of 16 steps: inside a block the
@@ -200,6 +210,16 @@ __global__ __launch_bounds__(256) void sw_fill_pk16_kernel(const SwArgs a) {
         };
 
         constexpr uint32_t tsteps = tb_tile_steps(NW);
+        auto store_pair = [&](uint32_t s_even) {  // words of steps s_even (pend) and s_even + 1 (w), see tb_word_off()
+            const uint32_t off = (s_even / tsteps) * 1024u + (s_even % tsteps) * NW;
+            if (NW == 1) {
+                *(uint2*)&tb0[off] = make_uint2(pendA[0], wA[0]);
+                *(uint2*)&tb1[off] = make_uint2(pendB[0], wB[0]);
+            } else {
+                *(uint4*)&tb0[off] = make_uint4(pendA[0], pendA[NW - 1], wA[0], wA[NW - 1]);
+                *(uint4*)&tb1[off] = make_uint4(pendB[0], pendB[NW - 1], wB[0], wB[NW - 1]);
+            }
+        };
         // MRk >= 0: every pair of this wavefront has its row m at r == MRk of its owner lane (equal read
         // lengths, the usual short-read case): the x-suffix-clip candidate drops out of the other rows
         auto run_steps = [&](auto mr_tag) {
@@ -242,8 +262,8 @@ __global__ __launch_bounds__(256) void sw_fill_pk16_kernel(const SwArgs a) {
                         const pk Dv_t = pk_max(pk_adds(Dl[r], GE), pk_adds(Sl[r], GOT));
                         const pk Iv = Iv_t & CLEAN, Dv = Dv_t & CLEAN;
                         // mod.rs:757-786: first maximum wins == max over (score | priority)
-                        pk kb = pk_max(m_key, Iv | (0x00010001u * C_INS));
-                        kb = pk_max(pk_max(kb, Dv | (0x00010001u * C_DEL)), XKEY);
+                        pk kb = pk_max(pk_max(m_key, Dv | (0x00010001u * C_DEL)), XKEY);
+                        kb = pk_max(kb, Iv | (0x00010001u * C_INS));  // the value that waits for the row above comes last
                         if (maybe_m) kb = pk_max(kb, is_m ? ((cmk & CLEAN) | (0x00010001u * C_XS)) : FLOORK);
                         const pk best = kb & CLEAN;
                         diag = Sl[r];
@@ -268,8 +288,13 @@ __global__ __launch_bounds__(256) void sw_fill_pk16_kernel(const SwArgs a) {
                 if (mrow >= 0 && mrow < R) {  // the lane that owns row m publishes Lx[j]
                     const pk is15 = nz_mask(slo ^ 0x000f000fu, ONE);  // 0xffff where slo != 15
                     lx_n = bfi(is15, pk_add_u16(slo, mbase), ca_in);
-                    gLx0[j] = (int32_t)(lx_n & 0xffffu);
-                    gLx1[j] = (int32_t)(lx_n >> 16);
+                    lxaccA = __builtin_amdgcn_perm(lx_n, lxaccA, 0x04030201u);  // acc >> 8 | Lx_A << 24
+                    lxaccB = __builtin_amdgcn_perm(lx_n, lxaccB, 0x06030201u);  // acc >> 8 | Lx_B << 24
+                    if ((j & 3u) == 3u || j == n) {
+                        const uint32_t sh = 8u * (3u - (j & 3u));  // the last dword of the row may be partial
+                        ((uint32_t*)gLx0)[j >> 2] = lxaccA >> sh;
+                        ((uint32_t*)gLx1)[j >> 2] = lxaccB >> sh;
+                    }
                 }
                 {
                     const pk is15 = nz_mask(lo ^ 0x000f000fu, ONE);
@@ -285,17 +310,13 @@ __global__ __launch_bounds__(256) void sw_fill_pk16_kernel(const SwArgs a) {
                     hw[k] ^= (k == NH - 1) ? INV_LAST : INV;
                     hwlast[k] = hw[k];
                 }
-                const uint32_t off = (s / tsteps) * 1024u + (s % tsteps) * NW;
                 const pk h0 = hw[0], h1 = NH > 1 ? hw[NH > 1 ? 1 : 0] : 0u;
-                if (NW == 1) {
-                    tb0[off] = __builtin_amdgcn_perm(h1, h0, 0x05040100u);
-                    tb1[off] = __builtin_amdgcn_perm(h1, h0, 0x07060302u);
-                } else {
+                wA[0] = __builtin_amdgcn_perm(h1, h0, 0x05040100u);
+                wB[0] = __builtin_amdgcn_perm(h1, h0, 0x07060302u);
+                if (NW == 2) {
                     const pk h2 = hw[NH > 2 ? 2 : 0], h3 = NH > 3 ? hw[NH > 3 ? 3 : 0] : 0u;
-                    *(uint2*)&tb0[off] = make_uint2(__builtin_amdgcn_perm(h1, h0, 0x05040100u),
-                                                    __builtin_amdgcn_perm(h3, h2, 0x05040100u));
-                    *(uint2*)&tb1[off] = make_uint2(__builtin_amdgcn_perm(h1, h0, 0x07060302u),
-                                                    __builtin_amdgcn_perm(h3, h2, 0x07060302u));
+                    wA[NW - 1] = __builtin_amdgcn_perm(h3, h2, 0x05040100u);
+                    wB[NW - 1] = __builtin_amdgcn_perm(h3, h2, 0x07060302u);
                 }
                 S_out = S_up;
                 I_out = I_up;
@@ -303,10 +324,21 @@ __global__ __launch_bounds__(256) void sw_fill_pk16_kernel(const SwArgs a) {
                 ca_out = ca;
                 q_out = q;
             }
+            if ((s & 1u) == 0) {  // wave-uniform: the even step of a store pair waits for the odd one
+#pragma unroll
+                for (int w = 0; w < NW; w++) {
+                    pendA[w] = wA[w];
+                    pendB[w] = wB[w];
+                }
+            } else if (col_ok || prev_ok) {  // a lane outside its columns on one of the two steps stores garbage there
+                store_pair(s - 1);
+            }
+            prev_ok = col_ok;
             if ((s & 15u) == 15u) merge_rows(s & ~15u);  // wave-uniform
         }
         };
         run_steps(std::integral_constant<int, FAST ? R - 1 : -1>{});
+        if ((nsteps_w & 1u) && prev_ok) store_pair(nsteps_w - 1);  // the last step was the even one of its pair
         if (nsteps_w) merge_rows((nsteps_w - 1) & ~15u);
 
         // =========== epilogue of the last column (mod.rs:808-843), one pair of the couple at a time ===========
