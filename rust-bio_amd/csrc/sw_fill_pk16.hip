@@ -9,7 +9,8 @@
 // The two pairs of a lane group ("couple") are pairs g of the wavefront jobs 2w and 2w+1; they share the
 // lane-level control (column validity, the row that owns row m), so they must have equal lengths — a
 // couple with different lengths is simply processed in two passes, each pair against itself.
-// Traceback words: 3 cells x 5 bits per 16-bit half (SwGeom::tb_fmt == 1), same tiles as K1.
+// Traceback words: 3 cells x 5 bits (I extends | move << 1 | D extends << 4) per 16-bit half
+// (SwGeom::tb_fmt == 1), same tiles as K1.
 #include <type_traits>
 
 #include "sw_kernels.h"
@@ -57,7 +58,7 @@ constexpr int32_t kFloor16 = -2048;  // 'minus infinity' of the 12-bit score ran
 // the other wavefronts, and the second pair of every couple whose lengths differ.  Both derive the split
 // from the lengths alone, so no flags travel between the two launches.
 template <int R, int LP, bool FAST>
-__global__ __launch_bounds__(256) void sw_fill_pk16_kernel(const SwArgs a) {
+__device__ __forceinline__ void sw_fill_pk16_body(const SwArgs& a) {
     constexpr int PW = 64 / LP;
     constexpr int NW = tb_words(R);
     constexpr int NH = (R + 2) / 3;  // 16-bit halves of traceback cells per pair and step
@@ -80,11 +81,19 @@ __global__ __launch_bounds__(256) void sw_fill_pk16_kernel(const SwArgs a) {
     auto scl = [](int32_t v) -> int32_t { return max(v, kFloor16) * 16; };
     const int32_t go_s = sc.go * 16, xs_s = scl(sc.xs);
     (void)xs_s;
-    const pk GE = dup16(sc.ge * 16), GOT = dup16(sc.go * 16 + 8);  // "open" carries bit 3: it wins ties
-    const pk MISK = dup16((sc.mismatch * 16) | (int32_t)C_SUBST);
-    const pk DELTA = dup16(((sc.match * 16) | (int32_t)C_MATCH) - ((sc.mismatch * 16) | (int32_t)C_SUBST));
-    const pk XKEY = dup16((int32_t)C_XP);  // xclip_j == 0 for local
-    const pk C32 = dup16(32), C1024 = dup16(1024);
+    // Keys: score << 4 | move code << 1 | "opens".  The I and D values keep their move code in the low bits
+    // (bit 0, the open/extend decision, is cleared when they are stored), so they enter the cell's maximum
+    // as they are; bit 0 sits below the code and only ever decides between the two candidates of one value
+    // (open wins ties, like the reference's strict '>' for extend, mod.rs:738,749).
+    constexpr int32_t K_XS = C_XS << 1, K_MATCH = C_MATCH << 1, K_SUBST = C_SUBST << 1, K_INS = C_INS << 1,
+                      K_DEL = C_DEL << 1, K_XP = C_XP << 1;
+    constexpr pk NOFLAG = 0xfffefffeu;
+    const pk GE = dup16(sc.ge * 16);
+    const pk GOT_I = dup16(sc.go * 16 + K_INS + 1), GOT_D = dup16(sc.go * 16 + K_DEL + 1);
+    const pk MISK = dup16((sc.mismatch * 16) | K_SUBST);
+    const pk DELTA = dup16(((sc.match * 16) | K_MATCH) - ((sc.mismatch * 16) | K_SUBST));
+    const pk XKEY = dup16(K_XP);  // xclip_j == 0 for local
+    const pk C16 = dup16(16), C32 = dup16(32), C1024 = dup16(1024);
 
     // ---- the couple of this lane group
     const uint32_t pA = (2 * wv) * PW + g, pB = (2 * wv + 1) * PW + g;
@@ -136,6 +145,7 @@ __global__ __launch_bounds__(256) void sw_fill_pk16_kernel(const SwArgs a) {
             n_w = max(n_w, (uint32_t)__shfl_xor((int)n_w, o));
         }
         (void)m_w;
+        n_w = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_w);  // tell the compiler it is wave-uniform
         const uint32_t nsteps_w = n_w ? n_w + LP - 1 : 0;
 
         int32_t fold0;
@@ -169,7 +179,7 @@ __global__ __launch_bounds__(256) void sw_fill_pk16_kernel(const SwArgs a) {
                 px[r] = (uint32_t)x0[i - 1] | ((uint32_t)x1[i - 1] << 16);
                 const Col0 c = col0_cell(sc, i, m, fold0);
                 Sl[r] = dup16(scl(c.S));
-                Il[r] = dup16(scl(c.I));
+                Il[r] = dup16(scl(c.I) | K_INS);
                 nib0S |= (uint64_t)c.sbits << (4 * r);
                 nib0I |= (uint64_t)c.ibits << (4 * r);
                 SnR[r] = dup16(scl(c.S) + scl(sc.ys));  // mod.rs:667-670 (always taken: S(i,0) >= 0, ys == 0)
@@ -258,13 +268,13 @@ __global__ __launch_bounds__(256) void sw_fill_pk16_kernel(const SwArgs a) {
                         // mod.rs:733-755: substitution score with the MATCH/SUBST move code in its low bits
                         const pk e = pk_subs_u16(ONE, px[r] ^ q);  // 1 where the characters agree
                         const pk m_key = pk_adds(diag, pk_mad_u16(e, DELTA, MISK));
-                        const pk Iv_t = pk_max(pk_adds(I_up, GE), pk_adds(S_up, GOT));
-                        const pk Dv_t = pk_max(pk_adds(Dl[r], GE), pk_adds(Sl[r], GOT));
-                        const pk Iv = Iv_t & CLEAN, Dv = Dv_t & CLEAN;
+                        const pk Iv_t = pk_max(pk_adds(I_up, GE), pk_adds(S_up, GOT_I));
+                        const pk Dv_t = pk_max(pk_adds(Dl[r], GE), pk_adds(Sl[r], GOT_D));
+                        const pk Iv = Iv_t & NOFLAG, Dv = Dv_t & NOFLAG;
                         // mod.rs:757-786: first maximum wins == max over (score | priority)
-                        pk kb = pk_max(pk_max(m_key, Dv | (0x00010001u * C_DEL)), XKEY);
-                        kb = pk_max(kb, Iv | (0x00010001u * C_INS));  // the value that waits for the row above comes last
-                        if (maybe_m) kb = pk_max(kb, is_m ? ((cmk & CLEAN) | (0x00010001u * C_XS)) : FLOORK);
+                        pk kb = pk_max(pk_max(m_key, Dv_t), XKEY);
+                        kb = pk_max(kb, Iv_t);  // the value that waits for the row above comes last
+                        if (maybe_m) kb = pk_max(kb, is_m ? ((cmk & CLEAN) | (0x00010001u * K_XS)) : FLOORK);
                         const pk best = kb & CLEAN;
                         diag = Sl[r];
                         Sl[r] = best;
@@ -275,8 +285,8 @@ __global__ __launch_bounds__(256) void sw_fill_pk16_kernel(const SwArgs a) {
                         if (maybe_m) snap = is_m ? cmk : snap;
                         cmk = pk_max(cmk, best | (0x00010001u * (uint32_t)(14 - r)));  // mod.rs:793-796
                         SnB[r] = pk_max(SnB[r], best | sprio);                           // mod.rs:799-802
-                        // packed cell: 3-bit move | I opens << 3 | D opens << 4 (inverted to "extends" below)
-                        const pk c5 = bfi(0x00070007u, kb, bfi(0x00080008u, Iv_t, Dv_t << 1)) & 0x001f001fu;
+                        // packed cell: I opens | 3-bit move << 1 | D opens << 4 (flipped to "extends" below)
+                        const pk c5 = pk_mad_u16(Dv_t & ONE, C16, (kb & 0x000e000eu) | (Iv_t & ONE));
                         if (r % 3 == 0)
                             hw[r / 3] = c5;
                         else
@@ -301,10 +311,10 @@ __global__ __launch_bounds__(256) void sw_fill_pk16_kernel(const SwArgs a) {
                     ca = bfi(is15, pk_add_u16(lo, mbase), ca_in);
                 }
                 cm = cmk & CLEAN;
-                // 24 = both "opens" bits: stored as "extends" like K1's cells
-                constexpr pk INV = 0x00010001u * (24u | (24u << 5) | (24u << 10));
-                constexpr pk INV_LAST = 0x00010001u * ((R % 3 == 0) ? (24u | (24u << 5) | (24u << 10))
-                                                      : (R % 3 == 1) ? 24u : (24u | (24u << 5)));
+                // 17 = both "opens" bits: stored as "extends" like K1's cells
+                constexpr pk INV = 0x00010001u * (17u | (17u << 5) | (17u << 10));
+                constexpr pk INV_LAST = 0x00010001u * ((R % 3 == 0) ? (17u | (17u << 5) | (17u << 10))
+                                                      : (R % 3 == 1) ? 17u : (17u | (17u << 5)));
 #pragma unroll
                 for (int k = 0; k < NH; k++) {
                     hw[k] ^= (k == NH - 1) ? INV_LAST : INV;
@@ -386,7 +396,10 @@ __global__ __launch_bounds__(256) void sw_fill_pk16_kernel(const SwArgs a) {
             uint32_t sbf_carry = TB_START, sb2_carry = TB_START;
             int64_t c1v = INT64_MIN, c2v = INT64_MIN;
             uint32_t c1i = 0, c2i = 0;
-            auto cell_of = [&](int r) -> uint32_t { return (park[(4 * R + r / 3) * 256] >> (hs + 5 * (r % 3))) & 31u; };
+            auto cell_of = [&](int r) -> uint32_t {  // K1's bit order: move | I extends << 3 | D extends << 4
+                const uint32_t c = (park[(4 * R + r / 3) * 256] >> (hs + 5 * (r % 3))) & 31u;
+                return ((c >> 1) & 7u) | ((c & 1u) << 3) | (c & 16u);
+            };
             {
                 // the names the shared body expects
                 int32_t(&Sl)[R] = Sl_u;
@@ -406,11 +419,21 @@ __global__ __launch_bounds__(256) void sw_fill_pk16_kernel(const SwArgs a) {
     }
 }
 
+// the fast launch is tuned for three wavefronts per SIMD up to R = 10 (168 VGPRs, 46 KB of LDS per block)
+template <int R, int LP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(R <= 10 ? 3 : 2, R <= 10 ? 3 : 2))) void sw_fill_pk16_kernel(const SwArgs a) {
+    sw_fill_pk16_body<R, LP, true>(a);
+}
+template <int R, int LP>
+__global__ __launch_bounds__(256) void sw_fill_pk16_rest_kernel(const SwArgs a) {
+    sw_fill_pk16_body<R, LP, false>(a);
+}
+
 }  // namespace pk16
 
 sw_fill_fn get_fill_pk16(int lp, int r, bool fast) {
 #define CASE(LP, R) \
-    if (lp == LP && r == R) return fast ? pk16::sw_fill_pk16_kernel<R, LP, true> : pk16::sw_fill_pk16_kernel<R, LP, false>;
+    if (lp == LP && r == R) return fast ? pk16::sw_fill_pk16_kernel<R, LP> : pk16::sw_fill_pk16_rest_kernel<R, LP>;
     CASE(16, 2) CASE(16, 3) CASE(16, 4) CASE(16, 5) CASE(16, 6) CASE(16, 7) CASE(16, 8) CASE(16, 9) CASE(16, 10)
     CASE(16, 11) CASE(16, 12)
 #undef CASE

@@ -50,8 +50,10 @@ __global__ __launch_bounds__(256) void sw_traceback_kernel(const SwArgs a) {
         }
         const uint32_t w = seg[(uint32_t)(g % tsteps) * NW + rr / 6];
         const uint32_t c = rr % 6;
-        // tb_fmt 1 (K1p): three cells per 16-bit half
-        return (w >> (geo.tb_fmt ? 5 * (c % 3) + 16 * (c / 3) : 5 * c)) & 31u;
+        if (!geo.tb_fmt) return (w >> (5 * c)) & 31u;
+        // tb_fmt 1 (K1p): three cells per 16-bit half, each I extends | move << 1 | D extends << 4
+        const uint32_t v = (w >> (5 * (c % 3) + 16 * (c / 3))) & 31u;
+        return ((v >> 1) & 7u) | ((v & 1u) << 3) | (v & 16u);
     };
     // S nibble of cell (i,j), j < n (or the fill-time value for j == n, never requested)
     auto s_fill = [&](uint32_t i, uint32_t j) -> uint32_t {
