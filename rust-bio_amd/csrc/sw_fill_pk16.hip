@@ -70,7 +70,14 @@ __device__ __forceinline__ void sw_fill_pk16_body(const SwArgs& a) {
     static_assert(R >= 1 && R <= 12, "rows per lane");
     (void)NARROW;
     (void)LOCAL;
-    __shared__ pk s_park[256 * (4 * R + NH + 1)];
+    // LDS, two uses that never overlap in time: during the fill, the traceback words of the current tile (a
+    // lane's 64 bytes per pair, kTileStride dwords apart: 8-byte writes, 16-byte aligned reads); after it, the
+    // packed rows parked for the epilogue
+    constexpr int kTileStride = 20;
+    constexpr int kParkDw = 64 * (4 * R + NH + 1), kTileDw = 2 * 64 * kTileStride;  // per wavefront
+    constexpr int kWaveDw = kParkDw > kTileDw ? kParkDw : kTileDw;
+    __shared__ __align__(16) pk s_lds[4 * kWaveDw];
+    pk* const wave_lds = s_lds + (threadIdx.x >> 6) * kWaveDw;  // wavefronts of a block run unsynchronised
 
     const int lane = threadIdx.x & 63;
     const uint32_t wv = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -195,12 +202,12 @@ __device__ __forceinline__ void sw_fill_pk16_body(const SwArgs& a) {
         for (int k = 0; k < NH; k++) hwlast[k] = 0;
         pk lx_n = dup16((int32_t)lx0);
         // VMEM store instructions are the scarce resource of this kernel (four per step cost 5 ms of 17 on
-        // 1M x 150 bp): traceback words leave as one 2*NW-dword store per TWO steps and pair, Lx[j] (<= m < 256)
-        // as bytes, four columns per dword store
-        pk wA[NW], wB[NW], pendA[NW], pendB[NW];
-#pragma unroll
-        for (int w = 0; w < NW; w++) wA[w] = wB[w] = pendA[w] = pendB[w] = 0;
-        bool prev_ok = false;
+        // 1M x 150 bp), and 64-byte slots filled 8 or 16 bytes at a time get evicted half-written (1.5x HBM
+        // write traffic): a lane's traceback words collect in LDS and leave as its complete 64-byte slot of the
+        // tile, four back-to-back 16-byte stores per pair every 16 / NW steps; Lx[j] (<= m < 256) leaves as bytes,
+        // four columns per dword store
+        pk* tileA = wave_lds + (0 * 64 + lane) * kTileStride;
+        pk* tileB = wave_lds + (1 * 64 + lane) * kTileStride;
         uint32_t lxaccA = lx0 << 24, lxaccB = lx0 << 24;  // Lx[0] ends up in byte 0 of the first dword
         if (pair_ok && (uint32_t)ll < n) ychunk_nx = (uint32_t)y0[ll] | ((uint32_t)y1[ll] << 16);
 
@@ -220,14 +227,13 @@ __device__ __forceinline__ void sw_fill_pk16_body(const SwArgs& a) {
         };
 
         constexpr uint32_t tsteps = tb_tile_steps(NW);
-        auto store_pair = [&](uint32_t s_even) {  // words of steps s_even (pend) and s_even + 1 (w), see tb_word_off()
-            const uint32_t off = (s_even / tsteps) * 1024u + (s_even % tsteps) * NW;
-            if (NW == 1) {
-                *(uint2*)&tb0[off] = make_uint2(pendA[0], wA[0]);
-                *(uint2*)&tb1[off] = make_uint2(pendB[0], wB[0]);
-            } else {
-                *(uint4*)&tb0[off] = make_uint4(pendA[0], pendA[NW - 1], wA[0], wA[NW - 1]);
-                *(uint4*)&tb1[off] = make_uint4(pendB[0], pendB[NW - 1], wB[0], wB[NW - 1]);
+        auto store_tile = [&](uint32_t s_any) {  // the tile that holds step s_any, see tb_word_off()
+            if (!pair_ok) return;
+            const uint32_t off = (s_any / tsteps) * 1024u;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                *(uint4*)&tb0[off + 4 * k] = *(const uint4*)&tileA[4 * k];
+                *(uint4*)&tb1[off + 4 * k] = *(const uint4*)&tileB[4 * k];
             }
         };
         // MRk >= 0: every pair of this wavefront has its row m at r == MRk of its owner lane (equal read
@@ -321,12 +327,16 @@ __device__ __forceinline__ void sw_fill_pk16_body(const SwArgs& a) {
                     hwlast[k] = hw[k];
                 }
                 const pk h0 = hw[0], h1 = NH > 1 ? hw[NH > 1 ? 1 : 0] : 0u;
-                wA[0] = __builtin_amdgcn_perm(h1, h0, 0x05040100u);
-                wB[0] = __builtin_amdgcn_perm(h1, h0, 0x07060302u);
-                if (NW == 2) {
+                const uint32_t slot = (s % tsteps) * NW;
+                if (NW == 1) {
+                    tileA[slot] = __builtin_amdgcn_perm(h1, h0, 0x05040100u);
+                    tileB[slot] = __builtin_amdgcn_perm(h1, h0, 0x07060302u);
+                } else {
                     const pk h2 = hw[NH > 2 ? 2 : 0], h3 = NH > 3 ? hw[NH > 3 ? 3 : 0] : 0u;
-                    wA[NW - 1] = __builtin_amdgcn_perm(h3, h2, 0x05040100u);
-                    wB[NW - 1] = __builtin_amdgcn_perm(h3, h2, 0x07060302u);
+                    *(uint2*)&tileA[slot] = make_uint2(__builtin_amdgcn_perm(h1, h0, 0x05040100u),
+                                                       __builtin_amdgcn_perm(h3, h2, 0x05040100u));
+                    *(uint2*)&tileB[slot] = make_uint2(__builtin_amdgcn_perm(h1, h0, 0x07060302u),
+                                                       __builtin_amdgcn_perm(h3, h2, 0x07060302u));
                 }
                 S_out = S_up;
                 I_out = I_up;
@@ -334,37 +344,28 @@ __device__ __forceinline__ void sw_fill_pk16_body(const SwArgs& a) {
                 ca_out = ca;
                 q_out = q;
             }
-            if ((s & 1u) == 0) {  // wave-uniform: the even step of a store pair waits for the odd one
-#pragma unroll
-                for (int w = 0; w < NW; w++) {
-                    pendA[w] = wA[w];
-                    pendB[w] = wB[w];
-                }
-            } else if (col_ok || prev_ok) {  // a lane outside its columns on one of the two steps stores garbage there
-                store_pair(s - 1);
-            }
-            prev_ok = col_ok;
+            if (s % tsteps == tsteps - 1) store_tile(s);  // wave-uniform
             if ((s & 15u) == 15u) merge_rows(s & ~15u);  // wave-uniform
         }
         };
         run_steps(std::integral_constant<int, FAST ? R - 1 : -1>{});
-        if ((nsteps_w & 1u) && prev_ok) store_pair(nsteps_w - 1);  // the last step was the even one of its pair
+        if (nsteps_w % tsteps) store_tile(nsteps_w - 1);  // the last, partial tile
         if (nsteps_w) merge_rows((nsteps_w - 1) & ~15u);
 
         // =========== epilogue of the last column (mod.rs:808-843), one pair of the couple at a time ===========
-        // The packed rows are parked in LDS (thread-private slots, stride 256: conflict-free) so that the
+        // The packed rows are parked in LDS (thread-private slots, stride 64: conflict-free) so that the
         // epilogue's 64-bit scans do not have to share the register file with them.
-        pk* park = s_park + threadIdx.x;
+        pk* park = wave_lds + lane;
 #pragma unroll
         for (int r = 0; r < R; r++) {
-            park[(0 * R + r) * 256] = Sl[r];
-            park[(1 * R + r) * 256] = Il[r];
-            park[(2 * R + r) * 256] = SnR[r];
-            park[(3 * R + r) * 256] = Ly[r];
+            park[(0 * R + r) * 64] = Sl[r];
+            park[(1 * R + r) * 64] = Il[r];
+            park[(2 * R + r) * 64] = SnR[r];
+            park[(3 * R + r) * 64] = Ly[r];
         }
 #pragma unroll
-        for (int k = 0; k < NH; k++) park[(4 * R + k) * 256] = hwlast[k];
-        park[(4 * R + NH) * 256] = lx_n;
+        for (int k = 0; k < NH; k++) park[(4 * R + k) * 64] = hwlast[k];
+        park[(4 * R + NH) * 64] = lx_n;
         const int nhalf = (pair_ok && P1 != P0) ? 2 : 1;
         const int nhalf_w = __any(nhalf == 2) ? 2 : 1;
 #pragma unroll 1
@@ -379,25 +380,25 @@ __device__ __forceinline__ void sw_fill_pk16_body(const SwArgs& a) {
             struct HalfS {
                 const pk* p;
                 uint32_t hs;
-                __device__ int32_t operator[](int r) const { return (int32_t)(int16_t)(p[r * 256] >> hs); }
+                __device__ int32_t operator[](int r) const { return (int32_t)(int16_t)(p[r * 64] >> hs); }
             };
             struct HalfU {
                 const pk* p;
                 uint32_t hs;
-                __device__ uint32_t operator[](int r) const { return (p[r * 256] >> hs) & 0xffffu; }
+                __device__ uint32_t operator[](int r) const { return (p[r * 64] >> hs) & 0xffffu; }
             };
             int32_t Sl_u[R];  // the epilogue overwrites S(i, n)
 #pragma unroll
-            for (int r = 0; r < R; r++) Sl_u[r] = (int32_t)(int16_t)(park[r * 256] >> hs);
-            const HalfS Il_u{park + 1 * R * 256, hs}, Sn_u{park + 2 * R * 256, hs};
-            const HalfU Ly_u{park + 3 * R * 256, hs};
-            const uint32_t lx_n_u = (park[(4 * R + NH) * 256] >> hs) & 0xffffu;
+            for (int r = 0; r < R; r++) Sl_u[r] = (int32_t)(int16_t)(park[r * 64] >> hs);
+            const HalfS Il_u{park + 1 * R * 64, hs}, Sn_u{park + 2 * R * 64, hs};
+            const HalfU Ly_u{park + 3 * R * 64, hs};
+            const uint32_t lx_n_u = (park[(4 * R + NH) * 64] >> hs) & 0xffffu;
             int64_t e_carry = INT64_MIN;
             uint32_t sbf_carry = TB_START, sb2_carry = TB_START;
             int64_t c1v = INT64_MIN, c2v = INT64_MIN;
             uint32_t c1i = 0, c2i = 0;
             auto cell_of = [&](int r) -> uint32_t {  // K1's bit order: move | I extends << 3 | D extends << 4
-                const uint32_t c = (park[(4 * R + r / 3) * 256] >> (hs + 5 * (r % 3))) & 31u;
+                const uint32_t c = (park[(4 * R + r / 3) * 64] >> (hs + 5 * (r % 3))) & 31u;
                 return ((c >> 1) & 7u) | ((c & 1u) << 3) | (c & 16u);
             };
             {

@@ -19,8 +19,8 @@ out = sys.argv[1]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + "/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0]
-        if "bgsw" not in k:
+        k = r["Kernel_Name"].split("(bgsw")[0]
+        if "bgsw" not in r["Kernel_Name"]:
             continue
         acc[k][r["Counter_Name"]].append((r["Dispatch_Id"], float(r["Counter_Value"])))
 for k, cs in acc.items():
