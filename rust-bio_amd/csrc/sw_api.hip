@@ -149,13 +149,13 @@ extern "C" int bg_align_batch_dev(bg_ctx* ctx, const bg_scoring_t* sc, int mode,
                           : get_fill_matrix(cfg.lp, cfg.r, sm, narrow);
     // K1p: local alignment of short reads whose scores fit 12 bits (sw_fill_pk16.hip) — two pairs per lane.
     // Bound: no real DP value, nor the epilogue's go * i terms, may leave +-2040.
-    const bool pk16 = !ctx->no_pk16 && sm == SCORE_PARAMS && all_zero_clips && cfg.lp == 16 && max_xlen >= 1 &&
+    const bool pk16 = !ctx->no_pk16 && sm == SCORE_PARAMS && all_zero_clips && cfg.lp <= 32 && max_xlen >= 1 &&
                       mag * ((int64_t)std::max(max_xlen, max_ylen) + 2) <= 2040;
     sw_fill_fn fill_rest = nullptr;
     if (pk16) {
         // rows per lane: K1p's fast launch wants row m on the last row of a lane (m % R == 0); reads of a
         // batch usually share one length, so prefer an R that divides the longest
-        for (int r = std::max(2, (int)((max_xlen + 15) / 16)); r <= 12; r++)
+        for (int r = std::max(cfg.lp == 16 ? 2 : 7, (int)((max_xlen + cfg.lp - 1) / cfg.lp)); r <= 12; r++)
             if (max_xlen % r == 0) {
                 cfg.r = r;
                 break;

@@ -246,8 +246,10 @@ __device__ __forceinline__ void sw_fill_pk16_body(const SwArgs& a) {
                 const uint32_t nb = s + LP + ll;
                 if (pair_ok && nb < n) ychunk_nx = (uint32_t)y0[nb] | ((uint32_t)y1[nb] << 16);
             }
-            pk S_up = (pk)wave_shr1((int)S_out), I_up = (pk)wave_shr1((int)I_out), cm = (pk)wave_shr1((int)cm_out);
-            pk ca = (pk)wave_shr1((int)ca_out), q = (pk)wave_shr1((int)q_out);
+            // lane 0 of the wavefront keeps its own value ("old" == source): it is a row-0 lane and overrides it
+            pk S_up = (pk)wave_shr1((int)S_out, (int)S_out), I_up = (pk)wave_shr1((int)I_out, (int)I_out);
+            pk cm = (pk)wave_shr1((int)cm_out, (int)cm_out), ca = (pk)wave_shr1((int)ca_out, (int)ca_out);
+            pk q = (pk)wave_shr1((int)q_out, (int)q_out);
             const uint32_t j = s + 1 - (uint32_t)ll;
             const bool col_ok = pair_ok && (j - 1) < n;  // 1 <= j <= n
             if (ll == 0) {  // row 0 of the matrix (mod.rs:678-721) for a local alignment
@@ -257,7 +259,7 @@ __device__ __forceinline__ void sw_fill_pk16_body(const SwArgs& a) {
                 cm = FLOORK;
                 ca = 0;
             }
-            ychunk = (pk)wave_shl1((int)ychunk);
+            ychunk = (pk)wave_shl1((int)ychunk, (int)ychunk);
 
             if (col_ok) {
                 const pk sprio = dup16((int32_t)(15u - (s & 15u)));
@@ -437,6 +439,7 @@ sw_fill_fn get_fill_pk16(int lp, int r, bool fast) {
     if (lp == LP && r == R) return fast ? pk16::sw_fill_pk16_kernel<R, LP> : pk16::sw_fill_pk16_rest_kernel<R, LP>;
     CASE(16, 2) CASE(16, 3) CASE(16, 4) CASE(16, 5) CASE(16, 6) CASE(16, 7) CASE(16, 8) CASE(16, 9) CASE(16, 10)
     CASE(16, 11) CASE(16, 12)
+    CASE(32, 7) CASE(32, 8) CASE(32, 9) CASE(32, 10) CASE(32, 11) CASE(32, 12)
 #undef CASE
     return nullptr;
 }

@@ -65,6 +65,17 @@ def test_uniform_read_lengths_every_rows_per_lane(m):
         local_vs_oracle(BASE, xs, ys)
 
 
+@pytest.mark.parametrize("m", [193, 200, 250, 256, 300, 301, 384])
+def test_uniform_read_lengths_two_pairs_per_wavefront(m):
+    # 192 < m <= 384: 32 lanes per pair
+    rng = np.random.default_rng(m)
+    for n in sorted({m, m + 7, m // 2, 1}):
+        xs, ys = related_pairs(rng, 13, lambda p: m, lambda p: n)
+        local_vs_oracle(BASE, xs, ys)
+    xs, ys = related_pairs(rng, 21, lambda p: m - (p % 3) * 17, lambda p: m + (p % 2) * 5)
+    local_vs_oracle(BASE, xs, ys)
+
+
 def test_couples_with_different_lengths_take_two_passes():
     rng = np.random.default_rng(5)
     # pair p and pair p + 4 share lanes: make some couples agree and some not
