@@ -15,7 +15,10 @@ namespace bgsw {
 sw_fill_fn get_fill_params_narrow(int lp, int r, bool local);
 sw_fill_fn get_fill_params_wide(int lp, int r, bool local);
 sw_fill_fn get_fill_matrix(int lp, int r, int sm, bool narrow);
-sw_fill_fn get_fill_pk16(int lp, int r, bool fast);
+sw_fill_fn get_fill_pk16_local(int lp, int r, bool fast);
+sw_fill_fn get_fill_pk16_semiglobal(int lp, int r, bool fast);
+sw_fill_fn get_fill_pk16_global(int lp, int r, bool fast);
+sw_fill_fn get_fill_pk16_custom(int lp, int r, bool fast);
 void launch_traceback(const SwArgs& a, int nw, hipStream_t st);
 
 struct Config {
@@ -147,22 +150,29 @@ extern "C" int bg_align_batch_dev(bg_ctx* ctx, const bg_scoring_t* sc, int mode,
                           ? (narrow ? get_fill_params_narrow(cfg.lp, cfg.r, all_zero_clips)
                                     : get_fill_params_wide(cfg.lp, cfg.r, all_zero_clips))
                           : get_fill_matrix(cfg.lp, cfg.r, sm, narrow);
-    // K1p: local alignment of short reads whose scores fit 12 bits (sw_fill_pk16.hip) — two pairs per lane.
-    // Bound: no real DP value, nor the epilogue's go * i terms, may leave +-2040.
-    const bool pk16 = !ctx->no_pk16 && sm == SCORE_PARAMS && all_zero_clips && cfg.lp <= 32 && max_xlen >= 1 &&
-                      mag * ((int64_t)std::max(max_xlen, max_ylen) + 2) <= 2040;
+    // K1p: short reads whose scores fit 12 bits (sw_fill_pk16.inc) — two pairs per lane, one instantiation
+    // unit per clip pattern.  Bound: no real DP value, nor the epilogue's go * i terms, may leave +-2040.
     sw_fill_fn fill_rest = nullptr;
+    const bool pk16 = !ctx->no_pk16 && sm == SCORE_PARAMS && cfg.lp <= 32 && max_xlen >= 1 &&
+                      mag * ((int64_t)std::max(max_xlen, max_ylen) + 2) <= 2040;
     if (pk16) {
-        // rows per lane: K1p's fast launch wants row m on the last row of a lane (m % R == 0); reads of a
-        // batch usually share one length, so prefer an R that divides the longest
-        for (int r = std::max(cfg.lp == 16 ? 2 : 7, (int)((max_xlen + cfg.lp - 1) / cfg.lp)); r <= 12; r++)
-            if (max_xlen % r == 0) {
-                cfg.r = r;
-                break;
-            }
-        fill = get_fill_pk16(cfg.lp, cfg.r, true);
-        fill_rest = get_fill_pk16(cfg.lp, cfg.r, false);
-        if (!fill || !fill_rest) return BG_ERR_UNSUPPORTED;
+        const SwScoring& c = a.sc;
+        const int32_t M = BG_MIN_SCORE;
+        auto getter = all_zero_clips ? get_fill_pk16_local
+                      : (c.xp == M && c.xs == M && c.yp == 0 && c.ys == 0) ? get_fill_pk16_semiglobal
+                      : (c.xp == M && c.xs == M && c.yp == M && c.ys == M) ? get_fill_pk16_global
+                                                                           : get_fill_pk16_custom;
+        // rows per lane: the fast launch wants row m on the last row of a lane (m % R == 0); reads of a
+        // batch usually share one length, so prefer an instantiated R that divides the longest
+        int r_pick = 0;
+        for (int r = (int)((max_xlen + cfg.lp - 1) / cfg.lp); r <= 12 && !r_pick; r++)
+            if (max_xlen % r == 0 && getter(cfg.lp, r, true)) r_pick = r;
+        for (int r = (int)((max_xlen + cfg.lp - 1) / cfg.lp); r <= 12 && !r_pick; r++)
+            if (getter(cfg.lp, r, true)) r_pick = r;
+        if (!r_pick) return BG_ERR_UNSUPPORTED;
+        cfg.r = r_pick;
+        fill = getter(cfg.lp, cfg.r, true);
+        fill_rest = getter(cfg.lp, cfg.r, false);
         a.g.tb_fmt = 1;
     }
     if (!fill) return BG_ERR_UNSUPPORTED;

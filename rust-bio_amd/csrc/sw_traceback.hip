@@ -143,8 +143,10 @@ __global__ __launch_bounds__(256) void sw_traceback_kernel(const SwArgs a) {
                 next = s_nib(0, j);
                 break;
             case TB_XCLIP_SUFFIX: {
-                // K1p (tb_fmt 1) publishes Lx[j] <= m < 256 as bytes
-                const uint32_t lx = (j == n) ? lxn : (geo.tb_fmt ? (uint32_t)((const uint8_t*)gLx)[j] : (uint32_t)gLx[j]);
+                // K1p (tb_fmt 1) publishes Lx[j] <= m packed: bytes with 16 lanes per pair (m <= 192), else 16 bits
+                const uint32_t lx = (j == n) ? lxn
+                                    : !geo.tb_fmt ? (uint32_t)gLx[j]
+                                    : geo.lp == 16 ? (uint32_t)((const uint8_t*)gLx)[j] : (uint32_t)((const uint16_t*)gLx)[j];
                 push_clip(BG_OP_XCLIP, lx);
                 i -= lx;
                 xend = i;

@@ -37,19 +37,25 @@ def related_pairs(rng, n_pairs, m_of, n_of, alpha=ALPHA):
     return xs, ys
 
 
-def local_vs_oracle(kw, xs, ys):
-    al = Aligner.with_scoring(Scoring.from_scores(kw["gap_open"], kw["gap_extend"], kw["match"], kw["mismatch"]))
+MODES = {"custom": 0, "global": 1, "semiglobal": 2, "local": 3}
+
+
+def local_vs_oracle(kw, xs, ys, mode="local", clips=None):
+    sc = Scoring.from_scores(kw["gap_open"], kw["gap_extend"], kw["match"], kw["mismatch"])
+    for c, v in (clips or {}).items():
+        setattr(sc, c, v)
+    al = Aligner.with_scoring(sc)
     x, xo = _lib.concat(xs)
     y, yo = _lib.concat(ys)
-    out, ops = al.align_arrays(3, x, xo, y, yo)
-    oout, oops, stride = orc.align_batch(orc.make_scoring(**kw, **CLIPS), "local", x, xo, y, yo, threads=8)
+    out, ops = al.align_arrays(MODES[mode], x, xo, y, yo)
+    oout, oops, stride = orc.align_batch(orc.make_scoring(**kw, **dict(CLIPS, **(clips or {}))), mode, x, xo, y, yo, threads=8)
     for f in ("score", "xstart", "xend", "ystart", "yend", "xlen", "ylen", "n_ops"):
         bad = np.nonzero(out[f].astype(np.int64) != oout[f].astype(np.int64))[0]
-        assert len(bad) == 0, (f, kw, bad[:5], xs[bad[0]], ys[bad[0]], out[f][bad[0]], oout[f][bad[0]])
+        assert len(bad) == 0, (f, mode, clips, kw, bad[:5], xs[bad[0]], ys[bad[0]], out[f][bad[0]], oout[f][bad[0]])
     assert (out["status"] == 0).all()
     for p in range(len(xs)):
         want = orc.decode_ops(oops[p * stride:p * stride + int(oout["n_ops"][p])])
-        assert decode_ops(out[p], ops) == want, (kw, p, xs[p], ys[p])
+        assert decode_ops(out[p], ops) == want, (mode, clips, kw, p, xs[p], ys[p])
 
 
 BASE = dict(gap_open=-5, gap_extend=-1, match=1, mismatch=-1)
@@ -131,3 +137,49 @@ def test_same_answers_as_k1_at_scale():
     al.ctx.set_option("no_pk16", 0)
     assert out.tobytes() == out1.tobytes()
     assert (ops == ops1).all()
+
+
+@pytest.mark.parametrize("mode", ["semiglobal", "global"])
+@pytest.mark.parametrize("m", [8, 37, 60, 100, 150, 192, 250, 384])
+def test_other_modes_uniform_and_ragged(mode, m):
+    rng = np.random.default_rng(m + len(mode))
+    for n in sorted({m, m + 16, max(1, m - 9)}):
+        xs, ys = related_pairs(rng, 29, lambda p: m, lambda p: n)
+        local_vs_oracle(BASE, xs, ys, mode)
+    xs, ys = related_pairs(rng, 40, lambda p: max(1, m - (p % 5) * 3), lambda p: m + 11 - (p % 4))
+    xs += [b"", b"ACGT", b"", b"A"]
+    ys += [b"", b"", b"ACGT", b"C"]
+    local_vs_oracle(BASE, xs, ys, mode)
+    local_vs_oracle(dict(gap_open=-3, gap_extend=-2, match=2, mismatch=-3), xs, ys, mode)
+
+
+def test_custom_clip_patterns_uniform_reads():
+    rng = np.random.default_rng(21)
+    xs, ys = related_pairs(rng, 48, lambda p: 150, lambda p: 166)
+    xs2, ys2 = related_pairs(rng, 40, lambda p: 96 - (p % 3), lambda p: 90 + (p % 7))
+    M = MIN_SCORE
+    for clips in (dict(xclip_prefix=-3, xclip_suffix=-4, yclip_prefix=-2, yclip_suffix=0),
+                  dict(xclip_prefix=0, xclip_suffix=M, yclip_prefix=M, yclip_suffix=-1),
+                  dict(xclip_prefix=M, xclip_suffix=0, yclip_prefix=0, yclip_suffix=M),
+                  dict(xclip_prefix=M, xclip_suffix=-7, yclip_prefix=-9, yclip_suffix=M),
+                  dict(xclip_prefix=-1, xclip_suffix=-1, yclip_prefix=M, yclip_suffix=M),
+                  dict(xclip_prefix=0, xclip_suffix=0, yclip_prefix=-5, yclip_suffix=-5),
+                  dict(xclip_prefix=-12, xclip_suffix=0, yclip_prefix=0, yclip_suffix=-12)):
+        for kw in (BASE, dict(gap_open=0, gap_extend=-1, match=2, mismatch=-2), dict(gap_open=-4, gap_extend=0, match=1, mismatch=0)):
+            local_vs_oracle(kw, xs, ys, "custom", clips)
+            local_vs_oracle(kw, xs2, ys2, "custom", clips)
+
+
+def test_semiglobal_same_answers_as_k1_at_scale():
+    rng = np.random.default_rng(8)
+    xs, ys = related_pairs(rng, 40_000, lambda p: 150 if p % 101 else 140, lambda p: 166 if p % 67 else 150)
+    x, xo = _lib.concat(xs)
+    y, yo = _lib.concat(ys)
+    al = Aligner.with_scoring(Scoring.from_scores(-5, -1, 1, -1))
+    for mode in (2, 1):
+        out, ops = al.align_arrays(mode, x, xo, y, yo)
+        al.ctx.set_option("no_pk16", 1)
+        out1, ops1 = al.align_arrays(mode, x, xo, y, yo)
+        al.ctx.set_option("no_pk16", 0)
+        assert out.tobytes() == out1.tobytes()
+        assert (ops == ops1).all()
