@@ -283,6 +283,46 @@ uint64_t bg_sparse_expand_kmer_matches(const uint8_t* x, uint64_t m, const uint8
                                        uint32_t k, const uint32_t* matches_xy, uint64_t n_matches,
                                        uint32_t allowed_mismatches, uint32_t* out_xy, uint64_t cap);
 
+/* ---- FASTQ ingest and CIGAR emission --------------------------------------
+ * bio::io::fastq::Reader::read / Records on a text that is in memory (io/fastq.rs:266-303, 508-527: header
+ * line '@id desc', sequence lines up to a line that starts with '+', then as many quality lines as there were
+ * sequence lines; every line trimmed with str::trim_end) and Record::check (fastq.rs:388-410).  Records are
+ * read until the end of the text or the first ReadError: *status is that error (BG_FASTQ_*), *err_pos the byte
+ * offset of the line that raised it (the header line for IncompleteRecord), *n_records the records before it.
+ * seq/qual are the concatenated trimmed lines; seq_off/qual_off have n_records+1 entries (seq_off is directly
+ * the x_off of bg_align_batch_dev); capacity of seq/qual: `len` bytes, of the offsets: rec_cap+1.
+ * Returns BG_ERR_TOO_LARGE if there are more than rec_cap records (n_records says how many). */
+enum { BG_FASTQ_OK = 0, BG_FASTQ_MISSING_AT = 1, BG_FASTQ_INCOMPLETE = 2, BG_FASTQ_IO = 3 };   /* ReadError, fastq.rs:113-126 */
+enum { BG_FQCHECK_OK = 0, BG_FQCHECK_EMPTY_ID = 1, BG_FQCHECK_NONASCII_SEQ = 2, BG_FQCHECK_INVALID_SEQ = 3,
+       BG_FQCHECK_NONASCII_QUAL = 4, BG_FQCHECK_UNEQUAL = 5 };                                   /* CheckError, fastq.rs:129-150 */
+typedef struct {
+    uint64_t id_off, desc_off;   /* into the text */
+    uint64_t seq_off, qual_off;  /* into seq / qual */
+    uint32_t id_len, desc_len, seq_len, qual_len;
+    int32_t has_desc;            /* 0: Record::desc() is None */
+    int32_t check;               /* Record::check(): BG_FQCHECK_* (first failing rule) */
+} bg_fastq_record_t;
+int bg_fastq_parse(bg_ctx* ctx, const uint8_t* text, uint64_t len, bg_fastq_record_t* recs, uint64_t rec_cap,
+                   uint8_t* seq, uint64_t* seq_off, uint8_t* qual, uint64_t* qual_off, uint64_t* n_records,
+                   int32_t* status, uint64_t* err_pos);
+/* the same with text, records, sequences, qualities and offsets in device memory (n_records/status/err_pos are
+ * host pointers; the call synchronises `stream`) */
+int bg_fastq_parse_dev(bg_ctx* ctx, const uint8_t* d_text, uint64_t len, bg_fastq_record_t* d_recs,
+                       uint64_t rec_cap, uint8_t* d_seq, uint64_t* d_seq_off, uint8_t* d_qual,
+                       uint64_t* d_qual_off, uint64_t* n_records, int32_t* status, uint64_t* err_pos,
+                       void* stream);
+/* bio_types::alignment::Alignment::cigar(hard_clip) (bio-types 1.0, a dependency that is not in the reference
+ * tree: restated from its documentation, parity unpinned) for n alignments as returned by bg_align_batch
+ * (ops_off into `ops`): xstart as a leading soft/hard clip, runs of '=' 'X' 'D' 'I', xlen - xend as the
+ * trailing clip, "" without operations.  out_off has n+1 entries.  BG_ERR_UNSUPPORTED if some alignment has
+ * AlignmentMode::Custom (the crate panics; its string is empty), BG_ERR_OPS_CAP if out_cap is too small. */
+int bg_cigar_batch(bg_ctx* ctx, uint64_t n, const bg_alignment_t* aln, const uint8_t* ops, uint64_t ops_bytes,
+                   int hard_clip, char* out, uint64_t out_cap, uint64_t* out_off);
+/* device flavour: one slot of `stride` chars (>= 2 * max n_ops + 24) per alignment, d_len[p] = chars written
+ * or a negative bg_status */
+int bg_cigar_batch_dev(bg_ctx* ctx, uint64_t n, const bg_alignment_t* d_aln, const uint8_t* d_ops, int hard_clip,
+                       char* d_out, uint64_t stride, int32_t* d_len, void* stream);
+
 /* Timing of the last *_dev / batch call's kernels on this ctx, measured with HIP events on
  * the stream the kernels ran on (used by bench.py for the roofline line). */
 typedef struct {

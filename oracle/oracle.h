@@ -140,6 +140,25 @@ int64_t orc_fmd_smems(const uint8_t* bwt, uint64_t n, const uint64_t* less, uint
 int orc_fmd_interval(const uint8_t* bwt, uint64_t n, const uint64_t* less, uint64_t less_len,
                      const orc_occ* occ, int op, const uint64_t* iv, uint8_t a, uint64_t* out);
 
+/* ---- bio::io::fastq (io/fastq.rs) on a byte buffer, and bio-types Alignment::cigar ---- */
+enum { ORC_FASTQ_OK = 0, ORC_FASTQ_MISSING_AT = 1, ORC_FASTQ_INCOMPLETE = 2, ORC_FASTQ_IO = 3 }; /* ReadError, fastq.rs:113-126 */
+enum { ORC_FQCHECK_OK = 0, ORC_FQCHECK_EMPTY_ID = 1, ORC_FQCHECK_NONASCII_SEQ = 2, ORC_FQCHECK_INVALID_SEQ = 3,
+       ORC_FQCHECK_NONASCII_QUAL = 4, ORC_FQCHECK_UNEQUAL = 5 }; /* CheckError, fastq.rs:129-150 */
+typedef struct {
+    uint64_t id_off, id_len;     /* into the text */
+    uint64_t desc_off, desc_len; /* into the text; has_desc == 0: None */
+    uint64_t seq_off, seq_len;   /* into the concatenated sequence output */
+    uint64_t qual_off, qual_len; /* into the concatenated quality output */
+    int32_t has_desc;
+    int32_t check;               /* Record::check() of this record */
+} orc_fastq_rec_t;
+/* Parses records until the end of the text or the first ReadError (status / err_pos = byte offset of the line
+ * that raised it); n_records = records read before it.  seq / qual must hold `len` bytes (or be NULL). */
+int orc_fastq_parse(const uint8_t* text, uint64_t len, orc_fastq_rec_t* recs, uint64_t rec_cap, uint8_t* seq, uint8_t* qual,
+                    uint64_t* n_records, int32_t* status, uint64_t* err_pos);
+/* Alignment::cigar(hard_clip): returns the length written, -1 if cap is too small, -2 for AlignmentMode::Custom */
+int64_t orc_cigar(const orc_alignment_t* a, const uint64_t* ops, int hard_clip, char* out, uint64_t cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -122,6 +122,9 @@ def lib():
             ("orc_sa_sample_export", None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
             ("orc_sampled_sa_get", C.c_int,
              [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, u64p]),
+            ("orc_fastq_parse", C.c_int,
+             [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, u64p, C.POINTER(C.c_int32), u64p]),
+            ("orc_cigar", C.c_int64, [C.POINTER(AlignmentRec), C.c_void_p, C.c_int, C.c_void_p, C.c_uint64]),
         ]:
             if hasattr(L, name):
                 f = getattr(L, name)
@@ -505,3 +508,47 @@ class FMDIndex:
 
     def smems(self, pattern, i, l): return self._smems(pattern, i, l, 0)
     def all_smems(self, pattern, l): return self._smems(pattern, 0, l, 1)
+
+
+# ---- bio::io::fastq::Reader (io/fastq.rs:266-303) and bio-types Alignment::cigar -------------------------
+FASTQ_STATUS = ["ok", "MissingAt", "IncompleteRecord", "Io"]
+FASTQ_CHECK = ["ok", "EmptyId", "NonAsciiSequence", "InvalidSequence", "NonAsciiQualities", "UnequalLength"]
+FQREC_DTYPE = np.dtype([("id_off", "<u8"), ("id_len", "<u8"), ("desc_off", "<u8"), ("desc_len", "<u8"),
+                        ("seq_off", "<u8"), ("seq_len", "<u8"), ("qual_off", "<u8"), ("qual_len", "<u8"),
+                        ("has_desc", "<i4"), ("check", "<i4")])
+
+
+def fastq_parse(text):
+    """-> (records: list of dict(id, desc, seq, qual, check), status name, err_pos); records read before the
+    first ReadError, like collecting `Reader::records()` up to the first Err."""
+    t = _buf(text)
+    cap = len(t) // 4 + 2
+    recs = np.zeros(cap, dtype=FQREC_DTYPE)
+    seq = np.zeros(max(1, len(t)), dtype=np.uint8)
+    qual = np.zeros(max(1, len(t)), dtype=np.uint8)
+    n, st, ep = C.c_uint64(0), C.c_int32(0), C.c_uint64(0)
+    lib().orc_fastq_parse(t.ctypes.data, len(t), recs.ctypes.data, cap, seq.ctypes.data, qual.ctypes.data,
+                          C.byref(n), C.byref(st), C.byref(ep))
+    tb = t.tobytes()
+    out = []
+    for r in recs[:n.value]:
+        out.append({"id": tb[int(r["id_off"]):int(r["id_off"] + r["id_len"])],
+                    "desc": tb[int(r["desc_off"]):int(r["desc_off"] + r["desc_len"])] if r["has_desc"] else None,
+                    "seq": seq[int(r["seq_off"]):int(r["seq_off"] + r["seq_len"])].tobytes(),
+                    "qual": qual[int(r["qual_off"]):int(r["qual_off"] + r["qual_len"])].tobytes(),
+                    "check": FASTQ_CHECK[int(r["check"])]})
+    return out, FASTQ_STATUS[st.value], int(ep.value)
+
+
+def cigar(aln, ops_u64, hard_clip):
+    """aln: dict with xstart/xend/xlen/mode (ints); ops: uint64 kind | len << 8.  None for Custom (panic)."""
+    rec = AlignmentRec()
+    rec.xstart, rec.xend, rec.xlen, rec.mode = int(aln["xstart"]), int(aln["xend"]), int(aln["xlen"]), int(aln["mode"])
+    ops = np.ascontiguousarray(ops_u64, dtype=np.uint64)
+    rec.n_ops = len(ops)
+    buf = np.zeros(24 * (len(ops) + 4), dtype=np.uint8)
+    n = lib().orc_cigar(C.byref(rec), ops.ctypes.data, 1 if hard_clip else 0, buf.ctypes.data, len(buf))
+    if n == -2:
+        return None
+    assert n >= 0
+    return buf[:n].tobytes().decode()

@@ -66,6 +66,11 @@ ALN_DTYPE = np.dtype([("score", "<i4"), ("xstart", "<u4"), ("xend", "<u4"), ("ys
                       ("ops_off", "<u8"), ("clip_len", "<u4", (4,)), ("n_clips", "u1"),
                       ("mode", "u1"), ("status", "i1"), ("_pad", "u1"), ("_tail", "<u4")])
 assert ALN_DTYPE.itemsize == 64, ALN_DTYPE.itemsize
+# bg_fastq_record_t
+FQREC_DTYPE = np.dtype([("id_off", "<u8"), ("desc_off", "<u8"), ("seq_off", "<u8"), ("qual_off", "<u8"),
+                        ("id_len", "<u4"), ("desc_len", "<u4"), ("seq_len", "<u4"), ("qual_len", "<u4"),
+                        ("has_desc", "<i4"), ("check", "<i4")])
+assert FQREC_DTYPE.itemsize == 56, FQREC_DTYPE.itemsize
 
 SYMBOLS = ["bg_device_count", "bg_init", "bg_free", "bg_strerror", "bg_last_error",
            "bg_set_option", "bg_suffix_array", "bg_bwt", "bg_less", "bg_fm_build", "bg_fm_free",
@@ -74,8 +79,8 @@ SYMBOLS = ["bg_device_count", "bg_init", "bg_free", "bg_strerror", "bg_last_erro
            "bg_interval_occ_batch", "bg_interval_occ_batch_dev", "bg_fmd_smems_batch", "bg_fmd_smems_batch_dev", "bg_fmd_interval_batch",
            "bg_align_batch", "bg_align_batch_dev", "bg_align_banded_batch", "bg_align_banded_batch_dev", "bg_band_create_batch",
            "bg_align_banded_bands_batch", "bg_band_from_matches_batch", "bg_sparse_find_kmer_matches", "bg_sparse_sdpkpp",
-           "bg_sparse_lcskpp", "bg_sparse_sdpkpp_union_lcskpp_path", "bg_sparse_expand_kmer_matches", "bg_get_timing",
-           "bg_enable_timing"]
+           "bg_sparse_lcskpp", "bg_sparse_sdpkpp_union_lcskpp_path", "bg_sparse_expand_kmer_matches", "bg_fastq_parse",
+           "bg_fastq_parse_dev", "bg_cigar_batch", "bg_cigar_batch_dev", "bg_get_timing", "bg_enable_timing"]
 
 
 def build(force=False):
@@ -121,6 +126,10 @@ def lib():
         L.bg_fm_set_suffix_array.argtypes = [vp, vp, u64]
         L.bg_fm_set_sampled_suffix_array.argtypes = [vp, vp, u64, u32, C.c_uint8, vp, vp, u64]
         L.bg_sa_get_batch.argtypes = [vp, u64, vp, vp]
+        L.bg_fastq_parse.argtypes = [vp, vp, u64, vp, u64, vp, vp, vp, vp, C.POINTER(u64), C.POINTER(i32), C.POINTER(u64)]
+        L.bg_fastq_parse_dev.argtypes = [vp, vp, u64, vp, u64, vp, vp, vp, vp, C.POINTER(u64), C.POINTER(i32), C.POINTER(u64), vp]
+        L.bg_cigar_batch.argtypes = [vp, u64, vp, vp, u64, i32, vp, u64, vp]
+        L.bg_cigar_batch_dev.argtypes = [vp, u64, vp, vp, i32, vp, u64, vp, vp]
         L.bg_sa_get_batch_dev.argtypes = [vp, u64, vp, vp, vp]
         L.bg_interval_occ_batch.argtypes = [vp, u64, vp, vp, vp, vp, u64]
         L.bg_interval_occ_batch_dev.argtypes = [vp, u64, vp, vp, u64, vp, vp]

@@ -1,0 +1,645 @@
+// FASTQ ingest on the device: bio::io::fastq::Reader::read / Records and Record::check
+// (/root/reference/src/io/fastq.rs:266-303, 388-410, 508-527) over a text that is already in HBM, and CIGAR
+// emission (bio-types 1.0 Alignment::cigar) for a batch of alignment records.
+//
+// The reader is a sequential state machine over LINES (a record is a header line, sequence lines up to a line
+// that starts with '+', then as many quality lines as there were sequence lines), but nearly every FASTQ is four
+// lines per record.  So:
+//   F1  line index — newline count per 4 KB chunk, scan of the counts, scatter of the line starts;
+//   F2  per line: first byte, length after str::trim_end (Unicode White_Space), UTF-8 validity;
+//   F3  four-line hypothesis, one thread per record: record k is lines 4k..4k+3 iff line 4k starts with '@',
+//       4k+1 does not start with '+', 4k+2 starts with '+' and the quality trims to something.  By induction the
+//       reader agrees with every record before the first one that fails;
+//   F4  from that record on (wrapped, truncated or malformed input), one wavefront walks the lines with the
+//       reference's rules, 64 lines of look-ahead per ballot;
+//   F5  lengths -> exclusive scans -> offsets (seq_off is directly the x_off of bg_align_batch_dev);
+//   F6  one wavefront per record gathers the trimmed lines and evaluates Record::check on the way.
+// Everything is byte/integer work bound by HBM reads of the text (about three passes).
+#include <algorithm>
+#include <vector>
+
+#include "bg_common.h"
+
+namespace {
+
+constexpr uint32_t kChunk = 4096;
+struct LineInfo {
+    uint32_t trim;  // bytes left by trim_end (the line's '\n' is whitespace too)
+    uint8_t first;  // first byte of the line
+    uint8_t bad;    // not UTF-8: read_line fails with io::ErrorKind::InvalidData
+    uint16_t pad;
+};
+struct RecLines {  // lines of one record
+    uint64_t hdr;     // header line
+    uint64_t qual0;   // first quality line (may be >= n_lines at the end of the text)
+    uint32_t n_seq;   // sequence lines hdr+1 .. hdr+n_seq; quality lines qual0 .. qual0+n_seq-1 (those that exist)
+    uint32_t pad;
+};
+
+// ---- F1 ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fq_count_newlines_kernel(const uint8_t* __restrict__ t, uint64_t len, uint32_t* __restrict__ cnt) {
+    const uint64_t base = (uint64_t)blockIdx.x * kChunk + threadIdx.x * 16u;
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++)
+        if (base + i < len && t[base + i] == '\n') c++;
+    __shared__ uint32_t s[4];
+#pragma unroll
+    for (int o = 32; o; o >>= 1) c += __shfl_xor(c, o);
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) cnt[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
+}
+// exclusive scan of up to 2^32 items by one block (items are per-chunk / per-block partial sums: few)
+template <typename T>
+__global__ __launch_bounds__(1024) void fq_scan_small_kernel(const T* __restrict__ in, uint64_t* __restrict__ out, uint64_t n, uint64_t* total) {
+    __shared__ uint64_t s[1024];
+    uint64_t carry = 0;
+    for (uint64_t b = 0; b < n; b += 1024) {
+        const uint64_t i = b + threadIdx.x;
+        const uint64_t v = i < n ? (uint64_t)in[i] : 0;
+        s[threadIdx.x] = v;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            const uint64_t u = threadIdx.x >= (unsigned)o ? s[threadIdx.x - o] : 0;
+            __syncthreads();
+            s[threadIdx.x] += u;
+            __syncthreads();
+        }
+        if (i < n) out[i] = carry + s[threadIdx.x] - v;
+        carry += s[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && total) *total = carry;
+}
+__global__ __launch_bounds__(256) void fq_line_starts_kernel(const uint8_t* __restrict__ t, uint64_t len, const uint64_t* __restrict__ base,
+                                                             uint64_t* __restrict__ ls) {
+    const uint64_t b0 = (uint64_t)blockIdx.x * kChunk + threadIdx.x * 16u;
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++)
+        if (b0 + i < len && t[b0 + i] == '\n') c++;
+    __shared__ uint32_t s[256];
+    s[threadIdx.x] = c;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+        const uint32_t u = threadIdx.x >= (unsigned)o ? s[threadIdx.x - o] : 0;
+        __syncthreads();
+        s[threadIdx.x] += u;
+        __syncthreads();
+    }
+    uint64_t k = base[blockIdx.x] + s[threadIdx.x] - c;  // newlines before this thread's bytes
+#pragma unroll
+    for (int i = 0; i < 16; i++)
+        if (b0 + i < len && t[b0 + i] == '\n') ls[++k] = b0 + i + 1;
+    if (blockIdx.x == 0 && threadIdx.x == 0) ls[0] = 0;
+}
+
+// ---- F2 ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool is_ws(uint32_t cp) {  // char::is_whitespace
+    return (cp >= 9 && cp <= 13) || cp == 0x20 || cp == 0x85 || cp == 0xA0 || cp == 0x1680 || (cp >= 0x2000 && cp <= 0x200A) ||
+           cp == 0x2028 || cp == 0x2029 || cp == 0x202F || cp == 0x205F || cp == 0x3000;
+}
+__device__ bool valid_utf8(const uint8_t* s, uint64_t n) {
+    uint64_t i = 0;
+    while (i < n) {
+        const uint8_t c = s[i];
+        if (c < 0x80) {
+            i++;
+            continue;
+        }
+        int k;
+        uint32_t cp, lo;
+        if (c >= 0xC2 && c <= 0xDF) {
+            k = 1, cp = c & 0x1F, lo = 0x80;
+        } else if (c >= 0xE0 && c <= 0xEF) {
+            k = 2, cp = c & 0x0F, lo = 0x800;
+        } else if (c >= 0xF0 && c <= 0xF4) {
+            k = 3, cp = c & 0x07, lo = 0x10000;
+        } else {
+            return false;
+        }
+        for (int j = 1; j <= k; j++) {
+            if (i + j >= n || (s[i + j] & 0xC0) != 0x80) return false;
+            cp = (cp << 6) | (s[i + j] & 0x3F);
+        }
+        if (cp < lo || cp > 0x10FFFF || (cp >= 0xD800 && cp <= 0xDFFF)) return false;
+        i += k + 1;
+    }
+    return true;
+}
+__device__ uint64_t trim_end(const uint8_t* s, uint64_t n) {  // str::trim_end on valid UTF-8
+    while (n) {
+        uint64_t b = n - 1;
+        while (b > 0 && (s[b] & 0xC0) == 0x80) b--;
+        const uint8_t c = s[b];
+        uint32_t cp = c < 0x80 ? c : c < 0xE0 ? (c & 0x1F) : c < 0xF0 ? (c & 0x0F) : (c & 0x07);
+        for (uint64_t j = b + 1; j < n; j++) cp = (cp << 6) | (s[j] & 0x3F);
+        if (!is_ws(cp)) break;
+        n = b;
+    }
+    return n;
+}
+__global__ __launch_bounds__(256) void fq_line_info_kernel(const uint8_t* __restrict__ t, const uint64_t* __restrict__ ls, uint64_t n_lines,
+                                                           LineInfo* __restrict__ info) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_lines) return;
+    const uint64_t a = ls[i], n = ls[i + 1] - a;
+    const uint8_t* s = t + a;
+    bool hi = false;
+    for (uint64_t k = 0; k < n; k++) hi |= s[k] >= 0x80;
+    LineInfo li;
+    li.first = n ? s[0] : 0;
+    li.bad = hi && !valid_utf8(s, n);
+    li.trim = li.bad ? 0u : (uint32_t)trim_end(s, n);
+    li.pad = 0;
+    info[i] = li;
+}
+
+// ---- F3 ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fq_four_line_kernel(const LineInfo* __restrict__ info, uint64_t n_rec4, unsigned long long* first_bad) {
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_rec4) return;
+    const LineInfo h = info[4 * k], s = info[4 * k + 1], p = info[4 * k + 2], q = info[4 * k + 3];
+    const bool ok = !h.bad && !s.bad && !p.bad && !q.bad && h.first == '@' && s.first != '+' && p.first == '+' && q.trim != 0;
+    if (!ok) atomicMin(first_bad, (unsigned long long)k);
+}
+__global__ __launch_bounds__(256) void fq_four_line_records_kernel(uint64_t n_rec, RecLines* __restrict__ rl) {
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_rec) return;
+    RecLines r;
+    r.hdr = 4 * k;
+    r.qual0 = 4 * k + 3;
+    r.n_seq = 1;
+    r.pad = 0;
+    rl[k] = r;
+}
+
+// ---- F4: the reader's state machine from line `line0` on, one wavefront -------------------------------
+// out[0] = records appended, out[1] = status, out[2] = line that raised the error
+__global__ __launch_bounds__(64) void fq_walk_kernel(const LineInfo* __restrict__ info, uint64_t n_lines, uint64_t line0, RecLines* __restrict__ rl,
+                                                     uint64_t rec0, uint64_t rec_cap, uint64_t* __restrict__ out) {
+    const int lane = threadIdx.x;
+    uint64_t h = line0, nrec = 0;
+    int status = BG_FASTQ_OK;
+    uint64_t err_line = 0;
+    while (h < n_lines) {  // fastq.rs:266-274
+        const LineInfo hi = info[h];
+        if (hi.bad) {
+            status = BG_FASTQ_IO, err_line = h;
+            break;
+        }
+        if (hi.first != '@') {
+            status = BG_FASTQ_MISSING_AT, err_line = h;
+            break;
+        }
+        // fastq.rs:280-288: sequence lines until a line that starts with '+' (or the end of the text)
+        uint64_t i = h + 1;
+        bool io = false;
+        while (true) {
+            const uint64_t li = i + lane;
+            bool stop = li >= n_lines, bad = false;
+            if (!stop) {
+                const LineInfo x = info[li];
+                bad = x.bad;
+                stop = bad || x.first == '+';
+            }
+            const uint64_t m = __ballot(stop);
+            if (m) {
+                const int f = __ffsll((long long)m) - 1;
+                i += f;
+                io = (__ballot(bad) >> f) & 1;
+                break;
+            }
+            i += 64;
+        }
+        if (io || (i < n_lines && info[i].bad)) {
+            status = BG_FASTQ_IO, err_line = i;
+            break;
+        }
+        const uint64_t n_seq = i - (h + 1);
+        const uint64_t q0 = i < n_lines ? i + 1 : i;  // the '+' line is consumed if it exists
+        // fastq.rs:290-300: n_seq quality lines (those that exist), their trimmed lengths must not sum to 0
+        uint64_t qsum = 0;
+        bool qbad = false;
+        uint64_t qbad_line = 0;
+        for (uint64_t b = 0; b < n_seq; b += 64) {
+            const uint64_t li = q0 + b + lane;
+            uint32_t tl = 0;
+            bool bad = false;
+            if (b + lane < n_seq && li < n_lines) {
+                const LineInfo x = info[li];
+                bad = x.bad;
+                tl = x.trim;
+            }
+            const uint64_t mb = __ballot(bad);
+            if (mb && !qbad) {
+                qbad = true;
+                qbad_line = q0 + b + (__ffsll((long long)mb) - 1);
+            }
+            uint64_t v = tl;
+#pragma unroll
+            for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
+            qsum += v;
+        }
+        if (qbad) {
+            status = BG_FASTQ_IO, err_line = qbad_line;
+            break;
+        }
+        if (qsum == 0) {
+            status = BG_FASTQ_INCOMPLETE, err_line = h;
+            break;
+        }
+        if (lane == 0 && rec0 + nrec < rec_cap) {
+            RecLines r;
+            r.hdr = h;
+            r.qual0 = q0;
+            r.n_seq = (uint32_t)n_seq;
+            r.pad = 0;
+            rl[rec0 + nrec] = r;
+        }
+        nrec++;
+        h = min(q0 + n_seq, n_lines);
+    }
+    if (lane == 0) {
+        out[0] = nrec;
+        out[1] = (uint64_t)status;
+        out[2] = err_line;
+    }
+}
+
+// ---- F5 ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fq_measure_kernel(const uint8_t* __restrict__ t, const uint64_t* __restrict__ ls, const LineInfo* __restrict__ info,
+                                                         uint64_t n_lines, const RecLines* __restrict__ rl, uint64_t n_rec,
+                                                         bg_fastq_record_t* __restrict__ recs, uint32_t* __restrict__ seq_len, uint32_t* __restrict__ qual_len) {
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_rec) return;
+    const RecLines r = rl[k];
+    uint64_t sl = 0, ql = 0;
+    for (uint32_t i = 0; i < r.n_seq; i++) {
+        sl += info[r.hdr + 1 + i].trim;
+        if (r.qual0 + i < n_lines) ql += info[r.qual0 + i].trim;
+    }
+    bg_fastq_record_t o = {};
+    {  // fastq.rs:275-277: line[1..].trim_end().splitn(2, ' ')
+        const uint64_t a = ls[r.hdr] + 1;
+        const uint32_t n = info[r.hdr].trim - 1;  // the '@' is not whitespace: trim >= 1
+        uint32_t sp = 0;
+        while (sp < n && t[a + sp] != ' ') sp++;
+        o.id_off = a;
+        o.id_len = sp;
+        if (sp < n) {
+            o.desc_off = a + sp + 1;
+            o.desc_len = n - sp - 1;
+            o.has_desc = 1;
+        }
+    }
+    o.seq_len = (uint32_t)sl;
+    o.qual_len = (uint32_t)ql;
+    recs[k] = o;
+    seq_len[k] = (uint32_t)sl;
+    qual_len[k] = (uint32_t)ql;
+}
+// exclusive scan of uint32 lengths into uint64 offsets, three kernels
+__global__ __launch_bounds__(256) void fq_block_sums_kernel(const uint32_t* __restrict__ in, uint64_t n, uint64_t* __restrict__ sums) {
+    const uint64_t b0 = (uint64_t)blockIdx.x * 2048;
+    uint64_t v = 0;
+    for (int i = 0; i < 8; i++) {
+        const uint64_t j = b0 + (uint64_t)i * 256 + threadIdx.x;
+        if (j < n) v += in[j];
+    }
+    __shared__ uint64_t s[4];
+#pragma unroll
+    for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) sums[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
+}
+__global__ __launch_bounds__(256) void fq_scan_apply_kernel(const uint32_t* __restrict__ in, uint64_t n, const uint64_t* __restrict__ base,
+                                                            uint64_t* __restrict__ out) {
+    __shared__ uint64_t s[256];
+    const uint64_t b0 = (uint64_t)blockIdx.x * 2048 + (uint64_t)threadIdx.x * 8;
+    uint64_t loc[8], v = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        loc[i] = b0 + i < n ? in[b0 + i] : 0;
+        v += loc[i];
+    }
+    s[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+        const uint64_t u = threadIdx.x >= (unsigned)o ? s[threadIdx.x - o] : 0;
+        __syncthreads();
+        s[threadIdx.x] += u;
+        __syncthreads();
+    }
+    uint64_t run = base[blockIdx.x] + s[threadIdx.x] - v;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        if (b0 + i <= n) out[b0 + i] = run;  // index n: the closing offset
+        run += loc[i];
+    }
+}
+
+// ---- F6: gather + Record::check (fastq.rs:388-410) ----------------------------------------------------
+__global__ __launch_bounds__(256) void fq_gather_kernel(const uint8_t* __restrict__ t, const uint64_t* __restrict__ ls, const LineInfo* __restrict__ info,
+                                                        uint64_t n_lines, const RecLines* __restrict__ rl, uint64_t n_rec,
+                                                        bg_fastq_record_t* __restrict__ recs, const uint64_t* __restrict__ seq_off,
+                                                        const uint64_t* __restrict__ qual_off, uint8_t* __restrict__ seq, uint8_t* __restrict__ qual) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t k = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (k >= n_rec) return;
+    const RecLines r = rl[k];
+    uint64_t so = seq_off[k], qo = qual_off[k];
+    bool seq_hi = false, seq_bad = false, qual_hi = false;
+    for (uint32_t i = 0; i < r.n_seq; i++) {
+        const uint64_t l = r.hdr + 1 + i, a = ls[l];
+        const uint32_t n = info[l].trim;
+        for (uint32_t b = lane; b < n; b += 64) {
+            const uint8_t c = t[a + b];
+            seq[so + b] = c;
+            seq_hi |= c >= 0x80;
+            seq_bad |= !((c >= 'A' && c <= 'Z') || (c >= 'a' && c <= 'z') || c == '-' || c == '.' || c == '*');
+        }
+        so += n;
+        if (r.qual0 + i < n_lines) {
+            const uint64_t lq = r.qual0 + i, aq = ls[lq];
+            const uint32_t nq = info[lq].trim;
+            for (uint32_t b = lane; b < nq; b += 64) {
+                const uint8_t c = t[aq + b];
+                qual[qo + b] = c;
+                qual_hi |= c >= 0x80;
+            }
+            qo += nq;
+        }
+    }
+    seq_hi = __any(seq_hi);
+    seq_bad = __any(seq_bad);
+    qual_hi = __any(qual_hi);
+    if (lane == 0) {
+        bg_fastq_record_t o = recs[k];
+        o.seq_off = seq_off[k];
+        o.qual_off = qual_off[k];
+        o.check = o.id_len == 0    ? BG_FQCHECK_EMPTY_ID
+                  : seq_hi         ? BG_FQCHECK_NONASCII_SEQ
+                  : seq_bad        ? BG_FQCHECK_INVALID_SEQ
+                  : qual_hi        ? BG_FQCHECK_NONASCII_QUAL
+                  : o.seq_len != o.qual_len ? BG_FQCHECK_UNEQUAL
+                                            : BG_FQCHECK_OK;
+        recs[k] = o;
+    }
+}
+
+int scan_lengths(const uint32_t* d_len, uint64_t n, uint64_t* d_off, uint64_t* d_sums, hipStream_t st) {
+    const uint32_t nb = (uint32_t)(n / 2048 + 1);  // one more block than items need: it writes the closing offset
+    fq_block_sums_kernel<<<dim3(nb), dim3(256), 0, st>>>(d_len, n, d_sums);
+    fq_scan_small_kernel<uint64_t><<<dim3(1), dim3(1024), 0, st>>>(d_sums, d_sums + nb, nb, nullptr);
+    fq_scan_apply_kernel<<<dim3(nb), dim3(256), 0, st>>>(d_len, n, d_sums + nb, d_off);
+    BG_HIP(hipGetLastError());
+    return BG_OK;
+}
+
+// ---- CIGAR ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t put_num(char* o, uint32_t v) {
+    char tmp[10];
+    uint32_t n = 0;
+    do {
+        tmp[n++] = (char)('0' + v % 10);
+        v /= 10;
+    } while (v);
+    for (uint32_t i = 0; i < n; i++) o[i] = tmp[n - 1 - i];
+    return n;
+}
+// one thread per alignment; out slot of `stride` chars per alignment, len[p] = chars written or a negative status
+__global__ __launch_bounds__(256) void cigar_kernel(const bg_alignment_t* __restrict__ aln, const uint8_t* __restrict__ ops, uint64_t n, int hard_clip,
+                                                    char* __restrict__ out, uint64_t stride, int32_t* __restrict__ len) {
+    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const bg_alignment_t a = aln[p];
+    if (a.mode == BG_MODE_CUSTOM) {  // bio-types: "Cigar fn not supported for custom alignment mode" (panic)
+        len[p] = BG_ERR_UNSUPPORTED;
+        return;
+    }
+    char* o = out + p * stride;
+    uint64_t w = 0;
+    const char clip = hard_clip ? 'H' : 'S';
+    bool overflow = false;
+    auto emit = [&](uint32_t k, char c) {
+        if (w + 11 > stride) {
+            overflow = true;
+            return;
+        }
+        w += put_num(o + w, k);
+        o[w++] = c;
+    };
+    auto add = [&](uint32_t kind, uint32_t k) {
+        if (kind == BG_OP_MATCH) emit(k, '=');
+        else if (kind == BG_OP_SUBST) emit(k, 'X');
+        else if (kind == BG_OP_DEL) emit(k, 'D');
+        else if (kind == BG_OP_INS) emit(k, 'I');
+    };
+    if (a.n_ops) {
+        const uint8_t* q = ops + a.ops_off;
+        uint32_t last = q[0], k = 1;
+        if (a.xstart > 0) emit(a.xstart, clip);
+        for (uint32_t i = 1; i < a.n_ops; i++) {
+            const uint32_t op = q[i];
+            if (op == last) {
+                k++;
+            } else {
+                add(last, k);
+                k = 1;
+            }
+            last = op;
+        }
+        add(last, k);
+        if (a.xlen > a.xend) emit(a.xlen - a.xend, clip);
+    }
+    len[p] = overflow ? BG_ERR_OPS_CAP : (int32_t)w;
+}
+
+}  // namespace
+
+extern "C" int bg_fastq_parse_dev(bg_ctx* ctx, const uint8_t* d_text, uint64_t len, bg_fastq_record_t* d_recs, uint64_t rec_cap, uint8_t* d_seq,
+                                  uint64_t* d_seq_off, uint8_t* d_qual, uint64_t* d_qual_off, uint64_t* n_records, int32_t* status,
+                                  uint64_t* err_pos, void* stream) {
+    if (!ctx || !n_records || !status || !err_pos) return BG_ERR_INVALID_ARG;
+    *n_records = 0;
+    *status = BG_FASTQ_OK;
+    *err_pos = 0;
+    hipStream_t st = (hipStream_t)stream;
+    BG_HIP(hipSetDevice(ctx->device));
+    if (len == 0) {
+        const uint64_t z = 0;
+        if (d_seq_off) BG_HIP(hipMemcpyAsync(d_seq_off, &z, 8, hipMemcpyHostToDevice, st));
+        if (d_qual_off) BG_HIP(hipMemcpyAsync(d_qual_off, &z, 8, hipMemcpyHostToDevice, st));
+        BG_HIP(hipStreamSynchronize(st));
+        return BG_OK;
+    }
+    if (!d_text || !d_recs || !d_seq || !d_seq_off || !d_qual || !d_qual_off) return BG_ERR_INVALID_ARG;
+    int rc;
+    // F1: newline counts per chunk, their scan (+ total), line starts
+    const uint64_t nchunks = (len + kChunk - 1) / kChunk;
+    const size_t head = nchunks * 4 + (nchunks + 2) * 8 + 64;
+    if ((rc = bg_reserve(&ctx->aux, &ctx->aux_bytes, head))) return rc;
+    uint32_t* d_cnt = (uint32_t*)ctx->aux;
+    uint64_t* d_base = (uint64_t*)((uint8_t*)ctx->aux + ((nchunks * 4 + 15) & ~(size_t)15));
+    uint64_t* d_total = d_base + nchunks;
+    fq_count_newlines_kernel<<<dim3((uint32_t)nchunks), dim3(256), 0, st>>>(d_text, len, d_cnt);
+    fq_scan_small_kernel<uint32_t><<<dim3(1), dim3(1024), 0, st>>>(d_cnt, d_base, nchunks, d_total);
+    BG_HIP(hipGetLastError());
+    uint64_t n_nl = 0;
+    uint8_t last_byte = 0;
+    BG_HIP(hipMemcpyAsync(&n_nl, d_total, 8, hipMemcpyDeviceToHost, st));
+    BG_HIP(hipMemcpyAsync(&last_byte, d_text + len - 1, 1, hipMemcpyDeviceToHost, st));
+    BG_HIP(hipStreamSynchronize(st));
+    const uint64_t n_lines = n_nl + (last_byte != '\n' ? 1 : 0);
+    const uint64_t max_rec = n_lines / 2 + 1;  // a record has at least a header and a quality line... be generous
+    // scratch: line starts, line info, record lines, lengths, scan partials, walker output, first_bad
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        const size_t o = off;
+        off += (bytes + 255) & ~(size_t)255;
+        return o;
+    };
+    const size_t o_ls = take((n_lines + 2) * 8), o_info = take((n_lines + 1) * sizeof(LineInfo)), o_rl = take(max_rec * sizeof(RecLines)),
+                 o_sl = take(max_rec * 4), o_ql = take(max_rec * 4), o_sum = take((max_rec / 2048 + 2) * 2 * 8), o_misc = take(64);
+    if ((rc = bg_reserve(&ctx->tb, &ctx->tb_bytes, off))) return rc;
+    uint8_t* S = (uint8_t*)ctx->tb;
+    uint64_t* d_ls = (uint64_t*)(S + o_ls);
+    LineInfo* d_info = (LineInfo*)(S + o_info);
+    RecLines* d_rl = (RecLines*)(S + o_rl);
+    uint32_t *d_sl = (uint32_t*)(S + o_sl), *d_ql = (uint32_t*)(S + o_ql);
+    uint64_t* d_sum = (uint64_t*)(S + o_sum);
+    uint64_t* d_misc = (uint64_t*)(S + o_misc);  // [0] first_bad, [1..3] walker output
+    fq_line_starts_kernel<<<dim3((uint32_t)nchunks), dim3(256), 0, st>>>(d_text, len, d_base, d_ls);
+    BG_HIP(hipMemcpyAsync(d_ls + n_lines, &len, 8, hipMemcpyHostToDevice, st));  // closing offset (a no-op rewrite if the text ends in '\n')
+    // F2
+    fq_line_info_kernel<<<dim3((uint32_t)((n_lines + 255) / 256)), dim3(256), 0, st>>>(d_text, d_ls, n_lines, d_info);
+    // F3
+    const uint64_t n_rec4 = n_lines / 4;
+    const uint64_t none = ~0ull;
+    BG_HIP(hipMemcpyAsync(d_misc, &none, 8, hipMemcpyHostToDevice, st));
+    if (n_rec4) fq_four_line_kernel<<<dim3((uint32_t)((n_rec4 + 255) / 256)), dim3(256), 0, st>>>(d_info, n_rec4, (unsigned long long*)d_misc);
+    BG_HIP(hipGetLastError());
+    uint64_t first_bad = 0;
+    BG_HIP(hipMemcpyAsync(&first_bad, d_misc, 8, hipMemcpyDeviceToHost, st));
+    BG_HIP(hipStreamSynchronize(st));
+    uint64_t n_fast = std::min(first_bad, n_rec4);
+    if (n_fast) fq_four_line_records_kernel<<<dim3((uint32_t)((n_fast + 255) / 256)), dim3(256), 0, st>>>(n_fast, d_rl);
+    uint64_t n_rec = n_fast;
+    // F4: whatever follows the four-line prefix
+    if (4 * n_fast < n_lines) {
+        fq_walk_kernel<<<dim3(1), dim3(64), 0, st>>>(d_info, n_lines, 4 * n_fast, d_rl, n_fast, max_rec, d_misc + 1);
+        BG_HIP(hipGetLastError());
+        uint64_t w[3];
+        BG_HIP(hipMemcpyAsync(w, d_misc + 1, 24, hipMemcpyDeviceToHost, st));
+        BG_HIP(hipStreamSynchronize(st));
+        n_rec += w[0];
+        *status = (int32_t)w[1];
+        if (*status != BG_FASTQ_OK) BG_HIP(hipMemcpy(err_pos, d_ls + w[2], 8, hipMemcpyDeviceToHost));
+    }
+    *n_records = n_rec;
+    if (n_rec > rec_cap) return BG_ERR_TOO_LARGE;
+    if (n_rec == 0) {
+        const uint64_t z = 0;
+        BG_HIP(hipMemcpyAsync(d_seq_off, &z, 8, hipMemcpyHostToDevice, st));
+        BG_HIP(hipMemcpyAsync(d_qual_off, &z, 8, hipMemcpyHostToDevice, st));
+        BG_HIP(hipStreamSynchronize(st));
+        return BG_OK;
+    }
+    // F5, F6
+    fq_measure_kernel<<<dim3((uint32_t)((n_rec + 255) / 256)), dim3(256), 0, st>>>(d_text, d_ls, d_info, n_lines, d_rl, n_rec, d_recs, d_sl, d_ql);
+    if ((rc = scan_lengths(d_sl, n_rec, d_seq_off, d_sum, st))) return rc;
+    if ((rc = scan_lengths(d_ql, n_rec, d_qual_off, d_sum, st))) return rc;
+    fq_gather_kernel<<<dim3((uint32_t)((n_rec + 3) / 4)), dim3(256), 0, st>>>(d_text, d_ls, d_info, n_lines, d_rl, n_rec, d_recs, d_seq_off, d_qual_off,
+                                                                                d_seq, d_qual);
+    BG_HIP(hipGetLastError());
+    BG_HIP(hipStreamSynchronize(st));
+    return BG_OK;
+}
+
+extern "C" int bg_fastq_parse(bg_ctx* ctx, const uint8_t* text, uint64_t len, bg_fastq_record_t* recs, uint64_t rec_cap, uint8_t* seq,
+                              uint64_t* seq_off, uint8_t* qual, uint64_t* qual_off, uint64_t* n_records, int32_t* status, uint64_t* err_pos) {
+    if (!ctx || !n_records || !status || !err_pos) return BG_ERR_INVALID_ARG;
+    if (len && (!text || !recs || !seq || !seq_off || !qual || !qual_off)) return BG_ERR_INVALID_ARG;
+    BG_HIP(hipSetDevice(ctx->device));
+    int rc;
+    const size_t need[6] = {std::max<uint64_t>(len, 16), std::max<uint64_t>(len, 16), (rec_cap + 1) * 8, (rec_cap + 1) * 8,
+                            std::max<uint64_t>(rec_cap, 1) * sizeof(bg_fastq_record_t), std::max<uint64_t>(len, 16)};
+    for (int i = 0; i < 6; i++)
+        if ((rc = bg_reserve(&ctx->io[i], &ctx->io_cap[i], need[i]))) return rc;
+    uint8_t *d_text = (uint8_t*)ctx->io[0], *d_seq = (uint8_t*)ctx->io[1], *d_qual = (uint8_t*)ctx->io[5];
+    uint64_t *d_so = (uint64_t*)ctx->io[2], *d_qo = (uint64_t*)ctx->io[3];
+    bg_fastq_record_t* d_recs = (bg_fastq_record_t*)ctx->io[4];
+    hipStream_t st = ctx->stream;
+    if (len) BG_HIP(hipMemcpyAsync(d_text, text, len, hipMemcpyHostToDevice, st));
+    rc = bg_fastq_parse_dev(ctx, d_text, len, d_recs, rec_cap, d_seq, d_so, d_qual, d_qo, n_records, status, err_pos, st);
+    if (rc) return rc;
+    const uint64_t n = *n_records;
+    if (seq_off) BG_HIP(hipMemcpyAsync(seq_off, d_so, (n + 1) * 8, hipMemcpyDeviceToHost, st));
+    if (qual_off) BG_HIP(hipMemcpyAsync(qual_off, d_qo, (n + 1) * 8, hipMemcpyDeviceToHost, st));
+    if (n) BG_HIP(hipMemcpyAsync(recs, d_recs, n * sizeof(bg_fastq_record_t), hipMemcpyDeviceToHost, st));
+    BG_HIP(hipStreamSynchronize(st));
+    if (n) {
+        BG_HIP(hipMemcpyAsync(seq, d_seq, seq_off[n], hipMemcpyDeviceToHost, st));
+        BG_HIP(hipMemcpyAsync(qual, d_qual, qual_off[n], hipMemcpyDeviceToHost, st));
+        BG_HIP(hipStreamSynchronize(st));
+    }
+    return BG_OK;
+}
+
+extern "C" int bg_cigar_batch_dev(bg_ctx* ctx, uint64_t n, const bg_alignment_t* d_aln, const uint8_t* d_ops, int hard_clip, char* d_out,
+                                  uint64_t stride, int32_t* d_len, void* stream) {
+    if (!ctx) return BG_ERR_INVALID_ARG;
+    if (n == 0) return BG_OK;
+    if (!d_aln || !d_out || !d_len || stride < 24) return BG_ERR_INVALID_ARG;
+    BG_HIP(hipSetDevice(ctx->device));
+    cigar_kernel<<<dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(d_aln, d_ops, n, hard_clip, d_out, stride, d_len);
+    BG_HIP(hipGetLastError());
+    return BG_OK;
+}
+
+extern "C" int bg_cigar_batch(bg_ctx* ctx, uint64_t n, const bg_alignment_t* aln, const uint8_t* ops, uint64_t ops_bytes, int hard_clip, char* out,
+                              uint64_t out_cap, uint64_t* out_off) {
+    if (!ctx || !out_off) return BG_ERR_INVALID_ARG;
+    out_off[0] = 0;
+    if (n == 0) return BG_OK;
+    if (!aln || (!ops && ops_bytes) || !out) return BG_ERR_INVALID_ARG;
+    BG_HIP(hipSetDevice(ctx->device));
+    uint32_t max_ops = 0;
+    for (uint64_t p = 0; p < n; p++) {
+        if (aln[p].n_ops && aln[p].ops_off + aln[p].n_ops > ops_bytes) return BG_ERR_INVALID_ARG;
+        max_ops = std::max(max_ops, aln[p].n_ops);
+    }
+    const uint64_t stride = ((uint64_t)max_ops * 2 + 24 + 11 + 15) & ~15ull;  // every run is at least "1=": two chars per op, + two clips
+    int rc;
+    const size_t need[4] = {n * sizeof(bg_alignment_t), std::max<uint64_t>(ops_bytes, 16), n * stride, n * 4};
+    for (int i = 0; i < 4; i++)
+        if ((rc = bg_reserve(&ctx->io[i], &ctx->io_cap[i], need[i]))) return rc;
+    hipStream_t st = ctx->stream;
+    BG_HIP(hipMemcpyAsync(ctx->io[0], aln, need[0], hipMemcpyHostToDevice, st));
+    if (ops_bytes) BG_HIP(hipMemcpyAsync(ctx->io[1], ops, ops_bytes, hipMemcpyHostToDevice, st));
+    rc = bg_cigar_batch_dev(ctx, n, (const bg_alignment_t*)ctx->io[0], (const uint8_t*)ctx->io[1], hard_clip, (char*)ctx->io[2], stride,
+                            (int32_t*)ctx->io[3], st);
+    if (rc) return rc;
+    std::vector<char> h((size_t)(n * stride));
+    std::vector<int32_t> hl(n);
+    BG_HIP(hipMemcpyAsync(h.data(), ctx->io[2], n * stride, hipMemcpyDeviceToHost, st));
+    BG_HIP(hipMemcpyAsync(hl.data(), ctx->io[3], n * 4, hipMemcpyDeviceToHost, st));
+    BG_HIP(hipStreamSynchronize(st));
+    uint64_t used = 0;
+    int status = BG_OK;
+    for (uint64_t p = 0; p < n; p++) {
+        if (hl[p] < 0) {
+            status = hl[p];  // BG_ERR_UNSUPPORTED: AlignmentMode::Custom (the reference panics)
+            out_off[p + 1] = used;
+            continue;
+        }
+        if (used + (uint64_t)hl[p] > out_cap) return BG_ERR_OPS_CAP;
+        memcpy(out + used, h.data() + p * stride, (size_t)hl[p]);
+        used += (uint64_t)hl[p];
+        out_off[p + 1] = used;
+    }
+    return status;
+}

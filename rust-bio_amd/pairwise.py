@@ -115,6 +115,15 @@ class Alignment:
     operations: list = field(default_factory=list)
     mode: str = "Custom"
 
+    def cigar(self, hard_clip):
+        """bio_types `Alignment::cigar(hard_clip)` (bio-types 1.0; parity unpinned, see include/biogpu.h)."""
+        rec = np.zeros(1, dtype=_lib.ALN_DTYPE)
+        rec["xstart"], rec["xend"], rec["xlen"] = self.xstart, self.xend, self.xlen
+        rec["mode"] = MODE_NAMES.index(self.mode)
+        ops = np.array([OP_TOKENS.index(o[0]) for o in self.operations], dtype=np.uint8)
+        rec["n_ops"] = len(ops)
+        return cigar_batch(rec, ops, hard_clip)[0]
+
 
 def decode_ops(rec, ops_buf):
     ops = ops_buf[int(rec["ops_off"]):int(rec["ops_off"]) + int(rec["n_ops"])]
@@ -126,6 +135,25 @@ def decode_ops(rec, ops_buf):
         else:
             out.append(OP_TOKENS[o])
     return out
+
+
+def cigar_batch(recs, ops_buf, hard_clip, ctx=None):
+    """CIGAR strings of a batch of bg_alignment_t records (as returned by align_arrays) on the device.
+    AlignmentMode::Custom panics in bio-types: AssertionError here."""
+    import ctypes as C
+    ctx = ctx or _lib.default_context()
+    recs = np.ascontiguousarray(recs, dtype=_lib.ALN_DTYPE)
+    ops_buf = np.ascontiguousarray(ops_buf if ops_buf is not None else np.zeros(0, np.uint8), dtype=np.uint8)
+    n = len(recs)
+    cap = int(recs["n_ops"].astype(np.int64).sum()) * 2 + 24 * n + 64
+    out = np.zeros(cap, dtype=np.uint8)
+    off = np.zeros(n + 1, dtype=np.uint64)
+    st = _lib.lib().bg_cigar_batch(ctx.h, n, recs.ctypes.data, ops_buf.ctypes.data, len(ops_buf), 1 if hard_clip else 0,
+                                   out.ctypes.data, cap, off.ctypes.data)
+    assert st != -11, " Cigar fn not supported for custom alignment mode"
+    _lib.check(st, "bg_cigar_batch")
+    b = out.tobytes()
+    return [b[int(off[p]):int(off[p + 1])].decode() for p in range(n)]
 
 
 def to_alignment(rec, ops_buf):
