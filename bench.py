@@ -29,7 +29,7 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
 import numpy as np
 import torch
 
-from rust_bio_amd import _lib, shard, synth_gpu
+from rust_bio_amd import _lib, shard, synth, synth_gpu
 from rust_bio_amd.bwt import Occ, bwt, less
 from rust_bio_amd.fmindex import FMIndex
 from rust_bio_amd.pairwise import Aligner, Scoring
@@ -98,6 +98,8 @@ def main():
     ap.add_argument("--banded-pairs", type=int, default=32768, help="banded leg: 10 kb pairs per GPU (configs[3] is 100k over 8 GPUs)")
     ap.add_argument("--skip-pipeline", action="store_true")
     ap.add_argument("--pipeline-reads", type=int, default=1_000_000, help="seed-and-extend leg: reads per GPU")
+    ap.add_argument("--skip-ingest", action="store_true")
+    ap.add_argument("--ingest-reads", type=int, default=1_000_000, help="FASTQ ingest leg: four-line records per GPU")
     ap.add_argument("--skip-cpu", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
@@ -404,6 +406,44 @@ def main():
                                       "sample": f"{nsb} of the {Pb} pairs, C++ restatement of rust-bio 4.0.1 "
                                                 "banded::Aligner::semiglobal incl. band construction (oracle/)"}
         result["banded"] = banded
+
+    # ------------------------------------------------------------------ ingest leg
+    if not args.skip_ingest:
+        from rust_bio_amd import fastq as bgfastq
+        n_fq = args.ingest_reads
+        text = synth.fastq_text(n_fq, L, seed=6 + 100003 * rank)
+        d_text = torch.from_numpy(text).to(dev)
+        bgfastq.parse_dev(d_text, ctx=ctx, stream=stream)  # warm-up: sizes the scratch
+        shard.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            k, st, _, d_recs, d_seq, d_so, d_qual, d_qo = bgfastq.parse_dev(d_text, ctx=ctx, stream=stream)
+        torch.cuda.synchronize()
+        it = shard.max_over_ranks((time.perf_counter() - t0) / 3, dev)
+        seq_bytes = int(d_so[-1].item())
+        ingest = {"value": round(world * len(text) / it / 1e9, 2), "unit": "GB/s of FASTQ text (device-resident text -> records, "
+                  "concatenated sequences/qualities + offsets, Record::check)", "reads_per_s": round(world * k / it, 1),
+                  "config": {"workload": f"{n_fq} four-line records of {L} bp per GPU ({len(text)} bytes)"},
+                  "status": st, "records": int(k),
+                  "roofline": {"bound": "hbm", "achieved": round((len(text) + 2 * seq_bytes + 56 * k + 16 * k) / it / 1e9, 2),
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
+                               "note": "algorithmic bytes: text once + sequences, qualities, records and offsets written"}}
+        ingest["roofline"]["frac"] = round(ingest["roofline"]["achieved"] / HBM_PEAK_GBS, 5)
+        if do_cpu:
+            ns = min(n_fq, 200_000)
+            sample = synth.fastq_text(ns, L, seed=6)
+            t0 = time.perf_counter()
+            want, wst, _ = orc.fastq_parse_raw(sample)
+            ct = time.perf_counter() - t0
+            got = bgfastq.parse_arrays(sample, ctx=ctx)
+            okf = wst == 0 and len(got) == len(want[0]) and bytes(got.seq) == want[1] and bytes(got.qual) == want[2]
+            parity["ingest_sample_records"] = ns
+            parity["ingest_bit_exact"] = bool(okf)
+            ingest["cpu_baseline"] = {"value": round(len(sample) / ct / 1e9, 3), "unit": "GB/s of FASTQ text", "cores": 1, "kind": "port",
+                                      "sample": f"{ns} records, C++ restatement of bio::io::fastq::Reader::read + Record::check (oracle/)"}
+        del d_text
+        result["ingest"] = ingest
 
     if rank == 0:
         if cpu_baseline is not None:

@@ -90,6 +90,25 @@ struct Alignment {
         return score == o.score && ystart == o.ystart && xstart == o.xstart && yend == o.yend && xend == o.xend &&
                ylen == o.ylen && xlen == o.xlen && operations == o.operations && mode == o.mode;
     }
+    // Alignment::cigar(hard_clip) of bio-types 1.0 (restated from its documentation: parity unpinned);
+    // panics for AlignmentMode::Custom like the crate
+    std::string cigar(bool hard_clip) const {
+        bg_alignment_t rec = {};
+        rec.xstart = (uint32_t)xstart;
+        rec.xend = (uint32_t)xend;
+        rec.xlen = (uint32_t)xlen;
+        rec.n_ops = (uint32_t)operations.size();
+        rec.mode = (uint8_t)mode;
+        std::vector<uint8_t> ops(operations.size() + 1);
+        for (size_t i = 0; i < operations.size(); i++) ops[i] = (uint8_t)operations[i].kind;
+        std::string out(2 * operations.size() + 64, '\0');
+        uint64_t off[2] = {0, 0};
+        const int rc = bg_cigar_batch(Context::shared_default()->raw(), 1, &rec, ops.data(), operations.size(), hard_clip ? 1 : 0, &out[0], out.size(), off);
+        if (rc == BG_ERR_UNSUPPORTED) throw Panic(" Cigar fn not supported for custom alignment mode");
+        check(rc, "bg_cigar_batch");
+        out.resize(off[1]);
+        return out;
+    }
 };
 
 // alignment::sparse (sparse.rs): the pieces the banded aligner's entry points take or produce
@@ -679,5 +698,84 @@ inline SampledSuffixArray sample(const RawSuffixArray& sa, const Text& t, const 
 
 }  // namespace suffix_array
 }  // namespace data_structures
+
+// bio::io::fastq, reading side (io/fastq.rs:153-527), over a text held in memory; parsed on the device
+namespace io {
+namespace fastq {
+struct ReadError : Panic {  // fastq.rs:113-126
+    enum Kind { MissingAt = BG_FASTQ_MISSING_AT, IncompleteRecord = BG_FASTQ_INCOMPLETE, Io = BG_FASTQ_IO } kind;
+    uint64_t pos;
+    ReadError(Kind k, uint64_t p) : Panic(k == MissingAt ? "MissingAt" : k == IncompleteRecord ? "IncompleteRecord" : "Io"), kind(k), pos(p) {}
+};
+enum class CheckError { Ok = 0, EmptyId, NonAsciiSequence, InvalidSequence, NonAsciiQualities, UnequalLength };  // fastq.rs:129-150
+
+class Record {  // fastq.rs:309-452
+public:
+    Record() = default;
+    Record(std::string id, std::optional<std::string> desc, Text seq, Text qual, CheckError chk = CheckError::Ok)
+        : id_(std::move(id)), desc_(std::move(desc)), seq_(std::move(seq)), qual_(std::move(qual)), check_(chk) {}
+    bool is_empty() const { return id_.empty() && !desc_ && seq_.empty() && qual_.empty(); }
+    CheckError check() const { return check_; }  // Ok(()) == CheckError::Ok; evaluated on the device with the parse
+    const std::string& id() const { return id_; }
+    const std::optional<std::string>& desc() const { return desc_; }
+    const Text& seq() const { return seq_; }
+    const Text& qual() const { return qual_; }
+    bool operator==(const Record& o) const { return id_ == o.id_ && desc_ == o.desc_ && seq_ == o.seq_ && qual_ == o.qual_; }
+
+private:
+    std::string id_;
+    std::optional<std::string> desc_;
+    Text seq_, qual_;
+    CheckError check_ = CheckError::Ok;
+};
+
+// `Reader::new(&[u8])` + `read()` / `records()`: all records are parsed by one device call; read() hands them
+// out one by one, an empty Record at the end (fastq.rs:228), ReadError where the reference returns Err
+class Reader {
+public:
+    explicit Reader(const Text& t, std::shared_ptr<Context> ctx = nullptr) {
+        if (!ctx) ctx = Context::shared_default();
+        const uint64_t cap = t.size() / 4 + 2;
+        std::vector<bg_fastq_record_t> recs(cap);
+        std::vector<uint8_t> seq(t.size() + 1), qual(t.size() + 1);
+        std::vector<uint64_t> so(cap + 1), qo(cap + 1);
+        uint64_t n = 0, err = 0;
+        int32_t st = 0;
+        check(bg_fastq_parse(ctx->raw(), t.data(), t.size(), recs.data(), cap, seq.data(), so.data(), qual.data(), qo.data(), &n, &st, &err),
+              "bg_fastq_parse");
+        for (uint64_t k = 0; k < n; k++) {
+            const bg_fastq_record_t& r = recs[k];
+            std::optional<std::string> d;
+            if (r.has_desc) d = std::string(t.begin() + r.desc_off, t.begin() + r.desc_off + r.desc_len);
+            records_.emplace_back(std::string(t.begin() + r.id_off, t.begin() + r.id_off + r.id_len), std::move(d),
+                                  Text(seq.begin() + so[k], seq.begin() + so[k + 1]), Text(qual.begin() + qo[k], qual.begin() + qo[k + 1]),
+                                  (CheckError)r.check);
+        }
+        status_ = st;
+        err_pos_ = err;
+    }
+    void read(Record& record) {
+        if (next_ < records_.size()) {
+            record = records_[next_++];
+        } else if (status_ != BG_FASTQ_OK && !raised_) {
+            raised_ = true;
+            throw ReadError((ReadError::Kind)status_, err_pos_);
+        } else {
+            record = Record();
+        }
+    }
+    // the records read before the first error; `status()` tells whether the iterator would end with Err
+    const std::vector<Record>& records() const { return records_; }
+    int status() const { return status_; }
+
+private:
+    std::vector<Record> records_;
+    size_t next_ = 0;
+    int status_ = 0;
+    uint64_t err_pos_ = 0;
+    bool raised_ = false;
+};
+}  // namespace fastq
+}  // namespace io
 }  // namespace bio
 #endif

@@ -552,3 +552,19 @@ def cigar(aln, ops_u64, hard_clip):
         return None
     assert n >= 0
     return buf[:n].tobytes().decode()
+
+
+def fastq_parse_raw(text):
+    """timed flavour: -> ((recs, seq bytes, qual bytes), status code, err_pos) without per-record Python objects"""
+    t = _buf(text)
+    cap = len(t) // 4 + 2
+    recs = np.zeros(cap, dtype=FQREC_DTYPE)
+    seq = np.zeros(max(1, len(t)), dtype=np.uint8)
+    qual = np.zeros(max(1, len(t)), dtype=np.uint8)
+    n, st, ep = C.c_uint64(0), C.c_int32(0), C.c_uint64(0)
+    lib().orc_fastq_parse(t.ctypes.data, len(t), recs.ctypes.data, cap, seq.ctypes.data, qual.ctypes.data,
+                          C.byref(n), C.byref(st), C.byref(ep))
+    k = int(n.value)
+    sl = int(recs["seq_off"][k - 1] + recs["seq_len"][k - 1]) if k else 0
+    ql = int(recs["qual_off"][k - 1] + recs["qual_len"][k - 1]) if k else 0
+    return (recs[:k], seq[:sl].tobytes(), qual[:ql].tobytes()), st.value, int(ep.value)

@@ -129,3 +129,25 @@ def fm_patterns(text, n_q, plen, seed, frac_exact=0.799, frac_mut=0.2):
         code[is_rand] = (splitmix64(seed + 77, nr * plen) >> np.uint64(62)).astype(np.uint8).reshape(nr, plen)
     off = np.arange(n_q + 1, dtype=np.uint64) * np.uint64(plen)
     return ACGT[code].reshape(-1), off
+
+
+def fastq_text(n_reads, length, seed):
+    """A four-line FASTQ of `n_reads` records as a uint8 array: '@r<10 digits> s<seed>', ACGT read, '+', Phred+33
+    qualities in [33, 74)."""
+    rng = np.random.default_rng(seed)
+    hdr = np.frombuffer(b"@r0000000000 s%04d\n" % (seed % 10000), dtype=np.uint8)
+    rec_len = len(hdr) + length + 1 + 2 + length + 1
+    out = np.empty((n_reads, rec_len), dtype=np.uint8)
+    out[:, :len(hdr)] = hdr
+    idx = np.arange(n_reads, dtype=np.int64)
+    for d in range(10):
+        out[:, 2 + 9 - d] = 48 + (idx // 10 ** d) % 10
+    o = len(hdr)
+    out[:, o:o + length] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=(n_reads, length), dtype=np.uint8)]
+    out[:, o + length] = 10
+    out[:, o + length + 1] = ord("+")
+    out[:, o + length + 2] = 10
+    o2 = o + length + 3
+    out[:, o2:o2 + length] = rng.integers(33, 74, size=(n_reads, length), dtype=np.uint8)
+    out[:, o2 + length] = 10
+    return out.reshape(-1)

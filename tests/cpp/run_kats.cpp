@@ -171,6 +171,69 @@ static void kat_fmdindex_smems() {
     }
 }
 
+// io/fastq.rs:606-866 and the bio-types cigar documentation example
+static void kat_fastq_reader_and_cigar() {
+    using namespace bio::io;
+    {
+        fastq::Reader reader(text("@id desc\nACCGTAGGCTGA\n+\nIIIIIIJJJJJJ\n"));
+        CHECK_EQ(reader.records().size(), (size_t)1);
+        const auto& record = reader.records()[0];
+        CHECK(record.check() == fastq::CheckError::Ok);
+        CHECK_EQ(record.id(), std::string("id"));
+        CHECK_EQ(*record.desc(), std::string("desc"));
+        CHECK(record.seq() == text("ACCGTAGGCTGA"));
+        CHECK(record.qual() == text("IIIIIIJJJJJJ"));
+    }
+    {  // test_read_header_does_not_start_with_correct_char_raises_err / test_read_quality_is_empty_raises_err
+        fastq::Reader r1(text(">id description\nACGT\n+\n!!!!\n"));
+        fastq::Record rec;
+        bool missing_at = false, incomplete = false;
+        try { r1.read(rec); } catch (const fastq::ReadError& e) { missing_at = e.kind == fastq::ReadError::MissingAt; }
+        CHECK(missing_at);
+        fastq::Reader r2(text("@id description\nACGT\n+\n"));
+        try { r2.read(rec); } catch (const fastq::ReadError& e) { incomplete = e.kind == fastq::ReadError::IncompleteRecord; }
+        CHECK(incomplete);
+    }
+    {  // test_read_sequence_and_quality_are_wrapped_is_handled_with_three_sequences
+        fastq::Reader reader(text("@id description\nACGT\nGGGG\nC\n+\n@@@@\n!!!!\n$\n@id2 description\nACGT\nGGGG\nC\n+\n@@@@\n!!!!\n$\n"
+                                  "@id3 desc1 desc2\nAAA\nAAA\nAA\n+\n^^^\n^^^\n^^\n"));
+        fastq::Record actual;
+        reader.read(actual);
+        CHECK(actual == fastq::Record("id", std::string("description"), text("ACGTGGGGC"), text("@@@@!!!!$")));
+        reader.read(actual);
+        CHECK(actual == fastq::Record("id2", std::string("description"), text("ACGTGGGGC"), text("@@@@!!!!$")));
+        reader.read(actual);
+        CHECK(actual == fastq::Record("id3", std::string("desc1 desc2"), text("AAAAAAAA"), text("^^^^^^^^")));
+        reader.read(actual);
+        CHECK(actual.is_empty());
+    }
+    {  // test_read_wrapped_record_with_inconsistent_wrapping_errors
+        fastq::Reader reader(text("@id description\nACGT\nGGGG\nC\n+\n@@@@\n!!!!$\n@id2 description\nACGT\nGGGG\nC\n+\n@@@@\n!!!!\n$\n"));
+        fastq::Record record;
+        reader.read(record);
+        bool missing_at = false;
+        try { reader.read(record); } catch (const fastq::ReadError& e) { missing_at = e.kind == fastq::ReadError::MissingAt; }
+        CHECK(missing_at);
+    }
+    {  // Record::check (fastq.rs:731-788)
+        CHECK(fastq::Reader(text("@\nACGT\n+\n!!!!\n")).records()[0].check() == fastq::CheckError::EmptyId);
+        CHECK(fastq::Reader(text("@id\nATGC1234\n+\nQQQQQQQQ\n")).records()[0].check() == fastq::CheckError::InvalidSequence);
+        CHECK(fastq::Reader(text("@id\nATGC\n+\nQQ\n")).records()[0].check() == fastq::CheckError::UnequalLength);
+        CHECK(fastq::Reader(text("@id_str desc\nATGCGGG\n+\nQQQQQQQ\n")).records()[0].check() == fastq::CheckError::Ok);
+    }
+    {  // bio-types: Alignment::cigar documentation example
+        Alignment alignment;
+        alignment.score = 5;
+        alignment.xstart = 3, alignment.xend = 9, alignment.ystart = 0, alignment.yend = 10, alignment.ylen = 10, alignment.xlen = 10;
+        alignment.operations = {Match, Match, Match, Subst, Ins, Ins, Del, Del};
+        alignment.mode = AlignmentMode::Semiglobal;
+        CHECK_EQ(alignment.cigar(false), std::string("3S3=1X2I2D1S"));
+        CHECK_EQ(alignment.cigar(true), std::string("3H3=1X2I2D1H"));
+        alignment.mode = AlignmentMode::Custom;
+        CHECK(panics([&] { alignment.cigar(false); }));
+    }
+}
+
 int main(int argc, char** argv) {
     const char* filter = argc > 1 ? argv[1] : "";
     int ran = 0;
@@ -192,6 +255,7 @@ int main(int argc, char** argv) {
     run("kat_batches_equal_single_calls", kat_batches_equal_single_calls);
     run("kat_banded_with_matches_and_prehash", kat_banded_with_matches_and_prehash);
     run("kat_fmdindex_smems", kat_fmdindex_smems);
+    run("kat_fastq_reader_and_cigar", kat_fastq_reader_and_cigar);
     std::printf("%d tests, %d failed\n", ran, g_failed);
     return g_failed ? 1 : 0;
 }
