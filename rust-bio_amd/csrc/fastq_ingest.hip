@@ -37,18 +37,39 @@ struct RecLines {  // lines of one record
 };
 
 // ---- F1 ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void fq_count_newlines_kernel(const uint8_t* __restrict__ t, uint64_t len, uint32_t* __restrict__ cnt) {
-    const uint64_t base = (uint64_t)blockIdx.x * kChunk + threadIdx.x * 16u;
-    uint32_t c = 0;
+// 16 bytes of the text for this thread (zero past the end; a zero is neither a newline nor a high byte)
+__device__ __forceinline__ uint4 load16(const uint8_t* __restrict__ t, uint64_t len, uint64_t base, bool aligned) {
+    if (aligned && base + 16 <= len) return *(const uint4*)(t + base);
+    uint32_t w[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int i = 0; i < 16; i++)
-        if (base + i < len && t[base + i] == '\n') c++;
-    __shared__ uint32_t s[4];
+        if (base + i < len) w[i >> 2] |= (uint32_t)t[base + i] << (8 * (i & 3));
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+__device__ __forceinline__ uint32_t newline_bits(uint32_t w) {  // bit 7 of every byte that equals '\n'
+    const uint32_t x = w ^ 0x0a0a0a0au;
+    return ~(((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u;
+}
+// cnt[chunk] = newlines; hi[chunk] = the chunk has a byte >= 0x80 (only such lines need the UTF-8 machinery)
+__global__ __launch_bounds__(256) void fq_count_newlines_kernel(const uint8_t* __restrict__ t, uint64_t len, uint32_t* __restrict__ cnt,
+                                                                uint8_t* __restrict__ hi) {
+    const uint64_t base = (uint64_t)blockIdx.x * kChunk + threadIdx.x * 16u;
+    const uint4 v = load16(t, len, base, ((uintptr_t)t & 15) == 0);
+    uint32_t c = __popc(newline_bits(v.x)) + __popc(newline_bits(v.y)) + __popc(newline_bits(v.z)) + __popc(newline_bits(v.w));
+    uint32_t h = ((v.x | v.y | v.z | v.w) & 0x80808080u) ? 1u : 0u;
+    __shared__ uint32_t s[4], sh[4];
 #pragma unroll
     for (int o = 32; o; o >>= 1) c += __shfl_xor(c, o);
-    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = c;
+    h = __any(h) ? 1u : 0u;
+    if ((threadIdx.x & 63) == 0) {
+        s[threadIdx.x >> 6] = c;
+        sh[threadIdx.x >> 6] = h;
+    }
     __syncthreads();
-    if (threadIdx.x == 0) cnt[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
+    if (threadIdx.x == 0) {
+        cnt[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
+        hi[blockIdx.x] = (uint8_t)(sh[0] | sh[1] | sh[2] | sh[3]);
+    }
 }
 // exclusive scan of up to 2^32 items by one block (items are per-chunk / per-block partial sums: few)
 template <typename T>
@@ -75,10 +96,9 @@ __global__ __launch_bounds__(1024) void fq_scan_small_kernel(const T* __restrict
 __global__ __launch_bounds__(256) void fq_line_starts_kernel(const uint8_t* __restrict__ t, uint64_t len, const uint64_t* __restrict__ base,
                                                              uint64_t* __restrict__ ls) {
     const uint64_t b0 = (uint64_t)blockIdx.x * kChunk + threadIdx.x * 16u;
-    uint32_t c = 0;
-#pragma unroll
-    for (int i = 0; i < 16; i++)
-        if (b0 + i < len && t[b0 + i] == '\n') c++;
+    const uint4 v = load16(t, len, b0, ((uintptr_t)t & 15) == 0);
+    const uint32_t nb[4] = {newline_bits(v.x), newline_bits(v.y), newline_bits(v.z), newline_bits(v.w)};
+    const uint32_t c = __popc(nb[0]) + __popc(nb[1]) + __popc(nb[2]) + __popc(nb[3]);
     __shared__ uint32_t s[256];
     s[threadIdx.x] = c;
     __syncthreads();
@@ -89,9 +109,11 @@ __global__ __launch_bounds__(256) void fq_line_starts_kernel(const uint8_t* __re
         __syncthreads();
     }
     uint64_t k = base[blockIdx.x] + s[threadIdx.x] - c;  // newlines before this thread's bytes
+    if (c) {
 #pragma unroll
-    for (int i = 0; i < 16; i++)
-        if (b0 + i < len && t[b0 + i] == '\n') ls[++k] = b0 + i + 1;
+        for (int i = 0; i < 16; i++)
+            if (nb[i >> 2] & (0x80u << (8 * (i & 3)))) ls[++k] = b0 + i + 1;
+    }
     if (blockIdx.x == 0 && threadIdx.x == 0) ls[0] = 0;
 }
 
@@ -141,18 +163,26 @@ __device__ uint64_t trim_end(const uint8_t* s, uint64_t n) {  // str::trim_end o
     return n;
 }
 __global__ __launch_bounds__(256) void fq_line_info_kernel(const uint8_t* __restrict__ t, const uint64_t* __restrict__ ls, uint64_t n_lines,
-                                                           LineInfo* __restrict__ info) {
+                                                           const uint8_t* __restrict__ chunk_hi, LineInfo* __restrict__ info) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_lines) return;
     const uint64_t a = ls[i], n = ls[i + 1] - a;
     const uint8_t* s = t + a;
     bool hi = false;
-    for (uint64_t k = 0; k < n; k++) hi |= s[k] >= 0x80;
+    if (n)
+        for (uint64_t c = a / kChunk; c <= (a + n - 1) / kChunk; c++) hi |= chunk_hi[c] != 0;
     LineInfo li;
     li.first = n ? s[0] : 0;
-    li.bad = hi && !valid_utf8(s, n);
-    li.trim = li.bad ? 0u : (uint32_t)trim_end(s, n);
     li.pad = 0;
+    if (!hi) {  // plain ASCII around here: trim_end is the ASCII white space at the end of the line
+        uint64_t k = n;
+        while (k && (s[k - 1] == ' ' || (s[k - 1] >= 9 && s[k - 1] <= 13))) k--;
+        li.bad = 0;
+        li.trim = (uint32_t)k;
+    } else {
+        li.bad = !valid_utf8(s, n);
+        li.trim = li.bad ? 0u : (uint32_t)trim_end(s, n);
+    }
     info[i] = li;
 }
 
@@ -342,34 +372,71 @@ __global__ __launch_bounds__(256) void fq_scan_apply_kernel(const uint32_t* __re
 }
 
 // ---- F6: gather + Record::check (fastq.rs:388-410) ----------------------------------------------------
-__global__ __launch_bounds__(256) void fq_gather_kernel(const uint8_t* __restrict__ t, const uint64_t* __restrict__ ls, const LineInfo* __restrict__ info,
-                                                        uint64_t n_lines, const RecLines* __restrict__ rl, uint64_t n_rec,
-                                                        bg_fastq_record_t* __restrict__ recs, const uint64_t* __restrict__ seq_off,
+// one wavefront copies n bytes (arbitrary alignments): dword stores on the destination's alignment, the source
+// read as aligned dword pairs and funnel-shifted; collects "has a byte >= 0x80" and, for sequences, "has a byte
+// that is not alphabetic or one of - . *" (fastq.rs:392-401)
+template <bool SEQ>
+__device__ __forceinline__ void copy_line(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, uint32_t n, int lane, const uint8_t* t_end,
+                                          bool& hi, bool& bad) {
+    auto classify = [&](uint32_t c) {
+        hi |= c >= 0x80;
+        if (SEQ) bad |= !((c >= 'A' && c <= 'Z') || (c >= 'a' && c <= 'z') || c == '-' || c == '.' || c == '*');
+    };
+    const uint32_t head = min(n, (uint32_t)((4 - ((uintptr_t)dst & 3)) & 3));
+    if ((uint32_t)lane < head) {
+        const uint8_t c = src[lane];
+        dst[lane] = c;
+        classify(c);
+    }
+    const uint32_t nd = (n - head) >> 2;
+    for (uint32_t j = lane; j < nd; j += 64) {
+        const uint8_t* p = src + head + 4 * j;
+        const uint32_t sh = 8u * (uint32_t)((uintptr_t)p & 3);
+        const uint8_t* pa = p - ((uintptr_t)p & 3);
+        uint32_t w;
+        if (sh == 0) {
+            w = *(const uint32_t*)pa;
+        } else if (pa + 8 <= t_end) {
+            w = (*(const uint32_t*)pa >> sh) | (*(const uint32_t*)(pa + 4) << (32 - sh));
+        } else {
+            w = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+        }
+        *(uint32_t*)(dst + head + 4 * j) = w;
+        if (SEQ) {
+            classify(w & 0xff);
+            classify((w >> 8) & 0xff);
+            classify((w >> 16) & 0xff);
+            classify(w >> 24);
+        } else {
+            hi |= (w & 0x80808080u) != 0;
+        }
+    }
+    const uint32_t done = head + 4 * nd;
+    if ((uint32_t)lane < n - done) {
+        const uint8_t c = src[done + lane];
+        dst[done + lane] = c;
+        classify(c);
+    }
+}
+__global__ __launch_bounds__(256) void fq_gather_kernel(const uint8_t* __restrict__ t, uint64_t len, const uint64_t* __restrict__ ls,
+                                                        const LineInfo* __restrict__ info, uint64_t n_lines, const RecLines* __restrict__ rl,
+                                                        uint64_t n_rec, bg_fastq_record_t* __restrict__ recs, const uint64_t* __restrict__ seq_off,
                                                         const uint64_t* __restrict__ qual_off, uint8_t* __restrict__ seq, uint8_t* __restrict__ qual) {
     const int lane = threadIdx.x & 63;
     const uint64_t k = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (k >= n_rec) return;
     const RecLines r = rl[k];
     uint64_t so = seq_off[k], qo = qual_off[k];
-    bool seq_hi = false, seq_bad = false, qual_hi = false;
+    bool seq_hi = false, seq_bad = false, qual_hi = false, unused = false;
     for (uint32_t i = 0; i < r.n_seq; i++) {
-        const uint64_t l = r.hdr + 1 + i, a = ls[l];
+        const uint64_t l = r.hdr + 1 + i;
         const uint32_t n = info[l].trim;
-        for (uint32_t b = lane; b < n; b += 64) {
-            const uint8_t c = t[a + b];
-            seq[so + b] = c;
-            seq_hi |= c >= 0x80;
-            seq_bad |= !((c >= 'A' && c <= 'Z') || (c >= 'a' && c <= 'z') || c == '-' || c == '.' || c == '*');
-        }
+        copy_line<true>(seq + so, t + ls[l], n, lane, t + len, seq_hi, seq_bad);
         so += n;
         if (r.qual0 + i < n_lines) {
-            const uint64_t lq = r.qual0 + i, aq = ls[lq];
+            const uint64_t lq = r.qual0 + i;
             const uint32_t nq = info[lq].trim;
-            for (uint32_t b = lane; b < nq; b += 64) {
-                const uint8_t c = t[aq + b];
-                qual[qo + b] = c;
-                qual_hi |= c >= 0x80;
-            }
+            copy_line<false>(qual + qo, t + ls[lq], nq, lane, t + len, qual_hi, unused);
             qo += nq;
         }
     }
@@ -480,12 +547,13 @@ extern "C" int bg_fastq_parse_dev(bg_ctx* ctx, const uint8_t* d_text, uint64_t l
     int rc;
     // F1: newline counts per chunk, their scan (+ total), line starts
     const uint64_t nchunks = (len + kChunk - 1) / kChunk;
-    const size_t head = nchunks * 4 + (nchunks + 2) * 8 + 64;
+    const size_t head = nchunks * 4 + (nchunks + 2) * 8 + nchunks + 128;
     if ((rc = bg_reserve(&ctx->aux, &ctx->aux_bytes, head))) return rc;
     uint32_t* d_cnt = (uint32_t*)ctx->aux;
     uint64_t* d_base = (uint64_t*)((uint8_t*)ctx->aux + ((nchunks * 4 + 15) & ~(size_t)15));
     uint64_t* d_total = d_base + nchunks;
-    fq_count_newlines_kernel<<<dim3((uint32_t)nchunks), dim3(256), 0, st>>>(d_text, len, d_cnt);
+    uint8_t* d_hi = (uint8_t*)(d_total + 2);
+    fq_count_newlines_kernel<<<dim3((uint32_t)nchunks), dim3(256), 0, st>>>(d_text, len, d_cnt, d_hi);
     fq_scan_small_kernel<uint32_t><<<dim3(1), dim3(1024), 0, st>>>(d_cnt, d_base, nchunks, d_total);
     BG_HIP(hipGetLastError());
     uint64_t n_nl = 0;
@@ -515,7 +583,7 @@ extern "C" int bg_fastq_parse_dev(bg_ctx* ctx, const uint8_t* d_text, uint64_t l
     fq_line_starts_kernel<<<dim3((uint32_t)nchunks), dim3(256), 0, st>>>(d_text, len, d_base, d_ls);
     BG_HIP(hipMemcpyAsync(d_ls + n_lines, &len, 8, hipMemcpyHostToDevice, st));  // closing offset (a no-op rewrite if the text ends in '\n')
     // F2
-    fq_line_info_kernel<<<dim3((uint32_t)((n_lines + 255) / 256)), dim3(256), 0, st>>>(d_text, d_ls, n_lines, d_info);
+    fq_line_info_kernel<<<dim3((uint32_t)((n_lines + 255) / 256)), dim3(256), 0, st>>>(d_text, d_ls, n_lines, d_hi, d_info);
     // F3
     const uint64_t n_rec4 = n_lines / 4;
     const uint64_t none = ~0ull;
@@ -552,7 +620,7 @@ extern "C" int bg_fastq_parse_dev(bg_ctx* ctx, const uint8_t* d_text, uint64_t l
     fq_measure_kernel<<<dim3((uint32_t)((n_rec + 255) / 256)), dim3(256), 0, st>>>(d_text, d_ls, d_info, n_lines, d_rl, n_rec, d_recs, d_sl, d_ql);
     if ((rc = scan_lengths(d_sl, n_rec, d_seq_off, d_sum, st))) return rc;
     if ((rc = scan_lengths(d_ql, n_rec, d_qual_off, d_sum, st))) return rc;
-    fq_gather_kernel<<<dim3((uint32_t)((n_rec + 3) / 4)), dim3(256), 0, st>>>(d_text, d_ls, d_info, n_lines, d_rl, n_rec, d_recs, d_seq_off, d_qual_off,
+    fq_gather_kernel<<<dim3((uint32_t)((n_rec + 3) / 4)), dim3(256), 0, st>>>(d_text, len, d_ls, d_info, n_lines, d_rl, n_rec, d_recs, d_seq_off, d_qual_off,
                                                                                 d_seq, d_qual);
     BG_HIP(hipGetLastError());
     BG_HIP(hipStreamSynchronize(st));
