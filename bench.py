@@ -192,13 +192,14 @@ def main():
             ok = ok and bool((hops[dev_mask] == kind[or_mask]).all())
         parity.update({"sw_sample_pairs": ns, "sw_bit_exact": bool(ok)})
         # PCIe-inclusive rate of the host-buffer entry point (bg_align_batch): never the headline value
-        nh = min(n_pairs, 250_000)
+        nh = n_pairs
         hxa, hya = x[:nh * L].cpu().numpy(), y[:nh * L].cpu().numpy()
         hoa = np.arange(nh + 1, dtype=np.uint64) * np.uint64(L)
-        aligner.align_arrays(3, hxa, hoa, hya, hoa)
+        hout, hopsb = aligner.align_arrays(3, hxa, hoa, hya, hoa)  # warm-up: sizes the staging sets, touches the result pages
         t0 = time.perf_counter()
-        aligner.align_arrays(3, hxa, hoa, hya, hoa)
+        aligner.align_arrays(3, hxa, hoa, hya, hoa, out=hout, ops=hopsb)
         host_api_gcups = nh * L * L / (time.perf_counter() - t0) / 1e9
+        del hout, hopsb
         cpu_baseline = {"value": round(ns * L * L / t_all / 1e9, 4), "unit": "GCUPS", "cores": threads,
                         "kind": "port",
                         "sample": f"{ns} of the {n_pairs} pairs, C++ restatement of rust-bio 4.0.1 "
@@ -215,7 +216,8 @@ def main():
               "roofline": roofline}
     if do_cpu:
         result["host_api"] = {"value": round(host_api_gcups, 2), "unit": "GCUPS", "pairs": nh,
-                              "note": "bg_align_batch with pageable host buffers in and out (PCIe-inclusive)"}
+                              "note": "bg_align_batch with pageable host buffers in and out (PCIe-inclusive): stages of 131072 pairs through "
+                                      "three pinned staging sets, upload / kernels / download / compaction overlapped"}
     del x, y, d_ops, d_out
     torch.cuda.empty_cache()
 

@@ -24,6 +24,8 @@ extern thread_local std::string bg_tls_error;
 
 struct bg_band_scratch;  // banded_api.hip
 void bg_band_scratch_free(bg_band_scratch*);
+struct bg_host_pipe;  // sw_api.hip: staging sets of the pipelined host-buffer path
+void bg_host_pipe_free(bg_host_pipe*);
 
 struct bg_ctx {
     int device = 0;
@@ -42,6 +44,8 @@ struct bg_ctx {
     void* table = nullptr;  // compacted scoring table + code map
     size_t table_bytes = 0;
     bg_band_scratch* band = nullptr;  // persistent scratch of the banded pipeline
+    bg_host_pipe* pipe = nullptr;     // persistent staging of bg_align_batch's pipelined path
+    int64_t host_chunk_pairs = 0;     // pairs per pipeline stage of bg_align_batch (0 = default)
     int64_t chunk_pairs = 0;  // 0 = default
     bool force_wide = false;  // tests: disable the NARROW (28-bit key) kernels
     bool no_pk16 = false;     // tests: disable K1p (two pairs per lane in packed int16 halves)

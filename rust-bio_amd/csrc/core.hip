@@ -76,6 +76,7 @@ extern "C" int bg_free(bg_ctx* ctx) {
     for (void* p : ctx->io) hipFree(p);
     if (ctx->h_ops) hipHostFree(ctx->h_ops);
     bg_band_scratch_free(ctx->band);
+    bg_host_pipe_free(ctx->pipe);
     if (ctx->ev[0]) hipEventDestroy(ctx->ev[0]);
     if (ctx->ev[1]) hipEventDestroy(ctx->ev[1]);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
@@ -120,6 +121,10 @@ extern "C" int bg_set_option(bg_ctx* ctx, const char* key, int64_t value) {
     }
     if (!strcmp(key, "band_on_host")) {
         ctx->band_on_host = value != 0;
+        return BG_OK;
+    }
+    if (!strcmp(key, "host_chunk_pairs")) {
+        ctx->host_chunk_pairs = value;
         return BG_OK;
     }
     if (!strcmp(key, "no_pk16")) {

@@ -240,6 +240,161 @@ extern "C" int bg_align_batch_dev(bg_ctx* ctx, const bg_scoring_t* sc, int mode,
     return BG_OK;
 }
 
+// ---- pipelined host-buffer path ------------------------------------------------------------------------------
+// bg_align_batch on a large batch is PCIe + host memcpy + kernels; run as one serial sequence it spends three
+// quarters of its time outside the kernels.  The batch is cut into stages of `host_chunk_pairs` pairs that flow
+// through three staging sets: host threads copy a stage's sequences into pinned memory (and rebase its offsets),
+// the copy-in stream uploads it, the kernel stream aligns it (bg_align_batch_dev), the copy-out stream downloads
+// records + strided operations into pinned memory, and host threads compact those into the caller's buffers
+// while the following stages are in flight.
+struct bg_host_pipe {
+    static constexpr int NSET = 3;
+    struct Set {
+        uint8_t *h_in = nullptr, *h_out = nullptr;  // pinned: x | y | x_off | y_off   and   records | ops
+        uint8_t *d_in = nullptr, *d_out = nullptr;
+        size_t in_cap = 0, out_cap = 0;
+        hipEvent_t in_done = nullptr, k_done = nullptr, out_done = nullptr;
+    } set[NSET];
+    hipStream_t s_in = nullptr, s_out = nullptr;
+};
+void bg_host_pipe_free(bg_host_pipe* p) {
+    if (!p) return;
+    for (auto& s : p->set) {
+        if (s.h_in) hipHostFree(s.h_in);
+        if (s.h_out) hipHostFree(s.h_out);
+        hipFree(s.d_in);
+        hipFree(s.d_out);
+        for (hipEvent_t e : {s.in_done, s.k_done, s.out_done})
+            if (e) hipEventDestroy(e);
+    }
+    if (p->s_in) hipStreamDestroy(p->s_in);
+    if (p->s_out) hipStreamDestroy(p->s_out);
+    delete p;
+}
+namespace {
+template <typename F>
+void parallel_for(uint64_t n, uint64_t grain, F&& f) {  // f(begin, end) on the host threads this process may use
+    const unsigned nt = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(bg_host_threads(), n / std::max<uint64_t>(grain, 1) + 1));
+    if (nt == 1) {
+        f((uint64_t)0, n);
+        return;
+    }
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; t++) th.emplace_back([&, t] { f(n * t / nt, n * (t + 1) / nt); });
+    for (auto& t : th) t.join();
+}
+void parallel_memcpy(uint8_t* dst, const uint8_t* src, uint64_t n) {
+    parallel_for(n, 1 << 20, [&](uint64_t a, uint64_t b) { memcpy(dst + a, src + a, b - a); });
+}
+
+int align_batch_pipelined(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint64_t n_pairs, const uint8_t* x, const uint64_t* x_off,
+                          const uint8_t* y, const uint64_t* y_off, uint32_t max_x, uint32_t max_y, uint64_t chunk, bg_alignment_t* out,
+                          uint8_t* ops_buf, uint64_t ops_cap, uint64_t* ops_used) {
+    if (!ctx->pipe) {
+        ctx->pipe = new bg_host_pipe();
+        BG_HIP(hipStreamCreateWithFlags(&ctx->pipe->s_in, hipStreamNonBlocking));
+        BG_HIP(hipStreamCreateWithFlags(&ctx->pipe->s_out, hipStreamNonBlocking));
+        for (auto& s : ctx->pipe->set)
+            for (hipEvent_t* e : {&s.in_done, &s.k_done, &s.out_done}) BG_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    }
+    bg_host_pipe& P = *ctx->pipe;
+    const uint64_t stride = ops_buf ? (uint64_t)max_x + max_y + 4 : 0;
+    const uint64_t nch = (n_pairs + chunk - 1) / chunk;
+    // capacity of a staging set: the largest stage
+    uint64_t max_xb = 0, max_yb = 0;
+    for (uint64_t c = 0; c < nch; c++) {
+        const uint64_t p0 = c * chunk, p1 = std::min(n_pairs, p0 + chunk);
+        max_xb = std::max(max_xb, x_off[p1] - x_off[p0]);
+        max_yb = std::max(max_yb, y_off[p1] - y_off[p0]);
+    }
+    const uint64_t o_y = (max_xb + 255) & ~255ull, o_xo = o_y + ((max_yb + 255) & ~255ull), o_yo = o_xo + (chunk + 1) * 8;
+    const size_t in_need = o_yo + (chunk + 1) * 8 + 256;
+    const uint64_t o_ops = chunk * sizeof(bg_alignment_t);
+    const size_t out_need = o_ops + chunk * stride + 256;
+    for (auto& s : P.set) {
+        if (s.in_cap < in_need) {
+            if (s.h_in) hipHostFree(s.h_in);
+            hipFree(s.d_in);
+            s.h_in = s.d_in = nullptr;
+            s.in_cap = 0;
+            BG_HIP(hipHostMalloc((void**)&s.h_in, in_need, hipHostMallocDefault));
+            BG_HIP(hipMalloc((void**)&s.d_in, in_need));
+            s.in_cap = in_need;
+        }
+        if (s.out_cap < out_need) {
+            if (s.h_out) hipHostFree(s.h_out);
+            hipFree(s.d_out);
+            s.h_out = s.d_out = nullptr;
+            s.out_cap = 0;
+            BG_HIP(hipHostMalloc((void**)&s.h_out, out_need, hipHostMallocDefault));
+            BG_HIP(hipMalloc((void**)&s.d_out, out_need));
+            s.out_cap = out_need;
+        }
+    }
+    hipStream_t s_k = ctx->stream;
+    uint64_t used = 0;
+    int status = BG_OK;
+    // finish stage c: wait for its download, then records and operations into the caller's buffers
+    auto drain = [&](uint64_t c) -> int {
+        bg_host_pipe::Set& S = P.set[c % bg_host_pipe::NSET];
+        BG_HIP(hipEventSynchronize(S.out_done));
+        const uint64_t p0 = c * chunk, np = std::min(n_pairs, p0 + chunk) - p0;
+        const bg_alignment_t* h_rec = (const bg_alignment_t*)S.h_out;
+        const uint8_t* h_ops = S.h_out + o_ops;
+        std::vector<uint64_t> dst(np + 1);
+        dst[0] = used;
+        for (uint64_t p = 0; p < np; p++) {
+            if (h_rec[p].status) status = h_rec[p].status;
+            dst[p + 1] = dst[p] + h_rec[p].n_ops;
+        }
+        if (ops_buf && dst[np] > ops_cap && status == BG_OK) status = BG_ERR_OPS_CAP;
+        parallel_for(np, 4096, [&](uint64_t a, uint64_t b) {
+            for (uint64_t p = a; p < b; p++) {
+                bg_alignment_t r = h_rec[p];
+                if (ops_buf && dst[p + 1] <= ops_cap) memcpy(ops_buf + dst[p], h_ops + r.ops_off, r.n_ops);
+                r.ops_off = dst[p];
+                out[p0 + p] = r;
+            }
+        });
+        used = dst[np];
+        return BG_OK;
+    };
+    int rc;
+    for (uint64_t c = 0; c < nch; c++) {
+        if (c >= bg_host_pipe::NSET && (rc = drain(c - bg_host_pipe::NSET))) return rc;  // frees this stage's set
+        bg_host_pipe::Set& S = P.set[c % bg_host_pipe::NSET];
+        const uint64_t p0 = c * chunk, np = std::min(n_pairs, p0 + chunk) - p0;
+        const uint64_t xb = x_off[p0 + np] - x_off[p0], yb = y_off[p0 + np] - y_off[p0];
+        parallel_memcpy(S.h_in, x + x_off[p0], xb);
+        parallel_memcpy(S.h_in + o_y, y + y_off[p0], yb);
+        uint64_t *hxo = (uint64_t*)(S.h_in + o_xo), *hyo = (uint64_t*)(S.h_in + o_yo);
+        for (uint64_t p = 0; p <= np; p++) {
+            hxo[p] = x_off[p0 + p] - x_off[p0];
+            hyo[p] = y_off[p0 + p] - y_off[p0];
+        }
+        if (xb) BG_HIP(hipMemcpyAsync(S.d_in, S.h_in, xb, hipMemcpyHostToDevice, P.s_in));
+        if (yb) BG_HIP(hipMemcpyAsync(S.d_in + o_y, S.h_in + o_y, yb, hipMemcpyHostToDevice, P.s_in));
+        BG_HIP(hipMemcpyAsync(S.d_in + o_xo, S.h_in + o_xo, 2 * (chunk + 1) * 8, hipMemcpyHostToDevice, P.s_in));
+        BG_HIP(hipEventRecord(S.in_done, P.s_in));
+        BG_HIP(hipStreamWaitEvent(s_k, S.in_done, 0));
+        rc = bg_align_batch_dev(ctx, sc, mode, np, S.d_in, (const uint64_t*)(S.d_in + o_xo), S.d_in + o_y, (const uint64_t*)(S.d_in + o_yo), max_x,
+                                max_y, (bg_alignment_t*)S.d_out, stride ? S.d_out + o_ops : nullptr, stride, s_k);
+        if (rc) {
+            hipDeviceSynchronize();
+            return rc;
+        }
+        BG_HIP(hipEventRecord(S.k_done, s_k));
+        BG_HIP(hipStreamWaitEvent(P.s_out, S.k_done, 0));
+        BG_HIP(hipMemcpyAsync(S.h_out, S.d_out, o_ops + np * stride, hipMemcpyDeviceToHost, P.s_out));
+        BG_HIP(hipEventRecord(S.out_done, P.s_out));
+    }
+    for (uint64_t c = nch > bg_host_pipe::NSET ? nch - bg_host_pipe::NSET : 0; c < nch; c++)
+        if ((rc = drain(c))) return rc;
+    if (ops_used) *ops_used = used;
+    return status;
+}
+}  // namespace
+
 extern "C" int bg_align_batch(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint64_t n_pairs,
                               const uint8_t* x, const uint64_t* x_off, const uint8_t* y,
                               const uint64_t* y_off, bg_alignment_t* out, uint8_t* ops_buf,
@@ -260,6 +415,12 @@ extern "C" int bg_align_batch(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uin
         max_sum = std::max(max_sum, lx + ly);
     }
     if (max_x > (1u << 24) || max_y > (1u << 24)) return BG_ERR_TOO_LARGE;
+    {  // large batches flow through the staged pipeline
+        const uint64_t chunk = ctx->host_chunk_pairs > 0 ? (uint64_t)ctx->host_chunk_pairs : 131072;
+        if (n_pairs >= 2 * chunk && !sc->matrix)
+            return align_batch_pipelined(ctx, sc, mode, n_pairs, x, x_off, y, y_off, (uint32_t)max_x, (uint32_t)max_y, chunk, out, ops_buf, ops_cap,
+                                         ops_used);
+    }
     const uint64_t xb = x_off[n_pairs], yb = y_off[n_pairs];
     const uint64_t stride = ops_buf ? max_x + max_y + 4 : 0;
     (void)max_sum;

@@ -138,6 +138,26 @@ def test_sub_batching_reuses_scratch():
     differential(BASE, "local", xs, ys, ctx_opts={"chunk_pairs": 64})
 
 
+def test_pipelined_host_buffer_path():
+    # bg_align_batch cuts large batches into stages that flow through three staging sets (upload, kernels, download,
+    # compaction overlap); tiny stages force many of them, a partial last one included
+    xs, ys = synth.ragged_pairs(1000, 60, seed=14)
+    xs += [b"", b"ACGT", b""]
+    ys += [b"", b"", b"ACGT"]
+    differential(BASE, "local", xs, ys, ctx_opts={"host_chunk_pairs": 64})
+    differential(BASE, "semiglobal", xs, ys, ctx_opts={"host_chunk_pairs": 100})
+    kw = dict(BASE, xclip_prefix=-3, xclip_suffix=-4, yclip_prefix=-2, yclip_suffix=0)
+    differential(kw, "custom", xs, ys, ctx_opts={"host_chunk_pairs": 333})
+    # and at the default stage size: same bytes as one serial batch
+    x, xo, y, yo = synth.sw_pairs(280_000, 150, seed=5)
+    al = Aligner.with_scoring(engine_scoring(BASE))
+    out, ops = al.align_arrays(3, x, xo, y, yo)
+    al.ctx.set_option("host_chunk_pairs", 1 << 30)
+    out1, ops1 = al.align_arrays(3, x, xo, y, yo)
+    al.ctx.set_option("host_chunk_pairs", 0)
+    assert out.tobytes() == out1.tobytes() and (ops == ops1).all()
+
+
 def test_blosum62_protein_batches():
     rng = np.random.default_rng(4)
     aa = b"ARNDCQEGHILKMFPSTWYVBZX"
