@@ -181,6 +181,8 @@ extern "C" int bg_align_batch_dev(bg_ctx* ctx, const bg_scoring_t* sc, int mode,
     SwGeom& g = a.g;
     g.lp = cfg.lp;
     g.r = cfg.r;
+    g.r_inv = (uint32_t)(((1ull << 32) + cfg.r - 1) / cfg.r);
+    g.lp_shift = cfg.lp == 16 ? 4 : cfg.lp == 32 ? 5 : 6;
     g.m_cap = max_xlen;
     g.n_cap = max_ylen;
     g.nsteps = max_ylen ? max_ylen + cfg.lp - 1 : 0;

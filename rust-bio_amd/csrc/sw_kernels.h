@@ -61,7 +61,9 @@ struct SwScoring {
 //   Ly[m_cap+1]  Lx[n_cap+1]  colBits[m_cap+1 bytes]: (S nibble | I nibble << 4) of column n
 struct SwGeom {
     uint32_t lp, r, nsteps, nstrips, m_cap, n_cap, aux_stride;
-    uint32_t tb_fmt;  // 0: six 5-bit cells per word (K1); 1: three per 16-bit half (K1p, sw_fill_pk16.hip)
+    uint32_t tb_fmt;  // 0: six 5-bit cells per word (K1); 1: three per 16-bit half (K1p, sw_fill_pk16.inc)
+    uint32_t r_inv;     // ceil(2^32 / r): (row * r_inv) >> 32 == row / r for row < 2^24 (K2 divides per traceback step)
+    uint32_t lp_shift;  // log2(lp)
     __host__ __device__ uint32_t off_Ly() const { return 4; }
     __host__ __device__ uint32_t off_Lx() const { return 4 + (m_cap + 1); }
     __host__ __device__ uint32_t off_bits() const { return 4 + (m_cap + 1) + (n_cap + 1); }

@@ -38,8 +38,8 @@ __global__ __launch_bounds__(256) void sw_traceback_kernel(const SwArgs a) {
     uint64_t seg_tag = ~0ull;
     // packed 5 bits of inner cell (1 <= i <= m, 1 <= j <= n)
     auto cell = [&](uint32_t i, uint32_t j) -> uint32_t {
-        const uint32_t i1 = i - 1, lrow = i1 / R, rr = i1 - lrow * R;
-        const uint32_t st = lrow / LP, llc = lrow - st * LP;
+        const uint32_t i1 = i - 1, lrow = __umulhi(i1, geo.r_inv), rr = i1 - lrow * R;  // i1 / R, exact (sw_kernels.h)
+        const uint32_t st = lrow >> geo.lp_shift, llc = lrow & (LP - 1);
         const uint64_t g = (uint64_t)st * geo.nsteps + (j - 1 + llc);
         constexpr uint32_t tsteps = 16 / NW;
         const uint64_t base = (g / tsteps) * 1024ull + (grp * LP + llc) * 16u;
