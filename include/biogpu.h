@@ -190,6 +190,7 @@ typedef struct {
     uint8_t mode;         /* BG_MODE_* */
     int8_t status;        /* BG_OK or BG_ERR_TRACEBACK for this pair */
     uint8_t _pad;
+    uint32_t _reserved;   /* 0: the record is 64 bytes, every one of them defined */
 } bg_alignment_t;
 
 /* Aligner::{custom,global,semiglobal,local} for n_pairs independent pairs

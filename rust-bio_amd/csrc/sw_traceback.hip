@@ -195,6 +195,7 @@ __global__ __launch_bounds__(256) void sw_traceback_kernel(const SwArgs a) {
     rec.mode = (uint8_t)a.mode;
     rec.status = (int8_t)status;
     rec._pad = 0;
+    rec._reserved = 0;
     a.out[a.pair0 + pair] = rec;
 }
 
