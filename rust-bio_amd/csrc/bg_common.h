@@ -49,6 +49,7 @@ struct bg_ctx {
     int64_t chunk_pairs = 0;  // 0 = default
     bool force_wide = false;  // tests: disable the NARROW (28-bit key) kernels
     bool no_pk16 = false;     // tests: disable K1p (two pairs per lane in packed int16 halves)
+    bool no_couples = false;  // tests: K1p without the (m, n) slot order on ragged batches
     int band_chain_global = -1;  // chain_kernel tree placement: -1 by batch size, 0 LDS, 1 global scratch
     bool band_fill_v1 = false;  // tests: K3 (one pair per wavefront) even where K3v2 applies
     bool band_on_host = false;  // build bands with the host builder (band_host.cpp) instead of band_device.hip

@@ -127,6 +127,10 @@ extern "C" int bg_set_option(bg_ctx* ctx, const char* key, int64_t value) {
         ctx->host_chunk_pairs = value;
         return BG_OK;
     }
+    if (!strcmp(key, "no_couples")) {
+        ctx->no_couples = value != 0;
+        return BG_OK;
+    }
     if (!strcmp(key, "no_pk16")) {
         ctx->no_pk16 = value != 0;
         return BG_OK;

@@ -65,6 +65,132 @@ static int compact_matrix(const int32_t* matrix, std::vector<uint8_t>& code_map,
 }
 }  // namespace bgsw
 
+// ---- couples for K1p: visit the pairs of a ragged sub-batch in (m, n) order ---------------------------------
+// K1p aligns two pairs per lane group and needs them to have equal lengths (else each costs a pass of its own).
+// Reads of one length usually exist in numbers, just not next to each other: a counting sort on the 20-bit key
+// m << 11 | n (histogram with atomics, scan, scatter with atomic cursors) puts them into neighbouring slots.
+// The order inside a key is whatever the atomics give; results do not depend on a pair's partner.
+namespace bgsw {
+constexpr uint32_t kLenKeys = 1u << 20;  // m <= 384 < 2^9, n <= 2038 < 2^11 (the 12-bit score bound)
+__global__ __launch_bounds__(256) void sw_len_stats_kernel(const uint64_t* __restrict__ x_off, const uint64_t* __restrict__ y_off, uint64_t pair0,
+                                                           uint32_t n, uint32_t* __restrict__ st /* min m, max m, min n, max n */) {
+    uint32_t m = 0, nn = 0, m_lo = ~0u, n_lo = ~0u;
+    for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {  // few blocks: few atomics
+        const uint32_t a = (uint32_t)(x_off[pair0 + p + 1] - x_off[pair0 + p]), b = (uint32_t)(y_off[pair0 + p + 1] - y_off[pair0 + p]);
+        m = max(m, a);
+        m_lo = min(m_lo, a);
+        nn = max(nn, b);
+        n_lo = min(n_lo, b);
+    }
+#pragma unroll
+    for (int o = 32; o; o >>= 1) {
+        m = max(m, (uint32_t)__shfl_xor((int)m, o));
+        nn = max(nn, (uint32_t)__shfl_xor((int)nn, o));
+        m_lo = min(m_lo, (uint32_t)__shfl_xor((int)m_lo, o));
+        n_lo = min(n_lo, (uint32_t)__shfl_xor((int)n_lo, o));
+    }
+    __shared__ uint32_t s[4][4];
+    if ((threadIdx.x & 63) == 0) {
+        s[threadIdx.x >> 6][0] = m_lo;
+        s[threadIdx.x >> 6][1] = m;
+        s[threadIdx.x >> 6][2] = n_lo;
+        s[threadIdx.x >> 6][3] = nn;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {  // four atomics per block
+        atomicMin(&st[0], min(min(s[0][0], s[1][0]), min(s[2][0], s[3][0])));
+        atomicMax(&st[1], max(max(s[0][1], s[1][1]), max(s[2][1], s[3][1])));
+        atomicMin(&st[2], min(min(s[0][2], s[1][2]), min(s[2][2], s[3][2])));
+        atomicMax(&st[3], max(max(s[0][3], s[1][3]), max(s[2][3], s[3][3])));
+    }
+}
+__device__ __forceinline__ uint32_t len_key(const uint64_t* x_off, const uint64_t* y_off, uint64_t r) {
+    const uint32_t m = (uint32_t)(x_off[r + 1] - x_off[r]), n = (uint32_t)(y_off[r + 1] - y_off[r]);
+    return min(m, 511u) << 11 | min(n, 2047u);
+}
+// one atomic per distinct key of a wavefront (a batch that is nearly of one length would otherwise hammer a single
+// counter a million times): returns this lane's rank among the lanes with its key and, in the key's first lane, adds
+// their number to counter[key] — `base` is what the counter held before
+__device__ __forceinline__ uint32_t wave_key_add(uint32_t* counter, uint32_t key, bool valid, uint32_t& base) {
+    const int lane = threadIdx.x & 63;
+    uint32_t rank = 0;
+    base = 0;
+    uint64_t todo = __ballot(valid);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t k = (uint32_t)__shfl((int)key, leader);
+        const uint64_t same = __ballot(valid && key == k) & todo;
+        uint32_t b = 0;
+        if (lane == leader) b = atomicAdd(&counter[k], (uint32_t)__popcll(same));
+        b = (uint32_t)__shfl((int)b, leader);
+        if (valid && key == k) {
+            base = b;
+            rank = (uint32_t)__popcll(same & ((1ull << lane) - 1));
+        }
+        todo &= ~same;
+    }
+    return rank;
+}
+__global__ __launch_bounds__(256) void sw_key_hist_kernel(const uint64_t* __restrict__ x_off, const uint64_t* __restrict__ y_off, uint64_t pair0,
+                                                          uint32_t n, uint32_t* __restrict__ cnt, const uint32_t* __restrict__ st) {
+    if (st && st[0] == st[1] && st[2] == st[3]) return;  // one length: no order needed
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = p < n;
+    uint32_t base;
+    wave_key_add(cnt, valid ? len_key(x_off, y_off, pair0 + p) : 0u, valid, base);
+}
+// exclusive scan of the 2^20 counters in place: 1024 blocks x 1024 counters, block totals scanned by block 0 of
+// the second launch
+__global__ __launch_bounds__(256) void sw_key_block_sums_kernel(const uint32_t* __restrict__ cnt, uint32_t* __restrict__ sums,
+                                                                const uint32_t* __restrict__ st) {
+    if (st && st[0] == st[1] && st[2] == st[3]) return;
+    uint32_t v = 0;
+    for (int i = 0; i < 4; i++) v += cnt[blockIdx.x * 1024u + i * 256u + threadIdx.x];
+    __shared__ uint32_t s[4];
+#pragma unroll
+    for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) sums[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
+}
+__global__ __launch_bounds__(1024) void sw_key_scan_kernel(uint32_t* __restrict__ cnt, const uint32_t* __restrict__ sums,
+                                                           const uint32_t* __restrict__ st) {
+    if (st && st[0] == st[1] && st[2] == st[3]) return;
+    __shared__ uint32_t s[1024];
+    // offset of this block = sum of the totals of the blocks before it (1024 totals: every block scans them itself)
+    s[threadIdx.x] = sums[threadIdx.x];
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const uint32_t u = threadIdx.x >= (unsigned)o ? s[threadIdx.x - o] : 0;
+        __syncthreads();
+        s[threadIdx.x] += u;
+        __syncthreads();
+    }
+    const uint32_t base = blockIdx.x ? s[blockIdx.x - 1] : 0;
+    __syncthreads();
+    const uint32_t v = cnt[blockIdx.x * 1024u + threadIdx.x];
+    s[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const uint32_t u = threadIdx.x >= (unsigned)o ? s[threadIdx.x - o] : 0;
+        __syncthreads();
+        s[threadIdx.x] += u;
+        __syncthreads();
+    }
+    cnt[blockIdx.x * 1024u + threadIdx.x] = base + s[threadIdx.x] - v;
+}
+__global__ __launch_bounds__(256) void sw_key_scatter_kernel(const uint64_t* __restrict__ x_off, const uint64_t* __restrict__ y_off, uint64_t pair0,
+                                                             uint32_t n, uint32_t* __restrict__ cursor, uint32_t* __restrict__ perm,
+                                                             const uint32_t* __restrict__ st) {
+    if (st && st[0] == st[1] && st[2] == st[3]) return;
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = p < n;
+    uint32_t base;
+    const uint32_t rank = wave_key_add(cursor, valid ? len_key(x_off, y_off, pair0 + p) : 0u, valid, base);
+    if (valid) perm[base + rank] = p;  // pairs of one wavefront and key stay in order: neighbours in memory stay neighbours
+}
+}  // namespace bgsw
+
 using namespace bgsw;
 
 // shared with banded_api.hip
@@ -81,11 +207,13 @@ static int check_scoring(const bg_scoring_t* sc) {
     return BG_OK;
 }
 
-extern "C" int bg_align_batch_dev(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint64_t n_pairs,
-                                  const uint8_t* d_x, const uint64_t* d_x_off, const uint8_t* d_y,
-                                  const uint64_t* d_y_off, uint32_t max_xlen, uint32_t max_ylen,
-                                  bg_alignment_t* d_out, uint8_t* d_ops, uint64_t ops_stride,
-                                  void* stream) {
+// len_hint: what the caller knows about the lengths of the batch — 1 every pair has the same (m, n), 0 they differ,
+// -1 unknown (a reduction on the device + one stream synchronisation per sub-batch finds out)
+static int align_batch_dev_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint64_t n_pairs,
+                                const uint8_t* d_x, const uint64_t* d_x_off, const uint8_t* d_y,
+                                const uint64_t* d_y_off, uint32_t max_xlen, uint32_t max_ylen,
+                                bg_alignment_t* d_out, uint8_t* d_ops, uint64_t ops_stride,
+                                void* stream, int len_hint) {
     if (!ctx || !sc || mode < BG_MODE_CUSTOM || mode > BG_MODE_LOCAL) return BG_ERR_INVALID_ARG;
     int rc = check_scoring(sc);
     if (rc) return rc;
@@ -206,11 +334,41 @@ extern "C" int bg_align_batch_dev(bg_ctx* ctx, const bg_scoring_t* sc, int mode,
     a.tb = ctx->tb;
     a.aux = (int32_t*)ctx->aux;
     a.bnd = (int4*)ctx->bnd;
+    // K1p on a ragged batch: slots in (m, n) order (the strip buffer is free: K1p has one strip)
+    uint32_t *d_keycnt = nullptr, *d_keysum = nullptr, *d_perm = nullptr, *d_lenst = nullptr;
+    if (pk16 && !ctx->no_couples) {
+        const size_t need = (size_t)kLenKeys * 4 + 1024 * 4 + 64 + chunk * 4;
+        if ((rc = bg_reserve(&ctx->bnd, &ctx->bnd_bytes, need))) return rc;
+        a.bnd = (int4*)ctx->bnd;
+        d_keycnt = (uint32_t*)ctx->bnd;
+        d_keysum = d_keycnt + kLenKeys;
+        d_lenst = d_keysum + 1024;
+        d_perm = d_lenst + 16;
+    }
 
     for (uint64_t p0 = 0; p0 < n_pairs; p0 += chunk) {
         a.pair0 = p0;
         a.n_pairs = (uint32_t)std::min<uint64_t>(chunk, n_pairs - p0);
         const uint32_t njobs = (a.n_pairs + pw - 1) / pw;
+        a.perm = nullptr;
+        a.len_stats = nullptr;
+        if (d_perm && a.n_pairs >= 64 && len_hint != 1) {
+            const uint32_t* d_st = nullptr;
+            if (len_hint < 0) {  // unknown: the device finds out and every kernel below looks at its answer — no host round trip
+                const uint32_t init[4] = {~0u, 0u, ~0u, 0u};
+                BG_HIP(hipMemcpyAsync(d_lenst, init, 16, hipMemcpyHostToDevice, st));
+                sw_len_stats_kernel<<<dim3(std::min<uint32_t>((a.n_pairs + 255) / 256, 256)), dim3(256), 0, st>>>(d_x_off, d_y_off, p0, a.n_pairs, d_lenst);
+                d_st = d_lenst;
+            }
+            BG_HIP(hipMemsetAsync(d_keycnt, 0, (size_t)kLenKeys * 4, st));
+            sw_key_hist_kernel<<<dim3((a.n_pairs + 255) / 256), dim3(256), 0, st>>>(d_x_off, d_y_off, p0, a.n_pairs, d_keycnt, d_st);
+            sw_key_block_sums_kernel<<<dim3(1024), dim3(256), 0, st>>>(d_keycnt, d_keysum, d_st);
+            sw_key_scan_kernel<<<dim3(1024), dim3(1024), 0, st>>>(d_keycnt, d_keysum, d_st);
+            sw_key_scatter_kernel<<<dim3((a.n_pairs + 255) / 256), dim3(256), 0, st>>>(d_x_off, d_y_off, p0, a.n_pairs, d_keycnt, d_perm, d_st);
+            BG_HIP(hipGetLastError());
+            a.perm = d_perm;
+            a.len_stats = d_st;
+        }
         if (ctx->timing) BG_HIP(hipEventRecord(ctx->ev[0], st));
         const uint32_t nwaves = pk16 ? (njobs + 1) / 2 : njobs;  // a K1p wavefront takes two jobs
         fill<<<dim3((nwaves + 3) / 4), dim3(256), 0, st>>>(a);
@@ -240,6 +398,14 @@ extern "C" int bg_align_batch_dev(bg_ctx* ctx, const bg_scoring_t* sc, int mode,
         }
     }
     return BG_OK;
+}
+
+extern "C" int bg_align_batch_dev(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint64_t n_pairs,
+                                  const uint8_t* d_x, const uint64_t* d_x_off, const uint8_t* d_y,
+                                  const uint64_t* d_y_off, uint32_t max_xlen, uint32_t max_ylen,
+                                  bg_alignment_t* d_out, uint8_t* d_ops, uint64_t ops_stride,
+                                  void* stream) {
+    return align_batch_dev_impl(ctx, sc, mode, n_pairs, d_x, d_x_off, d_y, d_y_off, max_xlen, max_ylen, d_out, d_ops, ops_stride, stream, -1);
 }
 
 // ---- pipelined host-buffer path ------------------------------------------------------------------------------
@@ -379,8 +545,10 @@ int align_batch_pipelined(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint64_
         BG_HIP(hipMemcpyAsync(S.d_in + o_xo, S.h_in + o_xo, 2 * (chunk + 1) * 8, hipMemcpyHostToDevice, P.s_in));
         BG_HIP(hipEventRecord(S.in_done, P.s_in));
         BG_HIP(hipStreamWaitEvent(s_k, S.in_done, 0));
-        rc = bg_align_batch_dev(ctx, sc, mode, np, S.d_in, (const uint64_t*)(S.d_in + o_xo), S.d_in + o_y, (const uint64_t*)(S.d_in + o_yo), max_x,
-                                max_y, (bg_alignment_t*)S.d_out, stride ? S.d_out + o_ops : nullptr, stride, s_k);
+        bool uniform = true;  // the host knows the lengths: no reduction + synchronisation on the device
+        for (uint64_t p = 1; p < np && uniform; p++) uniform = hxo[p + 1] - hxo[p] == hxo[1] && hyo[p + 1] - hyo[p] == hyo[1];
+        rc = align_batch_dev_impl(ctx, sc, mode, np, S.d_in, (const uint64_t*)(S.d_in + o_xo), S.d_in + o_y, (const uint64_t*)(S.d_in + o_yo),
+                                  max_x, max_y, (bg_alignment_t*)S.d_out, stride ? S.d_out + o_ops : nullptr, stride, s_k, uniform ? 1 : 0);
         if (rc) {
             hipDeviceSynchronize();
             return rc;
@@ -409,12 +577,14 @@ extern "C" int bg_align_batch(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uin
     if (!x_off || !y_off || !out) return BG_ERR_INVALID_ARG;
     BG_HIP(hipSetDevice(ctx->device));
     uint64_t max_x = 0, max_y = 0, max_sum = 0;
+    bool uniform_len = true;
     for (uint64_t p = 0; p < n_pairs; p++) {
         if (x_off[p + 1] < x_off[p] || y_off[p + 1] < y_off[p]) return BG_ERR_INVALID_ARG;
         const uint64_t lx = x_off[p + 1] - x_off[p], ly = y_off[p + 1] - y_off[p];
         max_x = std::max(max_x, lx);
         max_y = std::max(max_y, ly);
         max_sum = std::max(max_sum, lx + ly);
+        uniform_len = uniform_len && lx == x_off[1] - x_off[0] && ly == y_off[1] - y_off[0];
     }
     if (max_x > (1u << 24) || max_y > (1u << 24)) return BG_ERR_TOO_LARGE;
     {  // large batches flow through the staged pipeline
@@ -446,7 +616,8 @@ extern "C" int bg_align_batch(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uin
     if (yb) BG_HIP(hipMemcpyAsync(d_y, y, yb, hipMemcpyHostToDevice, st));
     BG_HIP(hipMemcpyAsync(d_xo, x_off, (n_pairs + 1) * 8, hipMemcpyHostToDevice, st));
     BG_HIP(hipMemcpyAsync(d_yo, y_off, (n_pairs + 1) * 8, hipMemcpyHostToDevice, st));
-    rc = bg_align_batch_dev(ctx, sc, mode, n_pairs, d_x, d_xo, d_y, d_yo, (uint32_t)max_x, (uint32_t)max_y, d_out, d_ops, stride, st);
+    rc = align_batch_dev_impl(ctx, sc, mode, n_pairs, d_x, d_xo, d_y, d_yo, (uint32_t)max_x, (uint32_t)max_y, d_out, d_ops, stride, st,
+                              uniform_len ? 1 : 0);
     if (rc) return rc;
     BG_HIP(hipMemcpyAsync(out, d_out, n_pairs * sizeof(bg_alignment_t), hipMemcpyDeviceToHost, st));
     if (stride) BG_HIP(hipMemcpyAsync(ctx->h_ops, d_ops, n_pairs * stride, hipMemcpyDeviceToHost, st));

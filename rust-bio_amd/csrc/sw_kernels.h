@@ -104,6 +104,15 @@ struct SwArgs {
     void* tb;
     int32_t* aux;
     int4* bnd;  // strip hand-over rows: per pair (n_cap+1) x {S, I, cmax, carg}
+    // K1p couples pairs of equal lengths: with ragged batches the pairs are visited in (m, n) order — slot s of the
+    // sub-batch holds pair perm[s]; traceback words and aux records are per slot, results per pair.  NULL: identity.
+    const uint32_t* perm;
+    const uint32_t* len_stats;  // {min m, max m, min n, max n} of the sub-batch: perm applies only if they differ (device-side decision)
+    __device__ const uint32_t* slot_perm() const {
+        if (!perm) return nullptr;
+        if (len_stats && len_stats[0] == len_stats[1] && len_stats[2] == len_stats[3]) return nullptr;
+        return perm;
+    }
     SwGeom g;
     // K2 outputs
     bg_alignment_t* out;

@@ -9,8 +9,10 @@ constexpr uint32_t kSegStride = 20;  // dwords per thread slot: 16 of data, padd
 
 template <int NW>
 __global__ __launch_bounds__(256) void sw_traceback_kernel(const SwArgs a) {
-    const uint32_t pair = blockIdx.x * blockDim.x + threadIdx.x;
-    if (pair >= a.n_pairs) return;
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;  // traceback words and aux records are per slot
+    if (slot >= a.n_pairs) return;
+    const uint32_t* perm = a.slot_perm();
+    const uint32_t pair = perm ? perm[slot] : slot;            // sequences and results per pair (sw_kernels.h)
     const SwScoring sc = a.sc;
     const SwGeom geo = a.g;
     const uint32_t R = geo.r, LP = geo.lp, PW = 64 / geo.lp;
@@ -19,7 +21,7 @@ __global__ __launch_bounds__(256) void sw_traceback_kernel(const SwArgs a) {
     const uint32_t m = (uint32_t)(a.x_off[a.pair0 + pair + 1] - xo);
     const uint32_t n = (uint32_t)(a.y_off[a.pair0 + pair + 1] - yo);
 
-    const int32_t* aux = a.aux + (size_t)pair * geo.aux_stride;
+    const int32_t* aux = a.aux + (size_t)slot * geo.aux_stride;
     const int32_t* gLy = aux + geo.off_Ly();
     const int32_t* gLx = aux + geo.off_Lx();
     const uint8_t* bits = (const uint8_t*)(aux + geo.off_bits());  // column n: S | I << 4
@@ -27,7 +29,7 @@ __global__ __launch_bounds__(256) void sw_traceback_kernel(const SwArgs a) {
     const int32_t score = aux[1];
     const uint32_t lxn = (uint32_t)aux[2];
 
-    const uint32_t job = pair / PW, grp = pair % PW;
+    const uint32_t job = slot / PW, grp = slot % PW;
     const uint32_t* tbj = (const uint32_t*)a.tb + (size_t)job * tb_job_words(geo.nstrips, geo.nsteps, NW);
     // A diagonal step stays in the same lane's stream nine times out of ten (R = 10) and moves one step
     // back in it: the 64 bytes a lane wrote for 16 / NW consecutive steps (one tile row, tb_word_off) are

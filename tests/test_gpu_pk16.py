@@ -183,3 +183,35 @@ def test_semiglobal_same_answers_as_k1_at_scale():
         al.ctx.set_option("no_pk16", 0)
         assert out.tobytes() == out1.tobytes()
         assert (ops == ops1).all()
+
+
+def test_ragged_batches_visit_pairs_in_length_order():
+    # slots in (m, n) order (counting sort on the device), results per pair: same bytes with and without it
+    rng = np.random.default_rng(31)
+    xs, ys = related_pairs(rng, 20_000, lambda p: int(rng.integers(90, 151)), lambda p: int(rng.integers(100, 161)))
+    x, xo = _lib.concat(xs)
+    y, yo = _lib.concat(ys)
+    al = Aligner.with_scoring(Scoring.from_scores(-5, -1, 1, -1))
+    for mode in (3, 2):
+        out, ops = al.align_arrays(mode, x, xo, y, yo)
+        al.ctx.set_option("no_couples", 1)
+        out1, ops1 = al.align_arrays(mode, x, xo, y, yo)
+        al.ctx.set_option("no_couples", 0)
+        assert out.tobytes() == out1.tobytes() and (ops == ops1).all()
+    # device-resident entry (the device decides), small sub-batches
+    import torch
+    n = len(xs)
+    dx, dy = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    dxo, dyo = torch.from_numpy(xo.astype(np.int64)).cuda(), torch.from_numpy(yo.astype(np.int64)).cuda()
+    stride = 150 + 160 + 4
+    d_out = torch.empty(n * 64, dtype=torch.uint8, device="cuda")
+    d_ops = torch.empty(n * stride, dtype=torch.uint8, device="cuda")
+    al.ctx.set_option("chunk_pairs", 4096)
+    al.align_dev(3, n, dx.data_ptr(), dxo.data_ptr(), dy.data_ptr(), dyo.data_ptr(), 150, 160, d_out.data_ptr(), d_ops.data_ptr(), stride,
+                 torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    al.ctx.set_option("chunk_pairs", 0)
+    out, _ = al.align_arrays(3, x, xo, y, yo)
+    rec = d_out.cpu().numpy().view(_lib.ALN_DTYPE)
+    for f in ("score", "xstart", "xend", "ystart", "yend", "n_ops"):
+        assert (rec[f] == out[f]).all(), f
