@@ -73,7 +73,7 @@ static int compact_matrix(const int32_t* matrix, std::vector<uint8_t>& code_map,
 namespace bgsw {
 constexpr uint32_t kLenKeys = 1u << 20;  // m <= 384 < 2^9, n <= 2038 < 2^11 (the 12-bit score bound)
 __global__ __launch_bounds__(256) void sw_len_stats_kernel(const uint64_t* __restrict__ x_off, const uint64_t* __restrict__ y_off, uint64_t pair0,
-                                                           uint32_t n, uint32_t* __restrict__ st /* min m, max m, min n, max n */) {
+                                                           uint32_t n, uint32_t* __restrict__ st /* min m, min n, max m, max n */) {
     uint32_t m = 0, nn = 0, m_lo = ~0u, n_lo = ~0u;
     for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {  // few blocks: few atomics
         const uint32_t a = (uint32_t)(x_off[pair0 + p + 1] - x_off[pair0 + p]), b = (uint32_t)(y_off[pair0 + p + 1] - y_off[pair0 + p]);
@@ -99,8 +99,8 @@ __global__ __launch_bounds__(256) void sw_len_stats_kernel(const uint64_t* __res
     __syncthreads();
     if (threadIdx.x == 0) {  // four atomics per block
         atomicMin(&st[0], min(min(s[0][0], s[1][0]), min(s[2][0], s[3][0])));
-        atomicMax(&st[1], max(max(s[0][1], s[1][1]), max(s[2][1], s[3][1])));
-        atomicMin(&st[2], min(min(s[0][2], s[1][2]), min(s[2][2], s[3][2])));
+        atomicMax(&st[2], max(max(s[0][1], s[1][1]), max(s[2][1], s[3][1])));
+        atomicMin(&st[1], min(min(s[0][2], s[1][2]), min(s[2][2], s[3][2])));
         atomicMax(&st[3], max(max(s[0][3], s[1][3]), max(s[2][3], s[3][3])));
     }
 }
@@ -133,7 +133,7 @@ __device__ __forceinline__ uint32_t wave_key_add(uint32_t* counter, uint32_t key
 }
 __global__ __launch_bounds__(256) void sw_key_hist_kernel(const uint64_t* __restrict__ x_off, const uint64_t* __restrict__ y_off, uint64_t pair0,
                                                           uint32_t n, uint32_t* __restrict__ cnt, const uint32_t* __restrict__ st) {
-    if (st && st[0] == st[1] && st[2] == st[3]) return;  // one length: no order needed
+    if (st && st[0] == st[2] && st[1] == st[3]) return;  // one length: no order needed
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = p < n;
     uint32_t base;
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void sw_key_hist_kernel(const uint64_t* __rest
 // the second launch
 __global__ __launch_bounds__(256) void sw_key_block_sums_kernel(const uint32_t* __restrict__ cnt, uint32_t* __restrict__ sums,
                                                                 const uint32_t* __restrict__ st) {
-    if (st && st[0] == st[1] && st[2] == st[3]) return;
+    if (st && st[0] == st[2] && st[1] == st[3]) return;
     uint32_t v = 0;
     for (int i = 0; i < 4; i++) v += cnt[blockIdx.x * 1024u + i * 256u + threadIdx.x];
     __shared__ uint32_t s[4];
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void sw_key_block_sums_kernel(const uint32_t* 
 }
 __global__ __launch_bounds__(1024) void sw_key_scan_kernel(uint32_t* __restrict__ cnt, const uint32_t* __restrict__ sums,
                                                            const uint32_t* __restrict__ st) {
-    if (st && st[0] == st[1] && st[2] == st[3]) return;
+    if (st && st[0] == st[2] && st[1] == st[3]) return;
     __shared__ uint32_t s[1024];
     // offset of this block = sum of the totals of the blocks before it (1024 totals: every block scans them itself)
     s[threadIdx.x] = sums[threadIdx.x];
@@ -182,12 +182,18 @@ __global__ __launch_bounds__(1024) void sw_key_scan_kernel(uint32_t* __restrict_
 __global__ __launch_bounds__(256) void sw_key_scatter_kernel(const uint64_t* __restrict__ x_off, const uint64_t* __restrict__ y_off, uint64_t pair0,
                                                              uint32_t n, uint32_t* __restrict__ cursor, uint32_t* __restrict__ perm,
                                                              const uint32_t* __restrict__ st) {
-    if (st && st[0] == st[1] && st[2] == st[3]) return;
+    if (st && st[0] == st[2] && st[1] == st[3]) return;
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = p < n;
     uint32_t base;
     const uint32_t rank = wave_key_add(cursor, valid ? len_key(x_off, y_off, pair0 + p) : 0u, valid, base);
     if (valid) perm[base + rank] = p;  // pairs of one wavefront and key stay in order: neighbours in memory stay neighbours
+}
+// n_eff[0] = pairs K2's identity flavour has to do, n_eff[1] = the permuted one's (sw_kernels.h); forced: 0 ragged, -1 ask st
+__global__ void sw_decide_kernel(const uint32_t* __restrict__ st, uint32_t n, int forced, uint32_t* __restrict__ n_eff) {
+    const bool uniform = forced < 0 && st[0] == st[2] && st[1] == st[3];
+    n_eff[0] = uniform ? n : 0u;
+    n_eff[1] = uniform ? 0u : n;
 }
 }  // namespace bgsw
 
@@ -352,11 +358,13 @@ static int align_batch_dev_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, u
         const uint32_t njobs = (a.n_pairs + pw - 1) / pw;
         a.perm = nullptr;
         a.len_stats = nullptr;
+        a.n_eff = nullptr;
         if (d_perm && a.n_pairs >= 64 && len_hint != 1) {
             const uint32_t* d_st = nullptr;
             if (len_hint < 0) {  // unknown: the device finds out and every kernel below looks at its answer — no host round trip
-                const uint32_t init[4] = {~0u, 0u, ~0u, 0u};
-                BG_HIP(hipMemcpyAsync(d_lenst, init, 16, hipMemcpyHostToDevice, st));
+                // minima start at ~0, maxima at 0 (memsets: a pageable upload would make the launching thread wait for the stream)
+                BG_HIP(hipMemsetAsync(d_lenst, 0xff, 8, st));
+                BG_HIP(hipMemsetAsync(d_lenst + 2, 0, 8, st));
                 sw_len_stats_kernel<<<dim3(std::min<uint32_t>((a.n_pairs + 255) / 256, 256)), dim3(256), 0, st>>>(d_x_off, d_y_off, p0, a.n_pairs, d_lenst);
                 d_st = d_lenst;
             }
@@ -366,8 +374,10 @@ static int align_batch_dev_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, u
             sw_key_scan_kernel<<<dim3(1024), dim3(1024), 0, st>>>(d_keycnt, d_keysum, d_st);
             sw_key_scatter_kernel<<<dim3((a.n_pairs + 255) / 256), dim3(256), 0, st>>>(d_x_off, d_y_off, p0, a.n_pairs, d_keycnt, d_perm, d_st);
             BG_HIP(hipGetLastError());
+            sw_decide_kernel<<<dim3(1), dim3(1), 0, st>>>(d_lenst, a.n_pairs, len_hint < 0 ? -1 : 0, d_lenst + 4);
             a.perm = d_perm;
             a.len_stats = d_st;
+            a.n_eff = d_lenst + 4;
         }
         if (ctx->timing) BG_HIP(hipEventRecord(ctx->ev[0], st));
         const uint32_t nwaves = pk16 ? (njobs + 1) / 2 : njobs;  // a K1p wavefront takes two jobs

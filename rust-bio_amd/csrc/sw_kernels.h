@@ -107,10 +107,13 @@ struct SwArgs {
     // K1p couples pairs of equal lengths: with ragged batches the pairs are visited in (m, n) order — slot s of the
     // sub-batch holds pair perm[s]; traceback words and aux records are per slot, results per pair.  NULL: identity.
     const uint32_t* perm;
-    const uint32_t* len_stats;  // {min m, max m, min n, max n} of the sub-batch: perm applies only if they differ (device-side decision)
+    const uint32_t* len_stats;  // {min m, min n, max m, max n} of the sub-batch: perm applies only if they differ (device-side decision)
+    // K2 is launched in both flavours; n_eff[0] / n_eff[1] = pairs the identity / the permuted one has to do (one of
+    // them 0), written on the device once the lengths are known.  NULL: identity, n_pairs.
+    const uint32_t* n_eff;
     __device__ const uint32_t* slot_perm() const {
         if (!perm) return nullptr;
-        if (len_stats && len_stats[0] == len_stats[1] && len_stats[2] == len_stats[3]) return nullptr;
+        if (len_stats && len_stats[0] == len_stats[2] && len_stats[1] == len_stats[3]) return nullptr;
         return perm;
     }
     SwGeom g;

@@ -7,12 +7,15 @@ namespace bgsw {
 
 constexpr uint32_t kSegStride = 20;  // dwords per thread slot: 16 of data, padded against bank conflicts
 
-template <int NW>
-__global__ __launch_bounds__(256) void sw_traceback_kernel(const SwArgs a) {
+// PERM: the slots of the sub-batch hold the pairs in (m, n) order (SwArgs::perm).  Whether that order is in force may
+// be decided on the device, so both instantiations are launched, each with its pair count read from SwArgs::n_eff
+// (one of the two is 0) — a single kernel that merely might go through the indirection was measured at 2.0 ms
+// against 1.4.
+template <int NW, bool PERM>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void sw_traceback_kernel(const SwArgs a) {
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;  // traceback words and aux records are per slot
-    if (slot >= a.n_pairs) return;
-    const uint32_t* perm = a.slot_perm();
-    const uint32_t pair = perm ? perm[slot] : slot;            // sequences and results per pair (sw_kernels.h)
+    if (slot >= (a.n_eff ? a.n_eff[PERM ? 1 : 0] : a.n_pairs)) return;
+    const uint32_t pair = PERM ? a.perm[slot] : slot;              // sequences and results per pair (sw_kernels.h)
     const SwScoring sc = a.sc;
     const SwGeom geo = a.g;
     const uint32_t R = geo.r, LP = geo.lp, PW = 64 / geo.lp;
@@ -204,9 +207,15 @@ __global__ __launch_bounds__(256) void sw_traceback_kernel(const SwArgs a) {
 void launch_traceback(const SwArgs& a, int nw, hipStream_t st) {
     const uint32_t blocks = (a.n_pairs + 255) / 256;
     if (nw == 2)
-        sw_traceback_kernel<2><<<dim3(blocks), dim3(256), 0, st>>>(a);
+        sw_traceback_kernel<2, false><<<dim3(blocks), dim3(256), 0, st>>>(a);
     else
-        sw_traceback_kernel<1><<<dim3(blocks), dim3(256), 0, st>>>(a);
+        sw_traceback_kernel<1, false><<<dim3(blocks), dim3(256), 0, st>>>(a);
+    if (a.perm) {
+        if (nw == 2)
+            sw_traceback_kernel<2, true><<<dim3(blocks), dim3(256), 0, st>>>(a);
+        else
+            sw_traceback_kernel<1, true><<<dim3(blocks), dim3(256), 0, st>>>(a);
+    }
 }
 
 }  // namespace bgsw
