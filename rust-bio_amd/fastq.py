@@ -94,25 +94,30 @@ def parse_arrays(text, ctx=None):
     return Parsed(t, recs[:k], seq[:int(so[k])], so[:k + 1], qual[:int(qo[k])], qo[:k + 1], st.value, int(ep.value))
 
 
-def parse_dev(d_text, ctx=None, stream=0):
+def parse_dev(d_text, ctx=None, stream=0, bufs=None):
     """d_text: uint8 torch tensor on the device.  Returns (n_records, status name, err_pos, d_recs, d_seq, d_seq_off,
-    d_qual, d_qual_off) with everything but the first three left in HBM (d_seq_off is an int64 tensor usable as x_off)."""
+    d_qual, d_qual_off) with everything but the first three left in HBM (d_seq_off is an int64 tensor usable as x_off).
+    `bufs`: the five tensors of `alloc_dev(len)` to reuse across calls (a caller's own buffers)."""
     import torch
     ctx = ctx or _lib.default_context()
     ln = int(d_text.numel())
     cap = ln // 4 + 2
-    dev = d_text.device
-    d_recs = torch.empty(cap * 56, dtype=torch.uint8, device=dev)
-    d_seq = torch.empty(max(1, ln), dtype=torch.uint8, device=dev)
-    d_qual = torch.empty(max(1, ln), dtype=torch.uint8, device=dev)
-    d_so = torch.empty(cap + 1, dtype=torch.int64, device=dev)
-    d_qo = torch.empty(cap + 1, dtype=torch.int64, device=dev)
+    d_recs, d_seq, d_qual, d_so, d_qo = bufs if bufs is not None else alloc_dev(ln, d_text.device)
     n, st, ep = C.c_uint64(0), C.c_int32(0), C.c_uint64(0)
     _lib.check(_lib.lib().bg_fastq_parse_dev(ctx.h, d_text.data_ptr(), ln, d_recs.data_ptr(), cap, d_seq.data_ptr(), d_so.data_ptr(),
                                              d_qual.data_ptr(), d_qo.data_ptr(), C.byref(n), C.byref(st), C.byref(ep), stream),
                "bg_fastq_parse_dev")
     k = int(n.value)
     return k, STATUS[st.value], int(ep.value), d_recs[:k * 56], d_seq, d_so[:k + 1], d_qual, d_qo[:k + 1]
+
+
+def alloc_dev(ln, device):
+    """output buffers of parse_dev for a text of `ln` bytes: records, sequences, qualities, their offsets"""
+    import torch
+    cap = ln // 4 + 2
+    return (torch.empty(cap * 56, dtype=torch.uint8, device=device), torch.empty(max(1, ln), dtype=torch.uint8, device=device),
+            torch.empty(max(1, ln), dtype=torch.uint8, device=device), torch.empty(cap + 1, dtype=torch.int64, device=device),
+            torch.empty(cap + 1, dtype=torch.int64, device=device))
 
 
 class Reader:
