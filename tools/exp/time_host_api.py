@@ -1,0 +1,19 @@
+import os, sys, time
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, R)
+import numpy as np, torch
+torch.cuda.init()
+from rust_bio_amd import _lib, synth
+from rust_bio_amd.pairwise import Aligner, Scoring
+n, L = 1_000_000, 150
+x, xo, y, yo = synth.sw_pairs(n, L, seed=2)
+al = Aligner.with_scoring(Scoring.from_scores(-5, -1, 1, -1))
+out, ops = al.align_arrays(3, x, xo, y, yo)
+for chunk in (16384, 32768, 65536, 131072, 262144, 1 << 30):
+    al.ctx.set_option("host_chunk_pairs", chunk)
+    al.align_arrays(3, x, xo, y, yo, out=out, ops=ops)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        al.align_arrays(3, x, xo, y, yo, out=out, ops=ops)
+    dt = (time.perf_counter() - t0) / 3
+    print("chunk %8d: %.2f ms  %.0f GCUPS" % (chunk, dt * 1e3, n * L * L / dt / 1e9))
