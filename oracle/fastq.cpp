@@ -32,7 +32,6 @@ bool valid_utf8(const uint8_t* s, uint64_t n) {
             if ((s[i + j] & 0xC0) != 0x80) return false;
             cp = (cp << 6) | (s[i + j] & 0x3F);
         }
-        (void)lo;
         if (cp < lo || cp > 0x10FFFF || (cp >= 0xD800 && cp <= 0xDFFF)) return false;
         i += k + 1;
     }
