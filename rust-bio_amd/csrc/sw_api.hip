@@ -15,10 +15,10 @@ namespace bgsw {
 sw_fill_fn get_fill_params_narrow(int lp, int r, bool local);
 sw_fill_fn get_fill_params_wide(int lp, int r, bool local);
 sw_fill_fn get_fill_matrix(int lp, int r, int sm, bool narrow);
-sw_fill_fn get_fill_pk16_local(int lp, int r, bool fast);
-sw_fill_fn get_fill_pk16_semiglobal(int lp, int r, bool fast);
-sw_fill_fn get_fill_pk16_global(int lp, int r, bool fast);
-sw_fill_fn get_fill_pk16_custom(int lp, int r, bool fast);
+sw_fill_fn get_fill_pk16_local(int lp, int r, int which);
+sw_fill_fn get_fill_pk16_semiglobal(int lp, int r, int which);
+sw_fill_fn get_fill_pk16_global(int lp, int r, int which);
+sw_fill_fn get_fill_pk16_custom(int lp, int r, int which);
 void launch_traceback(const SwArgs& a, int nw, hipStream_t st);
 
 struct Config {
@@ -286,7 +286,7 @@ static int align_batch_dev_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, u
                           : get_fill_matrix(cfg.lp, cfg.r, sm, narrow);
     // K1p: short reads whose scores fit 12 bits (sw_fill_pk16.inc) — two pairs per lane, one instantiation
     // unit per clip pattern.  Bound: no real DP value, nor the epilogue's go * i terms, may leave +-2040.
-    sw_fill_fn fill_rest = nullptr;
+    sw_fill_fn fill_rest = nullptr, fill_second = nullptr;
     const bool pk16 = !ctx->no_pk16 && sm == SCORE_PARAMS && cfg.lp <= 32 && max_xlen >= 1 &&
                       mag * ((int64_t)std::max(max_xlen, max_ylen) + 2) <= 2040;
     if (pk16) {
@@ -300,13 +300,14 @@ static int align_batch_dev_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, u
         // batch usually share one length, so prefer an instantiated R that divides the longest
         int r_pick = 0;
         for (int r = (int)((max_xlen + cfg.lp - 1) / cfg.lp); r <= 12 && !r_pick; r++)
-            if (max_xlen % r == 0 && getter(cfg.lp, r, true)) r_pick = r;
+            if (max_xlen % r == 0 && getter(cfg.lp, r, 0)) r_pick = r;
         for (int r = (int)((max_xlen + cfg.lp - 1) / cfg.lp); r <= 12 && !r_pick; r++)
-            if (getter(cfg.lp, r, true)) r_pick = r;
+            if (getter(cfg.lp, r, 0)) r_pick = r;
         if (!r_pick) return BG_ERR_UNSUPPORTED;
         cfg.r = r_pick;
-        fill = getter(cfg.lp, cfg.r, true);
-        fill_rest = getter(cfg.lp, cfg.r, false);
+        fill = getter(cfg.lp, cfg.r, 0);
+        fill_rest = getter(cfg.lp, cfg.r, 1);
+        fill_second = getter(cfg.lp, cfg.r, 2);
         a.g.tb_fmt = 1;
     }
     if (!fill) return BG_ERR_UNSUPPORTED;
@@ -384,8 +385,9 @@ static int align_batch_dev_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, u
         fill<<<dim3((nwaves + 3) / 4), dim3(256), 0, st>>>(a);
         BG_HIP(hipGetLastError());
         if (ctx->timing) BG_HIP(hipEventRecord(ctx->ev[1], st));
-        if (fill_rest) {  // picks up what the fast launch skipped (other read lengths, unequal couples)
+        if (fill_rest) {  // what the fast launch skipped: wavefronts with other read lengths, then the second pairs of unequal couples
             fill_rest<<<dim3((nwaves + 3) / 4), dim3(256), 0, st>>>(a);
+            fill_second<<<dim3((nwaves + 3) / 4), dim3(256), 0, st>>>(a);
             BG_HIP(hipGetLastError());
         }
         if (ctx->timing) {

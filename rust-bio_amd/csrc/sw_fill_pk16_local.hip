@@ -1,7 +1,7 @@
 // K1p instantiations for Aligner::local (mod.rs:995-999): all four clip penalties 0.
 #include "sw_fill_pk16.inc"
 namespace bgsw {
-sw_fill_fn get_fill_pk16_local(int lp, int r, bool fast) {
+sw_fill_fn get_fill_pk16_local(int lp, int r, int which) {
     constexpr int XP_ = pk16::CZ, XS_ = pk16::CZ, YP_ = pk16::CZ, YS_ = pk16::CZ;
     BG_PK16_CASE(16, 2) BG_PK16_CASE(16, 3) BG_PK16_CASE(16, 4) BG_PK16_CASE(16, 5) BG_PK16_CASE(16, 6) BG_PK16_CASE(16, 7)
     BG_PK16_CASE(16, 8) BG_PK16_CASE(16, 9) BG_PK16_CASE(16, 10) BG_PK16_CASE(16, 11) BG_PK16_CASE(16, 12)
