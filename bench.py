@@ -2,22 +2,27 @@
 """bench.py — BASELINE.json's metric on MI355X: GCUPS (Smith-Waterman) + FM-index queries/s.
 
     python bench.py --gpus N --steps K --warmup W
+        N > 1 without a launcher: re-executes itself under `python -m torch.distributed.run --nnodes=1
+        --nproc-per-node N --master-addr 127.0.0.1 ...`, one rank per GPU (RCCL over xGMI).
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+        (what the driver does): RANK / LOCAL_RANK / WORLD_SIZE come from the environment.
 
-One "step" = one pass of the hot path over one batch of synthetic input that is already
-resident in HBM:
-  * headline (`value`): BASELINE configs[1] — 1 M x 150 bp synthetic read pairs per GPU through
-    `Aligner::local` (affine gaps, Scoring::from_scores(-5,-1,1,-1)): K1 fill + K2 traceback,
-    score + coordinates + full operation list for every pair;
-  * second leg (`fm`): BASELINE configs[2] — FMIndex over a 100 Mbp synthetic genome,
-    10 M x 100 bp backward_search per GPU.
-Units (pairs / queries) shard across ranks, the index is replicated, and each step ends with
-the single all-gather of fixed-size result records (world_size > 1 only).  `scaling` is weak:
-every rank processes its own full batch.  Rank 0 prints ONE JSON line.
+One "step" = one pass of the hot path over one batch of synthetic input that is already resident in HBM:
+  * headline (`value`): BASELINE configs[1] — 1 M x 150 bp synthetic read pairs per GPU through `Aligner::local`
+    (affine gaps, Scoring::from_scores(-5,-1,1,-1)): fill + traceback, score + coordinates + full operation list;
+  * `fm`: BASELINE configs[2] — FMIndex over a 100 Mbp synthetic genome, 10 M x 100 bp backward_search per GPU
+    (weak), and `fm.strong`: the same 10 M queries in total split over the ranks (strong), both with the single
+    all-gather of the result records inside the timed step;
+  * `k1_int32`: the general int32 kernel (BLOSUM62 protein pairs; DNA with scores beyond 12 bits);
+  * `banded` (configs[3] shape), `seed_extend` (configs[4] shape), `ingest` (FASTQ text -> records).
+Units (pairs / queries / reads) shard across ranks, the index is built once on rank 0 and broadcast, and every
+rank holds a replica.  Rank 0 prints ONE JSON line.  The CPU legs (oracle parity over the whole workload +
+`cpu_baseline`, median of 3) run on rank 0 of the single-GPU run only.
 """
 import argparse
 import json
 import os
+import socket
 import sys
 import time
 
@@ -26,17 +31,59 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-import numpy as np
-import torch
-
-from rust_bio_amd import _lib, shard, synth, synth_gpu
-from rust_bio_amd.bwt import Occ, bwt, less
-from rust_bio_amd.fmindex import FMIndex
-from rust_bio_amd.pairwise import Aligner, Scoring
-from rust_bio_amd.suffix_array import suffix_array
-
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
+VALU_PEAK_LANE_OPS = 78.6e12  # 256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz (full-rate VALU ops)
 N_ALPHABET = b"ACGTNacgtn"
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--pairs", type=int, default=1_000_000, help="read pairs per GPU (configs[1]: 1M)")
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--genome", type=int, default=100_000_000, help="FM leg: genome length (configs[2]: 100 Mbp)")
+    ap.add_argument("--queries", type=int, default=10_000_000, help="FM leg: patterns per GPU (configs[2]: 10M)")
+    ap.add_argument("--pattern-len", type=int, default=100)
+    ap.add_argument("--skip-fm", action="store_true")
+    ap.add_argument("--skip-k1", action="store_true")
+    ap.add_argument("--k1-pairs", type=int, default=262_144, help="int32-kernel legs: pairs per GPU")
+    ap.add_argument("--skip-banded", action="store_true")
+    ap.add_argument("--banded-pairs", type=int, default=32768, help="banded leg: 10 kb pairs per GPU (configs[3] is 100k over 8 GPUs)")
+    ap.add_argument("--skip-pipeline", action="store_true")
+    ap.add_argument("--pipeline-reads", type=int, default=1_000_000, help="seed-and-extend leg: reads per GPU")
+    ap.add_argument("--skip-ingest", action="store_true")
+    ap.add_argument("--ingest-reads", type=int, default=1_000_000, help="FASTQ ingest leg: four-line records per GPU")
+    ap.add_argument("--skip-cpu", action="store_true", help="no oracle parity / cpu_baseline legs")
+    ap.add_argument("--parity-frac", type=float, default=1.0, help="fraction of every leg's output compared with the oracle")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    return ap.parse_args()
+
+
+def relaunch_under_torchrun(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher: start N ranks of this very command."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.execv(sys.executable, cmd)
+
+
+ARGS = parse_args()
+relaunch_under_torchrun(ARGS)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from rust_bio_amd import _lib, shard, synth, synth_gpu  # noqa: E402
+from rust_bio_amd.bwt import Occ, bwt, less  # noqa: E402
+from rust_bio_amd.fmindex import FMIndex  # noqa: E402
+from rust_bio_amd.pairwise import Aligner, Scoring  # noqa: E402
+from rust_bio_amd.suffix_array import suffix_array  # noqa: E402
 
 
 def host_cores():
@@ -54,19 +101,33 @@ def host_cores():
     return n
 
 
+def _newest_profile(pattern):
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+    return json.load(open(files[-1])) if files else None
+
+
 def pmc_traffic(kernel, shape_key, shape_val):
     """HBM bytes per launch of `kernel` from the newest committed PMC pass (tools/collect_profiles.sh:
     separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command).  None when no pass has
     been recorded for this launch shape — the counters cannot be read from inside the process."""
-    import glob
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_traffic.json")))
-    if not files:
-        return None
-    d = json.load(open(files[-1]))
-    if (d.get("launch_shape") or {}).get(shape_key) != shape_val:
+    d = _newest_profile("r*_pmc_traffic.json")
+    if not d or (d.get("launch_shape") or {}).get(shape_key) != shape_val:
         return None
     hits = [int(sum(v["mean_bytes"] for v in c.values())) for name, c in d["kernels"].items() if kernel in name]
     return max(hits) if hits else None  # several instantiations of one kernel: the one that did the work
+
+
+def valu_frac(kernel, launch_ms, shape_key, shape_val):
+    """VALU issue utilisation of `kernel`: SQ_INSTS_VALU (wave instructions per launch, from the newest committed
+    tools/sq_counters.sh pass of this command) x 64 lanes / launch time / 78.6 T full-rate lane-ops/s."""
+    d = _newest_profile("r*_sq_counters.json")
+    if not d or not launch_ms or (d.get("launch_shape") or {}).get(shape_key) != shape_val:
+        return None
+    hits = [c.get("SQ_INSTS_VALU") for name, c in d["kernels"].items() if kernel in name and c.get("SQ_INSTS_VALU")]
+    if not hits:
+        return None
+    return round(max(hits) * 64.0 / (launch_ms * 1e-3) / VALU_PEAK_LANE_OPS, 4)
 
 
 def timed_steps(fn, steps, warmup, device):
@@ -83,36 +144,92 @@ def timed_steps(fn, steps, warmup, device):
     return shard.max_over_ranks(dt, device)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--pairs", type=int, default=1_000_000, help="read pairs per GPU (configs[1]: 1M)")
-    ap.add_argument("--read-len", type=int, default=150)
-    ap.add_argument("--genome", type=int, default=100_000_000, help="FM leg: genome length (configs[2]: 100 Mbp)")
-    ap.add_argument("--queries", type=int, default=10_000_000, help="FM leg: patterns per GPU (configs[2]: 10M)")
-    ap.add_argument("--pattern-len", type=int, default=100)
-    ap.add_argument("--skip-fm", action="store_true")
-    ap.add_argument("--skip-banded", action="store_true")
-    ap.add_argument("--banded-pairs", type=int, default=32768, help="banded leg: 10 kb pairs per GPU (configs[3] is 100k over 8 GPUs)")
-    ap.add_argument("--skip-pipeline", action="store_true")
-    ap.add_argument("--pipeline-reads", type=int, default=1_000_000, help="seed-and-extend leg: reads per GPU")
-    ap.add_argument("--skip-ingest", action="store_true")
-    ap.add_argument("--ingest-reads", type=int, default=1_000_000, help="FASTQ ingest leg: four-line records per GPU")
-    ap.add_argument("--skip-cpu", action="store_true")
-    ap.add_argument("--cpu-threads", type=int, default=0)
-    args = ap.parse_args()
+def median_time(fn, reps=3):
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    return float(np.median(ts))
 
+
+def kernel_timing(ctx, fn, reps=2):
+    """per-kernel launch durations of `fn` from HIP events on the launch stream (outside the timed region)"""
+    ctx.enable_timing(True)
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    tm = ctx.timing()
+    ctx.enable_timing(False)
+    return tm
+
+
+def sw_ops_equal(hrec, hops, stride, oout, oops, ostride):
+    """records + every operation of every pair (device ops are right-aligned in their slot)"""
+    ns = len(hrec)
+    ok = all((hrec[f].astype(np.int64) == oout[f].astype(np.int64)).all()
+             for f in ("score", "xstart", "xend", "ystart", "yend", "n_ops"))
+    if not ok:
+        return False
+    kq = hrec["n_ops"].astype(np.int64)
+    base = int(hrec["ops_off"][0]) + int(kq[0]) - stride  # slot 0 of this chunk
+    if not (hrec["ops_off"].astype(np.int64) == base + (np.arange(ns) + 1) * stride - kq).all():
+        return False
+    dev_mask = np.arange(stride)[None, :] >= (stride - kq)[:, None]
+    or_mask = np.arange(ostride)[None, :] < kq[:, None]
+    kind = (oops.reshape(ns, ostride) & np.uint64(0xFF)).astype(np.uint8)
+    return bool((hops.reshape(ns, stride)[dev_mask] == kind[or_mask]).all())
+
+
+def sw_parity(orc, osc, mode, x, y, L, d_out, d_ops, stride, n_check, threads, chunk=100_000):
+    """oracle pass over the first n_check pairs, chunked (the oracle's ops are 8 bytes each); returns
+    (bit_exact, seconds of oracle time)"""
+    ok, t_cpu = True, 0.0
+    for c0 in range(0, n_check, chunk):
+        k = min(chunk, n_check - c0)
+        hx = x[c0 * L:(c0 + k) * L].cpu().numpy()
+        hy = y[c0 * L:(c0 + k) * L].cpu().numpy()
+        ho = np.arange(k + 1, dtype=np.uint64) * np.uint64(L)
+        t0 = time.perf_counter()
+        oout, oops, ostride = orc.align_batch(osc, mode, hx, ho, hy, ho, threads=threads)
+        t_cpu += time.perf_counter() - t0
+        hrec = d_out[c0 * 64:(c0 + k) * 64].cpu().numpy().view(_lib.ALN_DTYPE)
+        hops = d_ops[c0 * stride:(c0 + k) * stride].cpu().numpy()
+        ok = ok and sw_ops_equal(hrec, hops, stride, oout, oops, ostride)
+    return bool(ok), t_cpu
+
+
+def sw_roofline(kernel, fill_ms, tb_ms, pairs_per_launch, L, n_ops_mean, note, shape_key="sw_pairs_per_launch"):
+    # algorithmic bytes per pair (SURVEY.md §8d, traceback spilled to HBM):
+    #   m + n + 24 + n_ops + 2 B x (m+1)(n+1) reference traceback cells
+    alg = L + L + 24 + n_ops_mean + 2.0 * (L + 1) * (L + 1)
+    ach = alg * pairs_per_launch / (fill_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": kernel, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(kernel, shape_key, int(pairs_per_launch)),
+            "valu_frac": valu_frac(kernel, fill_ms, shape_key, int(pairs_per_launch)),
+            "launch_ms": round(fill_ms, 4), "traceback_launch_ms": round(tb_ms, 4),
+            "alg_bytes_per_pair": round(alg, 1), "pairs_per_launch": int(pairs_per_launch), "note": note}
+
+
+def main():
+    args = ARGS
     rank, local_rank, world = shard.init_process_group()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
+    if args.gpus != world and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; reporting n_gpus={world}", file=sys.stderr)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     ctx = _lib.Context(local_rank)
     stream = torch.cuda.current_stream().cuda_stream
     L = args.read_len
     n_pairs = args.pairs
+    do_cpu = rank == 0 and world == 1 and not args.skip_cpu
+    threads = args.cpu_threads or host_cores()
+    parity = {} if do_cpu else None
+    orc = None
+    if do_cpu:
+        import oracle_py as orc
 
     # ------------------------------------------------------------------ SW leg (headline)
     x, xo, y, yo = synth_gpu.sw_pairs_big(n_pairs, L, seed=2 + 100003 * rank, device=dev)
@@ -129,82 +246,46 @@ def main():
             shard.gather_records(rec, counts=[n_pairs] * world)
 
     sw_t = timed_steps(sw_step, args.steps, args.warmup, dev)
-    cells_per_step = float(n_pairs) * L * L
-    gcups = world * cells_per_step * args.steps / sw_t / 1e9
-
-    # kernel-level timing with HIP events on the launch stream (outside the timed region)
-    ctx.enable_timing(True)
-    for _ in range(2):
-        sw_step()
-    torch.cuda.synchronize()
-    tm = ctx.timing()
-    ctx.enable_timing(False)
+    gcups = world * float(n_pairs) * L * L * args.steps / sw_t / 1e9
+    tm = kernel_timing(ctx, sw_step)
     fill_ms = tm["fill_ms"] / max(1, tm["fill_launches"])
     tb_ms = tm["traceback_ms"] / max(1, tm["traceback_launches"])
-    launches_per_step = tm["fill_launches"] / 2
+    pairs_per_launch = n_pairs / (tm["fill_launches"] / 2)
     rec = d_out.view(torch.int32).view(n_pairs, 16)
-    n_ops_total = int(rec[:, 7].to(torch.int64).sum().item())
-    pairs_per_launch = n_pairs / launches_per_step
-    # algorithmic bytes per pair (traceback spilled to HBM):
-    #   m + n + 24 + n_ops + 2 B x (m+1)(n+1) reference traceback cells
-    alg_bytes_pair = L + L + 24 + n_ops_total / n_pairs + 2.0 * (L + 1) * (L + 1)
-    achieved = alg_bytes_pair * pairs_per_launch / (fill_ms * 1e-3) / 1e9
+    n_ops_mean = float(rec[:, 7].to(torch.int64).sum().item()) / n_pairs
     fill_kernel = "sw_fill_pk16_kernel" if L <= 192 else "sw_fill_kernel"  # K1p: two pairs per lane (short reads)
-    roofline = {"bound": "hbm", "kernel": fill_kernel, "achieved": round(achieved, 2),
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": pmc_traffic(fill_kernel, "sw_pairs_per_launch", int(pairs_per_launch)),
-                "launch_ms": round(fill_ms, 4),
-                "traceback_launch_ms": round(tb_ms, 4),
-                "alg_bytes_per_pair": round(alg_bytes_pair, 1),
-                "pairs_per_launch": int(pairs_per_launch),
-                "note": "VALU-bound integer DP; HBM fraction reported as required, see DESIGN.md"}
+    roofline = sw_roofline(fill_kernel, fill_ms, tb_ms, pairs_per_launch, L, n_ops_mean,
+                           "VALU-bound integer DP: `frac` is the required HBM figure on the reference's 2 B/cell "
+                           "traceback, `valu_frac` the issue-rate utilisation that actually bounds it (DESIGN.md §4)")
 
-    # parity of a sample against the oracle + CPU baseline on the same sample (rank 0)
-    # the CPU legs (oracle parity sample + cpu_baseline) run on rank 0 of the single-GPU run only
-    do_cpu = rank == 0 and world == 1 and not args.skip_cpu
-    parity = {} if do_cpu else None
     cpu_baseline = None
+    host_api = None
     if do_cpu:
-        import oracle_py as orc
-        threads = args.cpu_threads or host_cores()
-        # bounded sample: ~10-60 CPU-seconds of work spread over all host cores
-        ns = min(n_pairs, max(40_000, 1500 * threads))
+        osc = orc.make_scoring(-5, -1, 1, -1)
+        n_chk = max(1, int(n_pairs * args.parity_frac))
+        ok, t_par = sw_parity(orc, osc, "local", x, y, L, d_out, d_ops, stride, n_chk, threads)
+        parity.update({"sw_pairs_checked": n_chk, "sw_pairs_total": n_pairs, "sw_bit_exact": ok})
+        # CPU baseline: median of 3 on a bounded sample (all host threads; one thread)
+        ns = min(n_pairs, 12_000 * threads)
         hx, hy = x[:ns * L].cpu().numpy(), y[:ns * L].cpu().numpy()
         ho = np.arange(ns + 1, dtype=np.uint64) * np.uint64(L)
-        osc = orc.make_scoring(-5, -1, 1, -1)
-        t0 = time.perf_counter()
-        oout, oops, ostride = orc.align_batch(osc, "local", hx, ho, hy, ho, threads=threads)
-        t_all = time.perf_counter() - t0
+        t_all = median_time(lambda: orc.align_batch(osc, "local", hx, ho, hy, ho, threads=threads))
         n1 = min(ns, 5000)
-        t0 = time.perf_counter()
-        orc.align_batch(osc, "local", hx[:n1 * L], ho[:n1 + 1], hy[:n1 * L], ho[:n1 + 1], threads=1)
-        t_one = time.perf_counter() - t0
-        hrec = d_out[:ns * 64].cpu().numpy().view(_lib.ALN_DTYPE)
-        hops = d_ops[:ns * stride].cpu().numpy().reshape(ns, stride)
-        ok = all((hrec[f].astype(np.int64) == oout[f].astype(np.int64)).all()
-                 for f in ("score", "xstart", "xend", "ystart", "yend", "n_ops"))
-        if ok:  # every operation of every sampled pair (device ops are right-aligned in their slot)
-            kq = hrec["n_ops"].astype(np.int64)
-            ok = bool((hrec["ops_off"].astype(np.int64) == (np.arange(ns) + 1) * stride - kq).all())
-            dev_mask = np.arange(stride)[None, :] >= (stride - kq)[:, None]
-            or_mask = np.arange(ostride)[None, :] < kq[:, None]
-            kind = (oops.reshape(ns, ostride) & np.uint64(0xFF)).astype(np.uint8)
-            ok = ok and bool((hops[dev_mask] == kind[or_mask]).all())
-        parity.update({"sw_sample_pairs": ns, "sw_bit_exact": bool(ok)})
+        t_one = median_time(lambda: orc.align_batch(osc, "local", hx[:n1 * L], ho[:n1 + 1], hy[:n1 * L], ho[:n1 + 1], threads=1))
+        cpu_baseline = {"value": round(ns * L * L / t_all / 1e9, 4), "unit": "GCUPS", "cores": threads, "kind": "port",
+                        "sample": f"{ns} of the {n_pairs} pairs, median of 3 runs, C++ restatement of rust-bio 4.0.1 "
+                                  "Aligner::local (oracle/), one Aligner per thread; rust-bio itself cannot be built here",
+                        "single_thread_value": round(n1 * L * L / t_one / 1e9, 4),
+                        "full_parity_pass_value": round(n_chk * L * L / t_par / 1e9, 4)}
         # PCIe-inclusive rate of the host-buffer entry point (bg_align_batch): never the headline value
-        nh = n_pairs
-        hxa, hya = x[:nh * L].cpu().numpy(), y[:nh * L].cpu().numpy()
-        hoa = np.arange(nh + 1, dtype=np.uint64) * np.uint64(L)
+        hxa, hya = x.cpu().numpy(), y.cpu().numpy()
+        hoa = np.arange(n_pairs + 1, dtype=np.uint64) * np.uint64(L)
         hout, hopsb = aligner.align_arrays(3, hxa, hoa, hya, hoa)  # warm-up: sizes the staging sets, touches the result pages
-        t0 = time.perf_counter()
-        aligner.align_arrays(3, hxa, hoa, hya, hoa, out=hout, ops=hopsb)
-        host_api_gcups = nh * L * L / (time.perf_counter() - t0) / 1e9
-        del hout, hopsb
-        cpu_baseline = {"value": round(ns * L * L / t_all / 1e9, 4), "unit": "GCUPS", "cores": threads,
-                        "kind": "port",
-                        "sample": f"{ns} of the {n_pairs} pairs, C++ restatement of rust-bio 4.0.1 "
-                                  "Aligner::local (oracle/), one Aligner per thread",
-                        "single_thread_value": round(n1 * L * L / t_one / 1e9, 4)}
+        t_h = median_time(lambda: aligner.align_arrays(3, hxa, hoa, hya, hoa, out=hout, ops=hopsb))
+        host_api = {"value": round(n_pairs * L * L / t_h / 1e9, 2), "unit": "GCUPS", "pairs": n_pairs,
+                    "note": "bg_align_batch with pageable host buffers in and out (PCIe-inclusive), median of 3: stages of "
+                            "131072 pairs through three pinned staging sets, upload / kernels / download / compaction overlapped"}
+        del hout, hopsb, hxa, hya
 
     result = {"metric": "GCUPS (SW) + FM-index queries/sec", "value": round(gcups, 3), "unit": "GCUPS",
               "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -214,239 +295,26 @@ def main():
                                      "affine-gap (-5,-1,+1,-1), score+coords+traceback ops (BASELINE configs[1])",
                          "pairs_per_gpu": n_pairs, "read_len": L, "parallelism": f"shard{world}"},
               "roofline": roofline}
-    if do_cpu:
-        result["host_api"] = {"value": round(host_api_gcups, 2), "unit": "GCUPS", "pairs": nh,
-                              "note": "bg_align_batch with pageable host buffers in and out (PCIe-inclusive): stages of 131072 pairs through "
-                                      "three pinned staging sets, upload / kernels / download / compaction overlapped"}
+    if host_api:
+        result["host_api"] = host_api
     del x, y, d_ops, d_out
     torch.cuda.empty_cache()
 
+    # ------------------------------------------------------------------ int32 kernel legs (K1)
+    if not args.skip_k1:
+        result["k1_int32"] = k1_legs(args, ctx, dev, stream, rank, world, do_cpu, orc, threads, parity)
+
     # ------------------------------------------------------------------ FM leg
     if not args.skip_fm:
-        t0 = time.perf_counter()
-        g_dev = synth_gpu.genome(args.genome, seed=3, device=dev)
-        g = g_dev.cpu().numpy()
-        sa = suffix_array(g)
-        b = bwt(g, sa)
-        ls = less(b, N_ALPHABET)
-        fm = FMIndex(b, ls, Occ(b, 128, N_ALPHABET), ctx=ctx)
-        build_s = time.perf_counter() - t0
-        n_q, P = args.queries, args.pattern_len
-        pat, off = synth_gpu.fm_patterns(g_dev, n_q, P, seed=4 + 100003 * rank)
-        d_tag = torch.empty(n_q, dtype=torch.uint8, device=dev)
-        d_lo = torch.empty(n_q, dtype=torch.int64, device=dev)
-        d_hi = torch.empty(n_q, dtype=torch.int64, device=dev)
-        d_ml = torch.empty(n_q, dtype=torch.int32, device=dev)
-
-        def fm_step():
-            fm.backward_search_dev(n_q, pat.data_ptr(), off.data_ptr(), d_tag.data_ptr(),
-                                   d_lo.data_ptr(), d_hi.data_ptr(), d_ml.data_ptr(), stream)
-            if world > 1:  # the single collective: intervals of every query
-                shard.gather_records(torch.stack((d_lo, d_hi), dim=1), counts=[n_q] * world)
-
-        fm_t = timed_steps(fm_step, args.steps, args.warmup, dev)
-        qps = world * float(n_q) * args.steps / fm_t
-        ctx.enable_timing(True)
-        for _ in range(2):
-            fm_step()
-        torch.cuda.synchronize()
-        tm = ctx.timing()
-        ctx.enable_timing(False)
-        fm_ms = tm["fm_ms"] / max(1, tm["fm_launches"])
-        ml = d_ml.to(torch.int64)
-        steps_exec = int((ml + (d_tag == 1).to(torch.int64) + (d_tag == 2).to(torch.int64)).sum().item())
-        # algorithmic bytes per query: |P| + 24 + 128 x LF steps executed
-        alg_bytes = float(n_q) * (P + 24) + 128.0 * steps_exec
-        fm_ach = alg_bytes / (fm_ms * 1e-3) / 1e9
-        fm_res = {"value": round(qps, 1), "unit": "queries/s", "ms_per_step": round(fm_t / args.steps * 1e3, 3),
-                  "config": {"workload": f"FMIndex over {args.genome} bp synthetic genome + '$' (n_alphabet, Occ k=128), "
-                                         f"{n_q} x {P} bp backward_search per GPU (BASELINE configs[2])",
-                             "index_bytes": fm.device_bytes(), "index_build_s": round(build_s, 1)},
-                  "tags": {"complete": int((d_tag == 0).sum().item()), "partial": int((d_tag == 1).sum().item()),
-                           "absent": int((d_tag == 2).sum().item())},
-                  "roofline": {"bound": "hbm", "kernel": "fm_backward_search_kernel<true>", "achieved": round(fm_ach, 2),
-                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(fm_ach / HBM_PEAK_GBS, 5),
-                               "traffic": pmc_traffic("fm_backward_search_kernel<true>", "fm_queries_per_launch", n_q),
-                               "launch_ms": round(fm_ms, 4), "queries_per_launch": n_q,
-                               "alg_bytes_per_query": round(alg_bytes / n_q, 1)}}
-        if do_cpu:
-            import oracle_py as orc
-            nsq = min(n_q, 400_000)
-            threads = args.cpu_threads or host_cores()
-            occ = orc.Occ(b, 128, N_ALPHABET)
-            hp = pat[:nsq * P].cpu().numpy()
-            hoff = np.arange(nsq + 1, dtype=np.uint64) * np.uint64(P)
-            t0 = time.perf_counter()
-            otag, olo, ohi, oml = orc.backward_search_batch(b, ls, occ, hp, hoff, threads=threads)
-            t_all = time.perf_counter() - t0
-            n1 = max(1, nsq // 8)
-            t0 = time.perf_counter()
-            orc.backward_search_batch(b, ls, occ, hp[:n1 * P], hoff[:n1 + 1], threads=1)
-            t_one = time.perf_counter() - t0
-            ok = bool((d_tag[:nsq].cpu().numpy() == otag).all() and
-                      (d_lo[:nsq].cpu().numpy().astype(np.uint64) == olo).all() and
-                      (d_hi[:nsq].cpu().numpy().astype(np.uint64) == ohi).all() and
-                      (d_ml[:nsq].cpu().numpy().astype(np.uint64) == oml).all())
-            parity["fm_sample_queries"] = nsq
-            parity["fm_bit_exact"] = ok
-            fm_res["cpu_baseline"] = {"value": round(nsq / t_all, 1), "unit": "queries/s", "cores": threads,
-                                      "kind": "port",
-                                      "sample": f"{nsq} of the {n_q} queries, C++ restatement of rust-bio 4.0.1 "
-                                                "backward_search + Occ::get (oracle/), shared index",
-                                      "single_thread_value": round(n1 / t_one, 1)}
-        result["fm"] = fm_res
-        del pat, off, d_tag, d_lo, d_hi, d_ml
-
-        # -------------------------------------------------------------- seed-and-extend leg (configs[4] shape)
-        if not args.skip_pipeline:
-            from rust_bio_amd.pipeline import seed_and_extend
-            from rust_bio_amd.suffix_array import SampledSuffixArray
-            t0 = time.perf_counter()
-            SampledSuffixArray(sa, g, b, 32, fmindex=fm)
-            sa_s = time.perf_counter() - t0
-            Rp = args.pipeline_reads
-            reads, r_starts = synth_gpu.reads_from_genome(g_dev, Rp, L, seed=5 + 100003 * rank)
-            al2 = Aligner.with_scoring(Scoring.from_scores(-5, -1, 1, -1), ctx=ctx)
-            holder = {}
-
-            def pipe_step():
-                holder["res"] = seed_and_extend(fm, al2, g_dev, args.genome, reads, Rp, L)
-
-            pipe_t = timed_steps(pipe_step, max(1, args.steps // 2), 1, dev)
-            res = holder["res"]
-            mapped = res.score > -(1 << 29)
-            near = ((res.ref_start - r_starts).abs() <= 8) & mapped
-            result["seed_extend"] = {
-                "value": round(world * Rp * max(1, args.steps // 2) / pipe_t, 1), "unit": "reads/s",
-                "config": {"workload": f"{Rp} x {L} bp reads per GPU (5% sub, 1% ins, 1% del) vs the {args.genome} bp genome: "
-                                       "20-bp seeds at stride 10 -> backward_search -> Interval::occ (sampled SA, rate 32, "
-                                       "intervals <= 16 rows) -> Aligner::semiglobal on +-25 bp windows -> best hit "
-                                       "(BASELINE configs[4] shape, genome scaled to the FM leg's)",
-                           "sampled_sa_build_s": round(sa_s, 1)},
-                "seed_hits": res.n_seed_hits, "candidates": res.n_candidates,
-                "mapped_frac": round(float(mapped.float().mean().item()), 4),
-                "mapped_at_origin_frac": round(float(near.float().mean().item()), 4)}
-            del reads, res, holder
-        del sa, g_dev
-        torch.cuda.empty_cache()
+        fm_legs(args, ctx, dev, stream, rank, world, do_cpu, orc, threads, parity, result)
 
     # ------------------------------------------------------------------ banded leg (configs[3] shape)
     if not args.skip_banded:
-        from rust_bio_amd.banded import Aligner as BandedAligner
-        Pb, Lb, kb, wb = args.banded_pairs, 10_000, 16, 32
-        bx, bxo, by, byo = synth_gpu.sw_pairs_big(Pb, Lb, seed=4 + 100003 * rank, device=dev, sub=0.06, ins=0.02,
-                                                   dele=0.02, chunk=64)
-        hx, hy = bx.cpu().numpy(), by.cpu().numpy()
-        hoff = np.arange(Pb + 1, dtype=np.uint64) * np.uint64(Lb)
-        bal = BandedAligner.with_scoring(Scoring.from_scores(-5, -1, 1, -1), kb, wb, ctx=ctx)
-        bal.align_arrays(2, hx, hoff, hy, hoff)  # warm-up at full size: sizes the pinned staging and device scratch
-        shard.barrier()
-        t0 = time.perf_counter()
-        bout, bops = bal.align_arrays(2, hx, hoff, hy, hoff)
-        bt = shard.max_over_ranks(time.perf_counter() - t0, dev)
-        # device-resident flavour: sequences, records and operation slots stay in HBM
-        d_boff = torch.arange(Pb + 1, dtype=torch.int64, device=dev) * Lb
-        bstride = 2 * Lb + 8
-        d_bout = torch.empty(Pb * 64, dtype=torch.uint8, device=dev)
-        d_bops = torch.empty(Pb * bstride, dtype=torch.uint8, device=dev)
-        bal.align_dev(2, Pb, bx.data_ptr(), d_boff.data_ptr(), by.data_ptr(), d_boff.data_ptr(), d_bout.data_ptr(),
-                      d_bops.data_ptr(), bstride)
-        shard.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        bal.align_dev(2, Pb, bx.data_ptr(), d_boff.data_ptr(), by.data_ptr(), d_boff.data_ptr(), d_bout.data_ptr(),
-                      d_bops.data_ptr(), bstride)
-        torch.cuda.synchronize()
-        bt_dev = shard.max_over_ranks(time.perf_counter() - t0, dev)
-        dev_ok = bool((d_bout.view(torch.int32).view(Pb, 16)[:, 0].cpu().numpy() == bout["score"]).all())
-        del d_bout, d_bops, bx, by
-        # kernel durations from a second, event-timed pass (timing serialises the K3/K4/host pipeline)
-        ctx.enable_timing(True)
-        bal.align_arrays(2, hx, hoff, hy, hoff)
-        tm = ctx.timing()
-        ctx.enable_timing(False)
-        bcells = float(bal.last_cells.sum())
-        # algorithmic bytes per pair: m + n + 8(n+1) + 2 x band_cells + 24 + n_ops
-        balg = float(Pb) * (2 * Lb + 8 * (Lb + 1) + 24) + 2.0 * bcells + float(bout["n_ops"].sum())
-        bfill_s = tm["fill_ms"] * 1e-3
-        Pb_launch = int(Pb / max(1, tm["fill_launches"]))
-        banded = {"value": round(world * bcells / bt / 1e9, 3), "unit": "GCUPS (band cells, host-buffer API: PCIe + band "
-                  "construction on the device + K3 + K4)",
-                  "pairs_per_s": round(world * Pb / bt, 1),
-                  "device_resident": {"value": round(world * bcells / bt_dev / 1e9, 3), "unit": "GCUPS (band cells)",
-                                      "pairs_per_s": round(world * Pb / bt_dev, 1), "scores_equal_host_api": dev_ok},
-                  "config": {"workload": f"{Pb} x 10 kb read pairs per GPU (6% sub, 2% ins, 2% del), banded::Aligner::"
-                                         f"semiglobal, k-mer {kb}, w {wb} (BASELINE configs[3] shape)",
-                             "mean_band_cells": round(bcells / Pb, 1)},
-                  "kernel_ms": {"fill": round(tm["fill_ms"], 2), "traceback": round(tm["traceback_ms"], 2)},
-                  "dp_only_gcups": round(bcells / ((tm["fill_ms"] + tm["traceback_ms"]) * 1e-3) / 1e9, 2),
-                  "host_threads": host_cores(),
-                  "roofline": {"bound": "hbm", "kernel": "banded_fill2_kernel (+ banded_epilogue_kernel)", "achieved": round(balg / bfill_s / 1e9, 2),
-                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(balg / bfill_s / 1e9 / HBM_PEAK_GBS, 5),
-                               "traffic": pmc_traffic("banded_fill2_kernel", "banded_pairs_per_launch", Pb_launch),
-                               "alg_bytes_per_pair": round(balg / Pb, 1)},
-                  "pairs_per_launch": Pb_launch}
-        if do_cpu:
-            import oracle_py as orc
-            nsb = min(Pb, max(8, (args.cpu_threads or host_cores()) // 2))
-            threads = min(nsb, args.cpu_threads or host_cores())
-            osc = orc.make_scoring(-5, -1, 1, -1)
-            t0 = time.perf_counter()
-            oout, oops, ostride, ocells = orc.banded_align_batch(osc, "semiglobal", kb, wb, hx[:nsb * Lb], hoff[:nsb + 1],
-                                                                 hy[:nsb * Lb], hoff[:nsb + 1], threads=threads)
-            t_all = time.perf_counter() - t0
-            okb = bool((bout["score"][:nsb] == oout["score"]).all() and (bout["n_ops"][:nsb] == oout["n_ops"]).all() and
-                       (bal.last_cells[:nsb] == ocells).all())
-            kind = (oops.reshape(nsb, ostride) & 0xFF).astype(np.uint8)
-            for p in range(nsb):
-                kq, oq = int(bout["n_ops"][p]), int(bout["ops_off"][p])
-                okb = okb and bool((bops[oq:oq + kq] == kind[p, :kq]).all())
-            parity["banded_sample_pairs"] = nsb
-            parity["banded_bit_exact"] = okb
-            banded["cpu_baseline"] = {"value": round(float(ocells.sum()) / t_all / 1e9, 4), "unit": "GCUPS (band cells)",
-                                      "cores": threads, "kind": "port",
-                                      "sample": f"{nsb} of the {Pb} pairs, C++ restatement of rust-bio 4.0.1 "
-                                                "banded::Aligner::semiglobal incl. band construction (oracle/)"}
-        result["banded"] = banded
+        result["banded"] = banded_leg(args, ctx, dev, rank, world, do_cpu, orc, threads, parity)
 
     # ------------------------------------------------------------------ ingest leg
     if not args.skip_ingest:
-        from rust_bio_amd import fastq as bgfastq
-        n_fq = args.ingest_reads
-        text = synth.fastq_text(n_fq, L, seed=6 + 100003 * rank)
-        d_text = torch.from_numpy(text).to(dev)
-        fq_bufs = bgfastq.alloc_dev(len(text), dev)  # the caller's buffers, reused by every call
-        bgfastq.parse_dev(d_text, ctx=ctx, stream=stream, bufs=fq_bufs)  # warm-up: sizes the scratch
-        shard.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(3):
-            k, st, _, d_recs, d_seq, d_so, d_qual, d_qo = bgfastq.parse_dev(d_text, ctx=ctx, stream=stream, bufs=fq_bufs)
-        torch.cuda.synchronize()
-        it = shard.max_over_ranks((time.perf_counter() - t0) / 3, dev)
-        seq_bytes = int(d_so[-1].item())
-        ingest = {"value": round(world * len(text) / it / 1e9, 2), "unit": "GB/s of FASTQ text (device-resident text -> records, "
-                  "concatenated sequences/qualities + offsets, Record::check)", "reads_per_s": round(world * k / it, 1),
-                  "config": {"workload": f"{n_fq} four-line records of {L} bp per GPU ({len(text)} bytes)"},
-                  "status": st, "records": int(k),
-                  "roofline": {"bound": "hbm", "achieved": round((len(text) + 2 * seq_bytes + 56 * k + 16 * k) / it / 1e9, 2),
-                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
-                               "note": "algorithmic bytes: text once + sequences, qualities, records and offsets written"}}
-        ingest["roofline"]["frac"] = round(ingest["roofline"]["achieved"] / HBM_PEAK_GBS, 5)
-        if do_cpu:
-            ns = min(n_fq, 200_000)
-            sample = synth.fastq_text(ns, L, seed=6)
-            t0 = time.perf_counter()
-            want, wst, _ = orc.fastq_parse_raw(sample)
-            ct = time.perf_counter() - t0
-            got = bgfastq.parse_arrays(sample, ctx=ctx)
-            okf = wst == 0 and len(got) == len(want[0]) and bytes(got.seq) == want[1] and bytes(got.qual) == want[2]
-            parity["ingest_sample_records"] = ns
-            parity["ingest_bit_exact"] = bool(okf)
-            ingest["cpu_baseline"] = {"value": round(len(sample) / ct / 1e9, 3), "unit": "GB/s of FASTQ text", "cores": 1, "kind": "port",
-                                      "sample": f"{ns} records, C++ restatement of bio::io::fastq::Reader::read + Record::check (oracle/)"}
-        del d_text, fq_bufs
-        result["ingest"] = ingest
+        result["ingest"] = ingest_leg(args, ctx, dev, stream, rank, world, do_cpu, orc, parity)
 
     if rank == 0:
         if cpu_baseline is not None:
@@ -456,6 +324,380 @@ def main():
         print(json.dumps(result), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
+
+
+def k1_legs(args, ctx, dev, stream, rank, world, do_cpu, orc, threads, parity):
+    """The general kernel K1 (int32 DP values, LDS score table): what runs when K1p's conditions do not hold —
+    tabulated match functions (BLOSUM62 protein pairs, pairwise/mod.rs:1309-1337) and scores beyond 12 bits."""
+    L, n = 150, args.k1_pairs
+    stride = 2 * L + 4
+    mat = np.zeros((256, 256), dtype=np.int32)
+    for k, v in json.load(open(os.path.join(ROOT, "tests", "golden", "blosum62.json")))["pairs"].items():
+        mat[ord(k[0]), ord(k[1])] = v
+    legs = {}
+    cases = [("blosum62_protein", synth_gpu.protein_pairs(n, L, seed=12 + 100003 * rank, device=dev),
+              Scoring.new(-5, -1, mat), dict(matrix=mat),
+              f"{n} x {L} aa protein pairs per GPU, Aligner::local, blosum62 tabulated (27 byte classes in LDS), gaps -5/-1"),
+             ("wide_scores_dna", synth_gpu.sw_pairs_big(n, L, seed=13 + 100003 * rank, device=dev),
+              Scoring.from_scores(-500, -100, 100, -100), dict(match=100, mismatch=-100),
+              f"{n} x {L} bp DNA pairs per GPU, Aligner::local, from_scores(-500,-100,100,-100): scores beyond K1p's 12 bits")]
+    for name, (x, xo, y, yo), scoring, okw, desc in cases:
+        d_out = torch.empty(n * 64, dtype=torch.uint8, device=dev)
+        d_ops = torch.empty(n * stride, dtype=torch.uint8, device=dev)
+        al = Aligner.with_scoring(scoring, ctx=ctx)
+
+        def step():
+            al.align_dev(3, n, x.data_ptr(), xo.data_ptr(), y.data_ptr(), yo.data_ptr(), L, L, d_out.data_ptr(),
+                         d_ops.data_ptr(), stride, stream)
+
+        t = timed_steps(step, args.steps, args.warmup, dev)
+        tm = kernel_timing(ctx, step)
+        fill_ms = tm["fill_ms"] / max(1, tm["fill_launches"])
+        tb_ms = tm["traceback_ms"] / max(1, tm["traceback_launches"])
+        ppl = n / (tm["fill_launches"] / 2)
+        n_ops_mean = float(d_out.view(torch.int32).view(n, 16)[:, 7].to(torch.int64).sum().item()) / n
+        leg = {"value": round(world * float(n) * L * L * args.steps / t / 1e9, 2), "unit": "GCUPS", "dtype": "int32",
+               "ms_per_step": round(t / args.steps * 1e3, 3), "config": {"workload": desc},
+               "roofline": sw_roofline("sw_fill_kernel", fill_ms, tb_ms, ppl, L, n_ops_mean,
+                                       "K1 (int32): VALU-bound", shape_key="k1_pairs_per_launch")}
+        if do_cpu:
+            go, ge = scoring.gap_open, scoring.gap_extend
+            osc = orc.make_scoring(go, ge, **okw)
+            n_chk = max(1, int(min(n, 100_000) * args.parity_frac))
+            ok, t_par = sw_parity(orc, osc, "local", x, y, L, d_out, d_ops, stride, n_chk, threads)
+            parity[f"k1_{name}_pairs_checked"] = n_chk
+            parity[f"k1_{name}_bit_exact"] = ok
+            leg["cpu_baseline"] = {"value": round(n_chk * L * L / t_par / 1e9, 4), "unit": "GCUPS", "cores": threads,
+                                   "kind": "port", "sample": f"{n_chk} of the {n} pairs (the parity pass), oracle Aligner::local"}
+        legs[name] = leg
+        del x, y, d_out, d_ops
+    torch.cuda.empty_cache()
+    return legs
+
+
+def build_index(args, ctx, dev, rank, world, want_sa):
+    """The genome is generated on every rank (same seed); suffix array + BWT are built once, on rank 0, and the BWT
+    and the rate-32 suffix-array samples are broadcast (RCCL) — the host SA-IS is the slow part and the ranks
+    share the node's cores."""
+    from rust_bio_amd.suffix_array import SampledSuffixArray
+    t0 = time.perf_counter()
+    g_dev = synth_gpu.genome(args.genome, seed=3, device=dev)
+    g = g_dev.cpu().numpy()
+    n = len(g)
+    sa = None
+    if rank == 0:
+        sa = suffix_array(g)
+        b = bwt(g, sa)
+        ssa = SampledSuffixArray(sa, g, b, 32)
+        samp, erow, epos = ssa.sample, ssa.extra_rows, ssa.extra_pos
+    if world > 1:
+        d_b = torch.from_numpy(b).to(dev) if rank == 0 else torch.empty(n, dtype=torch.uint8, device=dev)
+        shard.broadcast(d_b, 0)
+        meta = torch.tensor([len(samp), len(erow)] if rank == 0 else [0, 0], dtype=torch.int64, device=dev)
+        shard.broadcast(meta, 0)
+        ns, ne = int(meta[0]), int(meta[1])
+        bufs = []
+        for arr, k in ((samp if rank == 0 else None, ns), (erow if rank == 0 else None, ne), (epos if rank == 0 else None, ne)):
+            t = torch.from_numpy(arr.astype(np.int64)).to(dev) if rank == 0 else torch.empty(k, dtype=torch.int64, device=dev)
+            shard.broadcast(t, 0)
+            bufs.append(t.cpu().numpy().astype(np.uint64))
+        if rank != 0:
+            b = d_b.cpu().numpy()
+            ssa = SampledSuffixArray.__new__(SampledSuffixArray)
+            ssa.s, ssa.sentinel, ssa.n, ssa.fm = 32, int(g[-1]), n, None
+            ssa.sample, ssa.extra_rows, ssa.extra_pos = (np.ascontiguousarray(v) for v in bufs)
+        del d_b
+    ls = less(b, N_ALPHABET)
+    fm = FMIndex(b, ls, Occ(b, 128, N_ALPHABET), ctx=ctx)
+    ssa.attach(fm)
+    return g_dev, g, (sa if want_sa else None), b, ls, fm, time.perf_counter() - t0
+
+
+def fm_legs(args, ctx, dev, stream, rank, world, do_cpu, orc, threads, parity, result):
+    L = args.read_len
+    g_dev, g, sa, b, ls, fm, build_s = build_index(args, ctx, dev, rank, world, want_sa=do_cpu and not args.skip_pipeline)
+    n_q, P = args.queries, args.pattern_len
+    pat, off = synth_gpu.fm_patterns(g_dev, n_q, P, seed=4 + 100003 * rank)
+    d_tag = torch.empty(n_q, dtype=torch.uint8, device=dev)
+    d_lo = torch.empty(n_q, dtype=torch.int64, device=dev)
+    d_hi = torch.empty(n_q, dtype=torch.int64, device=dev)
+    d_ml = torch.empty(n_q, dtype=torch.int32, device=dev)
+
+    def fm_step():
+        fm.backward_search_dev(n_q, pat.data_ptr(), off.data_ptr(), d_tag.data_ptr(),
+                               d_lo.data_ptr(), d_hi.data_ptr(), d_ml.data_ptr(), stream)
+        if world > 1:  # the single collective: intervals of every query
+            shard.gather_records(torch.stack((d_lo, d_hi), dim=1), counts=[n_q] * world)
+
+    fm_t = timed_steps(fm_step, args.steps, args.warmup, dev)
+    qps = world * float(n_q) * args.steps / fm_t
+    tm = kernel_timing(ctx, fm_step)
+    fm_ms = tm["fm_ms"] / max(1, tm["fm_launches"])
+    ml = d_ml.to(torch.int64)
+    steps_exec = int((ml + (d_tag == 1).to(torch.int64) + (d_tag == 2).to(torch.int64)).sum().item())
+    # algorithmic bytes per query (SURVEY.md §8d): |P| + 24 + 128 x LF steps executed
+    alg_bytes = float(n_q) * (P + 24) + 128.0 * steps_exec
+    fm_ach = alg_bytes / (fm_ms * 1e-3) / 1e9
+    fm_res = {"value": round(qps, 1), "unit": "queries/s", "ms_per_step": round(fm_t / args.steps * 1e3, 3), "scaling": "weak",
+              "config": {"workload": f"FMIndex over {args.genome} bp synthetic genome + '$' (n_alphabet, Occ k=128), "
+                                     f"{n_q} x {P} bp backward_search per GPU (BASELINE configs[2])",
+                         "index_bytes": fm.device_bytes(), "index_build_s": round(build_s, 1),
+                         "index_build": "suffix array + BWT on rank 0's host cores, broadcast to the other ranks"},
+              "tags": {"complete": int((d_tag == 0).sum().item()), "partial": int((d_tag == 1).sum().item()),
+                       "absent": int((d_tag == 2).sum().item())},
+              "roofline": {"bound": "hbm", "kernel": "fm_backward_search_kernel", "achieved": round(fm_ach, 2),
+                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(fm_ach / HBM_PEAK_GBS, 5),
+                           "traffic": pmc_traffic("fm_backward_search_kernel", "fm_queries_per_launch", n_q),
+                           "launch_ms": round(fm_ms, 4), "queries_per_launch": n_q,
+                           "alg_bytes_per_query": round(alg_bytes / n_q, 1),
+                           "note": "the 33 MB block index of a 100 Mbp text sits in the 256 MiB Infinity Cache: see fm_big "
+                                   "for an index that cannot"}}
+
+    # strong scaling on configs[2]: the SAME n_q queries in total, split over the ranks, gathered inside the step
+    q_lo, q_hi = shard.partition(n_q, rank, world)
+    if world > 1:  # every rank must search the same global query set: regenerate it from rank 0's seed
+        pat_s, off_s = synth_gpu.fm_patterns(g_dev, n_q, P, seed=4)
+    else:
+        pat_s, off_s = pat, off
+    my = q_hi - q_lo
+    counts = [shard.partition(n_q, r, world)[1] - shard.partition(n_q, r, world)[0] for r in range(world)]
+    s_off = (off_s[q_lo:q_hi + 1] - off_s[q_lo]).contiguous()
+    s_pat = pat_s[int(off_s[q_lo].item()):int(off_s[q_hi].item())].contiguous()
+    holder = {}
+
+    def fm_strong_step():
+        fm.backward_search_dev(my, s_pat.data_ptr(), s_off.data_ptr(), d_tag.data_ptr(), d_lo.data_ptr(),
+                               d_hi.data_ptr(), d_ml.data_ptr(), stream)
+        rec = torch.stack((d_lo[:my], d_hi[:my], d_ml[:my].to(torch.int64) | (d_tag[:my].to(torch.int64) << 32)), dim=1)
+        holder["all"] = shard.gather_records(rec, counts=counts)  # 24-byte records {lower, upper, tag|matched_len}
+
+    st_t = timed_steps(fm_strong_step, args.steps, args.warmup, dev)
+    fm_res["strong"] = {"value": round(float(n_q) * args.steps / st_t, 1), "unit": "queries/s", "scaling": "strong",
+                        "ms_per_step": round(st_t / args.steps * 1e3, 3), "queries_total": n_q, "queries_per_gpu": my,
+                        "collective": "one all-gather of 24-byte records per step (RCCL)" if world > 1 else "none (1 GPU)",
+                        "gathered_records": int(holder["all"].shape[0])}
+    if world > 1:  # the gathered records of the sharded run must be the unsharded answer
+        fm.backward_search_dev(n_q, pat_s.data_ptr(), off_s.data_ptr(), d_tag.data_ptr(), d_lo.data_ptr(),
+                               d_hi.data_ptr(), d_ml.data_ptr(), stream)
+        full = torch.stack((d_lo, d_hi, d_ml.to(torch.int64) | (d_tag.to(torch.int64) << 32)), dim=1)
+        fm_res["strong"]["sharded_equals_unsharded"] = bool((full == holder["all"]).all().item())
+        fm_step()  # restore this rank's own results for the checks below
+        del pat_s, off_s
+    del s_pat, s_off, holder
+
+    if do_cpu:
+        occ = orc.Occ(b, 128, N_ALPHABET)
+        n_chk = max(1, int(n_q * args.parity_frac))
+        hp = pat[:n_chk * P].cpu().numpy()
+        hoff = np.arange(n_chk + 1, dtype=np.uint64) * np.uint64(P)
+        t0 = time.perf_counter()
+        otag, olo, ohi, oml = orc.backward_search_batch(b, ls, occ, hp, hoff, threads=threads)
+        t_par = time.perf_counter() - t0
+        ok = bool((d_tag[:n_chk].cpu().numpy() == otag).all() and
+                  (d_lo[:n_chk].cpu().numpy().astype(np.uint64) == olo).all() and
+                  (d_hi[:n_chk].cpu().numpy().astype(np.uint64) == ohi).all() and
+                  (d_ml[:n_chk].cpu().numpy().astype(np.uint64) == oml).all())
+        parity.update({"fm_queries_checked": n_chk, "fm_queries_total": n_q, "fm_bit_exact": ok})
+        del otag, olo, ohi, oml
+        nsq = min(n_q, 60_000 * threads)
+        t_all = median_time(lambda: orc.backward_search_batch(b, ls, occ, hp[:nsq * P], hoff[:nsq + 1], threads=threads))
+        n1 = max(1, nsq // 16)
+        t_one = median_time(lambda: orc.backward_search_batch(b, ls, occ, hp[:n1 * P], hoff[:n1 + 1], threads=1))
+        fm_res["cpu_baseline"] = {"value": round(nsq / t_all, 1), "unit": "queries/s", "cores": threads, "kind": "port",
+                                  "sample": f"{nsq} of the {n_q} queries, median of 3 runs, C++ restatement of rust-bio 4.0.1 "
+                                            "backward_search + Occ::get (oracle/), shared index",
+                                  "single_thread_value": round(n1 / t_one, 1),
+                                  "full_parity_pass_value": round(n_chk / t_par, 1)}
+        # PCIe-inclusive figure of the host-buffer entry point (bg_fm_backward_search_batch)
+        hp_all = pat.cpu().numpy()
+        hoff_all = np.arange(n_q + 1, dtype=np.uint64) * np.uint64(P)
+        fm.backward_search_arrays(hp_all[:P * 1000], hoff_all[:1001])
+        t_h = median_time(lambda: fm.backward_search_arrays(hp_all, hoff_all))
+        fm_res["host_api"] = {"value": round(n_q / t_h, 1), "unit": "queries/s", "queries": n_q,
+                              "note": "bg_fm_backward_search_batch: pageable host buffers in and out (PCIe-inclusive), median of 3"}
+        del hp, hp_all
+    result["fm"] = fm_res
+    del pat, off, d_tag, d_lo, d_hi, d_ml
+
+    # -------------------------------------------------------------- seed-and-extend leg (configs[4] shape)
+    if not args.skip_pipeline:
+        result["seed_extend"] = seed_extend_leg(args, ctx, dev, stream, rank, world, do_cpu, orc, threads, parity,
+                                                fm, g_dev, g, sa, b, ls)
+    del sa, g_dev, fm
+    torch.cuda.empty_cache()
+
+
+def seed_extend_leg(args, ctx, dev, stream, rank, world, do_cpu, orc, threads, parity, fm, g_dev, g, sa, b, ls):
+    from rust_bio_amd.pipeline import seed_and_extend
+    L, Rp = args.read_len, args.pipeline_reads
+    reads, r_starts = synth_gpu.reads_from_genome(g_dev, Rp, L, seed=5 + 100003 * rank)
+    al2 = Aligner.with_scoring(Scoring.from_scores(-5, -1, 1, -1), ctx=ctx)
+    holder = {}
+
+    def pipe_step():
+        holder["res"] = seed_and_extend(fm, al2, g_dev, args.genome, reads, Rp, L)
+
+    k_steps = max(1, args.steps // 2)
+    pipe_t = timed_steps(pipe_step, k_steps, 1, dev)
+    res = holder["res"]
+    mapped = res.score > -(1 << 29)
+    near = ((res.ref_start - r_starts).abs() <= 8) & mapped
+    leg = {"value": round(world * Rp * k_steps / pipe_t, 1), "unit": "reads/s",
+           "config": {"workload": f"{Rp} x {L} bp reads per GPU (5% sub, 1% ins, 1% del) vs the {args.genome} bp genome: "
+                                  "20-bp seeds at stride 10 -> backward_search -> Interval::occ (sampled SA, rate 32, "
+                                  "intervals <= 16 rows) -> Aligner::semiglobal on +-25 bp windows -> best hit "
+                                  "(BASELINE configs[4] shape, genome scaled to the FM leg's)"},
+           "seed_hits": res.n_seed_hits, "candidates": res.n_candidates,
+           "mapped_frac": round(float(mapped.float().mean().item()), 4),
+           "mapped_at_origin_frac": round(float(near.float().mean().item()), 4)}
+    if do_cpu:
+        occ = orc.Occ(b, 128, N_ALPHABET)
+        osc = orc.make_scoring(-5, -1, 1, -1)
+        n_chk = max(1, int(min(Rp, 100_000) * args.parity_frac))
+        hr = reads[:n_chk * L].cpu().numpy()
+        ho = np.arange(n_chk + 1, dtype=np.uint64) * np.uint64(L)
+        t0 = time.perf_counter()
+        hits, _, _ = orc.seed_extend_batch(b, ls, occ, sa, g, args.genome, osc, hr, ho, threads=threads, want_ops=False)
+        t_par = time.perf_counter() - t0
+        o_rs = hits["ref_start"].astype(np.int64)  # UINT64_MAX -> -1
+        o_re = hits["ref_end"].astype(np.int64)
+        ok = bool((res.score[:n_chk].cpu().numpy() == hits["aln"]["score"]).all() and
+                  (res.ref_start[:n_chk].cpu().numpy() == o_rs).all() and (res.ref_end[:n_chk].cpu().numpy() == o_re).all())
+        parity.update({"seed_extend_reads_checked": n_chk, "seed_extend_reads_total": Rp, "seed_extend_bit_exact": ok})
+        ns = min(n_chk, 2_000 * threads)
+        t_all = median_time(lambda: orc.seed_extend_batch(b, ls, occ, sa, g, args.genome, osc, hr[:ns * L], ho[:ns + 1],
+                                                          threads=threads, want_ops=False))
+        leg["cpu_baseline"] = {"value": round(ns / t_all, 1), "unit": "reads/s", "cores": threads, "kind": "port",
+                               "sample": f"{ns} of the {Rp} reads, median of 3 runs: the same composition out of the oracle's "
+                                         "backward_search, Interval::occ (raw suffix array) and Aligner::semiglobal (oracle/pipeline.cpp)",
+                               "full_parity_pass_value": round(n_chk / t_par, 1)}
+    return leg
+
+
+def banded_leg(args, ctx, dev, rank, world, do_cpu, orc, threads, parity):
+    from rust_bio_amd.banded import Aligner as BandedAligner
+    Pb, Lb, kb, wb = args.banded_pairs, 10_000, 16, 32
+    bx, bxo, by, byo = synth_gpu.sw_pairs_big(Pb, Lb, seed=4 + 100003 * rank, device=dev, sub=0.06, ins=0.02,
+                                               dele=0.02, chunk=64)
+    hx, hy = bx.cpu().numpy(), by.cpu().numpy()
+    hoff = np.arange(Pb + 1, dtype=np.uint64) * np.uint64(Lb)
+    bal = BandedAligner.with_scoring(Scoring.from_scores(-5, -1, 1, -1), kb, wb, ctx=ctx)
+    bal.align_arrays(2, hx, hoff, hy, hoff)  # warm-up at full size: sizes the pinned staging and device scratch
+    shard.barrier()
+    t0 = time.perf_counter()
+    bout, bops = bal.align_arrays(2, hx, hoff, hy, hoff)
+    bt = shard.max_over_ranks(time.perf_counter() - t0, dev)
+    # device-resident flavour: sequences, records and operation slots stay in HBM
+    d_boff = torch.arange(Pb + 1, dtype=torch.int64, device=dev) * Lb
+    bstride = 2 * Lb + 8
+    d_bout = torch.empty(Pb * 64, dtype=torch.uint8, device=dev)
+    d_bops = torch.empty(Pb * bstride, dtype=torch.uint8, device=dev)
+    bal.align_dev(2, Pb, bx.data_ptr(), d_boff.data_ptr(), by.data_ptr(), d_boff.data_ptr(), d_bout.data_ptr(),
+                  d_bops.data_ptr(), bstride)
+    shard.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    bal.align_dev(2, Pb, bx.data_ptr(), d_boff.data_ptr(), by.data_ptr(), d_boff.data_ptr(), d_bout.data_ptr(),
+                  d_bops.data_ptr(), bstride)
+    torch.cuda.synchronize()
+    bt_dev = shard.max_over_ranks(time.perf_counter() - t0, dev)
+    dev_ok = bool((d_bout.view(torch.int32).view(Pb, 16)[:, 0].cpu().numpy() == bout["score"]).all())
+    del d_bout, d_bops, bx, by
+    # kernel durations from a second, event-timed pass (timing serialises the K3/K4/host pipeline)
+    ctx.enable_timing(True)
+    bal.align_arrays(2, hx, hoff, hy, hoff)
+    tm = ctx.timing()
+    ctx.enable_timing(False)
+    bcells = float(bal.last_cells.sum())
+    # algorithmic bytes per pair (SURVEY.md §8d): m + n + 8(n+1) + 2 x band_cells + 24 + n_ops
+    balg = float(Pb) * (2 * Lb + 8 * (Lb + 1) + 24) + 2.0 * bcells + float(bout["n_ops"].sum())
+    bfill_s = tm["fill_ms"] * 1e-3
+    Pb_launch = int(Pb / max(1, tm["fill_launches"]))
+    fill_launch_ms = tm["fill_ms"] / max(1, tm["fill_launches"])
+    banded = {"value": round(world * bcells / bt / 1e9, 3), "unit": "GCUPS (band cells, host-buffer API: PCIe + band "
+              "construction on the device + fill + traceback)",
+              "pairs_per_s": round(world * Pb / bt, 1),
+              "device_resident": {"value": round(world * bcells / bt_dev / 1e9, 3), "unit": "GCUPS (band cells)",
+                                  "pairs_per_s": round(world * Pb / bt_dev, 1), "scores_equal_host_api": dev_ok},
+              "config": {"workload": f"{Pb} x 10 kb read pairs per GPU (6% sub, 2% ins, 2% del), banded::Aligner::"
+                                     f"semiglobal, k-mer {kb}, w {wb} (BASELINE configs[3] shape)",
+                         "mean_band_cells": round(bcells / Pb, 1)},
+              "kernel_ms": {"fill": round(tm["fill_ms"], 2), "traceback": round(tm["traceback_ms"], 2)},
+              "dp_only_gcups": round(bcells / ((tm["fill_ms"] + tm["traceback_ms"]) * 1e-3) / 1e9, 2),
+              "host_threads": host_cores(),
+              "roofline": {"bound": "hbm", "kernel": "banded_fill", "achieved": round(balg / bfill_s / 1e9, 2),
+                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(balg / bfill_s / 1e9 / HBM_PEAK_GBS, 5),
+                           "traffic": pmc_traffic("banded_fill", "banded_pairs_per_launch", Pb_launch),
+                           "valu_frac": valu_frac("banded_fill", fill_launch_ms, "banded_pairs_per_launch", Pb_launch),
+                           "launch_ms": round(fill_launch_ms, 3),
+                           "alg_bytes_per_pair": round(balg / Pb, 1)},
+              "pairs_per_launch": Pb_launch}
+    if do_cpu:
+        nsb = min(Pb, max(8, int(512 * args.parity_frac)))  # >= 1 % of the 32 768 pairs
+        osc = orc.make_scoring(-5, -1, 1, -1)
+        t0 = time.perf_counter()
+        oout, oops, ostride, ocells = orc.banded_align_batch(osc, "semiglobal", kb, wb, hx[:nsb * Lb], hoff[:nsb + 1],
+                                                             hy[:nsb * Lb], hoff[:nsb + 1], threads=min(nsb, threads))
+        t_par = time.perf_counter() - t0
+        okb = bool(all((bout[f][:nsb].astype(np.int64) == oout[f].astype(np.int64)).all()
+                       for f in ("score", "xstart", "xend", "ystart", "yend", "n_ops")) and
+                   (bal.last_cells[:nsb] == ocells).all())
+        kind = (oops.reshape(nsb, ostride) & 0xFF).astype(np.uint8)
+        for p in range(nsb):
+            kq, oq = int(bout["n_ops"][p]), int(bout["ops_off"][p])
+            okb = okb and bool((bops[oq:oq + kq] == kind[p, :kq]).all())
+        parity.update({"banded_pairs_checked": nsb, "banded_pairs_total": Pb, "banded_bit_exact": okb})
+        nt = min(nsb, 4 * threads)
+        t_all = median_time(lambda: orc.banded_align_batch(osc, "semiglobal", kb, wb, hx[:nt * Lb], hoff[:nt + 1],
+                                                           hy[:nt * Lb], hoff[:nt + 1], threads=min(nt, threads), want_ops=False))
+        banded["cpu_baseline"] = {"value": round(float(ocells[:nt].sum()) / t_all / 1e9, 4), "unit": "GCUPS (band cells)",
+                                  "cores": min(nt, threads), "kind": "port",
+                                  "sample": f"{nt} of the {Pb} pairs, median of 3 runs, C++ restatement of rust-bio 4.0.1 "
+                                            "banded::Aligner::semiglobal incl. band construction (oracle/)",
+                                  "full_parity_pass_value": round(float(ocells.sum()) / t_par / 1e9, 4)}
+    return banded
+
+
+def ingest_leg(args, ctx, dev, stream, rank, world, do_cpu, orc, parity):
+    from rust_bio_amd import fastq as bgfastq
+    L = args.read_len
+    n_fq = args.ingest_reads
+    text = synth.fastq_text(n_fq, L, seed=6 + 100003 * rank)
+    d_text = torch.from_numpy(text).to(dev)
+    fq_bufs = bgfastq.alloc_dev(len(text), dev)  # the caller's buffers, reused by every call
+    bgfastq.parse_dev(d_text, ctx=ctx, stream=stream, bufs=fq_bufs)  # warm-up: sizes the scratch
+    shard.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        k, st, _, d_recs, d_seq, d_so, d_qual, d_qo = bgfastq.parse_dev(d_text, ctx=ctx, stream=stream, bufs=fq_bufs)
+    torch.cuda.synchronize()
+    it = shard.max_over_ranks((time.perf_counter() - t0) / 3, dev)
+    seq_bytes = int(d_so[-1].item())
+    ingest = {"value": round(world * len(text) / it / 1e9, 2), "unit": "GB/s of FASTQ text (device-resident text -> records, "
+              "concatenated sequences/qualities + offsets, Record::check)", "reads_per_s": round(world * k / it, 1),
+              "config": {"workload": f"{n_fq} four-line records of {L} bp per GPU ({len(text)} bytes)"},
+              "status": st, "records": int(k),
+              "roofline": {"bound": "hbm", "achieved": round((len(text) + 2 * seq_bytes + 56 * k + 16 * k) / it / 1e9, 2),
+                           "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "traffic": pmc_traffic("fastq_", "ingest_bytes", len(text)),
+                           "note": "algorithmic bytes: text once + sequences, qualities, records and offsets written; "
+                                   "several short kernels + host syncs per call (launch/sync bound)"}}
+    ingest["roofline"]["frac"] = round(ingest["roofline"]["achieved"] / HBM_PEAK_GBS, 5)
+    if do_cpu:
+        ns = min(n_fq, 200_000)
+        sample = synth.fastq_text(ns, L, seed=6)
+        t0 = time.perf_counter()
+        want, wst, _ = orc.fastq_parse_raw(sample)
+        ct = time.perf_counter() - t0
+        got = bgfastq.parse_arrays(sample, ctx=ctx)
+        okf = wst == 0 and len(got) == len(want[0]) and bytes(got.seq) == want[1] and bytes(got.qual) == want[2]
+        parity["ingest_sample_records"] = ns
+        parity["ingest_bit_exact"] = bool(okf)
+        ingest["cpu_baseline"] = {"value": round(len(sample) / ct / 1e9, 3), "unit": "GB/s of FASTQ text", "cores": 1, "kind": "port",
+                                  "sample": f"{ns} records, C++ restatement of bio::io::fastq::Reader::read + Record::check (oracle/)"}
+    del d_text, fq_bufs
+    return ingest
 
 
 if __name__ == "__main__":

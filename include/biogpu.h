@@ -17,6 +17,16 @@
  *   bg_*_batch      caller passes HOST buffers (the drop-in boundary; includes PCIe copies)
  *   bg_*_batch_dev  caller passes DEVICE pointers + a hipStream_t (as void*): inputs already
  *                   resident in HBM, results left in HBM, asynchronous on that stream.
+ *
+ * Streams and threads.  A bg_ctx owns ONE set of device scratch (traceback words, aux records, scoring table).
+ * *_dev calls that use it may be issued on different streams: a call arriving on another stream than the
+ * previous one first waits, on the device, for that call's last kernel (an event per ctx), so two calls in
+ * flight never share scratch — they serialise.  For real overlap use one bg_ctx per stream.  A bg_ctx must
+ * not be used from two host threads at once (like `&mut Aligner`).  A bg_fm is immutable after bg_fm_build /
+ * bg_fm_set_*; bg_fm_backward_search_batch_dev, bg_sa_get_batch_dev and bg_interval_occ_batch_dev use no ctx
+ * scratch and may be called from several threads on their own streams (with bg_enable_timing off — the timing
+ * events belong to the ctx); the host-buffer flavours and bg_fmd_smems_* go through the handle's ctx and share
+ * its single-thread rule.
  */
 #ifndef BIOGPU_H
 #define BIOGPU_H
@@ -44,7 +54,7 @@ typedef enum {
 #define BG_MIN_SCORE (-858993459) /* pairwise::MIN_SCORE, mod.rs:174 */
 
 typedef struct bg_ctx bg_ctx; /* one per device; not thread-safe (like `&mut Aligner`) */
-typedef struct bg_fm bg_fm;   /* device-resident FM index; immutable, shareable (like Arc<FMIndex>) */
+typedef struct bg_fm bg_fm;   /* device-resident FM index; immutable after construction (like Arc<FMIndex>): see "Streams and threads" */
 
 int bg_device_count(void);
 int bg_init(int device, bg_ctx** out);
@@ -72,7 +82,9 @@ int bg_less(const uint8_t* bwt, uint64_t n, const uint8_t* alphabet, uint32_t n_
  * bg_fm_build replaces `Occ::new(&bwt, k, &alphabet)` + `FMIndex::new(bwt, less, occ)`
  * (bwt.rs:94-125, fmindex.rs:245-247): the sampled-Occ table layout on the device is the
  * engine's own, `occ_k` is accepted for API fidelity and only validated (>= 1):
- * Occ::get's result does not depend on k.  BG_ERR_OUT_OF_ALPHABET when a BWT byte exceeds
+ * Occ::get's result does not depend on k.  The reference's third argument, the host-built `Occ` table itself,
+ * is deliberately NOT part of this signature: the engine ranks on its own packed blocks built from `bwt`, so a
+ * Rust shim drops its `Occ` (or never builds it) and passes (bwt, less, k, alphabet) — INTEGRATION.md.  BG_ERR_OUT_OF_ALPHABET when a BWT byte exceeds
  * the alphabet's max symbol (Occ::new would panic, bwt.rs:114). */
 int bg_fm_build(bg_ctx* ctx, const uint8_t* bwt, uint64_t n, const uint64_t* less,
                 uint32_t less_len, uint32_t occ_k, const uint8_t* alphabet, uint32_t n_sym,
@@ -85,8 +97,9 @@ enum { BG_FM_COMPLETE = 0, BG_FM_PARTIAL = 1, BG_FM_ABSENT = 2,
        BG_FM_PANIC = 3 /* this query reached a byte outside the alphabet */ };
 
 /* Options of an index handle: "jump_min_queries" — batch size from which backward search builds (once,
- * 256 MB) and uses a table of the search state after a pattern's last 12 symbols; < 0 disables it.
- * Results do not depend on it. */
+ * 256 MB, synchronously on the first such call's stream, under a lock) and uses a table of the search state
+ * after a pattern's last 12 symbols; < 0 disables it.  OFF by default: it buys 2.5 % on an index that sits in
+ * the Infinity Cache and nothing on one that does not.  Results do not depend on it. */
 int bg_fm_set_option(bg_fm* fm, const char* key, int64_t value);
 
 /* backward_search for n_q patterns (fmindex.rs:144-208).  Pattern q is
@@ -188,7 +201,7 @@ typedef struct {
     uint32_t clip_len[4]; /* lengths of the Xclip/Yclip ops, in order of appearance */
     uint8_t n_clips;
     uint8_t mode;         /* BG_MODE_* */
-    int8_t status;        /* BG_OK or BG_ERR_TRACEBACK for this pair */
+    int8_t status;        /* BG_OK, BG_ERR_TRACEBACK, or BG_ERR_INVALID_ARG (longer than the stated bounds) for this pair */
     uint8_t _pad;
     uint32_t _reserved;   /* 0: the record is 64 bytes, every one of them defined */
 } bg_alignment_t;
@@ -206,8 +219,9 @@ int bg_align_batch(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint64_t n_pai
 /* Device-resident flavour.  d_ops must hold n_pairs * ops_stride bytes where
  * ops_stride >= max(xlen+ylen)+4 over the batch; alignment p's ops end at
  * d_ops + (p+1)*ops_stride and ops_off points at its first op.  sc->matrix (if any) is a
- * HOST pointer (it is compacted and uploaded by the call).  max_xlen/max_ylen are upper
- * bounds on the sequence lengths in the batch. */
+ * HOST pointer (it is compacted and uploaded by the call, which then synchronises `stream` once).
+ * max_xlen/max_ylen are upper bounds on the sequence lengths in the batch: a pair that exceeds them is not
+ * aligned and gets status BG_ERR_INVALID_ARG in its record (xlen/ylen filled in, no operations). */
 int bg_align_batch_dev(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint64_t n_pairs,
                        const uint8_t* d_x, const uint64_t* d_x_off, const uint8_t* d_y,
                        const uint64_t* d_y_off, uint32_t max_xlen, uint32_t max_ylen,
@@ -215,7 +229,9 @@ int bg_align_batch_dev(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint64_t n
 
 /* banded::Aligner::{custom,global,semiglobal,local} (banded.rs:282,872,901,972) with k-mer
  * length k and window w.  The band (k-mer matching, sparse DP chaining, Band construction,
- * banded.rs:1278-1367) is built on the host by this call; pairs whose band exceeds MAX_CELLS
+ * banded.rs:1278-1367) is built on the device by this call (band_device.hip; the few pairs its fixed-size
+ * tables cannot hold — > 4095 matches, > 32 occurrences of one k-mer — are rebuilt by the host builder,
+ * band_host.cpp, with identical results); pairs whose band exceeds MAX_CELLS
  * (banded.rs:104) get the reference's sentinel alignment {score: MIN_SCORE, all zero, no ops,
  * mode Custom} (banded.rs:407-420).  band_cells (optional) receives Band::num_cells. */
 int bg_align_banded_batch(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint32_t k, uint32_t w,

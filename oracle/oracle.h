@@ -159,6 +159,20 @@ int orc_fastq_parse(const uint8_t* text, uint64_t len, orc_fastq_rec_t* recs, ui
 /* Alignment::cigar(hard_clip): returns the length written, -1 if cap is too small, -2 for AlignmentMode::Custom */
 int64_t orc_cigar(const orc_alignment_t* a, const uint64_t* ops, int hard_clip, char* out, uint64_t cap);
 
+/* ---- seed-and-extend composition (oracle/pipeline.cpp): backward_search -> Interval::occ -> Aligner::semiglobal,
+ * the caller pattern of src/lib.rs:129-165 / benches/fmindex.rs:20-38; the definition is stated in pipeline.cpp ---- */
+typedef struct {
+    orc_alignment_t aln;    /* the winning semiglobal alignment (y = the candidate window); score MIN_SCORE: unmapped */
+    uint64_t window_start;  /* text offset of the winning window */
+    uint64_t ref_start, ref_end; /* window_start + ystart / yend; UINT64_MAX: unmapped */
+    uint32_t n_candidates, n_seed_hits;
+} orc_seed_hit_t;
+int orc_seed_extend_batch(const uint8_t* bwt, uint64_t n, const uint64_t* less, uint64_t less_len,
+                          const orc_occ* occ, const uint64_t* sa, const uint8_t* text, uint64_t n_text,
+                          const orc_scoring_t* sc, uint64_t n_reads, const uint8_t* reads,
+                          const uint64_t* read_off, uint32_t seed_len, uint32_t stride, uint32_t max_occ,
+                          uint32_t pad, orc_seed_hit_t* out, uint64_t* ops, uint64_t ops_stride, int threads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -124,6 +124,10 @@ def lib():
              [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, u64p]),
             ("orc_fastq_parse", C.c_int,
              [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, u64p, C.POINTER(C.c_int32), u64p]),
+            ("orc_seed_extend_batch", C.c_int,
+             [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
+              C.POINTER(Scoring), C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+              C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]),
             ("orc_cigar", C.c_int64, [C.POINTER(AlignmentRec), C.c_void_p, C.c_int, C.c_void_p, C.c_uint64]),
         ]:
             if hasattr(L, name):
@@ -568,3 +572,33 @@ def fastq_parse_raw(text):
     sl = int(recs["seq_off"][k - 1] + recs["seq_len"][k - 1]) if k else 0
     ql = int(recs["qual_off"][k - 1] + recs["qual_len"][k - 1]) if k else 0
     return (recs[:k], seq[:sl].tobytes(), qual[:ql].tobytes()), st.value, int(ep.value)
+
+
+SEED_HIT_DTYPE = np.dtype([("aln", ALN_DTYPE), ("window_start", "<u8"), ("ref_start", "<u8"), ("ref_end", "<u8"),
+                           ("n_candidates", "<u4"), ("n_seed_hits", "<u4")])
+
+
+def seed_extend_batch(bwt_arr, less_arr, occ, sa, text, n_text, scoring, reads, read_off, seed_len=20, stride=10,
+                      max_occ=16, pad=25, threads=1, want_ops=True):
+    """The seed-and-extend composition of oracle/pipeline.cpp (backward_search -> Interval::occ over the raw
+    suffix array -> Aligner::semiglobal on the candidate windows -> best hit).  Returns (hits, ops, stride)."""
+    sc = scoring[0] if isinstance(scoring, tuple) else scoring
+    b, tx, rd = _buf(bwt_arr), _buf(text), _buf(reads)
+    ls = np.ascontiguousarray(less_arr, dtype=np.uint64)
+    sa = np.ascontiguousarray(sa, dtype=np.uint64)
+    off = np.ascontiguousarray(read_off, dtype=np.uint64)
+    n = len(off) - 1
+    out = np.zeros(n, dtype=SEED_HIT_DTYPE)
+    assert SEED_HIT_DTYPE.itemsize == ALN_DTYPE.itemsize + 32
+    stride_ops = 0
+    ops = None
+    if want_ops and n:
+        stride_ops = 2 * int(np.diff(off).max()) + 2 * pad + 8
+        ops = np.zeros(n * stride_ops, dtype=np.uint64)
+    rc = lib().orc_seed_extend_batch(b.ctypes.data, len(b), ls.ctypes.data, len(ls), occ.h, sa.ctypes.data,
+                                     tx.ctypes.data, n_text, C.byref(sc), n, rd.ctypes.data, off.ctypes.data,
+                                     seed_len, stride, max_occ, pad, out.ctypes.data,
+                                     ops.ctypes.data if ops is not None else None, stride_ops, threads)
+    if rc:
+        raise RuntimeError(f"oracle seed_extend_batch failed rc={rc}")
+    return out, ops, stride_ops

@@ -53,6 +53,11 @@ struct bg_ctx {
     int band_chain_global = -1;  // chain_kernel tree placement: -1 by batch size, 0 LDS, 1 global scratch
     bool band_fill_v1 = false;  // tests: K3 (one pair per wavefront) even where K3v2 applies
     bool band_on_host = false;  // build bands with the host builder (band_host.cpp) instead of band_device.hip
+    // the scratch above is one set per ctx: a *_dev call arriving on another stream than the previous one first
+    // waits (on the device) for that call's last kernel — see bg_scratch_guard
+    hipEvent_t scratch_done = nullptr;
+    hipStream_t scratch_stream = nullptr;
+    bool scratch_used = false;
     // timing
     bool timing = false;
     hipEvent_t ev[2] = {nullptr, nullptr};
@@ -61,6 +66,23 @@ struct bg_ctx {
 
 // grow-only device scratch
 int bg_reserve(void** p, size_t* cur, size_t need);
+// Serialises the users of a ctx's scratch across streams: constructed at the top of every *_dev entry point that
+// touches ctx->tb / aux / bnd / table, it makes `st` wait for the event the previous user recorded (if that was
+// another stream) and records its own when the entry point returns — two calls in flight on two streams with one
+// ctx then run one after the other instead of overwriting each other's traceback words.
+struct bg_scratch_guard {
+    bg_ctx* ctx;
+    hipStream_t st;
+    bg_scratch_guard(bg_ctx* c, hipStream_t s) : ctx(c), st(s) {
+        if (ctx->scratch_used && ctx->scratch_stream != st) hipStreamWaitEvent(st, ctx->scratch_done, 0);
+    }
+    ~bg_scratch_guard() {
+        if (hipEventRecord(ctx->scratch_done, st) == hipSuccess) {
+            ctx->scratch_stream = st;
+            ctx->scratch_used = true;
+        }
+    }
+};
 // host threads this process may really use (affinity mask and cgroup CPU quota)
 unsigned bg_host_threads();
 

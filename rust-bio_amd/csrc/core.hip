@@ -62,6 +62,7 @@ extern "C" int bg_init(int device, bg_ctx** out) {
     BG_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     BG_HIP(hipEventCreate(&ctx->ev[0]));
     BG_HIP(hipEventCreate(&ctx->ev[1]));
+    BG_HIP(hipEventCreateWithFlags(&ctx->scratch_done, hipEventDisableTiming));
     *out = ctx;
     return BG_OK;
 }
@@ -79,6 +80,7 @@ extern "C" int bg_free(bg_ctx* ctx) {
     bg_host_pipe_free(ctx->pipe);
     if (ctx->ev[0]) hipEventDestroy(ctx->ev[0]);
     if (ctx->ev[1]) hipEventDestroy(ctx->ev[1]);
+    if (ctx->scratch_done) hipEventDestroy(ctx->scratch_done);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
     return BG_OK;

@@ -535,6 +535,7 @@ extern "C" int bg_fastq_parse_dev(bg_ctx* ctx, const uint8_t* d_text, uint64_t l
     *status = BG_FASTQ_OK;
     *err_pos = 0;
     hipStream_t st = (hipStream_t)stream;
+    bg_scratch_guard guard(ctx, st);
     BG_HIP(hipSetDevice(ctx->device));
     if (len == 0) {
         const uint64_t z = 0;

@@ -363,7 +363,8 @@ extern "C" uint64_t bg_fm_device_bytes(const bg_fm* fm) { return fm ? fm->bytes 
 
 extern "C" int bg_fm_set_option(bg_fm* fm, const char* key, int64_t value) {
     if (!fm || !key) return BG_ERR_INVALID_ARG;
-    if (!strcmp(key, "jump_min_queries")) {  // batch size from which K5 builds / uses its jump table; < 0: never
+    if (!strcmp(key, "jump_min_queries")) {  // batch size from which K5 builds / uses its jump table; < 0: never (default)
+        std::lock_guard<std::mutex> lk(fm->jump_mu);
         fm->no_jump = value < 0;
         fm->jump_min_queries = value < 0 ? ~0ull : (uint64_t)value;
         if (fm->no_jump && fm->d_jump) {
@@ -388,8 +389,12 @@ extern "C" int bg_fm_backward_search_batch_dev(bg_fm* fm, uint64_t n_q, const ui
     uint64_t blocks = (n_q + quads_per_block - 1) / quads_per_block;
     blocks = std::min<uint64_t>(blocks, 256 * 8);  // 8 resident 256-thread blocks per CU
     // the jump table pays off from a few million LF steps on; it is built once per index, by the search itself
-    if (!fm->d_jump && !fm->no_jump && n_q >= fm->jump_min_queries && fm->n_codes == 4) {
+    const uint4* jump = nullptr;
+    if (!fm->no_jump && n_q >= fm->jump_min_queries && fm->n_codes == 4) {
+      std::lock_guard<std::mutex> lk(fm->jump_mu);
+      if (!fm->d_jump && !fm->no_jump) {
         const uint64_t nk = 1ull << (2 * kJumpK);
+        void* d_table = nullptr;
         uint8_t *t_pat = nullptr, *t_tag = nullptr;
         uint64_t *t_off = nullptr, *t_lo = nullptr, *t_hi = nullptr;
         uint32_t* t_ml = nullptr;
@@ -400,12 +405,12 @@ extern "C" int bg_fm_backward_search_batch_dev(bg_fm* fm, uint64_t n_q, const ui
             BG_HIP(hipMalloc((void**)&t_lo, nk * 8));
             BG_HIP(hipMalloc((void**)&t_hi, nk * 8));
             BG_HIP(hipMalloc((void**)&t_ml, nk * 4));
-            BG_HIP(hipMalloc(&fm->d_jump, nk * sizeof(uint4)));
+            BG_HIP(hipMalloc(&d_table, nk * sizeof(uint4)));
             const uint32_t cb = (uint32_t)fm->code_byte[0] | (uint32_t)fm->code_byte[1] << 8 | (uint32_t)fm->code_byte[2] << 16 |
                                 (uint32_t)fm->code_byte[3] << 24;
             fm_jump_patterns_kernel<<<dim3((unsigned)((nk + 256) / 256)), dim3(256), 0, st>>>(cb, t_pat, t_off);
             fm_backward_search_kernel<false><<<dim3(256 * 8), dim3(256), 0, st>>>(fm->dev, nk, t_pat, t_off, t_tag, t_lo, t_hi, t_ml, nullptr);
-            fm_jump_pack_kernel<<<dim3((unsigned)(nk / 256)), dim3(256), 0, st>>>(t_tag, t_lo, t_hi, t_ml, (uint4*)fm->d_jump);
+            fm_jump_pack_kernel<<<dim3((unsigned)(nk / 256)), dim3(256), 0, st>>>(t_tag, t_lo, t_hi, t_ml, (uint4*)d_table);
             BG_HIP(hipGetLastError());
             BG_HIP(hipStreamSynchronize(st));
             fm->bytes += nk * sizeof(uint4);
@@ -419,15 +424,18 @@ extern "C" int bg_fm_backward_search_batch_dev(bg_fm* fm, uint64_t n_q, const ui
         hipFree(t_hi);
         hipFree(t_ml);
         if (rcj) {  // no memory for the table: search without it
-            hipFree(fm->d_jump);
-            fm->d_jump = nullptr;
+            hipFree(d_table);
             fm->no_jump = true;
+        } else {
+            fm->d_jump = d_table;  // published complete
         }
+      }
+      jump = (const uint4*)fm->d_jump;
     }
     if (ctx->timing) BG_HIP(hipEventRecord(ctx->ev[0], st));
-    if (fm->d_jump && n_q >= fm->jump_min_queries)
+    if (jump)
         fm_backward_search_kernel<true><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(
-            fm->dev, n_q, d_pat, d_pat_off, d_tag, d_lower, d_upper, d_matched_len, (const uint4*)fm->d_jump);
+            fm->dev, n_q, d_pat, d_pat_off, d_tag, d_lower, d_upper, d_matched_len, jump);
     else
         fm_backward_search_kernel<false><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(
             fm->dev, n_q, d_pat, d_pat_off, d_tag, d_lower, d_upper, d_matched_len, nullptr);

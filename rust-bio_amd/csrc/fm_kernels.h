@@ -2,6 +2,8 @@
 // the 2-bit block layout, the quad rank helper and the index handle.  Layout notes: fm_index.hip.
 #ifndef BG_FM_KERNELS_H
 #define BG_FM_KERNELS_H
+#include <mutex>
+
 #include "bg_common.h"
 
 namespace bgfm {
@@ -82,9 +84,13 @@ struct bg_fm {
     uint32_t sa_rate = 0;
     uint8_t sa_sentinel = 0;
     uint8_t code_byte[4] = {0, 0, 0, 0};  // byte value of each 2-bit code
-    void* d_jump = nullptr;  // K5's jump table, built lazily by the first large batch
-    uint64_t jump_min_queries = 1u << 20;
-    bool no_jump = false;    // ... unless disabled (bg_fm_set_option) or out of memory
+    // K5's optional jump table (opt-in through bg_fm_set_option "jump_min_queries"; +2.5 % on a cache-resident
+    // index, nothing on an HBM-resident one): built once, under jump_mu, and published only after the build
+    // stream has synchronised — concurrent searches either see the finished table or none
+    void* d_jump = nullptr;
+    std::mutex jump_mu;
+    uint64_t jump_min_queries = ~0ull;
+    bool no_jump = true;
     int n_codes = 0;         // distinct bytes with a 2-bit code (<= 4)
     uint32_t less_len = 0;
     bool fmd_ok = false;  // the BWT is a word over dna::n_alphabet() + '$' (FMDIndex::from, fmindex.rs:323-327)

@@ -312,6 +312,7 @@ extern "C" int bg_fmd_smems_batch_dev(bg_fm* fm, int all, uint64_t n_p, const ui
     if (n_p == 0) return BG_OK;
     bg_ctx* ctx = fm->ctx;
     hipStream_t st = (hipStream_t)stream;
+    bg_scratch_guard guard(ctx, st);  // the interval lists live in the ctx's scratch
     uint64_t blocks = std::min<uint64_t>((n_p + 63) / 64, 256 * 4);
     const uint32_t list_cap = max_pattern_len + 2;
     int rc = bg_reserve(&ctx->bnd, &ctx->bnd_bytes, blocks * 64 * 2 * (size_t)list_cap * sizeof(uint4));

@@ -229,6 +229,7 @@ static int align_batch_dev_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, u
     if (max_xlen > (1u << 24) || max_ylen > (1u << 24)) return BG_ERR_TOO_LARGE;
     hipStream_t st = (hipStream_t)stream;
     BG_HIP(hipSetDevice(ctx->device));
+    bg_scratch_guard guard(ctx, st);
 
     SwArgs a = {};
     a.x = d_x;
@@ -287,7 +288,7 @@ static int align_batch_dev_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, u
     // K1p: short reads whose scores fit 12 bits (sw_fill_pk16.inc) — two pairs per lane, one instantiation
     // unit per clip pattern.  Bound: no real DP value, nor the epilogue's go * i terms, may leave +-2040.
     sw_fill_fn fill_rest = nullptr, fill_second = nullptr;
-    const bool pk16 = !ctx->no_pk16 && sm == SCORE_PARAMS && cfg.lp <= 32 && max_xlen >= 1 &&
+    bool pk16 = !ctx->no_pk16 && sm == SCORE_PARAMS && cfg.lp <= 32 && max_xlen >= 1 &&
                       mag * ((int64_t)std::max(max_xlen, max_ylen) + 2) <= 2040;
     if (pk16) {
         const SwScoring& c = a.sc;
@@ -303,12 +304,15 @@ static int align_batch_dev_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, u
             if (max_xlen % r == 0 && getter(cfg.lp, r, 0)) r_pick = r;
         for (int r = (int)((max_xlen + cfg.lp - 1) / cfg.lp); r <= 12 && !r_pick; r++)
             if (getter(cfg.lp, r, 0)) r_pick = r;
-        if (!r_pick) return BG_ERR_UNSUPPORTED;
-        cfg.r = r_pick;
-        fill = getter(cfg.lp, cfg.r, 0);
-        fill_rest = getter(cfg.lp, cfg.r, 1);
-        fill_second = getter(cfg.lp, cfg.r, 2);
-        a.g.tb_fmt = 1;
+        if (!r_pick) {
+            pk16 = false;  // no K1p instantiation for this shape: the general kernel K1 picked above runs
+        } else {
+            cfg.r = r_pick;
+            fill = getter(cfg.lp, cfg.r, 0);
+            fill_rest = getter(cfg.lp, cfg.r, 1);
+            fill_second = getter(cfg.lp, cfg.r, 2);
+            a.g.tb_fmt = 1;
+        }
     }
     if (!fill) return BG_ERR_UNSUPPORTED;
     const int nw = tb_words(cfg.r);

@@ -72,6 +72,10 @@ struct SwGeom {
     }
 };
 
+// A pair longer than the bounds the caller stated (max_xlen / max_ylen) has no scratch: the fill kernels treat
+// it as an empty pair, K2 writes a record with status BG_ERR_INVALID_ARG for it.
+__device__ __forceinline__ bool len_over(const SwGeom& g, uint32_t m, uint32_t n) { return m > g.m_cap || n > g.n_cap; }
+
 // packed traceback: R cells x 5 bits per lane per step, 6 cells per 32-bit word
 __host__ __device__ constexpr int tb_words(int r) { return (r + 5) / 6; }
 // Traceback words of one wavefront job are stored in tiles of kTbTile(NW) steps: tile t holds, for each

@@ -23,6 +23,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
     const uint64_t xo = a.x_off[a.pair0 + pair], yo = a.y_off[a.pair0 + pair];
     const uint32_t m = (uint32_t)(a.x_off[a.pair0 + pair + 1] - xo);
     const uint32_t n = (uint32_t)(a.y_off[a.pair0 + pair + 1] - yo);
+    if (len_over(geo, m, n)) {  // longer than the max_xlen / max_ylen the caller stated: its scratch does not exist
+        bg_alignment_t bad = {};
+        bad.xlen = m;
+        bad.ylen = n;
+        bad.ops_off = (a.pair0 + pair + 1) * a.ops_stride;
+        bad.mode = (uint8_t)a.mode;
+        bad.status = (int8_t)BG_ERR_INVALID_ARG;
+        a.out[a.pair0 + pair] = bad;
+        return;
+    }
 
     const int32_t* aux = a.aux + (size_t)slot * geo.aux_stride;
     const int32_t* gLy = aux + geo.off_Ly();

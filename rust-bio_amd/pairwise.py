@@ -29,8 +29,11 @@ class MatchParams:  # mod.rs:186-217
         return self.match_score if a == b else self.mismatch_score
 
 
-def tabulate(match_fn):
-    """A closure cannot cross the FFI: tabulate F over all byte pairs."""
+def tabulate(match_fn, undefined=None):
+    """A closure cannot cross the FFI: tabulate F over all byte pairs.  Byte pairs the function
+    is not defined on (it raises KeyError / IndexError there, e.g. blosum62 on digits — the reference panics when
+    such a pair is actually scored) are tabulated as 0 and flagged in `undefined` (bool[256, 256]) so that the
+    aligner can refuse a batch that contains them; any other exception is a bug in the closure and propagates."""
     if isinstance(match_fn, np.ndarray):
         m = np.ascontiguousarray(match_fn, dtype=np.int32)
         assert m.shape == (256, 256)
@@ -40,8 +43,9 @@ def tabulate(match_fn):
         for b in range(256):
             try:
                 m[a, b] = match_fn(a, b)
-            except Exception:
-                m[a, b] = 0  # bytes the function is not defined on (e.g. blosum62 on digits)
+            except (KeyError, IndexError):
+                if undefined is not None:
+                    undefined[a, b] = True
     return m
 
 
@@ -56,6 +60,7 @@ class Scoring:
         self.xclip_prefix, self.xclip_suffix = xclip_prefix, xclip_suffix
         self.yclip_prefix, self.yclip_suffix = yclip_prefix, yclip_suffix
         self._matrix = None
+        self._undefined = None  # byte pairs match_fn is not defined on (see tabulate)
 
     @staticmethod
     def from_scores(gap_open, gap_extend, match_score, mismatch_score):  # mod.rs:259-278
@@ -94,7 +99,10 @@ class Scoring:
             sc.matrix = None
         else:
             if self._matrix is None:
-                self._matrix = tabulate(self.match_fn).reshape(-1)
+                self._undefined = np.zeros((256, 256), dtype=bool)
+                self._matrix = tabulate(self.match_fn, self._undefined).reshape(-1)
+                if not self._undefined.any():
+                    self._undefined = None
             if self.match_scores is not None:
                 sc.match_score, sc.mismatch_score = self.match_scores
             sc.matrix = self._matrix.ctypes.data_as(C.POINTER(C.c_int32))
@@ -216,6 +224,11 @@ class Aligner:
             ops = None
         used = C.c_uint64(0)
         sc = self.scoring.to_c()
+        if self.scoring._undefined is not None:  # the reference would panic inside match_fn on such a pair
+            hit = self.scoring._undefined & np.outer(np.bincount(xb, minlength=256) > 0, np.bincount(yb, minlength=256) > 0)
+            if hit.any():
+                a, b = np.argwhere(hit)[0]
+                raise KeyError(f"match_fn is not defined on the byte pair ({int(a)}, {int(b)}) that occurs in this batch")
         rc = _lib.lib().bg_align_batch(self.ctx.h, C.byref(sc), mode, n, xb.ctypes.data,
                                        xo.ctypes.data, yb.ctypes.data, yo.ctypes.data,
                                        out.ctypes.data, ops.ctypes.data if want_ops else None,

@@ -13,18 +13,50 @@ def env_world():
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
+def single_gpu_mode():
+    """Several ranks on ONE GPU (tests on a 1-GPU box, BENCH_SINGLE_GPU=1): every rank uses device 0 and the
+    collective runs over gloo on host copies of the records — RCCL needs one device per rank."""
+    if os.environ.get("BENCH_SINGLE_GPU") == "1":
+        return True
+    return torch.cuda.is_available() and env_world()[2] > 1 and torch.cuda.device_count() == 1
+
+
+def device_index(local_rank):
+    return 0 if single_gpu_mode() else local_rank
+
+
 def init_process_group(backend=None):
+    """Returns (rank, local device index, world)."""
     rank, local_rank, world = env_world()
+    dev = device_index(local_rank)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29512")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = "nccl" if torch.cuda.is_available() and not single_gpu_mode() else "gloo"
         kw = {}
         if backend == "nccl":
-            kw["device_id"] = torch.device("cuda", local_rank)
+            kw["device_id"] = torch.device("cuda", dev)
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
-    return rank, local_rank, world
+    return rank, dev, world
+
+
+def _host_side():
+    """gloo carries host tensors: device records take a round trip through host memory"""
+    return dist.get_backend() == "gloo"
+
+
+def broadcast(t, src=0):
+    """Broadcast of a replicated table (the BWT, suffix-array samples) from rank `src`, in place."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return t
+    if _host_side() and t.is_cuda:
+        h = t.cpu()
+        dist.broadcast(h, src)
+        t.copy_(h)
+    else:
+        dist.broadcast(t, src)
+    return t
 
 
 def partition(n_units, rank, world):
@@ -52,6 +84,8 @@ def gather_records(local, counts=None):
     are padded to the largest and trimmed afterwards."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return local
+    if _host_side() and local.is_cuda:
+        return gather_records(local.cpu(), counts).to(local.device)
     world = dist.get_world_size()
     if counts is None:
         cnt = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
@@ -73,7 +107,7 @@ def gather_records(local, counts=None):
 def max_over_ranks(seconds, device):
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return seconds
-    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    t = torch.tensor([seconds], dtype=torch.float64, device="cpu" if _host_side() else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 

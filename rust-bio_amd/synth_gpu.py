@@ -160,3 +160,33 @@ def reads_from_genome(text, n_reads, length, seed, sub=0.05, ins=0.01, dele=0.01
         x, _ = mutate_fixed(refs, seed + 1000003 + 7919 * (c0 // chunk), sub, ins, dele)
         out.append(x.reshape(-1))
     return torch.cat(out), starts
+
+
+AMINO = b"ARNDCQEGHILKMFPSTWYV"
+
+
+def protein_pairs(n_pairs, length, seed, device, sub=0.15, chunk=1 << 16):
+    """Protein pairs for the tabulated-scoring (BLOSUM62) bench leg: y uniform over the 20 amino acids,
+    x = y with per-residue substitutions, one residue deleted and one inserted per pair (so the alignment
+    has gaps), same length.  Returns (x, off, y, off)."""
+    aa = torch.tensor(list(AMINO), dtype=torch.uint8, device=device)
+    xs, ys = [], []
+    ar = torch.arange(length, dtype=torch.int64, device=device)
+    for c0 in range(0, n_pairs, chunk):
+        k = min(chunk, n_pairs - c0)
+        sd = seed + 7919 * (c0 // chunk)
+        y = _umod(splitmix64(sd, k * length, device), 20).view(k, length)
+        r = splitmix64(sd + 1000003, k * length, device).view(k, length)
+        u = _lsr(r, 40).to(torch.float64) * (1.0 / (1 << 24))
+        x = torch.where(u < sub, _umod(_lsr(r, 8), 20), y)
+        p = splitmix64(sd + 2000003, k * 2, device).view(k, 2)
+        dpos = _umod(p[:, 0], length).view(k, 1)      # residue dropped from x ...
+        ipos = _umod(p[:, 1], length).view(k, 1)      # ... and a residue inserted elsewhere
+        src = ar.view(1, -1) + (ar.view(1, -1) >= dpos).to(torch.int64)
+        x = torch.gather(x, 1, torch.clamp(src, max=length - 1))
+        src2 = ar.view(1, -1) - (ar.view(1, -1) > ipos).to(torch.int64)
+        x = torch.gather(x, 1, src2)
+        xs.append(aa[x].reshape(-1))
+        ys.append(aa[y].reshape(-1))
+    off = torch.arange(n_pairs + 1, dtype=torch.int64, device=device) * length
+    return torch.cat(xs), off, torch.cat(ys), off.clone()

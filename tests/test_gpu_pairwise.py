@@ -225,3 +225,74 @@ def test_cfg2_sample_150bp_local_bit_exact():
                     j += 1
             prev = o
         assert sc == int(out["score"][p]) and i == int(out["xend"][p]) and j == int(out["yend"][p])
+
+
+def _dev_align(al, mode, x, xo, y, yo, max_x, max_y, stream=None, dev="cuda:0"):
+    """bg_align_batch_dev on host arrays: returns the device tensors (no synchronisation)."""
+    import torch
+    dx, dy = torch.from_numpy(np.array(x)).to(dev), torch.from_numpy(np.array(y)).to(dev)
+    dxo = torch.from_numpy(np.asarray(xo).astype(np.int64)).to(dev)
+    dyo = torch.from_numpy(np.asarray(yo).astype(np.int64)).to(dev)
+    n = len(xo) - 1
+    stride = max_x + max_y + 4
+    out = torch.zeros(n * 64, dtype=torch.uint8, device=dev)
+    ops = torch.zeros(n * stride, dtype=torch.uint8, device=dev)
+    st = stream if stream is not None else torch.cuda.current_stream()
+    al.align_dev(mode, n, dx.data_ptr(), dxo.data_ptr(), dy.data_ptr(), dyo.data_ptr(), max_x, max_y, out.data_ptr(),
+                 ops.data_ptr(), stride, st.cuda_stream)
+    return out, ops, (dx, dy, dxo, dyo)
+
+
+@pytest.mark.parametrize("pk16", [True, False])
+def test_pair_beyond_the_stated_bounds_is_reported_not_computed(pk16):
+    """bg_align_batch_dev trusts max_xlen / max_ylen for its scratch geometry: a pair that exceeds them must not be
+    aligned into someone else's traceback tile — its record says BG_ERR_INVALID_ARG, every other pair is unaffected."""
+    import torch
+    from rust_bio_amd import _lib
+    ctx = _lib.Context(0)
+    ctx.set_option("no_pk16", 0 if pk16 else 1)
+    xs, ys = [], []
+    rng = np.random.default_rng(5)
+    for p in range(300):
+        ln = 100 if p not in (17, 130) else 180      # two pairs are longer than the bound stated below
+        y = rng.integers(0, 4, size=ln)
+        x = y.copy()
+        x[rng.integers(0, ln, size=5)] = rng.integers(0, 4, size=5)
+        xs.append(np.frombuffer(b"ACGT", dtype=np.uint8)[x].tobytes())
+        ys.append(np.frombuffer(b"ACGT", dtype=np.uint8)[y].tobytes())
+    x, xo = _lib.concat(xs)
+    y, yo = _lib.concat(ys)
+    al = Aligner.with_scoring(Scoring.from_scores(-5, -1, 1, -1), ctx=ctx)
+    out, ops, keep = _dev_align(al, 3, x, xo, y, yo, 100, 100)
+    torch.cuda.synchronize()
+    rec = out.cpu().numpy().view(_lib.ALN_DTYPE)
+    oout, _, _ = orc.align_batch(orc.make_scoring(-5, -1, 1, -1), "local", x, xo, y, yo)
+    bad = np.zeros(300, dtype=bool)
+    bad[[17, 130]] = True
+    assert (rec["status"][bad] == -1).all() and (rec["n_ops"][bad] == 0).all() and (rec["xlen"][bad] == 180).all()
+    assert (rec["status"][~bad] == 0).all()
+    for f in ("score", "xstart", "xend", "ystart", "yend", "n_ops"):
+        assert (rec[f][~bad].astype(np.int64) == oout[f][~bad].astype(np.int64)).all(), f
+
+
+def test_two_streams_one_ctx_do_not_share_scratch_in_flight():
+    """Two *_dev calls on two streams with ONE ctx, nothing synchronised in between: the second call waits on the
+    device for the first one's last kernel (include/biogpu.h, "Streams and threads"), so both results are right."""
+    import torch
+    from rust_bio_amd import _lib
+    ctx = _lib.Context(0)
+    al = Aligner.with_scoring(Scoring.from_scores(-5, -1, 1, -1), ctx=ctx)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    batches = [synth.sw_pairs(60_000, 150, seed=21 + k) for k in range(4)]
+    torch.cuda.synchronize()
+    res = []
+    for k, (x, xo, y, yo) in enumerate(batches):
+        st = s1 if k % 2 == 0 else s2
+        with torch.cuda.stream(st):
+            res.append(_dev_align(al, 3, x, xo, y, yo, 150, 150, stream=st))
+    torch.cuda.synchronize()
+    for (x, xo, y, yo), (out, ops, _) in zip(batches, res):
+        rec = out.cpu().numpy().view(_lib.ALN_DTYPE)
+        oout, _, _ = orc.align_batch(orc.make_scoring(-5, -1, 1, -1), "local", x, xo, y, yo, threads=8, want_ops=False)
+        for f in ("score", "xstart", "xend", "ystart", "yend", "n_ops"):
+            assert (rec[f].astype(np.int64) == oout[f].astype(np.int64)).all(), f
