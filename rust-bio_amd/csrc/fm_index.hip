@@ -17,10 +17,18 @@
 //     the block (one coalesced 64-B request per rank), counts its share, and the quad
 //     reduces with two DPP adds.  rank(l-1) and rank(r) are issued together; when both fall
 //     in the same block (the common case once the interval is narrow) the line is loaded once;
-//   * symbol classes, Less[] and the exception list are staged in LDS.
+//   * symbol classes, Less[] and the exception list are staged in LDS;
+//   * general alphabets (bwt.rs:94-182 works for any): when more than 1024 BWT positions hold a byte outside the
+//     four most frequent ones (a genome with runs of N, a protein text), only the THREE most frequent bytes keep
+//     2-bit codes (1..3; code 0 = "something else"), the rare bytes stay sorted lists (<= 1024 positions in all),
+//     and every other byte gets a one-hot rank bit vector of its own — 64-byte blocks of a 32-bit counter + 480
+//     bits — so that Occ::get is still exactly one 64-byte line, whatever the symbol.  n / 7.5 bytes per such
+//     symbol (a 20-letter protein text: 2.7 bytes per symbol of index); the raw BWT is kept for K6 (bwt[pos]).
 // No MFMA: this is a latency/bandwidth-bound table walk (DESIGN.md §FM roofline).
 #include <algorithm>
+#include <array>
 #include <numeric>
+#include <thread>
 
 #include "fm_kernels.h"
 
@@ -39,16 +47,14 @@ __global__ __launch_bounds__(256) void fm_backward_search_kernel(
     FmDev fm, uint64_t n_q, const uint8_t* __restrict__ pat, const uint64_t* __restrict__ pat_off,
     uint8_t* __restrict__ tag, uint64_t* __restrict__ lower, uint64_t* __restrict__ upper,
     uint32_t* __restrict__ matched_len, const uint4* __restrict__ jump) {
-    __shared__ uint8_t s_class[256];
+    __shared__ uint16_t s_class[256];
     __shared__ uint32_t s_less[256];
     __shared__ uint32_t s_exc[kMaxExcLds];
     for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) {
         s_class[i] = fm.sym_class[i];
         s_less[i] = fm.less[i];
     }
-    const bool exc_in_lds = fm.n_exc <= kMaxExcLds;
-    if (exc_in_lds)
-        for (uint32_t i = threadIdx.x; i < fm.n_exc; i += blockDim.x) s_exc[i] = fm.exc_pos[i];
+    for (uint32_t i = threadIdx.x; i < fm.n_exc; i += blockDim.x) s_exc[i] = fm.exc_pos[i];  // n_exc <= kMaxExcLds
     __syncthreads();
 
     const uint32_t t = threadIdx.x & 3;
@@ -146,18 +152,26 @@ __global__ __launch_bounds__(256) void fm_backward_search_kernel(
                 }
                 occ_r = quad_sum(block_part(vr, t, orr, cls));
                 if (l > 0) occ_l = quad_sum(block_part(vl, t, ol, cls));
-                if (cls == 0 && fm.n_exc) {  // exceptions sit in the stream as code 0
-                    if (exc_in_lds) {
-                        occ_r -= count_le(s_exc, 0u, fm.n_exc, r);
-                        if (l > 0) occ_l -= count_le(s_exc, 0u, fm.n_exc, l - 1);
-                    } else {
-                        occ_r -= count_le(fm.exc_pos, 0u, fm.n_exc, r);
-                        if (l > 0) occ_l -= count_le(fm.exc_pos, 0u, fm.n_exc, l - 1);
-                    }
+                if (cls == 0 && fm.n_exc) {  // sparse exceptions sit in the stream as code 0
+                    occ_r -= count_le(s_exc, 0u, fm.n_exc, r);
+                    if (l > 0) occ_l -= count_le(s_exc, 0u, fm.n_exc, l - 1);
                 }
-            } else if (cls >= kClsExc) {
-                const uint32_t e = cls - kClsExc;
-                const uint32_t lo = fm.exc_sym_off[e], hi = fm.exc_sym_off[e + 1];
+            } else if (cls >= kClsDense) {  // one-hot bit vector of this symbol: one 64-byte block per rank
+                const uint32_t d = cls - kClsDense;
+                uint32_t orr, ol = 0;
+                const uint4 vr = bv_load(fm, d, r, t, orr);
+                uint4 vl = vr;
+                if (l > 0) {
+                    if ((l - 1) / kBvBits != r / kBvBits)
+                        vl = bv_load(fm, d, l - 1, t, ol);
+                    else
+                        ol = (l - 1) % kBvBits;
+                }
+                occ_r = quad_sum(bv_part(vr, t, orr));
+                if (l > 0) occ_l = quad_sum(bv_part(vl, t, ol));
+            } else if (cls >= kClsSparse) {
+                const uint32_t e = cls - kClsSparse;
+                const uint32_t lo = fm.sparse_off[e], hi = fm.sparse_off[e + 1];
                 occ_r = count_le(fm.exc_sym_pos, lo, hi, r) - lo;
                 if (l > 0) occ_l = count_le(fm.exc_sym_pos, lo, hi, l - 1) - lo;
             }  // kClsZero: both stay 0
@@ -231,66 +245,131 @@ extern "C" int bg_fm_build(bg_ctx* ctx, const uint8_t* bwt, uint64_t n, const ui
     if (less_len != max_symbol + 2) return BG_ERR_INVALID_ARG;
     if ((uint32_t)'$' < m) in_alpha['$'] = true;  // bwt.rs:101-104: '$' is always tabulated
 
+    // work is cut into chunks of whole 2-bit blocks AND whole bit-vector blocks (lcm(192, 480) = 960 symbols)
+    const unsigned nthreads = std::max(1u, bg_host_threads());
+    const uint64_t kAlign = 960;
+    const uint64_t n_chunks = std::max<uint64_t>(1, std::min<uint64_t>(nthreads * 4, (n + kAlign - 1) / kAlign));
+    const uint64_t per = ((n + n_chunks - 1) / n_chunks + kAlign - 1) / kAlign * kAlign;
+    auto chunk_lo = [&](uint64_t c) { return std::min(n, c * per); };
+    auto run_chunks = [&](auto&& fn) {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < std::min<uint64_t>(nthreads, n_chunks); t++)
+            th.emplace_back([&, t] {
+                for (uint64_t c = t; c < n_chunks; c += nthreads) fn(c);
+            });
+        for (auto& x : th) x.join();
+    };
+    std::vector<std::array<uint64_t, 256>> chist(n_chunks);
+    run_chunks([&](uint64_t c) {
+        std::array<uint64_t, 256> h{};
+        for (uint64_t i = chunk_lo(c), e = chunk_lo(c + 1); i < e; i++) h[bwt[i]]++;
+        chist[c] = h;
+    });
     uint64_t hist[256] = {};
-    for (uint64_t i = 0; i < n; i++) hist[bwt[i]]++;
+    for (auto& h : chist)
+        for (int c = 0; c < 256; c++) hist[c] += h[c];
     for (uint32_t c = m; c < 256; c++)
         if (hist[c]) return BG_ERR_OUT_OF_ALPHABET;  // Occ::new: curr_occ[c] out of bounds
 
-    // the four most frequent byte values get the 2-bit codes (ties: smaller byte first)
+    // the most frequent byte values get the 2-bit codes (ties: smaller byte first)
     int order[256];
     std::iota(order, order + 256, 0);
     std::stable_sort(order, order + 256, [&](int a, int b) { return hist[a] > hist[b]; });
-    int code_of[256];
+    uint64_t beyond4 = 0;
+    for (int i = 4; i < 256; i++) beyond4 += hist[order[i]];
+    const bool gen = beyond4 > kMaxExcLds;  // too many exceptions for the LDS list: dense symbols get bit vectors
+    int code_of[256], sparse_of[256], dense_of[256];
     std::fill(code_of, code_of + 256, -1);
+    std::fill(sparse_of, sparse_of + 256, -1);
+    std::fill(dense_of, dense_of + 256, -1);
     int n_codes = 0;
-    for (int i = 0; i < 4 && hist[order[i]] > 0; i++) code_of[order[i]] = n_codes++;
-    std::vector<int> exc_syms;
-    uint64_t n_exc = 0;
-    for (int c = 0; c < 256; c++)
-        if (hist[c] && code_of[c] < 0) {
-            exc_syms.push_back(c);
-            n_exc += hist[c];
+    std::vector<int> sparse_syms, dense_syms;
+    if (!gen) {
+        for (int i = 0; i < 4 && hist[order[i]] > 0; i++) code_of[order[i]] = n_codes++;
+        for (int c = 0; c < 256; c++)
+            if (hist[c] && code_of[c] < 0) sparse_syms.push_back(c);
+    } else {
+        for (int i = 0; i < 3; i++) code_of[order[i]] = 1 + n_codes++;  // code 0 = "none of the three"
+        uint64_t cum = 0;
+        for (int i = 255; i >= 3; i--) {  // ascending frequency: the rare ones stay lists while they fit
+            const int c = order[i];
+            if (!hist[c]) continue;
+            if (dense_syms.empty() && cum + hist[c] <= kMaxExcLds) {
+                cum += hist[c];
+                sparse_syms.push_back(c);
+            } else {
+                dense_syms.push_back(c);
+            }
         }
-    if (exc_syms.size() > kMaxExcSyms || n_exc > (1u << 26)) return BG_ERR_UNSUPPORTED;
+        std::sort(sparse_syms.begin(), sparse_syms.end());
+        std::sort(dense_syms.begin(), dense_syms.end());
+    }
+    for (size_t e = 0; e < sparse_syms.size(); e++) sparse_of[sparse_syms[e]] = (int)e;
+    for (size_t d = 0; d < dense_syms.size(); d++) dense_of[dense_syms[d]] = (int)d;
 
-    uint8_t cls[256];
+    uint16_t cls[256];
     for (int c = 0; c < 256; c++) {
         if (!in_alpha[c])
             cls[c] = kClsPanic;
         else if (code_of[c] >= 0)
-            cls[c] = (uint8_t)code_of[c];
+            cls[c] = (uint16_t)code_of[c];
         else if (hist[c] == 0)
             cls[c] = kClsZero;
+        else if (sparse_of[c] >= 0)
+            cls[c] = (uint16_t)(kClsSparse + sparse_of[c]);
         else
-            cls[c] = (uint8_t)(kClsExc +
-                               (std::find(exc_syms.begin(), exc_syms.end(), c) - exc_syms.begin()));
+            cls[c] = (uint16_t)(kClsDense + dense_of[c]);
     }
 
     const uint64_t nblk = (n + kSymPerBlock - 1) / kSymPerBlock;
+    const uint64_t nbv = (n + kBvBits - 1) / kBvBits;
+    const size_t n_dense = dense_syms.size();
     std::vector<uint32_t> blocks(nblk * 16, 0);
-    std::vector<uint32_t> exc_pos;
-    std::vector<std::vector<uint32_t>> exc_by_sym(exc_syms.size());
-    exc_pos.reserve(n_exc);
-    uint32_t running[4] = {0, 0, 0, 0};
-    for (uint64_t b = 0; b < nblk; b++) {
-        uint32_t* blk = &blocks[b * 16];
-        for (int c = 0; c < 4; c++) blk[c] = running[c];
-        const uint64_t lo = b * kSymPerBlock, hi = std::min<uint64_t>(n, lo + kSymPerBlock);
+    std::vector<uint32_t> bitvecs(n_dense * nbv * 16, 0);
+    std::vector<std::vector<uint32_t>> c_exc(n_chunks);                  // sparse positions per chunk, in order
+    std::vector<std::vector<std::vector<uint32_t>>> c_exc_sym(n_chunks);  // ... and per sparse symbol
+    run_chunks([&](uint64_t ck) {
+        uint64_t before[256] = {};
+        for (uint64_t c2 = 0; c2 < ck; c2++)
+            for (int c = 0; c < 256; c++) before[c] += chist[c2][c];
+        uint32_t running[4] = {0, 0, 0, 0};
+        for (int c = 0; c < 256; c++) running[code_of[c] >= 0 ? code_of[c] : 0] += (uint32_t)before[c];
+        std::vector<uint32_t> drun(n_dense);
+        for (size_t d = 0; d < n_dense; d++) drun[d] = (uint32_t)before[dense_syms[d]];
+        c_exc_sym[ck].resize(sparse_syms.size());
+        const uint64_t lo = chunk_lo(ck), hi = chunk_lo(ck + 1);
         for (uint64_t i = lo; i < hi; i++) {
+            const uint64_t s = i % kSymPerBlock;
+            uint32_t* blk = &blocks[(i / kSymPerBlock) * 16];
+            if (s == 0)
+                for (int c = 0; c < 4; c++) blk[c] = running[c];
+            if (n_dense && i % kBvBits == 0)
+                for (size_t d = 0; d < n_dense; d++) bitvecs[(d * nbv + i / kBvBits) * 16] = drun[d];
             const uint8_t ch = bwt[i];
             int code = code_of[ch];
             if (code < 0) {
                 code = 0;
-                exc_pos.push_back((uint32_t)i);
-                exc_by_sym[std::find(exc_syms.begin(), exc_syms.end(), (int)ch) - exc_syms.begin()]
-                    .push_back((uint32_t)i);
+                if (sparse_of[ch] >= 0) {
+                    c_exc[ck].push_back((uint32_t)i);
+                    c_exc_sym[ck][sparse_of[ch]].push_back((uint32_t)i);
+                } else {
+                    const size_t d = (size_t)dense_of[ch];
+                    const uint64_t o = i % kBvBits;
+                    bitvecs[(d * nbv + i / kBvBits) * 16 + 1 + (o >> 5)] |= 1u << (o & 31);
+                    drun[d]++;
+                }
             }
-            const uint32_t s = (uint32_t)(i - lo);
             blk[4 + (s >> 4)] |= (uint32_t)code << (2 * (s & 15));
             running[code]++;
         }
+    });
+    std::vector<uint32_t> exc_pos, exc_sym_pos, sparse_off(sparse_syms.size() + 1, 0);
+    for (auto& v : c_exc) exc_pos.insert(exc_pos.end(), v.begin(), v.end());
+    for (size_t e = 0; e < sparse_syms.size(); e++) {
+        for (uint64_t ck = 0; ck < n_chunks; ck++)
+            exc_sym_pos.insert(exc_sym_pos.end(), c_exc_sym[ck][e].begin(), c_exc_sym[ck][e].end());
+        sparse_off[e + 1] = (uint32_t)exc_sym_pos.size();
     }
-    std::vector<uint32_t> exc_sym_pos;
     std::vector<uint8_t> exc_byte(exc_pos.size());
     for (size_t e = 0; e < exc_pos.size(); e++) exc_byte[e] = bwt[exc_pos[e]];
     bg_fm* fm = new bg_fm;
@@ -301,14 +380,7 @@ extern "C" int bg_fm_build(bg_ctx* ctx, const uint8_t* bwt, uint64_t n, const ui
         if (hist[c] && (c == 0 || !strchr("ACGTNacgtn$", c))) fm->fmd_ok = false;
     for (int c = 0; c < 256; c++)
         if (code_of[c] >= 0) fm->code_byte[code_of[c]] = (uint8_t)c;
-    fm->n_codes = n_codes;
-    fm->dev.exc_sym_off[0] = 0;
-    for (size_t e = 0; e < exc_by_sym.size(); e++) {
-        exc_sym_pos.insert(exc_sym_pos.end(), exc_by_sym[e].begin(), exc_by_sym[e].end());
-        fm->dev.exc_sym_off[e + 1] = (uint32_t)exc_sym_pos.size();
-    }
-    for (size_t e = exc_by_sym.size(); e < kMaxExcSyms; e++)
-        fm->dev.exc_sym_off[e + 1] = fm->dev.exc_sym_off[e];
+    fm->n_codes = gen ? 3 : n_codes;
     uint32_t less32[256] = {};
     for (uint32_t i = 0; i < less_len && i < 256; i++) less32[i] = (uint32_t)less[i];
 
@@ -326,19 +398,26 @@ extern "C" int bg_fm_build(bg_ctx* ctx, const uint8_t* bwt, uint64_t n, const ui
     };
     int rc;
     if ((rc = upload(&fm->d_blocks, blocks.data(), blocks.size() * 4))) return fail(rc);
+    if ((rc = upload(&fm->d_bitvecs, bitvecs.data(), bitvecs.size() * 4))) return fail(rc);
     if ((rc = upload(&fm->d_exc_pos, exc_pos.data(), exc_pos.size() * 4))) return fail(rc);
-    if ((rc = upload(&fm->d_exc_sym_pos, exc_sym_pos.data(), exc_sym_pos.size() * 4)))
-        return fail(rc);
+    if ((rc = upload(&fm->d_exc_sym_pos, exc_sym_pos.data(), exc_sym_pos.size() * 4))) return fail(rc);
+    if ((rc = upload(&fm->d_sparse_off, sparse_off.data(), sparse_off.size() * 4))) return fail(rc);
     if ((rc = upload(&fm->d_exc_byte, exc_byte.data(), exc_byte.size()))) return fail(rc);
-    if ((rc = upload(&fm->d_class, cls, 256))) return fail(rc);
+    if ((rc = upload(&fm->d_class, cls, sizeof(cls)))) return fail(rc);
     if ((rc = upload(&fm->d_less, less32, sizeof(less32)))) return fail(rc);
+    if (gen && (rc = upload(&fm->d_bwt_raw, bwt, n))) return fail(rc);
     fm->dev.blocks = (const uint4*)fm->d_blocks;
+    fm->dev.bitvecs = (const uint4*)fm->d_bitvecs;
     fm->dev.exc_pos = (const uint32_t*)fm->d_exc_pos;
     fm->dev.exc_sym_pos = (const uint32_t*)fm->d_exc_sym_pos;
-    fm->dev.sym_class = (const uint8_t*)fm->d_class;
+    fm->dev.sparse_off = (const uint32_t*)fm->d_sparse_off;
+    fm->dev.sym_class = (const uint16_t*)fm->d_class;
     fm->dev.less = (const uint32_t*)fm->d_less;
+    fm->dev.bwt_raw = (const uint8_t*)fm->d_bwt_raw;
     fm->dev.n = (uint32_t)n;
-    fm->dev.n_exc = (uint32_t)exc_pos.size();
+    fm->dev.n_exc = gen ? 0u : (uint32_t)exc_pos.size();
+    fm->dev.nbv_blocks = (uint32_t)nbv;
+    fm->dev.n_dense = (uint32_t)n_dense;
     *out = fm;
     return BG_OK;
 }
@@ -351,6 +430,10 @@ extern "C" int bg_fm_free(bg_fm* fm) {
     hipFree(fm->d_class);
     hipFree(fm->d_less);
     hipFree(fm->d_exc_byte);
+    hipFree(fm->d_sparse_off);
+    hipFree(fm->d_bitvecs);
+    hipFree(fm->d_bwt_raw);
+    if (fm->text_owned) hipFree(fm->d_text);
     hipFree(fm->d_jump);
     hipFree(fm->d_sa);
     hipFree(fm->d_extra_row);

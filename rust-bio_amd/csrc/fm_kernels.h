@@ -9,22 +9,30 @@
 namespace bgfm {
 
 constexpr uint32_t kSymPerBlock = 192;
-constexpr uint32_t kMaxExcLds = 1024;   // exception positions staged in LDS
-constexpr uint32_t kMaxExcSyms = 32;    // distinct exception byte values supported
-constexpr uint8_t kClsZero = 4;         // in alphabet, never occurs in the BWT
-constexpr uint8_t kClsExc = 8;          // kClsExc + e : exception symbol e
+constexpr uint32_t kBvBits = 480;       // bits per 64-byte block of a dense symbol's rank bit vector (+ a 32-bit counter)
+constexpr uint32_t kMaxExcLds = 1024;   // sparse exception positions (all of them fit in LDS)
 constexpr uint32_t kJumpK = 12;  // symbols covered by the jump table of K5 (4^12 entries x 16 bytes = 256 MB)
-constexpr uint8_t kClsPanic = 255;      // not in the alphabet: the reference panics
+// symbol classes (uint16 per byte value): how Occ::get(r, a) is answered for byte a
+constexpr uint16_t kClsZero = 4;        // in the alphabet, never occurs in the BWT: 0
+constexpr uint16_t kClsSparse = 0x100;  // + e: sparse exception symbol e — sorted position list
+constexpr uint16_t kClsDense = 0x200;   // + d: dense symbol d — one-hot rank bit vector, one 64-byte block per rank
+constexpr uint16_t kClsPanic = 0xFFFF;  // not in the alphabet: the reference panics (fmindex.rs:229, bwt.rs:158)
+// 0..3: the symbol has a 2-bit code — rank inside the packed block stream
 
 struct FmDev {
-    const uint4* blocks;
-    const uint32_t* exc_pos;      // all exception positions, sorted
-    const uint32_t* exc_sym_pos;  // per exception symbol, sorted, concatenated
-    const uint8_t* sym_class;     // [256]
+    const uint4* blocks;          // 2-bit stream: cnt[4] + 192 symbols per 64-byte block
+    const uint4* bitvecs;         // dense symbol d: blocks [d * nbv_blocks, (d + 1) * nbv_blocks), counter + 480 bits each
+    const uint32_t* exc_pos;      // all sparse exception positions, sorted (they sit in the stream as code 0)
+    const uint32_t* exc_sym_pos;  // per sparse symbol, sorted, concatenated
+    const uint32_t* sparse_off;   // [n_sparse + 1] ranges of exc_sym_pos
+    const uint16_t* sym_class;    // [256]
     const uint32_t* less;         // [256]
-    uint32_t exc_sym_off[kMaxExcSyms + 1];
+    const uint8_t* bwt_raw;       // the BWT bytes (only with dense symbols: K6 reads bwt[pos] here)
     uint32_t n;
-    uint32_t n_exc;
+    uint32_t n_exc;               // sparse exceptions that need the code-0 correction (0 when dense symbols exist:
+                                  // code 0 then belongs to no symbol at all)
+    uint32_t nbv_blocks;
+    uint32_t n_dense;
 };
 
 // number of entries <= r in a sorted array
@@ -63,6 +71,36 @@ __device__ __forceinline__ uint32_t block_part(const uint4 v, uint32_t t, uint32
     return (uint32_t)(__popcll(e0 & m0) + __popcll(e1 & m1));
 }
 
+// this lane's share of rank1(o) inside one bit-vector block: lane 0 holds the counter and bits 0..95, lane t >= 1
+// bits 96 + 128 (t - 1) ... + 127
+__device__ __forceinline__ uint32_t bv_part(const uint4 v, uint32_t t, uint32_t o) {
+    uint64_t lo, hi;
+    int have;
+    uint32_t acc = 0;
+    if (t == 0) {
+        acc = v.x;
+        lo = ((uint64_t)v.z << 32) | v.y;
+        hi = v.w;
+        have = min((int)o + 1, 96);
+    } else {
+        lo = ((uint64_t)v.y << 32) | v.x;
+        hi = ((uint64_t)v.w << 32) | v.z;
+        have = (int)o + 1 - (96 + 128 * ((int)t - 1));
+        if (have <= 0) return 0;
+        have = min(have, 128);
+    }
+    const int h0 = min(have, 64), h1 = have - h0;
+    const uint64_t m0 = h0 == 64 ? ~0ull : ((1ull << h0) - 1);
+    const uint64_t m1 = h1 >= 64 ? ~0ull : ((1ull << h1) - 1);
+    return acc + (uint32_t)(__popcll(lo & m0) + __popcll(hi & m1));
+}
+// Occ::get(r, dense symbol d) for the quad: one 64-byte block
+__device__ __forceinline__ uint4 bv_load(const FmDev& fm, uint32_t d, uint32_t r, uint32_t t, uint32_t& o) {
+    const uint32_t b = r / kBvBits;
+    o = r - b * kBvBits;
+    return fm.bitvecs[((uint64_t)d * fm.nbv_blocks + b) * 4 + t];
+}
+
 }  // namespace bgfm
 
 struct bg_fm {
@@ -74,6 +112,12 @@ struct bg_fm {
     void* d_class = nullptr;
     void* d_less = nullptr;
     void* d_exc_byte = nullptr;  // byte value of every exception, parallel to exc_pos
+    void* d_sparse_off = nullptr;
+    void* d_bitvecs = nullptr;
+    void* d_bwt_raw = nullptr;
+    void* d_text = nullptr;      // the text the index was built from (bg_fm_set_text): seed-and-extend cuts its windows here
+    bool text_owned = false;
+    uint64_t n_text = 0;
     uint64_t bytes = 0;
     // suffix array attached for Interval::occ / SuffixArray::get (K6, sa_locate.hip)
     int sa_kind = 0;               // 0 none, 1 raw, 2 sampled

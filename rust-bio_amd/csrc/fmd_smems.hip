@@ -41,17 +41,14 @@ __constant__ uint8_t kExtOrder[11] = {'$', 'T', 'G', 'C', 'N', 'A', 't', 'g', 'c
 
 struct Ctx {
     const FmdArgs& a;
-    const uint8_t* s_class;
+    const uint16_t* s_class;
     const uint32_t* s_less;
     const uint8_t* s_comp;
     const uint32_t* s_exc;
-    bool exc_in_lds;
     uint32_t t;
     bool panic;
 
-    __device__ uint32_t exc_le(uint32_t r) const {
-        return exc_in_lds ? count_le(s_exc, 0u, a.fm.n_exc, r) : count_le(a.fm.exc_pos, 0u, a.fm.n_exc, r);
-    }
+    __device__ uint32_t exc_le(uint32_t r) const { return count_le(s_exc, 0u, a.fm.n_exc, r); }
     // counts of the four codes in bwt[0..=r]
     __device__ void counts(uint32_t r, uint32_t c[4]) const {
         const uint32_t b = r / kSymPerBlock, o = r - b * kSymPerBlock;
@@ -66,9 +63,14 @@ struct Ctx {
             panic = true;
             return 0;
         }
-        if (cls >= kClsExc) {
-            const uint32_t e = cls - kClsExc;
-            const uint32_t lo = a.fm.exc_sym_off[e], hi = a.fm.exc_sym_off[e + 1];
+        if (cls >= kClsDense) {  // a genome with many N: the fourth base and N are ranked in their bit vectors
+            uint32_t o;
+            const uint4 v = bv_load(a.fm, cls - kClsDense, r, t, o);
+            return quad_sum(bv_part(v, t, o));
+        }
+        if (cls >= kClsSparse) {
+            const uint32_t e = cls - kClsSparse;
+            const uint32_t lo = a.fm.sparse_off[e], hi = a.fm.sparse_off[e + 1];
             return count_le(a.fm.exc_sym_pos, lo, hi, r) - lo;
         }
         return 0;  // in the alphabet, never in the BWT
@@ -133,7 +135,7 @@ __device__ __forceinline__ uint4 pack(const BiIv& v) { return make_uint4(v.lower
 __device__ __forceinline__ BiIv unpack(const uint4 u) { return BiIv{u.x, u.y, u.z, u.w >> 16, u.w & 0xFFFFu}; }
 
 __global__ __launch_bounds__(256) void fmd_smems_kernel(const FmdArgs a) {
-    __shared__ uint8_t s_class[256];
+    __shared__ uint16_t s_class[256];
     __shared__ uint32_t s_less[256];
     __shared__ uint8_t s_comp[256];
     __shared__ uint32_t s_exc[kMaxExcLds];
@@ -149,9 +151,7 @@ __global__ __launch_bounds__(256) void fmd_smems_kernel(const FmdArgs a) {
         }
         s_comp[i] = c;
     }
-    const bool exc_in_lds = a.fm.n_exc <= kMaxExcLds;
-    if (exc_in_lds)
-        for (uint32_t i = threadIdx.x; i < a.fm.n_exc; i += blockDim.x) s_exc[i] = a.fm.exc_pos[i];
+    for (uint32_t i = threadIdx.x; i < a.fm.n_exc; i += blockDim.x) s_exc[i] = a.fm.exc_pos[i];  // n_exc <= kMaxExcLds
     __syncthreads();
 
     const uint32_t t = threadIdx.x & 3;
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void fmd_smems_kernel(const FmdArgs a) {
         const uint64_t off = a.pat_off[q];
         const uint32_t plen = (uint32_t)(a.pat_off[q + 1] - off);
         const uint8_t* pattern = a.pat + off;
-        Ctx cx{a, s_class, s_less, s_comp, s_exc, exc_in_lds, t, false};
+        Ctx cx{a, s_class, s_less, s_comp, s_exc, t, false};
         uint32_t n_out = 0;
         uint32_t* out = a.out + q * (uint64_t)a.cap * 6;
         auto emit = [&](const BiIv& iv, uint32_t pos, uint32_t len) {
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256) void fmd_smems_kernel(const FmdArgs a) {
 // 2 backward_ext(iv, a) (527-558), 3 forward_ext(iv, a) (560-564).  iv / out: lower, lower_rev, size, match_size.
 __global__ __launch_bounds__(256) void fmd_interval_kernel(FmdArgs a, uint64_t n_req, const uint8_t* op, const uint32_t* iv_in,
                                                            const uint8_t* sym, uint32_t* iv_out, uint8_t* ok) {
-    __shared__ uint8_t s_class[256];
+    __shared__ uint16_t s_class[256];
     __shared__ uint32_t s_less[256];
     __shared__ uint8_t s_comp[256];
     __shared__ uint32_t s_exc[kMaxExcLds];
@@ -276,14 +276,12 @@ __global__ __launch_bounds__(256) void fmd_interval_kernel(FmdArgs a, uint64_t n
         }
         s_comp[i] = c;
     }
-    const bool exc_in_lds = a.fm.n_exc <= kMaxExcLds;
-    if (exc_in_lds)
-        for (uint32_t i = threadIdx.x; i < a.fm.n_exc; i += blockDim.x) s_exc[i] = a.fm.exc_pos[i];
+    for (uint32_t i = threadIdx.x; i < a.fm.n_exc; i += blockDim.x) s_exc[i] = a.fm.exc_pos[i];  // n_exc <= kMaxExcLds
     __syncthreads();
     const uint32_t t = threadIdx.x & 3;
     const uint64_t q = (uint64_t)blockIdx.x * (blockDim.x >> 2) + (threadIdx.x >> 2);
     if (q >= n_req) return;  // quad-uniform
-    Ctx cx{a, s_class, s_less, s_comp, s_exc, exc_in_lds, t, false};
+    Ctx cx{a, s_class, s_less, s_comp, s_exc, t, false};
     BiIv in{iv_in[4 * q], iv_in[4 * q + 1], iv_in[4 * q + 2], iv_in[4 * q + 3], 0};
     BiIv r = in;
     switch (op[q]) {

@@ -54,17 +54,16 @@ __global__ __launch_bounds__(256) void interval_rows_kernel(uint64_t n_iv, const
 
 __global__ __launch_bounds__(256) void sa_sampled_get_kernel(FmDev fm, SaDev sa, uint64_t n, const uint64_t* index,
                                                              uint64_t* pos_out) {
-    __shared__ uint8_t s_class[256];
+    __shared__ uint16_t s_class[256];
     __shared__ uint32_t s_less[256];
     __shared__ uint32_t s_exc[kMaxExcLds];
     for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) {
         s_class[i] = fm.sym_class[i];
         s_less[i] = fm.less[i];
     }
-    const bool exc_in_lds = fm.n_exc <= kMaxExcLds;
-    if (exc_in_lds)
-        for (uint32_t i = threadIdx.x; i < fm.n_exc; i += blockDim.x) s_exc[i] = fm.exc_pos[i];
+    for (uint32_t i = threadIdx.x; i < fm.n_exc; i += blockDim.x) s_exc[i] = fm.exc_pos[i];  // n_exc <= kMaxExcLds
     __syncthreads();
+    const bool raw_bwt = fm.bwt_raw != nullptr;  // dense symbols exist: the stream's code 0 does not say which byte
 
     const uint32_t t = threadIdx.x & 3;
     const uint64_t n_quads = (uint64_t)gridDim.x * (blockDim.x >> 2);
@@ -104,12 +103,17 @@ __global__ __launch_bounds__(256) void sa_sampled_get_kernel(FmDev fm, SaDev sa,
             const uint32_t pb = pos / kSymPerBlock, po = pos - pb * kSymPerBlock;
             const uint32_t rb = (pos - 1) / kSymPerBlock, ro = (pos - 1) - rb * kSymPerBlock;
             const uint4 vr = fm.blocks[(uint64_t)rb * 4 + t];
-            const uint32_t word = blocks32[(uint64_t)pb * 16 + 4 + (po >> 4)];
-            const uint32_t code = (word >> (2 * (po & 15))) & 3u;
-            uint32_t c = (sa.code_byte >> (8 * code)) & 255u;
-            if (code == 0 && fm.n_exc) {  // exceptions sit in the stream as code 0
-                const uint32_t e = exc_in_lds ? count_le(s_exc, 0u, fm.n_exc, pos) : count_le(fm.exc_pos, 0u, fm.n_exc, pos);
-                if (e > 0 && (exc_in_lds ? s_exc[e - 1] : fm.exc_pos[e - 1]) == pos) c = sa.exc_byte[e - 1];
+            uint32_t c;
+            if (raw_bwt) {
+                c = fm.bwt_raw[pos];
+            } else {
+                const uint32_t word = blocks32[(uint64_t)pb * 16 + 4 + (po >> 4)];
+                const uint32_t code = (word >> (2 * (po & 15))) & 3u;
+                c = (sa.code_byte >> (8 * code)) & 255u;
+                if (code == 0 && fm.n_exc) {  // sparse exceptions sit in the stream as code 0
+                    const uint32_t e = count_le(s_exc, 0u, fm.n_exc, pos);
+                    if (e > 0 && s_exc[e - 1] == pos) c = sa.exc_byte[e - 1];
+                }
             }
             if (c == sa.sentinel) {  // suffix_array.rs:168-175
                 uint32_t lo = 0, hi = sa.n_extra;
@@ -130,11 +134,15 @@ __global__ __launch_bounds__(256) void sa_sampled_get_kernel(FmDev fm, SaDev sa,
             uint32_t occ = 0;
             if (cls < 4) {
                 occ = quad_sum(block_part(vr, t, ro, cls));
-                if (cls == 0 && fm.n_exc)
-                    occ -= exc_in_lds ? count_le(s_exc, 0u, fm.n_exc, pos - 1) : count_le(fm.exc_pos, 0u, fm.n_exc, pos - 1);
-            } else if (cls >= kClsExc && cls != kClsPanic) {
-                const uint32_t e = cls - kClsExc;
-                const uint32_t lo = fm.exc_sym_off[e], hi = fm.exc_sym_off[e + 1];
+                if (cls == 0 && fm.n_exc) occ -= count_le(s_exc, 0u, fm.n_exc, pos - 1);
+            } else if (cls == kClsPanic) {
+            } else if (cls >= kClsDense) {
+                uint32_t o;
+                const uint4 v = bv_load(fm, cls - kClsDense, pos - 1, t, o);
+                occ = quad_sum(bv_part(v, t, o));
+            } else if (cls >= kClsSparse) {
+                const uint32_t e = cls - kClsSparse;
+                const uint32_t lo = fm.sparse_off[e], hi = fm.sparse_off[e + 1];
                 occ = count_le(fm.exc_sym_pos, lo, hi, pos - 1) - lo;
             }
             pos = s_less[c] + occ;

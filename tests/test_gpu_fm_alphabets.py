@@ -1,0 +1,127 @@
+"""General-alphabet FM indexes on the GPU (bwt.rs:94-182 and fmindex.rs:225-230 work for any alphabet): BWTs
+with many symbols beyond the four most frequent — a genome with 5 % N, a 20-letter protein text, an IUPAC text —
+go through the dense-symbol layout (one-hot rank bit vectors, fm_index.hip) and must give the oracle's tags,
+intervals and matched lengths bit for bit; `Interval::occ` over a sampled suffix array (K6) and the FMD-index
+SMEMs (K7) run on the same indexes."""
+import numpy as np
+import pytest
+
+import oracle_py as orc
+from rust_bio_amd import _lib, synth
+from rust_bio_amd.bwt import Occ, bwt, less
+from rust_bio_amd.fmindex import FMDIndex, FMIndex
+from rust_bio_amd.suffix_array import SampledSuffixArray, suffix_array
+
+pytestmark = pytest.mark.gpu
+PROTEIN = b"ARNDCQEGHILKMFPSTWYV"
+IUPAC = b"ACGTRYSWKMBDHVNacgtryswkmbdhvn"
+
+
+def text_with_n(n, seed, n_frac=0.05):
+    """uniform ACGT with `n_frac` of the positions replaced by N: half as isolated bases, half in runs"""
+    g = synth.genome(n, seed).copy()
+    rng = np.random.default_rng(seed)
+    iso = rng.random(n) < n_frac / 2
+    g[:n][iso] = ord("N")
+    n_runs = max(1, int(n * n_frac / 2 / 500))
+    for s in rng.integers(0, max(1, n - 600), size=n_runs):
+        g[s:s + 500] = ord("N")
+    return g
+
+
+def patterns_from(text, n_q, plen, seed, alphabet_bytes, mutate=0.3):
+    rng = np.random.default_rng(seed)
+    n = len(text) - 1
+    al = np.frombuffer(alphabet_bytes, dtype=np.uint8)
+    starts = rng.integers(0, n - plen, size=n_q)
+    pats = text[starts[:, None] + np.arange(plen)[None, :]].copy()
+    mut = rng.random(n_q) < mutate
+    cols = rng.integers(0, plen, size=n_q)
+    pats[mut, cols[mut]] = al[rng.integers(0, len(al), size=int(mut.sum()))]
+    off = np.arange(n_q + 1, dtype=np.uint64) * np.uint64(plen)
+    return np.ascontiguousarray(pats.reshape(-1)), off
+
+
+def check(text, alphabet, pat, off, k=64, threads=8):
+    sa = suffix_array(text)
+    b = bwt(text, sa)
+    ls = less(b, alphabet)
+    fm = FMIndex(b, ls, Occ(b, k, alphabet))
+    occ = orc.Occ(b, k, alphabet)
+    otag, olo, ohi, oml = orc.backward_search_batch(b, ls, occ, pat, off, threads=threads)
+    assert not (otag == 3).any()
+    tag, lo, hi, ml = fm.backward_search_arrays(pat, off)
+    assert (tag == otag).all() and (lo == olo).all() and (hi == ohi).all() and (ml.astype(np.uint64) == oml).all()
+    return sa, b, ls, fm, tag
+
+
+@pytest.mark.parametrize("n", [300_000, 3_000_000])
+def test_genome_with_five_percent_n(n):
+    g = text_with_n(n, seed=11)
+    assert 0.04 < (g == ord("N")).mean() < 0.07
+    pat, off = patterns_from(g, 60_000, 40, 5, b"ACGTN")
+    sa, b, ls, fm, tag = check(g, b"ACGTNacgtn", pat, off)
+    assert (tag == 0).sum() > 10_000 and (tag == 1).sum() > 1000
+    # Interval::occ through a sampled suffix array on the same index (K6 reads bwt[pos] from the raw BWT here)
+    ssa = SampledSuffixArray(sa, g, b, 16, fmindex=fm)
+    rows = np.random.default_rng(1).integers(0, len(sa), size=50_000).astype(np.uint64)
+    assert (ssa.get_batch(rows) == sa[rows.astype(np.intp)]).all()
+
+
+def test_hundred_megabase_genome_with_n():
+    """the size the restriction was lifted for: > 2^22 exception positions (5 M N's) at 100 Mbp"""
+    g = text_with_n(100_000_000, seed=12)
+    pat, off = patterns_from(g, 400_000, 60, 6, b"ACGTN", mutate=0.25)
+    sa, b, ls, fm, tag = check(g, b"ACGTNacgtn", pat, off, k=128, threads=16)
+    assert (tag == 0).sum() > 200_000
+
+
+def test_protein_text():
+    rng = np.random.default_rng(3)
+    al = np.frombuffer(PROTEIN, dtype=np.uint8)
+    # a skewed composition, like real proteomes (L, A, G frequent; W, C rare)
+    w = np.array([8.3, 5.5, 4.1, 5.5, 1.4, 3.9, 6.8, 7.1, 2.3, 5.9, 9.7, 5.8, 2.4, 3.9, 4.7, 6.6, 5.3, 1.1, 2.9, 6.9])
+    t = np.append(al[rng.choice(20, size=1_500_000, p=w / w.sum())], np.uint8(ord("$")))
+    pat, off = patterns_from(t, 50_000, 12, 9, PROTEIN, mutate=0.4)
+    alphabet = bytes(sorted(PROTEIN))
+    sa, b, ls, fm, tag = check(t, alphabet, pat, off)
+    assert (tag == 0).sum() > 10_000 and (tag == 1).sum() > 5000
+    ssa = SampledSuffixArray(sa, t, b, 8, fmindex=fm)
+    rows = rng.integers(0, len(sa), size=20_000).astype(np.uint64)
+    assert (ssa.get_batch(rows) == sa[rows.astype(np.intp)]).all()
+
+
+def test_iupac_text_thirty_symbols():
+    """every IUPAC code in both cases: 30 symbols, the rare ones as sorted lists, the others as bit vectors"""
+    rng = np.random.default_rng(4)
+    al = np.frombuffer(IUPAC, dtype=np.uint8)
+    p = np.array([20.0] * 4 + [1.0] * 11 + [2.0] * 4 + [0.0005] * 11)
+    t = np.append(al[rng.choice(30, size=800_000, p=p / p.sum())], np.uint8(ord("$")))
+    pat, off = patterns_from(t, 40_000, 10, 2, IUPAC[:19], mutate=0.3)
+    check(t, IUPAC, pat, off)
+
+
+def test_fmd_smems_on_a_genome_with_many_n():
+    """FMDIndex::smems / all_smems (fmindex.rs:363-501) when T (or another base) and N are ranked in bit vectors"""
+    comp = bytes.maketrans(b"ACGTNacgtn", b"TGCANtgcan")
+    g = text_with_n(60_000, seed=21)[:-1].tobytes()
+    text = g + b"$" + g.translate(comp)[::-1] + b"$"
+    sa = suffix_array(text)
+    b = bwt(text, sa)
+    alpha = b"ACGTNacgtn"
+    ls = less(b, alpha)
+    fmd = FMDIndex(FMIndex(b, ls, Occ(b, 3, alpha)))
+    ofmd = orc.FMDIndex(b, ls, orc.Occ(b, 3, alpha))
+    rng = np.random.default_rng(8)
+    pats = []
+    for _ in range(300):
+        s = int(rng.integers(0, len(g) - 60))
+        p = bytearray(g[s:s + int(rng.integers(20, 60))])
+        for _ in range(int(rng.integers(0, 3))):
+            p[int(rng.integers(0, len(p)))] = b"ACGTN"[int(rng.integers(0, 5))]
+        pats.append(bytes(p))
+    got = fmd.all_smems_batch(pats, 8)
+    for p, r in zip(pats, got):
+        want = ofmd.all_smems(p, 8)
+        assert [(iv.lower, iv.lower_rev, iv.size, iv.match_size, pos, ln) for iv, pos, ln in r] == \
+               [(*w[0], w[1], w[2]) for w in want], p
