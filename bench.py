@@ -47,6 +47,9 @@ def parse_args():
     ap.add_argument("--queries", type=int, default=10_000_000, help="FM leg: patterns per GPU (configs[2]: 10M)")
     ap.add_argument("--pattern-len", type=int, default=100)
     ap.add_argument("--skip-fm", action="store_true")
+    ap.add_argument("--fm-big-genome", type=int, default=0,
+                    help="extra FM leg on an index that cannot sit in the 256 MiB Infinity Cache (e.g. 1000000000: 333 MB of "
+                         "blocks; the host suffix sort takes minutes, hence opt-in)")
     ap.add_argument("--skip-k1", action="store_true")
     ap.add_argument("--k1-pairs", type=int, default=262_144, help="int32-kernel legs: pairs per GPU")
     ap.add_argument("--skip-banded", action="store_true")
@@ -308,6 +311,9 @@ def main():
     if not args.skip_fm:
         fm_legs(args, ctx, dev, stream, rank, world, do_cpu, orc, threads, parity, result)
 
+    if args.fm_big_genome and rank == 0 and world == 1:
+        result["fm_big"] = fm_big_leg(args, ctx, dev, stream, do_cpu, orc, threads, parity)
+
     # ------------------------------------------------------------------ banded leg (configs[3] shape)
     if not args.skip_banded:
         result["banded"] = banded_leg(args, ctx, dev, rank, world, do_cpu, orc, threads, parity)
@@ -527,29 +533,110 @@ def fm_legs(args, ctx, dev, stream, rank, world, do_cpu, orc, threads, parity, r
     torch.cuda.empty_cache()
 
 
+def fm_big_leg(args, ctx, dev, stream, do_cpu, orc, threads, parity):
+    """backward_search on an index larger than the Infinity Cache: every rank is an HBM read"""
+    import resource
+    n_g, n_q, P = args.fm_big_genome, args.queries, args.pattern_len
+    g_dev = synth_gpu.genome(n_g, seed=33, device=dev)
+    g = g_dev.cpu().numpy()
+    t0 = time.perf_counter()
+    sa = suffix_array(g)
+    sa_s = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    b = bwt(g, sa)
+    del sa
+    ls = less(b, N_ALPHABET)
+    fm = FMIndex(b, ls, Occ(b, 128, N_ALPHABET), ctx=ctx)
+    idx_s = time.perf_counter() - t0
+    pat, off = synth_gpu.fm_patterns(g_dev, n_q, P, seed=34)
+    del g_dev
+    d_tag = torch.empty(n_q, dtype=torch.uint8, device=dev)
+    d_lo = torch.empty(n_q, dtype=torch.int64, device=dev)
+    d_hi = torch.empty(n_q, dtype=torch.int64, device=dev)
+    d_ml = torch.empty(n_q, dtype=torch.int32, device=dev)
+
+    def step():
+        fm.backward_search_dev(n_q, pat.data_ptr(), off.data_ptr(), d_tag.data_ptr(), d_lo.data_ptr(), d_hi.data_ptr(),
+                               d_ml.data_ptr(), stream)
+
+    t = timed_steps(step, args.steps, args.warmup, dev)
+    tm = kernel_timing(ctx, step)
+    ms = tm["fm_ms"] / max(1, tm["fm_launches"])
+    steps_exec = int((d_ml.to(torch.int64) + (d_tag == 1).to(torch.int64) + (d_tag == 2).to(torch.int64)).sum().item())
+    alg = float(n_q) * (P + 24) + 128.0 * steps_exec
+    leg = {"value": round(float(n_q) * args.steps / t, 1), "unit": "queries/s", "ms_per_step": round(t / args.steps * 1e3, 3),
+           "config": {"workload": f"FMIndex over {n_g} bp synthetic genome + '$', {n_q} x {P} bp backward_search, jump table off",
+                      "index_bytes": fm.device_bytes(), "suffix_array_host_s": round(sa_s, 1), "bwt_less_blocks_upload_s": round(idx_s, 1),
+                      "host_peak_rss_gb": round(resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6, 1)},
+           "tags": {"complete": int((d_tag == 0).sum().item()), "partial": int((d_tag == 1).sum().item())},
+           "roofline": {"bound": "hbm", "kernel": "fm_backward_search_kernel", "achieved": round(alg / (ms * 1e-3) / 1e9, 2),
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                        "traffic": pmc_traffic("fm_backward_search_kernel", "fm_big_queries_per_launch", n_q),
+                        "launch_ms": round(ms, 4), "queries_per_launch": n_q, "alg_bytes_per_query": round(alg / n_q, 1)}}
+    if do_cpu:
+        occ = orc.Occ(b, 128, N_ALPHABET)
+        n_chk = min(n_q, 1_000_000)
+        hp = pat[:n_chk * P].cpu().numpy()
+        hoff = np.arange(n_chk + 1, dtype=np.uint64) * np.uint64(P)
+        t0 = time.perf_counter()
+        otag, olo, ohi, oml = orc.backward_search_batch(b, ls, occ, hp, hoff, threads=threads)
+        t_par = time.perf_counter() - t0
+        ok = bool((d_tag[:n_chk].cpu().numpy() == otag).all() and (d_lo[:n_chk].cpu().numpy().astype(np.uint64) == olo).all() and
+                  (d_hi[:n_chk].cpu().numpy().astype(np.uint64) == ohi).all() and
+                  (d_ml[:n_chk].cpu().numpy().astype(np.uint64) == oml).all())
+        parity.update({"fm_big_queries_checked": n_chk, "fm_big_bit_exact": ok})
+        leg["cpu_baseline"] = {"value": round(n_chk / t_par, 1), "unit": "queries/s", "cores": threads, "kind": "port",
+                               "sample": f"{n_chk} of the {n_q} queries (the parity pass), oracle backward_search"}
+    return leg
+
+
 def seed_extend_leg(args, ctx, dev, stream, rank, world, do_cpu, orc, threads, parity, fm, g_dev, g, sa, b, ls):
-    from rust_bio_amd.pipeline import seed_and_extend
+    from rust_bio_amd.pipeline import SeedParams, attach_text, seed_extend_dev
     L, Rp = args.read_len, args.pipeline_reads
     reads, r_starts = synth_gpu.reads_from_genome(g_dev, Rp, L, seed=5 + 100003 * rank)
-    al2 = Aligner.with_scoring(Scoring.from_scores(-5, -1, 1, -1), ctx=ctx)
-    holder = {}
+    d_roff = torch.arange(Rp + 1, dtype=torch.int64, device=dev) * L
+    attach_text(fm, d_text=g_dev)
+    prm = SeedParams(20, 10, 16, 25)
+    sc = Scoring.from_scores(-5, -1, 1, -1)
+    stride = 2 * L + 2 * prm.pad + 4
+    d_hits = torch.empty(Rp * 96, dtype=torch.uint8, device=dev)
+    d_ops = torch.empty(Rp * stride, dtype=torch.uint8, device=dev)
+    tot = np.zeros(2, dtype=np.uint64)
 
     def pipe_step():
-        holder["res"] = seed_and_extend(fm, al2, g_dev, args.genome, reads, Rp, L)
+        seed_extend_dev(fm, sc, Rp, reads.data_ptr(), d_roff.data_ptr(), L, d_hits.data_ptr(), d_ops.data_ptr(), stride, prm,
+                        stream, tot)
 
-    k_steps = max(1, args.steps // 2)
-    pipe_t = timed_steps(pipe_step, k_steps, 1, dev)
-    res = holder["res"]
-    mapped = res.score > -(1 << 29)
-    near = ((res.ref_start - r_starts).abs() <= 8) & mapped
-    leg = {"value": round(world * Rp * k_steps / pipe_t, 1), "unit": "reads/s",
-           "config": {"workload": f"{Rp} x {L} bp reads per GPU (5% sub, 1% ins, 1% del) vs the {args.genome} bp genome: "
-                                  "20-bp seeds at stride 10 -> backward_search -> Interval::occ (sampled SA, rate 32, "
-                                  "intervals <= 16 rows) -> Aligner::semiglobal on +-25 bp windows -> best hit "
+    pipe_t = timed_steps(pipe_step, args.steps, args.warmup, dev)
+    tm = kernel_timing(ctx, pipe_step, reps=1)
+    hv = d_hits.view(torch.int32).view(Rp, 24)
+    score = hv[:, 0]
+    mapped = score > -(1 << 29)
+    ref_start = d_hits.view(torch.int64).view(Rp, 12)[:, 9]
+    near = ((ref_start - r_starts).abs() <= 8) & mapped
+    n_ops_total = int(hv[:, 7].to(torch.int64).sum().item())
+    C = int(tot[1])
+    # algorithmic bytes (SURVEY.md section 8d formulas of the three calls): seeds |P| + 24 + 128 x LF steps (20 per voting
+    # seed at most: counted as executed), 8 B per located row, and per candidate the aligner's m + n + 24 + 2 (m+1)(n+1)
+    n_seeds = Rp * ((L - prm.seed_len) // prm.stride + 1)
+    alg = n_seeds * (prm.seed_len + 24 + 128.0 * prm.seed_len) + 8.0 * int(tot[0]) + \
+        C * (L + (L + 2 * prm.pad) + 24 + 2.0 * (L + 1) * (L + 2 * prm.pad + 1)) + n_ops_total
+    ms = pipe_t / args.steps * 1e3
+    leg = {"value": round(world * Rp * args.steps / pipe_t, 1), "unit": "reads/s", "ms_per_step": round(ms, 3),
+           "config": {"workload": f"{Rp} x {L} bp reads per GPU (5% sub, 1% ins, 1% del) vs the {args.genome} bp genome through "
+                                  "bg_seed_extend_batch_dev: 20-bp seeds at stride 10 -> backward_search -> Interval::occ (sampled SA, "
+                                  "rate 32, intervals <= 16 rows) -> Aligner::semiglobal on +-25 bp windows -> best hit + its operations "
                                   "(BASELINE configs[4] shape, genome scaled to the FM leg's)"},
-           "seed_hits": res.n_seed_hits, "candidates": res.n_candidates,
+           "seed_hits": int(tot[0]), "candidates": C,
            "mapped_frac": round(float(mapped.float().mean().item()), 4),
-           "mapped_at_origin_frac": round(float(near.float().mean().item()), 4)}
+           "mapped_at_origin_frac": round(float(near.float().mean().item()), 4),
+           "kernel_ms": {"seed_search": round(tm["fm_ms"], 3), "align_fill": round(tm["fill_ms"], 3),
+                         "align_traceback": round(tm["traceback_ms"], 3)},
+           "roofline": {"bound": "hbm", "kernel": "whole pipeline (K5 seeds, K6 locate, gather, K1p semiglobal, K2, best hit)",
+                        "achieved": round(alg / (ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
+                        "alg_bytes_per_read": round(alg / Rp, 1),
+                        "note": "dominated by the candidates' semiglobal fill (VALU-bound like the headline kernel)"}}
     if do_cpu:
         occ = orc.Occ(b, 128, N_ALPHABET)
         osc = orc.make_scoring(-5, -1, 1, -1)
@@ -557,13 +644,20 @@ def seed_extend_leg(args, ctx, dev, stream, rank, world, do_cpu, orc, threads, p
         hr = reads[:n_chk * L].cpu().numpy()
         ho = np.arange(n_chk + 1, dtype=np.uint64) * np.uint64(L)
         t0 = time.perf_counter()
-        hits, _, _ = orc.seed_extend_batch(b, ls, occ, sa, g, args.genome, osc, hr, ho, threads=threads, want_ops=False)
+        ohits, oops, ostride = orc.seed_extend_batch(b, ls, occ, sa, g, args.genome, osc, hr, ho, threads=threads)
         t_par = time.perf_counter() - t0
-        o_rs = hits["ref_start"].astype(np.int64)  # UINT64_MAX -> -1
-        o_re = hits["ref_end"].astype(np.int64)
-        ok = bool((res.score[:n_chk].cpu().numpy() == hits["aln"]["score"]).all() and
-                  (res.ref_start[:n_chk].cpu().numpy() == o_rs).all() and (res.ref_end[:n_chk].cpu().numpy() == o_re).all())
-        parity.update({"seed_extend_reads_checked": n_chk, "seed_extend_reads_total": Rp, "seed_extend_bit_exact": ok})
+        hits = d_hits[:n_chk * 96].cpu().numpy().view(_lib.SEED_HIT_DTYPE)
+        ok = all((hits[f] == ohits[f]).all() for f in ("n_candidates", "n_seed_hits", "window_start", "ref_start", "ref_end"))
+        ok = ok and all((hits["aln"][f].astype(np.int64) == ohits["aln"][f].astype(np.int64)).all()
+                        for f in ("score", "xstart", "xend", "ystart", "yend", "n_ops"))
+        if ok:  # the winners' operations (right-aligned in their slot)
+            hops = d_ops[:n_chk * stride].cpu().numpy().reshape(n_chk, stride)
+            kq = hits["aln"]["n_ops"].astype(np.int64)
+            dev_mask = np.arange(stride)[None, :] >= (stride - kq)[:, None]
+            or_mask = np.arange(ostride)[None, :] < kq[:, None]
+            kind = (oops.reshape(n_chk, ostride) & np.uint64(0xFF)).astype(np.uint8)
+            ok = bool((hops[dev_mask] == kind[or_mask]).all())
+        parity.update({"seed_extend_reads_checked": n_chk, "seed_extend_reads_total": Rp, "seed_extend_bit_exact": bool(ok)})
         ns = min(n_chk, 2_000 * threads)
         t_all = median_time(lambda: orc.seed_extend_batch(b, ls, occ, sa, g, args.genome, osc, hr[:ns * L], ho[:ns + 1],
                                                           threads=threads, want_ops=False))

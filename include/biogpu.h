@@ -300,6 +300,49 @@ uint64_t bg_sparse_expand_kmer_matches(const uint8_t* x, uint64_t m, const uint8
                                        uint32_t k, const uint32_t* matches_xy, uint64_t n_matches,
                                        uint32_t allowed_mismatches, uint32_t* out_xy, uint64_t cap);
 
+/* ---- seed-and-extend read mapping (BASELINE configs[4]) ----------------------------------------------------
+ * rust-bio has no read mapper; its callers compose one from FMIndex::backward_search (fmindex.rs:144-208),
+ * Interval::occ (fmindex.rs:75-79) and Aligner::semiglobal (pairwise/mod.rs:954) — the pattern of src/lib.rs:129-165
+ * and benches/fmindex.rs:20-38.  bg_seed_extend_batch is that composition for a batch of reads with every
+ * intermediate in HBM; its definition (stated on the CPU by oracle/pipeline.cpp out of the oracle's three calls):
+ *   seeds        read[o .. o + seed_len) for o = 0, stride, 2 stride, ... while the window fits in the read;
+ *   votes        a seed votes when its search is Complete and its interval holds 1 ..= max_occ rows;
+ *   proposals    hit position p of the seed at offset o proposes the read start s = p - o; s < 0 or s >= n_text
+ *                (the text without its final sentinel) is dropped, equal (read, s) proposals are merged;
+ *   extension    Aligner::semiglobal(x = read, y = text[max(0, s - pad) .. min(n_text, s + read_len + pad)));
+ *   best hit     per read the highest score, the smallest s among equal scores; a read without candidates
+ *                reports score BG_MIN_SCORE, ref positions UINT64_MAX and no operations.
+ * The index handle needs the text (bg_fm_set_text[_dev]: all n bytes the index was built from, final sentinel
+ * included) and a suffix array (bg_fm_set_suffix_array / bg_fm_set_sampled_suffix_array). */
+int bg_fm_set_text(bg_fm* fm, const uint8_t* text, uint64_t n);         /* host text, copied to the device */
+int bg_fm_set_text_dev(bg_fm* fm, const uint8_t* d_text, uint64_t n);   /* device text, borrowed: must outlive the handle's use */
+typedef struct {
+    uint32_t seed_len, stride; /* benches/fmindex.rs:21-25 searches 20-mers */
+    uint32_t max_occ;          /* a seed with more occurrences does not vote */
+    uint32_t pad;              /* text taken on both sides of the proposed placement */
+} bg_seed_params_t;
+typedef struct {
+    bg_alignment_t aln;          /* Aligner::semiglobal(read, window) of the best candidate (y coordinates inside the window) */
+    uint64_t window_start;       /* text offset of that window */
+    uint64_t ref_start, ref_end; /* window_start + ystart / yend */
+    uint32_t n_candidates;       /* distinct proposed starts of this read (all were aligned) */
+    uint32_t n_seed_hits;        /* suffix-array rows its voting seeds resolved */
+} bg_seed_hit_t;
+/* reads: concatenated, n_reads + 1 offsets (reads up to 65535 bases; (seed slots) x max_occ <= 1024 per read).
+ * ops_buf (optional) receives the winners' operations back to back in read order, hits[r].aln.ops_off points there. */
+int bg_seed_extend_batch(bg_fm* fm, const bg_scoring_t* sc, const bg_seed_params_t* prm, uint64_t n_reads,
+                         const uint8_t* reads, const uint64_t* read_off, bg_seed_hit_t* hits, uint8_t* ops_buf,
+                         uint64_t ops_cap, uint64_t* ops_used);
+/* Device flavour: reads, offsets, hits and (optional) operation slots in HBM; read r's operations end at
+ * d_ops + (r + 1) * ops_stride (ops_stride >= 2 * max_read_len + 2 * pad + 4), hits[r].aln.ops_off points at the
+ * first.  totals (optional, host, 2 entries): suffix-array rows resolved, candidates aligned.  The call waits twice
+ * per 2^20 reads for a few counters that size the next stage; everything else is asynchronous on `stream`.
+ * It goes through the handle's ctx (scratch, aligner): the ctx's single-thread rule applies. */
+int bg_seed_extend_batch_dev(bg_fm* fm, const bg_scoring_t* sc, const bg_seed_params_t* prm, uint64_t n_reads,
+                             const uint8_t* d_reads, const uint64_t* d_read_off, uint32_t max_read_len,
+                             bg_seed_hit_t* d_hits, uint8_t* d_ops, uint64_t ops_stride, uint64_t* totals,
+                             void* stream);
+
 /* ---- FASTQ ingest and CIGAR emission --------------------------------------
  * bio::io::fastq::Reader::read / Records on a text that is in memory (io/fastq.rs:266-303, 508-527: header
  * line '@id desc', sequence lines up to a line that starts with '+', then as many quality lines as there were

@@ -66,6 +66,16 @@ ALN_DTYPE = np.dtype([("score", "<i4"), ("xstart", "<u4"), ("xend", "<u4"), ("ys
                       ("ops_off", "<u8"), ("clip_len", "<u4", (4,)), ("n_clips", "u1"),
                       ("mode", "u1"), ("status", "i1"), ("_pad", "u1"), ("_tail", "<u4")])
 assert ALN_DTYPE.itemsize == 64, ALN_DTYPE.itemsize
+# bg_seed_hit_t
+SEED_HIT_DTYPE = np.dtype([("aln", ALN_DTYPE), ("window_start", "<u8"), ("ref_start", "<u8"), ("ref_end", "<u8"),
+                           ("n_candidates", "<u4"), ("n_seed_hits", "<u4")])
+assert SEED_HIT_DTYPE.itemsize == 96, SEED_HIT_DTYPE.itemsize
+
+
+class SeedParamsC(C.Structure):
+    _fields_ = [("seed_len", C.c_uint32), ("stride", C.c_uint32), ("max_occ", C.c_uint32), ("pad", C.c_uint32)]
+
+
 # bg_fastq_record_t
 FQREC_DTYPE = np.dtype([("id_off", "<u8"), ("desc_off", "<u8"), ("seq_off", "<u8"), ("qual_off", "<u8"),
                         ("id_len", "<u4"), ("desc_len", "<u4"), ("seq_len", "<u4"), ("qual_len", "<u4"),
@@ -80,7 +90,8 @@ SYMBOLS = ["bg_device_count", "bg_init", "bg_free", "bg_strerror", "bg_last_erro
            "bg_align_batch", "bg_align_batch_dev", "bg_align_banded_batch", "bg_align_banded_batch_dev", "bg_band_create_batch",
            "bg_align_banded_bands_batch", "bg_band_from_matches_batch", "bg_sparse_find_kmer_matches", "bg_sparse_sdpkpp",
            "bg_sparse_lcskpp", "bg_sparse_sdpkpp_union_lcskpp_path", "bg_sparse_expand_kmer_matches", "bg_fastq_parse",
-           "bg_fastq_parse_dev", "bg_cigar_batch", "bg_cigar_batch_dev", "bg_get_timing", "bg_enable_timing"]
+           "bg_fastq_parse_dev", "bg_cigar_batch", "bg_cigar_batch_dev", "bg_get_timing", "bg_enable_timing",
+           "bg_fm_set_text", "bg_fm_set_text_dev", "bg_seed_extend_batch", "bg_seed_extend_batch_dev"]
 
 
 def build(force=False):
@@ -152,6 +163,10 @@ def lib():
                            ("bg_sparse_expand_kmer_matches", [vp, u64, vp, u64, u32, vp, u64, u32, vp, u64])]:
             getattr(L, name).restype = u64
             getattr(L, name).argtypes = args
+        L.bg_fm_set_text.argtypes = [vp, vp, u64]
+        L.bg_fm_set_text_dev.argtypes = [vp, vp, u64]
+        L.bg_seed_extend_batch.argtypes = [vp, C.POINTER(ScoringC), C.POINTER(SeedParamsC), u64, vp, vp, vp, vp, u64, C.POINTER(u64)]
+        L.bg_seed_extend_batch_dev.argtypes = [vp, C.POINTER(ScoringC), C.POINTER(SeedParamsC), u64, vp, vp, u32, vp, vp, u64, vp, vp]
         L.bg_get_timing.argtypes = [vp, C.POINTER(TimingC)]
         L.bg_enable_timing.argtypes = [vp, i32]
         for s in SYMBOLS:

@@ -24,6 +24,8 @@ extern thread_local std::string bg_tls_error;
 
 struct bg_band_scratch;  // banded_api.hip
 void bg_band_scratch_free(bg_band_scratch*);
+struct bg_seed_scratch;  // seed_extend.hip
+void bg_seed_scratch_free(bg_seed_scratch*);
 struct bg_host_pipe;  // sw_api.hip: staging sets of the pipelined host-buffer path
 void bg_host_pipe_free(bg_host_pipe*);
 
@@ -45,6 +47,7 @@ struct bg_ctx {
     size_t table_bytes = 0;
     bg_band_scratch* band = nullptr;  // persistent scratch of the banded pipeline
     bg_host_pipe* pipe = nullptr;     // persistent staging of bg_align_batch's pipelined path
+    bg_seed_scratch* seed = nullptr;  // persistent scratch of the seed-and-extend pipeline
     int64_t host_chunk_pairs = 0;     // pairs per pipeline stage of bg_align_batch (0 = default)
     int64_t chunk_pairs = 0;  // 0 = default
     bool force_wide = false;  // tests: disable the NARROW (28-bit key) kernels
@@ -66,6 +69,14 @@ struct bg_ctx {
 
 // grow-only device scratch
 int bg_reserve(void** p, size_t* cur, size_t need);
+// exclusive scan of n uint32 counts into n + 1 uint64 offsets (fastq_ingest.hip); d_sums: 2 * (n / 2048 + 1) uint64 of scratch
+int bg_scan_u32(const uint32_t* d_len, uint64_t n, uint64_t* d_off, uint64_t* d_sums, hipStream_t st);
+// bg_align_batch_dev with what the caller knows about the lengths: 1 all pairs share (m, n), 0 they differ, -1 unknown
+int bg_align_batch_dev_hint(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint64_t n_pairs, const uint8_t* d_x,
+                            const uint64_t* d_x_off, const uint8_t* d_y, const uint64_t* d_y_off, uint32_t max_xlen,
+                            uint32_t max_ylen, bg_alignment_t* d_out, uint8_t* d_ops, uint64_t ops_stride, void* stream,
+                            int len_hint);
+
 // Serialises the users of a ctx's scratch across streams: constructed at the top of every *_dev entry point that
 // touches ctx->tb / aux / bnd / table, it makes `st` wait for the event the previous user recorded (if that was
 // another stream) and records its own when the entry point returns — two calls in flight on two streams with one

@@ -78,6 +78,7 @@ extern "C" int bg_free(bg_ctx* ctx) {
     if (ctx->h_ops) hipHostFree(ctx->h_ops);
     bg_band_scratch_free(ctx->band);
     bg_host_pipe_free(ctx->pipe);
+    bg_seed_scratch_free(ctx->seed);
     if (ctx->ev[0]) hipEventDestroy(ctx->ev[0]);
     if (ctx->ev[1]) hipEventDestroy(ctx->ev[1]);
     if (ctx->scratch_done) hipEventDestroy(ctx->scratch_done);

@@ -527,6 +527,11 @@ __global__ __launch_bounds__(256) void cigar_kernel(const bg_alignment_t* __rest
 
 }  // namespace
 
+// shared with seed_extend.hip: exclusive scan of n uint32 counts into n + 1 uint64 offsets; d_sums holds 2 * (n / 2048 + 1) words
+int bg_scan_u32(const uint32_t* d_len, uint64_t n, uint64_t* d_off, uint64_t* d_sums, hipStream_t st) {
+    return scan_lengths(d_len, n, d_off, d_sums, st);
+}
+
 extern "C" int bg_fastq_parse_dev(bg_ctx* ctx, const uint8_t* d_text, uint64_t len, bg_fastq_record_t* d_recs, uint64_t rec_cap, uint8_t* d_seq,
                                   uint64_t* d_seq_off, uint8_t* d_qual, uint64_t* d_qual_off, uint64_t* n_records, int32_t* status,
                                   uint64_t* err_pos, void* stream) {

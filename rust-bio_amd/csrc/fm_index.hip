@@ -42,11 +42,17 @@ namespace {
 // that entry: one table read instead of kJumpK LF steps (2 block reads each).  The table is filled by
 // this very kernel (run without it: JUMP == false, which also keeps the two apart in profiles), so the
 // results cannot differ.
-template <bool JUMP>
+// SEEDS: the patterns are the seed windows of a batch of reads (seed-and-extend, seed_extend.hip) — query q is
+// seed q % S of read q / S: pat[pat_off[r] + k * stride ..+ seed_len) while it fits in the read (else an empty
+// pattern: Absent), so overlapping windows need no copy of the reads.
+struct SeedSrc {
+    uint32_t S, stride, seed_len;
+};
+template <bool JUMP, bool SEEDS>
 __global__ __launch_bounds__(256) void fm_backward_search_kernel(
     FmDev fm, uint64_t n_q, const uint8_t* __restrict__ pat, const uint64_t* __restrict__ pat_off,
     uint8_t* __restrict__ tag, uint64_t* __restrict__ lower, uint64_t* __restrict__ upper,
-    uint32_t* __restrict__ matched_len, const uint4* __restrict__ jump) {
+    uint32_t* __restrict__ matched_len, const uint4* __restrict__ jump, const SeedSrc seeds) {
     __shared__ uint16_t s_class[256];
     __shared__ uint32_t s_less[256];
     __shared__ uint32_t s_exc[kMaxExcLds];
@@ -80,8 +86,16 @@ __global__ __launch_bounds__(256) void fm_backward_search_kernel(
     auto fetch = [&]() {
         active = false;
         while (q < n_q) {
-            off = pat_off[q];
-            len = (uint32_t)(pat_off[q + 1] - off);
+            if (SEEDS) {
+                const uint64_t rd = q / seeds.S;
+                const uint32_t k = (uint32_t)(q - rd * seeds.S);
+                const uint64_t o = pat_off[rd];
+                off = o + (uint64_t)k * seeds.stride;
+                len = (uint64_t)k * seeds.stride + seeds.seed_len <= pat_off[rd + 1] - o ? seeds.seed_len : 0u;
+            } else {
+                off = pat_off[q];
+                len = (uint32_t)(pat_off[q + 1] - off);
+            }
             if (len) {
                 pos = len;
                 l = 0;
@@ -492,7 +506,7 @@ extern "C" int bg_fm_backward_search_batch_dev(bg_fm* fm, uint64_t n_q, const ui
             const uint32_t cb = (uint32_t)fm->code_byte[0] | (uint32_t)fm->code_byte[1] << 8 | (uint32_t)fm->code_byte[2] << 16 |
                                 (uint32_t)fm->code_byte[3] << 24;
             fm_jump_patterns_kernel<<<dim3((unsigned)((nk + 256) / 256)), dim3(256), 0, st>>>(cb, t_pat, t_off);
-            fm_backward_search_kernel<false><<<dim3(256 * 8), dim3(256), 0, st>>>(fm->dev, nk, t_pat, t_off, t_tag, t_lo, t_hi, t_ml, nullptr);
+            fm_backward_search_kernel<false, false><<<dim3(256 * 8), dim3(256), 0, st>>>(fm->dev, nk, t_pat, t_off, t_tag, t_lo, t_hi, t_ml, nullptr, SeedSrc{});
             fm_jump_pack_kernel<<<dim3((unsigned)(nk / 256)), dim3(256), 0, st>>>(t_tag, t_lo, t_hi, t_ml, (uint4*)d_table);
             BG_HIP(hipGetLastError());
             BG_HIP(hipStreamSynchronize(st));
@@ -517,11 +531,11 @@ extern "C" int bg_fm_backward_search_batch_dev(bg_fm* fm, uint64_t n_q, const ui
     }
     if (ctx->timing) BG_HIP(hipEventRecord(ctx->ev[0], st));
     if (jump)
-        fm_backward_search_kernel<true><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(
-            fm->dev, n_q, d_pat, d_pat_off, d_tag, d_lower, d_upper, d_matched_len, jump);
+        fm_backward_search_kernel<true, false><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(
+            fm->dev, n_q, d_pat, d_pat_off, d_tag, d_lower, d_upper, d_matched_len, jump, SeedSrc{});
     else
-        fm_backward_search_kernel<false><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(
-            fm->dev, n_q, d_pat, d_pat_off, d_tag, d_lower, d_upper, d_matched_len, nullptr);
+        fm_backward_search_kernel<false, false><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(
+            fm->dev, n_q, d_pat, d_pat_off, d_tag, d_lower, d_upper, d_matched_len, nullptr, SeedSrc{});
     BG_HIP(hipGetLastError());
     if (ctx->timing) {
         BG_HIP(hipEventRecord(ctx->ev[1], st));
@@ -531,6 +545,19 @@ extern "C" int bg_fm_backward_search_batch_dev(bg_fm* fm, uint64_t n_q, const ui
         ctx->last.fm_ms += ms;
         ctx->last.fm_launches += 1;
     }
+    return BG_OK;
+}
+
+// the seed windows of a batch of reads as patterns (see SeedSrc): n_reads * S queries, results indexed [read * S + seed]
+int bg_fm_search_seeds_dev(bg_fm* fm, uint64_t n_reads, const uint8_t* d_reads, const uint64_t* d_read_off, uint32_t S,
+                           uint32_t stride, uint32_t seed_len, uint8_t* d_tag, uint64_t* d_lower, uint64_t* d_upper,
+                           uint32_t* d_matched_len, hipStream_t st) {
+    const uint64_t n_q = n_reads * S;
+    if (n_q == 0) return BG_OK;
+    const uint64_t blocks = std::min<uint64_t>((n_q + 63) / 64, 256 * 8);
+    fm_backward_search_kernel<false, true><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(
+        fm->dev, n_q, d_reads, d_read_off, d_tag, d_lower, d_upper, d_matched_len, nullptr, SeedSrc{S, stride, seed_len});
+    BG_HIP(hipGetLastError());
     return BG_OK;
 }
 

@@ -140,4 +140,9 @@ struct bg_fm {
     bool fmd_ok = false;  // the BWT is a word over dna::n_alphabet() + '$' (FMDIndex::from, fmindex.rs:323-327)
 };
 
+// internal entry points shared between the FM translation units
+int bg_fm_search_seeds_dev(bg_fm* fm, uint64_t n_reads, const uint8_t* d_reads, const uint64_t* d_read_off, uint32_t S,
+                           uint32_t stride, uint32_t seed_len, uint8_t* d_tag, uint64_t* d_lower, uint64_t* d_upper,
+                           uint32_t* d_matched_len, hipStream_t st);
+
 #endif

@@ -416,6 +416,14 @@ static int align_batch_dev_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, u
     return BG_OK;
 }
 
+int bg_align_batch_dev_hint(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint64_t n_pairs, const uint8_t* d_x,
+                            const uint64_t* d_x_off, const uint8_t* d_y, const uint64_t* d_y_off, uint32_t max_xlen,
+                            uint32_t max_ylen, bg_alignment_t* d_out, uint8_t* d_ops, uint64_t ops_stride, void* stream,
+                            int len_hint) {
+    return align_batch_dev_impl(ctx, sc, mode, n_pairs, d_x, d_x_off, d_y, d_y_off, max_xlen, max_ylen, d_out, d_ops, ops_stride,
+                                stream, len_hint);
+}
+
 extern "C" int bg_align_batch_dev(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint64_t n_pairs,
                                   const uint8_t* d_x, const uint64_t* d_x_off, const uint8_t* d_y,
                                   const uint64_t* d_y_off, uint32_t max_xlen, uint32_t max_ylen,

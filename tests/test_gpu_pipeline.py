@@ -1,76 +1,50 @@
-"""Seed-and-extend (BASELINE configs[4] shape, scaled down): the device pipeline of
-rust_bio_amd.pipeline against the same composition made of CPU-oracle calls
-(backward_search -> Interval::occ -> Aligner::semiglobal, the caller pattern of
-/root/reference/src/lib.rs:129-165)."""
+"""Seed-and-extend (BASELINE configs[4] shape, scaled down): `bg_seed_extend_batch[_dev]` against the same
+composition made of the CPU oracle's three calls (oracle/pipeline.cpp: backward_search -> Interval::occ ->
+Aligner::semiglobal, the caller pattern of /root/reference/src/lib.rs:129-165) — best score, reference span,
+candidate / hit counts and the winner's complete operation list, read by read."""
 import numpy as np
 import pytest
 import torch
 
 import oracle_py as orc
-from rust_bio_amd import synth
+from rust_bio_amd import _lib, synth
 from rust_bio_amd.bwt import Occ, bwt, less
 from rust_bio_amd.fmindex import FMIndex
-from rust_bio_amd.pairwise import MIN_SCORE, Aligner, Scoring
-from rust_bio_amd.pipeline import seed_and_extend
+from rust_bio_amd.pairwise import MIN_SCORE, Scoring
+from rust_bio_amd.pipeline import SeedParams, attach_text, seed_extend_arrays, seed_extend_dev
 from rust_bio_amd.suffix_array import RawSuffixArray, SampledSuffixArray, suffix_array
 
 pytestmark = pytest.mark.gpu
 ALPHA = b"ACGTNacgtn$"
+NONE = np.uint64(0xFFFFFFFFFFFFFFFF)
 
 
-def oracle_pipeline(text, n_text, sa, b, ls, reads, L, seed_len, stride, max_occ, pad):
-    R = len(reads) // L
-    occ = orc.Occ(b, 64, ALPHA)
-    offs = list(range(0, L - seed_len + 1, stride))
-    seeds = np.concatenate([reads[r * L + o: r * L + o + seed_len] for r in range(R) for o in offs])
-    poff = np.arange(R * len(offs) + 1, dtype=np.uint64) * seed_len
-    tag, lo, hi, ml = orc.backward_search_batch(b, ls, occ, seeds, poff, threads=4)
-    cands = []
-    for q in range(R * len(offs)):
-        if tag[q] == 0 and 0 < hi[q] - lo[q] <= max_occ:
-            for p in sa[int(lo[q]):int(hi[q])]:
-                s = int(p) - offs[q % len(offs)]
-                if 0 <= s < n_text:
-                    cands.append((q // len(offs), s))
-    cands = sorted(set(cands))
-    xs, ys, wl = [], [], []
-    for r, s in cands:
-        a, e = max(0, s - pad), min(n_text, s + L + pad)
-        xs.append(reads[r * L:(r + 1) * L])
-        ys.append(text[a:e])
-        wl.append(a)
-    score = np.full(R, MIN_SCORE, dtype=np.int64)
-    rs = np.full(R, -1, dtype=np.int64)
-    re = np.full(R, -1, dtype=np.int64)
-    if cands:
-        xo = np.arange(len(cands) + 1, dtype=np.uint64) * L
-        yo = np.zeros(len(cands) + 1, dtype=np.uint64)
-        yo[1:] = np.cumsum([len(y) for y in ys])
-        out, _, _ = orc.align_batch(orc.make_scoring(-5, -1, 1, -1), "semiglobal", np.concatenate(xs), xo,
-                                    np.concatenate(ys), yo, threads=4, want_ops=False)
-        for c, (r, s) in enumerate(cands):
-            if out["score"][c] > score[r]:
-                score[r] = out["score"][c]
-                rs[r] = wl[c] + int(out["ystart"][c])
-                re[r] = wl[c] + int(out["yend"][c])
-    return score, rs, re, len(cands)
-
-
-@pytest.mark.parametrize("sampled", [0, 8])
-def test_seed_and_extend_matches_oracle_composition(sampled):
-    n_text, R, L = 200_000, 1500, 150
+def make_case(n_text=200_000, R=1500, L=150, ragged=False):
     g = synth.random_dna(n_text, seed=31).copy()
     g[50_000:50_400] = g[10_000:10_400]  # a repeat: seeds with several occurrences
-    text = g.tobytes() + b"$"
+    text = np.append(g, np.uint8(ord("$")))
     rng = np.random.default_rng(3)
     starts = rng.integers(0, n_text - L, size=R)
-    starts[:20] = np.arange(20) * 3           # reads hanging over the left end of the windows
+    starts[:20] = np.arange(20) * 3             # reads hanging over the left end of the windows
     starts[20:40] = n_text - L - np.arange(20)  # ... and the right end
+    starts[40:60] = 10_000 + np.arange(20) * 7  # inside the repeat: two candidates far apart
     refs = np.stack([g[s:s + L] for s in starts])
     reads, _ = synth.mutate_fixed(refs, 77, 0.04, 0.01, 0.01)
     reads[-50:] = synth.random_dna(50 * L, seed=5).reshape(50, L)  # unmappable reads
-    reads = np.ascontiguousarray(reads.reshape(-1))
+    if ragged:
+        lens = rng.integers(15, L + 1, size=R)   # some shorter than one seed
+        lens[:100] = L
+        seqs = [reads[r, :lens[r]] for r in range(R)]
+        flat = np.concatenate(seqs)
+        off = np.zeros(R + 1, dtype=np.uint64)
+        off[1:] = np.cumsum(lens)
+    else:
+        flat = np.ascontiguousarray(reads.reshape(-1))
+        off = np.arange(R + 1, dtype=np.uint64) * np.uint64(L)
+    return g, text, flat, off, starts
 
+
+def build(text, sampled):
     sa = suffix_array(text)
     b = bwt(text, sa)
     ls = less(b, ALPHA)
@@ -79,16 +53,75 @@ def test_seed_and_extend_matches_oracle_composition(sampled):
         SampledSuffixArray(sa, text, b, sampled, fmindex=fm)
     else:
         RawSuffixArray(sa, fm)
+    return sa, b, ls, fm
+
+
+def compare(hits, ops, ohits, oops, ostride, n_mapped_min=None):
+    for f in ("n_candidates", "n_seed_hits", "window_start", "ref_start", "ref_end"):
+        assert (hits[f] == ohits[f]).all(), f
+    for f in ("score", "xstart", "xend", "ystart", "yend", "xlen", "ylen", "n_ops"):
+        assert (hits["aln"][f].astype(np.int64) == ohits["aln"][f].astype(np.int64)).all(), f
+    mapped = ohits["aln"]["score"] > MIN_SCORE
+    assert (hits["aln"]["mode"][mapped] == 2).all()
+    for r in np.nonzero(mapped)[0]:
+        k, o = int(hits["aln"]["n_ops"][r]), int(hits["aln"]["ops_off"][r])
+        want = (oops[r * ostride:r * ostride + k] & np.uint64(0xFF)).astype(np.uint8)
+        assert (ops[o:o + k] == want).all(), r
+    return mapped
+
+
+@pytest.mark.parametrize("sampled", [0, 8])
+@pytest.mark.parametrize("ragged", [False, True])
+def test_seed_extend_matches_oracle_composition(sampled, ragged):
+    g, text, reads, off, starts = make_case(ragged=ragged)
+    sa, b, ls, fm = build(text, sampled)
+    attach_text(fm, text)
+    sc = Scoring.from_scores(-5, -1, 1, -1)
+    hits, ops = seed_extend_arrays(fm, sc, reads, off)
+    occ = orc.Occ(b, 64, ALPHA)
+    ohits, oops, ostride = orc.seed_extend_batch(b, ls, occ, sa, text, len(g), orc.make_scoring(-5, -1, 1, -1), reads, off, threads=8)
+    mapped = compare(hits, ops, ohits, oops, ostride)
+    if not ragged:
+        assert mapped[:-50].mean() > 0.95 and not mapped[-50:].any()
+        near = np.abs(ohits["ref_start"][:-50][mapped[:-50]].astype(np.int64) - starts[:-50][mapped[:-50]]) <= 8
+        assert near.mean() > 0.9  # most reads land where they were drawn from
+        assert (ohits["n_candidates"][40:60] >= 2).all()  # the repeat proposes both copies
+
+
+def test_seed_extend_device_resident_and_parameters():
+    """device pointers in and out, other seed parameters, right-aligned operation slots"""
+    g, text, reads, off, _ = make_case(n_text=120_000, R=700, L=100)
+    sa, b, ls, fm = build(text, 4)
     dev = torch.device("cuda:0")
-    al = Aligner.with_scoring(Scoring.from_scores(-5, -1, 1, -1))
-    res = seed_and_extend(fm, al, torch.from_numpy(g).to(dev), n_text, torch.from_numpy(reads).to(dev), R, L)
+    d_text = torch.from_numpy(text).to(dev)
+    attach_text(fm, d_text=d_text)
+    prm = SeedParams(seed_len=16, stride=7, max_occ=4, pad=12)
+    sc = Scoring.from_scores(-4, -2, 2, -3)
+    R, L = len(off) - 1, 100
+    d_reads = torch.from_numpy(reads).to(dev)
+    d_off = torch.from_numpy(off.astype(np.int64)).to(dev)
+    stride = 2 * L + 2 * prm.pad + 4
+    d_hits = torch.zeros(R * 96, dtype=torch.uint8, device=dev)
+    d_ops = torch.zeros(R * stride, dtype=torch.uint8, device=dev)
+    tot = np.zeros(2, dtype=np.uint64)
+    seed_extend_dev(fm, sc, R, d_reads.data_ptr(), d_off.data_ptr(), L, d_hits.data_ptr(), d_ops.data_ptr(), stride, prm,
+                    torch.cuda.current_stream().cuda_stream, tot)
     torch.cuda.synchronize()
-    o_score, o_rs, o_re, o_c = oracle_pipeline(g, n_text, sa, b, ls, reads, L, 20, 10, 16, 25)
-    assert res.n_candidates == o_c
-    assert (res.score.cpu().numpy().astype(np.int64) == o_score).all()
-    assert (res.ref_start.cpu().numpy() == o_rs).all()
-    assert (res.ref_end.cpu().numpy() == o_re).all()
-    mapped = o_score > MIN_SCORE
-    assert mapped[:-50].mean() > 0.95 and not mapped[-50:].any()
-    # most reads land where they were drawn from
-    assert (np.abs(o_rs[:-50][mapped[:-50]] - starts[:-50][mapped[:-50]]) <= 8).mean() > 0.9
+    hits = d_hits.cpu().numpy().view(_lib.SEED_HIT_DTYPE)
+    ops = d_ops.cpu().numpy()
+    occ = orc.Occ(b, 64, ALPHA)
+    ohits, oops, ostride = orc.seed_extend_batch(b, ls, occ, sa, text, len(g), orc.make_scoring(-4, -2, 2, -3), reads, off,
+                                                 seed_len=16, stride=7, max_occ=4, pad=12, threads=8)
+    compare(hits, ops, ohits, oops, ostride)
+    assert (hits["aln"]["ops_off"] == (np.arange(R) + 1) * stride - hits["aln"]["n_ops"]).all()
+    assert int(tot[0]) == int(ohits["n_seed_hits"].sum()) and int(tot[1]) == int(ohits["n_candidates"].sum())
+
+
+def test_seed_extend_needs_text_and_suffix_array():
+    g, text, reads, off, _ = make_case(n_text=30_000, R=50, L=80)
+    sa = suffix_array(text)
+    b = bwt(text, sa)
+    ls = less(b, ALPHA)
+    fm = FMIndex(b, ls, Occ(b, 64, ALPHA))
+    with pytest.raises(_lib.BiogpuError):
+        seed_extend_arrays(fm, Scoring.from_scores(-5, -1, 1, -1), reads, off)
