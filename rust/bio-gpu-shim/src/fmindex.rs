@@ -1,0 +1,86 @@
+//! `FMIndex::backward_search` / `Interval::occ` on the GPU (reference: src/data_structures/fmindex.rs:69-248,
+//! suffix_array.rs:86-184).  `suffix_array`, `bwt`, `less` stay rust-bio's host code; `FMIndex::new(bwt, less, occ)`
+//! (fmindex.rs:245) becomes `GpuFMIndex::new(ctx, bwt, less, k, alphabet)`: the reference's third argument, the
+//! host-built `Occ` table, is NOT uploaded — the engine ranks on its own packed blocks built from `bwt`
+//! (include/biogpu.h, bg_fm_build), so a caller may skip `Occ::new` altogether; `k` is only validated.
+use crate::{concat, strerror, sys, Context};
+use bio::alphabets::Alphabet;
+use bio::data_structures::bwt::{Less, BWT};
+use bio::data_structures::fmindex::{BackwardSearchResult, Interval};
+use bio::data_structures::suffix_array::RawSuffixArray;
+
+pub struct GpuFMIndex {
+    pub(crate) h: *mut sys::bg_fm,
+}
+// The handle is immutable after construction; searches use no shared scratch (include/biogpu.h, "Streams and threads").
+unsafe impl Send for GpuFMIndex {}
+unsafe impl Sync for GpuFMIndex {}
+
+impl GpuFMIndex {
+    pub fn new(ctx: &Context, bwt: &BWT, less: &Less, occ_k: u32, alphabet: &Alphabet) -> Self {
+        let less64: Vec<u64> = less.iter().map(|&v| v as u64).collect();
+        let syms: Vec<u8> = alphabet.symbols.iter().map(|s| s as u8).collect();
+        let mut h = std::ptr::null_mut();
+        let rc = unsafe {
+            sys::bg_fm_build(ctx.raw, bwt.as_ptr(), bwt.len() as u64, less64.as_ptr(), less64.len() as u32, occ_k,
+                             syms.as_ptr(), syms.len() as u32, &mut h)
+        };
+        assert!(rc == 0, "{}", strerror(rc)); // BG_ERR_OUT_OF_ALPHABET == Occ::new's index panic (bwt.rs:114)
+        GpuFMIndex { h }
+    }
+
+    /// `backward_search` (fmindex.rs:144-208) for many patterns.
+    pub fn backward_search_batch(&self, patterns: &[&[u8]]) -> Vec<BackwardSearchResult> {
+        let (pat, off) = concat(patterns);
+        let n = patterns.len();
+        let (mut tag, mut lo, mut hi, mut ml) = (vec![0u8; n], vec![0u64; n], vec![0u64; n], vec![0u32; n]);
+        let rc = unsafe {
+            sys::bg_fm_backward_search_batch(self.h, n as u64, pat.as_ptr(), off.as_ptr(), tag.as_mut_ptr(), lo.as_mut_ptr(),
+                                             hi.as_mut_ptr(), ml.as_mut_ptr())
+        };
+        // BG_ERR_OUT_OF_ALPHABET: some query reached a byte outside the alphabet — the reference panics with an
+        // index out of bounds there (fmindex.rs:229, bwt.rs:158)
+        assert!(rc == 0, "{}", strerror(rc));
+        (0..n)
+            .map(|q| {
+                let iv = Interval { lower: lo[q] as usize, upper: hi[q] as usize };
+                match tag[q] as i32 {
+                    sys::BG_FM_COMPLETE => BackwardSearchResult::Complete(iv),
+                    sys::BG_FM_PARTIAL => BackwardSearchResult::Partial(iv, ml[q] as usize),
+                    _ => BackwardSearchResult::Absent,
+                }
+            })
+            .collect()
+    }
+
+    pub fn backward_search<'b, P: Iterator<Item = &'b u8> + DoubleEndedIterator>(&self, pattern: P) -> BackwardSearchResult {
+        let p: Vec<u8> = pattern.copied().collect();
+        self.backward_search_batch(&[&p]).pop().unwrap()
+    }
+
+    /// attach the suffix array the index was built from (`RawSuffixArray`, suffix_array.rs:25)
+    pub fn attach_sa(&self, sa: &RawSuffixArray) {
+        let v: Vec<u64> = sa.iter().map(|&p| p as u64).collect();
+        let rc = unsafe { sys::bg_fm_set_suffix_array(self.h, v.as_ptr(), v.len() as u64) };
+        assert!(rc == 0, "{}", strerror(rc));
+    }
+
+    /// `Interval::occ` (fmindex.rs:75-79) for many intervals: positions of interval v are pos[off[v]..off[v+1]]
+    pub fn occ_batch(&self, ivs: &[Interval]) -> (Vec<u64>, Vec<u64>) {
+        let lo: Vec<u64> = ivs.iter().map(|i| i.lower as u64).collect();
+        let hi: Vec<u64> = ivs.iter().map(|i| i.upper as u64).collect();
+        let total: u64 = ivs.iter().map(|i| (i.upper - i.lower) as u64).sum();
+        let (mut off, mut pos) = (vec![0u64; ivs.len() + 1], vec![0u64; total as usize]);
+        let rc = unsafe {
+            sys::bg_interval_occ_batch(self.h, ivs.len() as u64, lo.as_ptr(), hi.as_ptr(), off.as_mut_ptr(), pos.as_mut_ptr(), total)
+        };
+        assert!(rc == 0, "Interval out of range of suffix array"); // fmindex.rs:77
+        (off, pos)
+    }
+}
+
+impl Drop for GpuFMIndex {
+    fn drop(&mut self) {
+        unsafe { sys::bg_fm_free(self.h) };
+    }
+}

@@ -1,0 +1,110 @@
+//! Drop-in delegation of rust-bio's hot path to the MI355X engine (libbiogpu.so, include/biogpu.h).
+//!
+//! * [`pairwise::Aligner`]  — `bio::alignment::pairwise::Aligner` (src/alignment/pairwise/mod.rs:472-1016)
+//! * [`banded::Aligner`]    — `bio::alignment::pairwise::banded::Aligner` (banded.rs:122-1004)
+//! * [`fmindex::GpuFMIndex`] — `FMIndex::backward_search`, `Interval::occ` (fmindex.rs:75-79,144-208)
+//! * [`mapper`]             — the seed-and-extend composition (src/lib.rs:129-165) in one call
+//!
+//! Same method names, argument meaning and panics as the reference; every single-pair method is a batch of one
+//! of the new `*_batch` siblings.  `Scoring`, `MatchFunc`, the alphabet and the BWT / Less / suffix-array builders
+//! stay rust-bio's own host code (north_star).  No rustc exists in the environment this repository is built in:
+//! the crate is source only; the same entry points are exercised through ctypes (rust-bio_amd/_lib.py) and the
+//! C++ mirror (include/biogpu.hpp), and tests/test_shim_matches_header.py pins biogpu-sys to the header.
+pub mod banded;
+pub mod fmindex;
+pub mod mapper;
+pub mod pairwise;
+
+use biogpu_sys as sys;
+use bio_types::alignment::{Alignment, AlignmentMode, AlignmentOperation};
+use std::ffi::CStr;
+
+/// One engine context per device; not `Sync` (like the `&mut self` workspace of `Aligner`, mod.rs:472-481).
+pub struct Context {
+    pub(crate) raw: *mut sys::bg_ctx,
+}
+
+impl Context {
+    pub fn new(device: i32) -> Self {
+        let mut raw = std::ptr::null_mut();
+        let rc = unsafe { sys::bg_init(device, &mut raw) };
+        assert!(rc == 0, "bg_init: {}", strerror(rc)); // no CPU fallback: without a gfx950 device this fails
+        Context { raw }
+    }
+}
+
+impl Drop for Context {
+    fn drop(&mut self) {
+        unsafe { sys::bg_free(self.raw) };
+    }
+}
+
+pub(crate) fn strerror(rc: i32) -> String {
+    unsafe { CStr::from_ptr(sys::bg_strerror(rc)) }.to_string_lossy().into_owned()
+}
+
+/// `AlignmentMode` -> `BG_MODE_*`, explicitly (bio-types' discriminant order is not part of its API).
+pub(crate) fn mode_to_c(mode: AlignmentMode) -> i32 {
+    match mode {
+        AlignmentMode::Custom => sys::BG_MODE_CUSTOM,
+        AlignmentMode::Global => sys::BG_MODE_GLOBAL,
+        AlignmentMode::Semiglobal => sys::BG_MODE_SEMIGLOBAL,
+        AlignmentMode::Local => sys::BG_MODE_LOCAL,
+    }
+}
+
+pub(crate) fn mode_from_c(mode: u8) -> AlignmentMode {
+    match mode as i32 {
+        sys::BG_MODE_GLOBAL => AlignmentMode::Global,
+        sys::BG_MODE_SEMIGLOBAL => AlignmentMode::Semiglobal,
+        sys::BG_MODE_LOCAL => AlignmentMode::Local,
+        _ => AlignmentMode::Custom,
+    }
+}
+
+/// concatenated sequences + n + 1 offsets, the layout every batched entry point takes
+pub(crate) fn concat(seqs: &[&[u8]]) -> (Vec<u8>, Vec<u64>) {
+    let mut buf = Vec::with_capacity(seqs.iter().map(|s| s.len()).sum());
+    let mut off = Vec::with_capacity(seqs.len() + 1);
+    off.push(0u64);
+    for s in seqs {
+        buf.extend_from_slice(s);
+        off.push(buf.len() as u64);
+    }
+    (buf, off)
+}
+
+/// `bg_alignment_t` + operation bytes -> `bio_types::alignment::Alignment` (fields as constructed at mod.rs:911-921)
+pub(crate) fn to_alignment(r: &sys::bg_alignment_t, ops: &[u8]) -> Alignment {
+    let mut clip = r.clip_len.iter();
+    let lo = r.ops_off as usize;
+    let operations = ops[lo..lo + r.n_ops as usize]
+        .iter()
+        .map(|&o| match o as i32 {
+            sys::BG_OP_MATCH => AlignmentOperation::Match,
+            sys::BG_OP_SUBST => AlignmentOperation::Subst,
+            sys::BG_OP_DEL => AlignmentOperation::Del,
+            sys::BG_OP_INS => AlignmentOperation::Ins,
+            sys::BG_OP_XCLIP => AlignmentOperation::Xclip(*clip.next().unwrap() as usize),
+            _ => AlignmentOperation::Yclip(*clip.next().unwrap() as usize),
+        })
+        .collect();
+    Alignment {
+        score: r.score,
+        ystart: r.ystart as usize,
+        xstart: r.xstart as usize,
+        yend: r.yend as usize,
+        xend: r.xend as usize,
+        ylen: r.ylen as usize,
+        xlen: r.xlen as usize,
+        operations,
+        mode: mode_from_c(r.mode),
+    }
+}
+
+pub(crate) fn zero_alignment() -> sys::bg_alignment_t {
+    sys::bg_alignment_t {
+        score: 0, xstart: 0, xend: 0, ystart: 0, yend: 0, xlen: 0, ylen: 0, n_ops: 0, ops_off: 0,
+        clip_len: [0; 4], n_clips: 0, mode: 0, status: 0, _pad: 0, _reserved: 0,
+    }
+}
