@@ -383,6 +383,16 @@ int bg_cigar_batch(bg_ctx* ctx, uint64_t n, const bg_alignment_t* aln, const uin
 int bg_cigar_batch_dev(bg_ctx* ctx, uint64_t n, const bg_alignment_t* d_aln, const uint8_t* d_ops, int hard_clip,
                        char* d_out, uint64_t stride, int32_t* d_len, void* stream);
 
+/* bio_types::alignment::Alignment::pretty(x, y, ncol) (bio-types, not in the reference tree: restated from the crate's
+ * source as documented — parity unpinned; rust-bio's tests only print it, e.g. pairwise/banded.rs:1805) for n
+ * alignments and the sequences they were computed from: rows x / marks / y ('|' match, '\\' mismatch, '+' insertion,
+ * 'x' deletion, ' ' clipped, '-' gap), cut into blocks of ncol columns, each block "x\nmarks\ny\n\n\n".
+ * out_off has n + 1 entries.  BG_ERR_UNSUPPORTED where the crate panics (a non-ASCII byte breaks its row-length
+ * assert) or the sequences do not have the alignment's xlen / ylen; BG_ERR_OPS_CAP if out_cap is too small. */
+int bg_pretty_batch(bg_ctx* ctx, uint64_t n, const bg_alignment_t* aln, const uint8_t* ops, uint64_t ops_bytes,
+                    const uint8_t* x, const uint64_t* x_off, const uint8_t* y, const uint64_t* y_off, uint32_t ncol,
+                    char* out, uint64_t out_cap, uint64_t* out_off);
+
 /* Timing of the last *_dev / batch call's kernels on this ctx, measured with HIP events on
  * the stream the kernels ran on (used by bench.py for the roofline line). */
 typedef struct {

@@ -152,6 +152,65 @@ extern "C" int orc_fastq_parse(const uint8_t* t, uint64_t len, orc_fastq_rec_t* 
 // bio_types::alignment::Alignment::cigar(hard_clip) — bio-types 1.0 (PARITY UNPINNED, see the file header).
 // x is the query: soft/hard clips are xstart and xlen - xend; runs of Match '=', Subst 'X', Del 'D', Ins 'I';
 // clip operations inside `operations` emit nothing; AlignmentMode::Custom is not supported there (panic).
+// bio_types::alignment::Alignment::pretty(x, y, ncol) — bio-types 1.0 (PARITY UNPINNED: the crate is not in the
+// reference tree and rust-bio only prints the result, e.g. pairwise/banded.rs:1805; restated from the crate's source).
+// Returns the length written, -1 if cap is too small, -2 where the crate panics.
+extern "C" int64_t orc_pretty(const orc_alignment_t* a, const uint64_t* ops, const uint8_t* x, uint64_t xl, const uint8_t* y,
+                              uint64_t yl, uint64_t ncol, char* out, uint64_t cap) {
+    std::string xp, ip, yp;
+    bool panic = false;
+    auto ch = [&](uint8_t c) -> std::string {  // format!("{}", String::from_utf8_lossy(&[c]))
+        if (c >= 0x80) return "\xEF\xBF\xBD";
+        return std::string(1, (char)c);
+    };
+    if (a->n_ops) {
+        uint64_t xi = 0, yi = 0;
+        if (a->mode != ORC_MODE_CUSTOM) {
+            xi = a->xstart;
+            yi = a->ystart;
+            for (uint64_t k = 0; k < a->xstart && k < xl; k++) { xp += ch(x[k]); ip += ' '; yp += ' '; }
+            for (uint64_t k = 0; k < a->ystart && k < yl; k++) { yp += ch(y[k]); ip += ' '; xp += ' '; }
+        }
+        for (uint64_t i = 0; i < a->n_ops && !panic; i++) {
+            const uint64_t kind = ops[i] & 0xFF, len = ops[i] >> 8;
+            switch (kind) {
+                case ORC_OP_MATCH:
+                case ORC_OP_SUBST:
+                    if (xi >= xl || yi >= yl) { panic = true; break; }
+                    xp += ch(x[xi++]); ip += kind == ORC_OP_MATCH ? '|' : '\\'; yp += ch(y[yi++]);
+                    break;
+                case ORC_OP_DEL:
+                    if (yi >= yl) { panic = true; break; }
+                    xp += '-'; ip += 'x'; yp += ch(y[yi++]);
+                    break;
+                case ORC_OP_INS:
+                    if (xi >= xl) { panic = true; break; }
+                    xp += ch(x[xi++]); ip += '+'; yp += '-';
+                    break;
+                case ORC_OP_XCLIP:  // `for k in x.iter().take(len)`: the first len symbols, wherever the clip sits
+                    for (uint64_t k = 0; k < len && k < xl; k++) { xp += ch(x[k]); xi++; ip += ' '; yp += ' '; }
+                    break;
+                default:
+                    for (uint64_t k = 0; k < len && k < yl; k++) { yp += ch(y[k]); yi++; ip += ' '; xp += ' '; }
+                    break;
+            }
+        }
+        if (a->mode != ORC_MODE_CUSTOM) {
+            for (uint64_t k = xi; k < xl; k++) { xp += ch(x[k]); ip += ' '; yp += ' '; }
+            for (uint64_t k = yi; k < yl; k++) { yp += ch(y[k]); ip += ' '; xp += ' '; }
+        }
+    }
+    if (panic || xp.size() != ip.size() || yp.size() != ip.size()) return -2;  // assert_eq!(x_pretty.len(), inb_pretty.len())
+    std::string s;
+    for (uint64_t idx = 0; idx < xp.size(); idx += ncol) {
+        const uint64_t e = std::min<uint64_t>(idx + ncol, xp.size());
+        s += xp.substr(idx, e - idx) + "\n" + ip.substr(idx, e - idx) + "\n" + yp.substr(idx, e - idx) + "\n" + "\n\n";
+    }
+    if (s.size() > cap) return -1;
+    memcpy(out, s.data(), s.size());
+    return (int64_t)s.size();
+}
+
 extern "C" int64_t orc_cigar(const orc_alignment_t* a, const uint64_t* ops, int hard_clip, char* out, uint64_t cap) {
     if (a->mode == ORC_MODE_CUSTOM) return -2;
     std::string c;

@@ -158,6 +158,9 @@ int orc_fastq_parse(const uint8_t* text, uint64_t len, orc_fastq_rec_t* recs, ui
                     uint64_t* n_records, int32_t* status, uint64_t* err_pos);
 /* Alignment::cigar(hard_clip): returns the length written, -1 if cap is too small, -2 for AlignmentMode::Custom */
 int64_t orc_cigar(const orc_alignment_t* a, const uint64_t* ops, int hard_clip, char* out, uint64_t cap);
+/* Alignment::pretty(x, y, ncol): returns the length written, -1 if cap is too small, -2 where the crate panics */
+int64_t orc_pretty(const orc_alignment_t* a, const uint64_t* ops, const uint8_t* x, uint64_t xl, const uint8_t* y, uint64_t yl,
+                   uint64_t ncol, char* out, uint64_t cap);
 
 /* ---- seed-and-extend composition (oracle/pipeline.cpp): backward_search -> Interval::occ -> Aligner::semiglobal,
  * the caller pattern of src/lib.rs:129-165 / benches/fmindex.rs:20-38; the definition is stated in pipeline.cpp ---- */

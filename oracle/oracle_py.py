@@ -128,6 +128,8 @@ def lib():
              [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
               C.POINTER(Scoring), C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
               C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]),
+            ("orc_pretty", C.c_int64, [C.POINTER(AlignmentRec), C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
+                                       C.c_uint64, C.c_void_p, C.c_uint64]),
             ("orc_cigar", C.c_int64, [C.POINTER(AlignmentRec), C.c_void_p, C.c_int, C.c_void_p, C.c_uint64]),
         ]:
             if hasattr(L, name):
@@ -602,3 +604,21 @@ def seed_extend_batch(bwt_arr, less_arr, occ, sa, text, n_text, scoring, reads, 
     if rc:
         raise RuntimeError(f"oracle seed_extend_batch failed rc={rc}")
     return out, ops, stride_ops
+
+
+def pretty(aln, ops_u64, x, y, ncol):
+    """bio-types `Alignment::pretty(x, y, ncol)`; aln: dict with xstart, ystart, mode (+ the ops as kind | len << 8)."""
+    rec = AlignmentRec()
+    for f in ("score", "xstart", "xend", "ystart", "yend", "xlen", "ylen"):
+        setattr(rec, f, int(aln.get(f, 0)))
+    rec.mode = MODES[aln["mode"]] if isinstance(aln["mode"], str) else int(aln["mode"])
+    ops = np.ascontiguousarray(ops_u64, dtype=np.uint64)
+    rec.n_ops = len(ops)
+    xb, yb = _buf(x), _buf(y)
+    cap = 3 * (len(xb) + len(yb)) * 3 + 5 * (len(xb) + len(yb) + 1) + 64
+    out = np.zeros(cap, dtype=np.uint8)
+    n = lib().orc_pretty(C.byref(rec), ops.ctypes.data, xb.ctypes.data, len(xb), yb.ctypes.data, len(yb), ncol, out.ctypes.data, cap)
+    if n == -2:
+        raise AssertionError("the crate panics here")
+    assert n >= 0
+    return out[:n].tobytes().decode()

@@ -525,6 +525,96 @@ __global__ __launch_bounds__(256) void cigar_kernel(const bg_alignment_t* __rest
     len[p] = overflow ? BG_ERR_OPS_CAP : (int32_t)w;
 }
 
+// Alignment::pretty(x, y, ncol) (bio-types): three rows — x, the operation marks ('|' match, '\\' mismatch, '+' insertion,
+// 'x' deletion, ' ' clipped), y — cut into blocks of ncol columns, every block "x row\n marks\n y row\n\n\n".  The standard
+// modes print the clipped prefixes / suffixes of x and y around the operations, AlignmentMode::Custom walks its
+// Xclip / Yclip operations instead (the crate prints the FIRST len symbols of the sequence for a clip operation,
+// wherever the clip sits: reproduced).  One thread per alignment; two passes over the operations (length, then text).
+__global__ __launch_bounds__(256) void pretty_kernel(const bg_alignment_t* __restrict__ aln, const uint8_t* __restrict__ ops, uint64_t n,
+                                                     const uint8_t* __restrict__ xs, const uint64_t* __restrict__ x_off,
+                                                     const uint8_t* __restrict__ ys, const uint64_t* __restrict__ y_off, uint32_t ncol,
+                                                     char* __restrict__ out, uint64_t stride, int64_t* __restrict__ len) {
+    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const bg_alignment_t a = aln[p];
+    const uint8_t* x = xs + x_off[p];
+    const uint8_t* y = ys + y_off[p];
+    const uint64_t xl = x_off[p + 1] - x_off[p], yl = y_off[p + 1] - y_off[p];
+    char* o = out + p * stride;
+    bool bad = xl != a.xlen || yl != a.ylen;  // not the sequences this alignment was computed from
+    uint64_t ml = 0;
+    for (int pass = 0; pass < 2 && !bad; pass++) {
+        uint64_t col = 0;
+        auto put = [&](uint8_t cx, char ci, uint8_t cy) {
+            if (pass == 1) {
+                const uint64_t blk = col / ncol, w = col - blk * ncol;
+                const uint64_t bl = min((uint64_t)ncol, ml - blk * ncol);
+                char* b = o + blk * (3ull * ncol + 5);
+                b[w] = (char)cx;
+                b[bl + 1 + w] = ci;
+                b[2 * (bl + 1) + w] = (char)cy;
+            }
+            bad = bad || cx >= 0x80 || cy >= 0x80;  // from_utf8_lossy widens such a byte: the crate's length assert fires
+            col++;
+        };
+        if (a.n_ops) {
+            uint64_t xi = 0, yi = 0;
+            const uint8_t* q = ops + a.ops_off;
+            uint32_t clip = 0;
+            if (a.mode != BG_MODE_CUSTOM) {
+                xi = a.xstart;
+                yi = a.ystart;
+                for (uint64_t k = 0; k < a.xstart && k < xl; k++) put(x[k], ' ', ' ');
+                for (uint64_t k = 0; k < a.ystart && k < yl; k++) put(' ', ' ', y[k]);
+            }
+            for (uint32_t i = 0; i < a.n_ops && !bad; i++) {
+                const uint32_t op = q[i];
+                if (op == BG_OP_MATCH || op == BG_OP_SUBST) {
+                    if (xi >= xl || yi >= yl) { bad = true; break; }
+                    put(x[xi++], op == BG_OP_MATCH ? '|' : '\\', y[yi++]);
+                } else if (op == BG_OP_DEL) {
+                    if (yi >= yl) { bad = true; break; }
+                    put('-', 'x', y[yi++]);
+                } else if (op == BG_OP_INS) {
+                    if (xi >= xl) { bad = true; break; }
+                    put(x[xi++], '+', '-');
+                } else {
+                    const uint32_t cl = clip < 4 ? a.clip_len[clip] : 0;
+                    clip++;
+                    if (op == BG_OP_XCLIP) {
+                        for (uint64_t k = 0; k < cl && k < xl; k++, xi++) put(x[k], ' ', ' ');
+                    } else {
+                        for (uint64_t k = 0; k < cl && k < yl; k++, yi++) put(' ', ' ', y[k]);
+                    }
+                }
+            }
+            if (a.mode != BG_MODE_CUSTOM) {
+                for (uint64_t k = xi; k < xl; k++) put(x[k], ' ', ' ');
+                for (uint64_t k = yi; k < yl; k++) put(' ', ' ', y[k]);
+            }
+        }
+        if (pass == 0) {
+            ml = col;
+            const uint64_t nb = (ml + ncol - 1) / ncol;
+            if (3 * ml + 5 * nb > stride) {
+                len[p] = BG_ERR_OPS_CAP;
+                return;
+            }
+        }
+    }
+    if (bad) {
+        len[p] = BG_ERR_UNSUPPORTED;
+        return;
+    }
+    const uint64_t nb = (ml + ncol - 1) / ncol;
+    for (uint64_t blk = 0; blk < nb; blk++) {
+        const uint64_t bl = min((uint64_t)ncol, ml - blk * ncol);
+        char* b = o + blk * (3ull * ncol + 5);
+        b[bl] = b[2 * bl + 1] = b[3 * bl + 2] = b[3 * bl + 3] = b[3 * bl + 4] = '\n';
+    }
+    len[p] = (int64_t)(3 * ml + 5 * nb);
+}
+
 }  // namespace
 
 // shared with seed_extend.hip: exclusive scan of n uint32 counts into n + 1 uint64 offsets; d_sums holds 2 * (n / 2048 + 1) words
@@ -672,6 +762,62 @@ extern "C" int bg_cigar_batch_dev(bg_ctx* ctx, uint64_t n, const bg_alignment_t*
     cigar_kernel<<<dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(d_aln, d_ops, n, hard_clip, d_out, stride, d_len);
     BG_HIP(hipGetLastError());
     return BG_OK;
+}
+
+extern "C" int bg_pretty_batch(bg_ctx* ctx, uint64_t n, const bg_alignment_t* aln, const uint8_t* ops, uint64_t ops_bytes, const uint8_t* x,
+                               const uint64_t* x_off, const uint8_t* y, const uint64_t* y_off, uint32_t ncol, char* out, uint64_t out_cap,
+                               uint64_t* out_off) {
+    if (!ctx || !out_off || ncol == 0) return BG_ERR_INVALID_ARG;
+    out_off[0] = 0;
+    if (n == 0) return BG_OK;
+    if (!aln || (!ops && ops_bytes) || !x_off || !y_off || !out) return BG_ERR_INVALID_ARG;
+    BG_HIP(hipSetDevice(ctx->device));
+    uint64_t max_ml = 0;
+    for (uint64_t p = 0; p < n; p++) {
+        if (aln[p].n_ops && aln[p].ops_off + aln[p].n_ops > ops_bytes) return BG_ERR_INVALID_ARG;
+        max_ml = std::max<uint64_t>(max_ml, (x_off[p + 1] - x_off[p]) + (y_off[p + 1] - y_off[p]));
+    }
+    const uint64_t stride = (3 * max_ml + 5 * ((max_ml + ncol - 1) / ncol) + 15) & ~15ull;
+    const uint64_t xb = x_off[n], yb = y_off[n];
+    void* d[8] = {};
+    const size_t need[8] = {n * sizeof(bg_alignment_t), std::max<uint64_t>(ops_bytes, 16), std::max<uint64_t>(xb, 16), (n + 1) * 8,
+                            std::max<uint64_t>(yb, 16), (n + 1) * 8, std::max<uint64_t>(n * stride, 16), n * 8};
+    const void* src[6] = {aln, ops, x, x_off, y, y_off};
+    const size_t src_bytes[6] = {need[0], (size_t)ops_bytes, (size_t)xb, need[3], (size_t)yb, need[5]};
+    std::vector<char> h;
+    std::vector<int64_t> hl(n);
+    auto run = [&]() -> int {
+        hipStream_t st = ctx->stream;
+        for (int i = 0; i < 8; i++) BG_HIP(hipMalloc(&d[i], need[i]));
+        for (int i = 0; i < 6; i++)
+            if (src_bytes[i]) BG_HIP(hipMemcpyAsync(d[i], src[i], src_bytes[i], hipMemcpyHostToDevice, st));
+        pretty_kernel<<<dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st>>>((const bg_alignment_t*)d[0], (const uint8_t*)d[1], n,
+                                                                              (const uint8_t*)d[2], (const uint64_t*)d[3], (const uint8_t*)d[4],
+                                                                              (const uint64_t*)d[5], ncol, (char*)d[6], stride, (int64_t*)d[7]);
+        BG_HIP(hipGetLastError());
+        h.resize((size_t)(n * stride));
+        BG_HIP(hipMemcpyAsync(h.data(), d[6], n * stride, hipMemcpyDeviceToHost, st));
+        BG_HIP(hipMemcpyAsync(hl.data(), d[7], n * 8, hipMemcpyDeviceToHost, st));
+        BG_HIP(hipStreamSynchronize(st));
+        return BG_OK;
+    };
+    int rc = run();
+    for (void* q : d) hipFree(q);
+    if (rc) return rc;
+    uint64_t used = 0;
+    int status = BG_OK;
+    for (uint64_t p = 0; p < n; p++) {
+        if (hl[p] < 0) {
+            status = (int)hl[p];
+            out_off[p + 1] = used;
+            continue;
+        }
+        if (used + (uint64_t)hl[p] > out_cap) return BG_ERR_OPS_CAP;
+        memcpy(out + used, h.data() + p * stride, (size_t)hl[p]);
+        used += (uint64_t)hl[p];
+        out_off[p + 1] = used;
+    }
+    return status;
 }
 
 extern "C" int bg_cigar_batch(bg_ctx* ctx, uint64_t n, const bg_alignment_t* aln, const uint8_t* ops, uint64_t ops_bytes, int hard_clip, char* out,

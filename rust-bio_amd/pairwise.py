@@ -133,6 +133,43 @@ class Alignment:
         return cigar_batch(rec, ops, hard_clip)[0]
 
 
+    def pretty(self, x, y, ncol):
+        """bio_types `Alignment::pretty(x, y, ncol)` (parity unpinned, see include/biogpu.h)."""
+        rec = np.zeros(1, dtype=_lib.ALN_DTYPE)
+        for f in ("score", "xstart", "xend", "ystart", "yend", "xlen", "ylen"):
+            rec[f] = getattr(self, f)
+        rec["mode"] = MODE_NAMES.index(self.mode)
+        ops, clips = [], []
+        for o in self.operations:
+            ops.append(OP_TOKENS.index(o[0]))
+            if o[0] in "XY":
+                clips.append(int(o[1:]))
+        assert len(clips) <= 4
+        rec["n_ops"], rec["n_clips"] = len(ops), len(clips)
+        rec["clip_len"][0, :len(clips)] = clips
+        return pretty_batch(rec, np.array(ops, dtype=np.uint8), [bytes(x)], [bytes(y)], ncol)[0]
+
+
+def pretty_batch(recs, ops_buf, xs, ys, ncol, ctx=None):
+    """`Alignment::pretty` for a batch of bg_alignment_t records + the sequences they were computed from."""
+    ctx = ctx or _lib.default_context()
+    recs = np.ascontiguousarray(recs, dtype=_lib.ALN_DTYPE)
+    ops_buf = np.ascontiguousarray(ops_buf if ops_buf is not None else np.zeros(0, np.uint8), dtype=np.uint8)
+    x, xo = _lib.concat(xs)
+    y, yo = _lib.concat(ys)
+    n = len(recs)
+    tot = int(xo[-1] + yo[-1])
+    cap = 3 * tot + 5 * (tot // max(1, ncol) + n) + 64
+    out = np.zeros(cap, dtype=np.uint8)
+    off = np.zeros(n + 1, dtype=np.uint64)
+    st = _lib.lib().bg_pretty_batch(ctx.h, n, recs.ctypes.data, ops_buf.ctypes.data, len(ops_buf), x.ctypes.data, xo.ctypes.data,
+                                    y.ctypes.data, yo.ctypes.data, ncol, out.ctypes.data, cap, off.ctypes.data)
+    assert st != -11, "the crate's row-length assert fires (non-ASCII byte) or the sequences are not the alignment's"
+    _lib.check(st, "bg_pretty_batch")
+    b = out.tobytes()
+    return [b[int(off[p]):int(off[p + 1])].decode() for p in range(n)]
+
+
 def decode_ops(rec, ops_buf):
     ops = ops_buf[int(rec["ops_off"]):int(rec["ops_off"]) + int(rec["n_ops"])]
     out, c = [], 0
