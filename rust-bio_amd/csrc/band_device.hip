@@ -634,7 +634,7 @@ __global__ __launch_bounds__(256) void band_rows_kernel(const BandDevArgs a) {
                 if (cf <= j_last && lo > j_first && cf <= lo - 1) {
                     rc = make_int2((int)cf, (int)(lo - 1));
                     covered += (uint64_t)(rc.y - rc.x + 1);
-                    if (i >= 1) width = ((uint32_t)(rc.y - rc.x + 1) + 3u) & ~3u;  // row 0 is not stored
+                    if (i >= 1) width = ((uint32_t)(rc.y - rc.x + 1) + (kTbRowAlign - 1)) & ~(kTbRowAlign - 1);  // row 0 is not stored
                 }
                 rowc[i] = rc;
             }

@@ -80,8 +80,8 @@ void rows_from_columns(const bgband::Band& b, HostPair& hp, int2* rowc, uint32_t
         const int2 rc = rowc[i];
         if (rc.y >= rc.x) {
             covered += (uint64_t)(rc.y - rc.x + 1);
-            // row 0 is a closed form, not stored; rows start dword-aligned (K3 stores four cells at a time)
-            if (i >= 1) off += ((uint64_t)(rc.y - rc.x + 1) + 3) & ~3ull;
+            // row 0 is a closed form, not stored; rows start 16-byte aligned (K3v2 stores complete 16-byte groups)
+            if (i >= 1) off += ((uint64_t)(rc.y - rc.x + 1) + (kTbRowAlign - 1)) & ~(uint64_t)(kTbRowAlign - 1);
         }
     }
     hp.tb_bytes = (off + 15) & ~15ull;

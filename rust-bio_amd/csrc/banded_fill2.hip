@@ -8,6 +8,12 @@
 //   * the last-column epilogue (banded.rs:683-723) needs scans over all rows of a pair; it runs afterwards
 //     in banded_epilogue_kernel (one wavefront per pair) from what the fill stored per row.
 //
+//   * traceback bytes (one per band cell, row-major per row: the layout K4 walks) are staged in LDS: every lane owns a
+//     ring of RING bytes per row, a cell is one ds_write_b8, and every FLUSH steps — a wave-uniform moment — all lanes
+//     hand the 16-byte groups that have become complete (plus the last, partial group of a finished row) to HBM as
+//     dwordx4 stores.  Every group is written exactly once, whole: WRITE_SIZE = the traceback bytes (+ the padding of
+//     rows to 16 bytes), where per-row dword streams used to be evicted from L2 half-filled (11x, round 1).
+//
 // MatchParams scoring only (Scoring::from_scores); tabulated match functions keep using K3.
 #include <type_traits>
 
@@ -39,6 +45,11 @@ __device__ __forceinline__ void wave_scan_first_max(int lane, int64_t& v, uint32
 // NEGS = -2^30 with offsets preserved, which is all the reference's arithmetic on it needs.
 template <int R, int LP, bool NARROW>
 __global__ __launch_bounds__(256) void banded_fill2_kernel(const BandArgs a) {
+    constexpr int RING = R <= 2 ? 128 : R <= 4 ? 64 : 32;  // bytes of LDS per row: twice the flush interval (+ a group) stays intact
+    constexpr int FLUSH = RING / 2;    // steps between two hand-overs of complete 16-byte groups
+    constexpr int LANE_LDS = R * RING + 16;  // + 16: consecutive lanes start four banks apart
+    __shared__ __align__(16) uint8_t s_tb_all[256 * LANE_LDS];
+    uint8_t* const s_row = s_tb_all + threadIdx.x * LANE_LDS;
     constexpr int32_t NEGS = NARROW ? (kNarrowFloor * 16) : NEG;
     // exact maps between the reference's integers and the scaled domain (identity for !NARROW)
     auto to_s = [](int32_t v) -> int32_t {
@@ -140,8 +151,8 @@ __global__ __launch_bounds__(256) void banded_fill2_kernel(const BandArgs a) {
         const uint32_t rb = (strip * LP + ll) * R;
         const int32_t mrow = (int32_t)m - (int32_t)rb - 1;
         int32_t Sl[R], Dl[R], Il[R], Sn[R], cf[R], cl[R], ycl[R];
-        uint32_t Ly[R], px[R], celln[R], icase[R], acc[R];
-        uint32_t* tbr[R];  // dword stream of the row: cells cf..cl, four per word
+        uint32_t Ly[R], px[R], celln[R], icase[R];
+        uint32_t trow[R];  // offset of the row's bytes (cells cf..cl) in the pair's traceback block
         int jlo = 0x7fffffff, jhi = -1;
 #pragma unroll
         for (int r = 0; r < R; r++) {
@@ -154,22 +165,20 @@ __global__ __launch_bounds__(256) void banded_fill2_kernel(const BandArgs a) {
             icase[r] = IC_OPEN;
             cf[r] = 1;
             cl[r] = 0;
-            tbr[r] = (uint32_t*)tb;
-            acc[r] = 0;
+            trow[r] = 0;
             if (live && i <= m) {
                 const int2 rc = rowc[i];
                 cf[r] = rc.x;
                 cl[r] = rc.y;
                 if (rc.y >= rc.x) {
-                    tbr[r] = (uint32_t*)(tb + roff[i]);
+                    trow[r] = roff[i];
                     px[r] = x[i - 1];
                     if (NARROW) ycl[r] = (int32_t)((uint32_t)to_s(sc.yp + sc.go + sc.ge * ((int32_t)i - 1)) | C_YP);
                     if (rc.x == 0) {  // (i, 0) is a band cell
                         const Col0 c = col0_cell(sc, i, m, fold0);
                         Sl[r] = to_s(c.S);
                         Il[r] = to_s(c.I);
-                        acc[r] = c.sbits | (c.ibits << 4);  // column 0 keeps whole nibbles
-                        if (rc.y == 0) tbr[r][0] = acc[r];
+                        s_row[r * RING] = (uint8_t)(c.sbits | (c.ibits << 4));  // column 0 keeps whole nibbles
                     }
                     jlo = min(jlo, max(1, rc.x));
                     jhi = max(jhi, rc.y);
@@ -191,7 +200,30 @@ __global__ __launch_bounds__(256) void banded_fill2_kernel(const BandArgs a) {
         int nsteps_w = nsteps;
 #pragma unroll
         for (int o = 32; o; o >>= 1) nsteps_w = max(nsteps_w, __shfl_xor(nsteps_w, o));
-        if (nsteps_w == 0) continue;  // no pair of this wavefront has band rows in the strip
+        // Hand the traceback bytes that became complete 16-byte groups since the previous hand-over to HBM (see the
+        // header).  j_now / j_prev: this lane's column after the current / the previous hand-over step.
+        auto flush_tb = [&](int j_now, int j_prev, bool final_pass) {
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int W = cl[r] - cf[r] + 1;  // cells of the row; <= 0: none
+                const int cn = final_pass ? W : min(max(j_now - cf[r] + 1, 0), W);
+                const int cp = min(max(j_prev - cf[r] + 1, 0), W);
+                const int g1 = cn == W ? (W + 15) >> 4 : cn >> 4;  // a finished row also hands over its last, partial group
+                const int g0 = cp == W ? g1 : cp >> 4;
+#pragma unroll
+                for (int k = 0; k < FLUSH / 16 + 2; k++) {
+                    const int gk = g0 + k;
+                    if (gk < g1) {
+                        const uint4 v = *(const uint4*)(s_row + r * RING + ((gk * 16) & (RING - 1)));
+                        *(uint4*)(tb + trow[r] + (uint32_t)gk * 16u) = v;
+                    }
+                }
+            }
+        };
+        if (nsteps_w == 0) {  // no pair of this wavefront has band rows beyond column 0 in the strip
+            flush_tb(0, -0x40000000, true);
+            continue;
+        }
 
         // row above this lane's first row, for the first lane of the pair
         int2 rc_above = make_int2(1, 0);
@@ -324,11 +356,9 @@ __global__ __launch_bounds__(256) void banded_fill2_kernel(const BandArgs a) {
                             Sn[r] = up ? t1 : Sn[r];
                             // traceback byte: four cells per store
                             const uint32_t cell = (((uint32_t)kb & 7u) | (((uint32_t)Dv_t & 8u) << 1) | ((uint32_t)Iv_t & 8u)) ^ 24u;
-                            const uint32_t cj = (uint32_t)(j - cf[r]);
-                            const uint32_t sh = 8u * (cj & 3u);
-                            const uint32_t merged = sh ? (acc[r] | (cell << sh)) : cell;
-                            acc[r] = inb ? merged : acc[r];
-                            if (inb && ((cj & 3u) == 3u || j == cl[r])) tbr[r][cj >> 2] = merged;
+                            // unconditional: outside the band the byte lands on a ring slot that is rewritten before its
+                            // group is handed over (left of the band) or never handed over (right of it)
+                            s_row[r * RING + ((uint32_t)(j - cf[r]) & (uint32_t)(RING - 1))] = (uint8_t)cell;
                             any_in = any_in || inb;
                             m_here = m_here || (inb && is_m);
                             v_best_m = (inb && is_m) ? best : v_best_m;
@@ -393,11 +423,7 @@ __global__ __launch_bounds__(256) void banded_fill2_kernel(const BandArgs a) {
                         // banded.rs:655-660
                         if (best + sc.ys > Sn[r]) { Sn[r] = best + sc.ys; Ly[r] = n - (uint32_t)j; }
                         const uint32_t cell = code | (iext ? 8u : 0u) | (dext ? 16u : 0u);
-                        {  // four cells per store
-                            const uint32_t cj = (uint32_t)(j - cf[r]);
-                            acc[r] = (cj & 3u) ? (acc[r] | (cell << (8 * (cj & 3u)))) : cell;
-                            if ((cj & 3u) == 3u || j == cl[r]) tbr[r][cj >> 2] = acc[r];
-                        }
+                        s_row[r * RING + ((uint32_t)(j - cf[r]) & (uint32_t)(RING - 1))] = (uint8_t)cell;
                         if (last_col) {
                             celln[r] = cell;
                             icase[r] = ic;
@@ -429,6 +455,11 @@ __global__ __launch_bounds__(256) void banded_fill2_kernel(const BandArgs a) {
                 Snl_out = Sn_prev;
                 if (ll == LP - 1 && strip + 1 < nstrips) bnd[j] = make_int4(S_up, I_up, cm, ca);
             }
+            if (((t + 1) & (FLUSH - 1)) == 0) flush_tb(jlo + t - ll, jlo + t - ll - FLUSH, false);  // wave-uniform
+        }
+        {
+            const int t_last = (nsteps_w & ~(FLUSH - 1)) - 1;  // step of the last hand-over inside the loop (-1: none)
+            flush_tb(0, t_last < 0 ? -0x40000000 : jlo + t_last - ll, true);
         }
 #pragma unroll
         for (int r = 0; r < R; r++) {
@@ -720,7 +751,11 @@ __global__ __launch_bounds__(256) void banded_epilogue_kernel(const BandArgs a) 
 }  // namespace
 
 bool launch_band_fill2(const BandArgs& a, bool narrow, hipStream_t st) {
-    constexpr int LP = 16, R = 4, PW = 64 / LP;
+#ifndef BF2_LP
+#define BF2_LP 8  // measured on 16 384 x 10 kb pairs (fill ms): LP x R = 8x4 58.6, 8x5 58.8, 16x4 67.7, 16x2 76.6, 4x6 79.4, 8x6 85.8, 4x4 86.7, 8x8 88.2, 32x4 88.8
+#define BF2_R 4
+#endif
+    constexpr int LP = BF2_LP, R = BF2_R, PW = 64 / LP;
     const uint32_t jobs = (a.n_pairs + PW - 1) / PW;
     if (narrow)
         banded_fill2_kernel<R, LP, true><<<dim3((jobs + 3) / 4), dim3(256), 0, st>>>(a);

@@ -26,6 +26,9 @@ namespace bgband_dev {
 using namespace bgsw;
 
 enum : uint32_t { BP_OK = 0, BP_TOO_MANY_CELLS = 1, BP_UNSUPPORTED = 2 };
+// every row's traceback bytes start on a 16-byte boundary of the pair's block: K3v2 hands them over in complete
+// 16-byte groups (banded_fill2.hip)
+constexpr uint32_t kTbRowAlign = 16;
 
 // One pair of a banded batch (device copy, built on the host)
 struct BandPair {
