@@ -121,6 +121,14 @@ def pmc_traffic(kernel, shape_key, shape_val):
     return max(hits) if hits else None  # several instantiations of one kernel: the one that did the work
 
 
+def ingest_traffic(text_bytes):
+    """HBM bytes of all the ingest kernels of one bg_fastq_parse_dev call (newest committed PMC pass)"""
+    d = _newest_profile("r*_pmc_traffic.json")
+    if not d or (d.get("launch_shape") or {}).get("ingest_bytes") != text_bytes or not d.get("ingest_bytes_per_call"):
+        return None
+    return int(d["ingest_bytes_per_call"])
+
+
 def valu_frac(kernel, launch_ms, shape_key, shape_val):
     """VALU issue utilisation of `kernel`: SQ_INSTS_VALU (wave instructions per launch, from the newest committed
     tools/sq_counters.sh pass of this command) x 64 lanes / launch time / 78.6 T full-rate lane-ops/s."""
@@ -347,7 +355,10 @@ def k1_legs(args, ctx, dev, stream, rank, world, do_cpu, orc, threads, parity):
              ("wide_scores_dna", synth_gpu.sw_pairs_big(n, L, seed=13 + 100003 * rank, device=dev),
               Scoring.from_scores(-500, -100, 100, -100), dict(match=100, mismatch=-100),
               f"{n} x {L} bp DNA pairs per GPU, Aligner::local, from_scores(-500,-100,100,-100): scores beyond K1p's 12 bits")]
+    # template arguments <R, LP, SM, LOCAL, NARROW> of the instantiation each case runs (profile lookups go by name)
+    knames = {"blosum62_protein": "sw_fill_kernel<10, 16, 1, true, true>", "wide_scores_dna": "sw_fill_kernel<10, 16, 0, true, true>"}
     for name, (x, xo, y, yo), scoring, okw, desc in cases:
+        kname = knames[name]
         d_out = torch.empty(n * 64, dtype=torch.uint8, device=dev)
         d_ops = torch.empty(n * stride, dtype=torch.uint8, device=dev)
         al = Aligner.with_scoring(scoring, ctx=ctx)
@@ -364,7 +375,7 @@ def k1_legs(args, ctx, dev, stream, rank, world, do_cpu, orc, threads, parity):
         n_ops_mean = float(d_out.view(torch.int32).view(n, 16)[:, 7].to(torch.int64).sum().item()) / n
         leg = {"value": round(world * float(n) * L * L * args.steps / t / 1e9, 2), "unit": "GCUPS", "dtype": "int32",
                "ms_per_step": round(t / args.steps * 1e3, 3), "config": {"workload": desc},
-               "roofline": sw_roofline("sw_fill_kernel", fill_ms, tb_ms, ppl, L, n_ops_mean,
+               "roofline": sw_roofline(kname, fill_ms, tb_ms, ppl, L, n_ops_mean,
                                        "K1 (int32): VALU-bound", shape_key="k1_pairs_per_launch")}
         if do_cpu:
             go, ge = scoring.gap_open, scoring.gap_extend
@@ -774,7 +785,7 @@ def ingest_leg(args, ctx, dev, stream, rank, world, do_cpu, orc, parity):
               "status": st, "records": int(k),
               "roofline": {"bound": "hbm", "achieved": round((len(text) + 2 * seq_bytes + 56 * k + 16 * k) / it / 1e9, 2),
                            "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "traffic": pmc_traffic("fastq_", "ingest_bytes", len(text)),
+                           "traffic": ingest_traffic(len(text)),
                            "note": "algorithmic bytes: text once + sequences, qualities, records and offsets written; "
                                    "several short kernels + host syncs per call (launch/sync bound)"}}
     ingest["roofline"]["frac"] = round(ingest["roofline"]["achieved"] / HBM_PEAK_GBS, 5)

@@ -78,6 +78,19 @@ int bg_bwt(const uint8_t* text, const uint64_t* sa, uint64_t n, uint8_t* bwt_out
 int bg_less(const uint8_t* bwt, uint64_t n, const uint8_t* alphabet, uint32_t n_sym,
             uint64_t* less_out, uint32_t* less_len);
 
+/* Device flavours for a text that already lives in HBM (sa_build.hip): suffix array by prefix doubling (radix sorts
+ * of (rank, rank) keys), n uint32 entries; BWT gather; RawSuffixArray::sample (suffix_array.rs:86-120) with the
+ * samples and the sentinel rows returned to host arrays (what bg_fm_set_sampled_suffix_array takes: sample holds
+ * ceil(n / rate) entries, extra rows come back sorted, *n_extra says how many; BG_ERR_OPS_CAP beyond extra_cap).
+ * The results equal the host functions' (the suffix array of a text with one sentinel is unique).  Texts whose
+ * sentinel byte occurs more than once (several sequences, suffix_array.rs:444-466) are not taken here:
+ * BG_ERR_UNSUPPORTED, use bg_suffix_array.  About 29 bytes of device scratch per symbol; synchronous. */
+int bg_suffix_array_dev(bg_ctx* ctx, const uint8_t* d_text, uint64_t n, uint32_t* d_sa, void* stream);
+int bg_bwt_dev(bg_ctx* ctx, const uint8_t* d_text, const uint32_t* d_sa, uint64_t n, uint8_t* d_bwt, void* stream);
+int bg_sa_sample_dev(bg_ctx* ctx, const uint32_t* d_sa, const uint8_t* d_bwt, uint64_t n, uint32_t sampling_rate,
+                     uint8_t sentinel, uint64_t* sample, uint64_t* extra_rows, uint64_t* extra_pos, uint64_t extra_cap,
+                     uint64_t* n_extra, void* stream);
+
 /* ------------------------------------------------------------------ FM index
  * bg_fm_build replaces `Occ::new(&bwt, k, &alphabet)` + `FMIndex::new(bwt, less, occ)`
  * (bwt.rs:94-125, fmindex.rs:245-247): the sampled-Occ table layout on the device is the

@@ -91,7 +91,7 @@ SYMBOLS = ["bg_device_count", "bg_init", "bg_free", "bg_strerror", "bg_last_erro
            "bg_align_banded_bands_batch", "bg_band_from_matches_batch", "bg_sparse_find_kmer_matches", "bg_sparse_sdpkpp",
            "bg_sparse_lcskpp", "bg_sparse_sdpkpp_union_lcskpp_path", "bg_sparse_expand_kmer_matches", "bg_fastq_parse",
            "bg_fastq_parse_dev", "bg_cigar_batch", "bg_cigar_batch_dev", "bg_get_timing", "bg_enable_timing",
-           "bg_pretty_batch", "bg_fm_set_text", "bg_fm_set_text_dev", "bg_seed_extend_batch", "bg_seed_extend_batch_dev"]
+           "bg_pretty_batch", "bg_suffix_array_dev", "bg_bwt_dev", "bg_sa_sample_dev", "bg_fm_set_text", "bg_fm_set_text_dev", "bg_seed_extend_batch", "bg_seed_extend_batch_dev"]
 
 
 def build(force=False):
@@ -164,6 +164,9 @@ def lib():
             getattr(L, name).restype = u64
             getattr(L, name).argtypes = args
         L.bg_pretty_batch.argtypes = [vp, u64, vp, vp, u64, vp, vp, vp, vp, u32, vp, u64, vp]
+        L.bg_suffix_array_dev.argtypes = [vp, vp, u64, vp, vp]
+        L.bg_bwt_dev.argtypes = [vp, vp, vp, u64, vp, vp]
+        L.bg_sa_sample_dev.argtypes = [vp, vp, vp, u64, u32, C.c_uint8, vp, vp, vp, u64, C.POINTER(u64), vp]
         L.bg_fm_set_text.argtypes = [vp, vp, u64]
         L.bg_fm_set_text_dev.argtypes = [vp, vp, u64]
         L.bg_seed_extend_batch.argtypes = [vp, C.POINTER(ScoringC), C.POINTER(SeedParamsC), u64, vp, vp, vp, vp, u64, C.POINTER(u64)]

@@ -82,3 +82,42 @@ class RawSuffixArray:
 
 
 NONE = 0xFFFFFFFFFFFFFFFF
+
+
+def suffix_array_dev(d_text, ctx=None, stream=0):
+    """`suffix_array` for a text that lives in HBM (a uint8 cuda tensor ending in a unique, smallest sentinel):
+    returns the suffix array as a cuda tensor of n uint32 values (dtype torch.int32 holds the bits; view it as
+    torch.uint32 or widen with `.to(torch.int64) & 0xFFFFFFFF`).  bg_suffix_array_dev."""
+    import torch
+    ctx = ctx or _lib.default_context()
+    n = d_text.numel()
+    d_sa = torch.empty(n, dtype=torch.int32, device=d_text.device)
+    _lib.check(_lib.lib().bg_suffix_array_dev(ctx.h, d_text.data_ptr(), n, d_sa.data_ptr(), stream), "suffix_array (device)")
+    return d_sa
+
+
+def bwt_dev(d_text, d_sa, ctx=None, stream=0):
+    """`bwt(text, pos)` (bwt.rs:39-49) on the device: a uint8 cuda tensor."""
+    import torch
+    ctx = ctx or _lib.default_context()
+    n = d_text.numel()
+    d_bwt = torch.empty(n, dtype=torch.uint8, device=d_text.device)
+    _lib.check(_lib.lib().bg_bwt_dev(ctx.h, d_text.data_ptr(), d_sa.data_ptr(), n, d_bwt.data_ptr(), stream), "bwt (device)")
+    return d_bwt
+
+
+def sample_dev(d_sa, d_bwt, sentinel_byte, sampling_rate, ctx=None, stream=0):
+    """`RawSuffixArray::sample` (suffix_array.rs:86-120) from device arrays: a SampledSuffixArray ready to attach."""
+    import ctypes as C
+    ctx = ctx or _lib.default_context()
+    n = d_sa.numel()
+    s = SampledSuffixArray.__new__(SampledSuffixArray)
+    s.s, s.sentinel, s.n, s.fm = int(sampling_rate), int(sentinel_byte), n, None
+    s.sample = np.zeros((n + s.s - 1) // s.s, dtype=np.uint64)
+    cap = 1 << 16
+    rows, pos = np.zeros(cap, dtype=np.uint64), np.zeros(cap, dtype=np.uint64)
+    ne = C.c_uint64(0)
+    _lib.check(_lib.lib().bg_sa_sample_dev(ctx.h, d_sa.data_ptr(), d_bwt.data_ptr(), n, s.s, s.sentinel, s.sample.ctypes.data,
+                                           rows.ctypes.data, pos.ctypes.data, cap, C.byref(ne), stream), "RawSuffixArray::sample (device)")
+    s.extra_rows, s.extra_pos = rows[:ne.value].copy(), pos[:ne.value].copy()
+    return s

@@ -1,0 +1,70 @@
+"""Suffix array / BWT / sampling on the device (bg_suffix_array_dev, bg_bwt_dev, bg_sa_sample_dev: prefix doubling over
+radix sorts) against the host builders behind `suffix_array` / `bwt` (suffix_array.rs:264-284, bwt.rs:39-49), which are
+pinned to the reference's known answers in tests/test_host_tables.py: identical arrays on random, repetitive,
+single-letter, protein and N-rich texts; the refusals the header documents."""
+import numpy as np
+import pytest
+import torch
+
+from rust_bio_amd import _lib, synth
+from rust_bio_amd.bwt import bwt
+from rust_bio_amd.suffix_array import SampledSuffixArray, bwt_dev, sample_dev, suffix_array, suffix_array_dev
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def dev_sa(text):
+    d_text = torch.from_numpy(np.ascontiguousarray(text)).to(DEV)
+    d_sa = suffix_array_dev(d_text)
+    torch.cuda.synchronize()
+    return d_text, d_sa, (d_sa.cpu().numpy().view(np.uint32)).astype(np.uint64)
+
+
+def texts():
+    rng = np.random.default_rng(5)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    yield "dollar", np.frombuffer(b"$", dtype=np.uint8)
+    yield "two", np.frombuffer(b"A$", dtype=np.uint8)
+    yield "kat", np.frombuffer(b"GCCTTAACATTATTACGCCTA$", dtype=np.uint8)            # suffix_array.rs:16-21
+    yield "random_1m", synth.genome(1_000_000, 3)
+    yield "all_a", np.frombuffer(b"A" * 70_000 + b"$", dtype=np.uint8)               # one group until the very end
+    yield "period_4", np.frombuffer(b"ACGT" * 40_000 + b"$", dtype=np.uint8)
+    rep = acgt[rng.integers(0, 4, size=5000)]
+    yield "long_repeats", np.concatenate([rep, acgt[rng.integers(0, 4, size=300)], rep, rep[:2500], np.frombuffer(b"$", np.uint8)])
+    g = synth.genome(400_000, 8).copy()
+    g[100_000:130_000] = ord("N")
+    yield "n_run", g
+    yield "protein", np.append(np.frombuffer(b"ARNDCQEGHILKMFPSTWYV", dtype=np.uint8)[rng.integers(0, 20, size=300_000)], np.uint8(ord("$")))
+    yield "bytes_0_255", np.append(rng.integers(1, 256, size=200_000).astype(np.uint8), np.uint8(0))
+
+
+@pytest.mark.parametrize("name,text", list(texts()), ids=[t[0] for t in texts()])
+def test_device_suffix_array_and_bwt_equal_the_host_builders(name, text):
+    want = suffix_array(text)
+    d_text, d_sa, got = dev_sa(text)
+    assert (got == want).all(), name
+    d_b = bwt_dev(d_text, d_sa)
+    assert (d_b.cpu().numpy() == bwt(text, want)).all()
+
+
+def test_sample_dev_equals_raw_suffix_array_sample():
+    text = synth.genome(300_000, 2)
+    sa = suffix_array(text)
+    b = bwt(text, sa)
+    d_text, d_sa, _ = dev_sa(text)
+    d_b = bwt_dev(d_text, d_sa)
+    for rate in (1, 7, 32):
+        want = SampledSuffixArray(sa, text, b, rate)
+        got = sample_dev(d_sa, d_b, int(text[-1]), rate)
+        assert (got.sample == want.sample).all()
+        assert (got.extra_rows == want.extra_rows).all() and (got.extra_pos == want.extra_pos).all()
+
+
+def test_refusals():
+    two = np.frombuffer(b"ACGT$TTGA$", dtype=np.uint8)  # several sentinels: ranked by position on the host only
+    with pytest.raises(_lib.BiogpuError) as e:
+        dev_sa(two)
+    assert e.value.status == -11
+    with pytest.raises(_lib.SentinelError):
+        dev_sa(np.frombuffer(b"AC#T$", dtype=np.uint8))  # '#' < '$': suffix_array.rs:431-437
