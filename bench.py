@@ -13,10 +13,12 @@ One "step" = one pass of the hot path over one batch of synthetic input that is 
   * `fm`: BASELINE configs[2] — FMIndex over a 100 Mbp synthetic genome, 10 M x 100 bp backward_search per GPU
     (weak), and `fm.strong`: the same 10 M queries in total split over the ranks (strong), both with the single
     all-gather of the result records inside the timed step;
+  * `fm_big`: the same searches on a 1 Gbp index (333 MB of rank blocks: beyond the 256 MiB Infinity Cache);
+  * `seed_extend` (configs[4]): reads vs that 1 Gbp genome through bg_seed_extend_batch_dev (3 Gbp: --fm-big-genome);
   * `k1_int32`: the general int32 kernel (BLOSUM62 protein pairs; DNA with scores beyond 12 bits);
-  * `banded` (configs[3] shape), `seed_extend` (configs[4] shape), `ingest` (FASTQ text -> records).
-Units (pairs / queries / reads) shard across ranks, the index is built once on rank 0 and broadcast, and every
-rank holds a replica.  Rank 0 prints ONE JSON line.  The CPU legs (oracle parity over the whole workload +
+  * `banded` (configs[3] shape), `ingest` (FASTQ text -> records).
+Units (pairs / queries / reads) shard across ranks; every rank builds its own replica of the index on its GPU
+(suffix array, BWT and SA samples on the device).  Rank 0 prints ONE JSON line.  The CPU legs (oracle parity over the whole workload +
 `cpu_baseline`, median of 3) run on rank 0 of the single-GPU run only.
 """
 import argparse
@@ -47,9 +49,11 @@ def parse_args():
     ap.add_argument("--queries", type=int, default=10_000_000, help="FM leg: patterns per GPU (configs[2]: 10M)")
     ap.add_argument("--pattern-len", type=int, default=100)
     ap.add_argument("--skip-fm", action="store_true")
-    ap.add_argument("--fm-big-genome", type=int, default=0,
-                    help="extra FM leg on an index that cannot sit in the 256 MiB Infinity Cache (e.g. 1000000000: 333 MB of "
-                         "blocks; the host suffix sort takes minutes, hence opt-in)")
+    ap.add_argument("--fm-big-genome", type=int, default=1_000_000_000,
+                    help="genome of the second FM leg and of the seed-and-extend leg: an index that cannot sit in the 256 MiB "
+                         "Infinity Cache (1 Gbp: 333 MB of rank blocks; configs[4] names 3000000000); 0: skip, seed-and-extend "
+                         "then runs on --genome")
+    ap.add_argument("--host-sa", action="store_true", help="build suffix arrays with the host SA-IS instead of the device builder")
     ap.add_argument("--skip-k1", action="store_true")
     ap.add_argument("--k1-pairs", type=int, default=262_144, help="int32-kernel legs: pairs per GPU")
     ap.add_argument("--skip-banded", action="store_true")
@@ -127,6 +131,14 @@ def ingest_traffic(text_bytes):
     if not d or (d.get("launch_shape") or {}).get("ingest_bytes") != text_bytes or not d.get("ingest_bytes_per_call"):
         return None
     return int(d["ingest_bytes_per_call"])
+
+
+def fm_big_traffic(n_q, index_bytes):
+    """FETCH + WRITE bytes per launch of the FM search on the big index (its own PMC passes, tools/collect_profiles.sh)"""
+    d = (_newest_profile("r*_pmc_traffic.json") or {}).get("fm_big")
+    if not d or d.get("queries_per_launch") != n_q or d.get("index_bytes") != index_bytes:
+        return None
+    return int(sum(d[c]["mean_bytes"] for c in ("FETCH_SIZE", "WRITE_SIZE") if c in d))
 
 
 def valu_frac(kernel, launch_ms, shape_key, shape_val):
@@ -319,8 +331,8 @@ def main():
     if not args.skip_fm:
         fm_legs(args, ctx, dev, stream, rank, world, do_cpu, orc, threads, parity, result)
 
-    if args.fm_big_genome and rank == 0 and world == 1:
-        result["fm_big"] = fm_big_leg(args, ctx, dev, stream, do_cpu, orc, threads, parity)
+    if args.fm_big_genome:
+        fm_big_leg(args, ctx, dev, stream, rank, world, do_cpu, orc, threads, parity, result)
 
     # ------------------------------------------------------------------ banded leg (configs[3] shape)
     if not args.skip_banded:
@@ -392,47 +404,49 @@ def k1_legs(args, ctx, dev, stream, rank, world, do_cpu, orc, threads, parity):
     return legs
 
 
-def build_index(args, ctx, dev, rank, world, want_sa):
-    """The genome is generated on every rank (same seed); suffix array + BWT are built once, on rank 0, and the BWT
-    and the rate-32 suffix-array samples are broadcast (RCCL) — the host SA-IS is the slow part and the ranks
-    share the node's cores."""
-    from rust_bio_amd.suffix_array import SampledSuffixArray
+def build_index(args, ctx, dev, n_genome, seed, want_sa):
+    """Genome (SplitMix64, generated in HBM) -> suffix array -> BWT -> FM index + rate-32 suffix-array samples.  Every
+    rank builds its own replica on its own GPU: bg_suffix_array_dev / bg_bwt_dev / bg_sa_sample_dev (1 Gbp in well under
+    a second); `--host-sa` runs rust-bio's host-side order of things instead (bg_suffix_array: SA-IS on host cores, ~100 s
+    per Gbp).  The rank blocks themselves are still laid out by host threads from the BWT (bg_fm_build)."""
+    from rust_bio_amd.suffix_array import SampledSuffixArray, bwt_dev, sample_dev, suffix_array_dev
+    t = {}
     t0 = time.perf_counter()
-    g_dev = synth_gpu.genome(args.genome, seed=3, device=dev)
+    g_dev = synth_gpu.genome(n_genome, seed=seed, device=dev)
     g = g_dev.cpu().numpy()
-    n = len(g)
     sa = None
-    if rank == 0:
+    t1 = time.perf_counter()
+    if args.host_sa:
         sa = suffix_array(g)
+        t["suffix_array_s"] = time.perf_counter() - t1
         b = bwt(g, sa)
         ssa = SampledSuffixArray(sa, g, b, 32)
-        samp, erow, epos = ssa.sample, ssa.extra_rows, ssa.extra_pos
-    if world > 1:
-        d_b = torch.from_numpy(b).to(dev) if rank == 0 else torch.empty(n, dtype=torch.uint8, device=dev)
-        shard.broadcast(d_b, 0)
-        meta = torch.tensor([len(samp), len(erow)] if rank == 0 else [0, 0], dtype=torch.int64, device=dev)
-        shard.broadcast(meta, 0)
-        ns, ne = int(meta[0]), int(meta[1])
-        bufs = []
-        for arr, k in ((samp if rank == 0 else None, ns), (erow if rank == 0 else None, ne), (epos if rank == 0 else None, ne)):
-            t = torch.from_numpy(arr.astype(np.int64)).to(dev) if rank == 0 else torch.empty(k, dtype=torch.int64, device=dev)
-            shard.broadcast(t, 0)
-            bufs.append(t.cpu().numpy().astype(np.uint64))
-        if rank != 0:
-            b = d_b.cpu().numpy()
-            ssa = SampledSuffixArray.__new__(SampledSuffixArray)
-            ssa.s, ssa.sentinel, ssa.n, ssa.fm = 32, int(g[-1]), n, None
-            ssa.sample, ssa.extra_rows, ssa.extra_pos = (np.ascontiguousarray(v) for v in bufs)
-        del d_b
+        if not want_sa:
+            sa = None
+    else:
+        d_sa = suffix_array_dev(g_dev, ctx=ctx)
+        torch.cuda.synchronize()
+        t["suffix_array_s"] = time.perf_counter() - t1
+        d_b = bwt_dev(g_dev, d_sa, ctx=ctx)
+        ssa = sample_dev(d_sa, d_b, int(g[-1]), 32, ctx=ctx)
+        b = d_b.cpu().numpy()
+        if want_sa:  # the oracle's Interval::occ walks the raw array
+            sa = d_sa.cpu().numpy().view(np.uint32).astype(np.uint64)
+        del d_sa, d_b
+    t2 = time.perf_counter()
     ls = less(b, N_ALPHABET)
     fm = FMIndex(b, ls, Occ(b, 128, N_ALPHABET), ctx=ctx)
     ssa.attach(fm)
-    return g_dev, g, (sa if want_sa else None), b, ls, fm, time.perf_counter() - t0
+    t["blocks_s"] = time.perf_counter() - t2
+    t["total_s"] = time.perf_counter() - t0
+    t["where"] = "host (SA-IS, --host-sa)" if args.host_sa else "device (prefix doubling over radix sorts)"
+    return g_dev, g, sa, b, ls, fm, t
 
 
 def fm_legs(args, ctx, dev, stream, rank, world, do_cpu, orc, threads, parity, result):
     L = args.read_len
-    g_dev, g, sa, b, ls, fm, build_s = build_index(args, ctx, dev, rank, world, want_sa=do_cpu and not args.skip_pipeline)
+    pipeline_here = not args.skip_pipeline and not args.fm_big_genome  # else the seed-and-extend leg runs on the big index
+    g_dev, g, sa, b, ls, fm, bt = build_index(args, ctx, dev, args.genome, 3, want_sa=do_cpu and pipeline_here)
     n_q, P = args.queries, args.pattern_len
     pat, off = synth_gpu.fm_patterns(g_dev, n_q, P, seed=4 + 100003 * rank)
     d_tag = torch.empty(n_q, dtype=torch.uint8, device=dev)
@@ -458,8 +472,10 @@ def fm_legs(args, ctx, dev, stream, rank, world, do_cpu, orc, threads, parity, r
     fm_res = {"value": round(qps, 1), "unit": "queries/s", "ms_per_step": round(fm_t / args.steps * 1e3, 3), "scaling": "weak",
               "config": {"workload": f"FMIndex over {args.genome} bp synthetic genome + '$' (n_alphabet, Occ k=128), "
                                      f"{n_q} x {P} bp backward_search per GPU (BASELINE configs[2])",
-                         "index_bytes": fm.device_bytes(), "index_build_s": round(build_s, 1),
-                         "index_build": "suffix array + BWT on rank 0's host cores, broadcast to the other ranks"},
+                         "index_bytes": fm.device_bytes(), "index_build_s": round(bt["total_s"], 2),
+                         "suffix_array_s": round(bt["suffix_array_s"], 3), "suffix_array_on": bt["where"],
+                         "index_build": "every rank builds its replica: genome, suffix array, BWT and SA samples on its GPU, "
+                                        "rank blocks by host threads from the BWT"},
               "tags": {"complete": int((d_tag == 0).sum().item()), "partial": int((d_tag == 1).sum().item()),
                        "absent": int((d_tag == 2).sum().item())},
               "roofline": {"bound": "hbm", "kernel": "fm_backward_search_kernel", "achieved": round(fm_ach, 2),
@@ -537,30 +553,21 @@ def fm_legs(args, ctx, dev, stream, rank, world, do_cpu, orc, threads, parity, r
     del pat, off, d_tag, d_lo, d_hi, d_ml
 
     # -------------------------------------------------------------- seed-and-extend leg (configs[4] shape)
-    if not args.skip_pipeline:
+    if pipeline_here:
         result["seed_extend"] = seed_extend_leg(args, ctx, dev, stream, rank, world, do_cpu, orc, threads, parity,
-                                                fm, g_dev, g, sa, b, ls)
+                                                fm, g_dev, g, sa, b, ls, args.genome)
     del sa, g_dev, fm
     torch.cuda.empty_cache()
 
 
-def fm_big_leg(args, ctx, dev, stream, do_cpu, orc, threads, parity):
-    """backward_search on an index larger than the Infinity Cache: every rank is an HBM read"""
+def fm_big_leg(args, ctx, dev, stream, rank, world, do_cpu, orc, threads, parity, result):
+    """backward_search on an index larger than the 256 MiB Infinity Cache — every rank is an HBM read — and the
+    seed-and-extend leg on the same genome (BASELINE configs[4]: 3 Gbp with --fm-big-genome 3000000000)."""
     import resource
     n_g, n_q, P = args.fm_big_genome, args.queries, args.pattern_len
-    g_dev = synth_gpu.genome(n_g, seed=33, device=dev)
-    g = g_dev.cpu().numpy()
-    t0 = time.perf_counter()
-    sa = suffix_array(g)
-    sa_s = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    b = bwt(g, sa)
-    del sa
-    ls = less(b, N_ALPHABET)
-    fm = FMIndex(b, ls, Occ(b, 128, N_ALPHABET), ctx=ctx)
-    idx_s = time.perf_counter() - t0
-    pat, off = synth_gpu.fm_patterns(g_dev, n_q, P, seed=34)
-    del g_dev
+    want_sa = do_cpu and not args.skip_pipeline
+    g_dev, g, sa, b, ls, fm, bt = build_index(args, ctx, dev, n_g, 33, want_sa=want_sa)
+    pat, off = synth_gpu.fm_patterns(g_dev, n_q, P, seed=34 + 100003 * rank)
     d_tag = torch.empty(n_q, dtype=torch.uint8, device=dev)
     d_lo = torch.empty(n_q, dtype=torch.int64, device=dev)
     d_hi = torch.empty(n_q, dtype=torch.int64, device=dev)
@@ -569,24 +576,30 @@ def fm_big_leg(args, ctx, dev, stream, do_cpu, orc, threads, parity):
     def step():
         fm.backward_search_dev(n_q, pat.data_ptr(), off.data_ptr(), d_tag.data_ptr(), d_lo.data_ptr(), d_hi.data_ptr(),
                                d_ml.data_ptr(), stream)
+        if world > 1:
+            shard.gather_records(torch.stack((d_lo, d_hi), dim=1), counts=[n_q] * world)
 
     t = timed_steps(step, args.steps, args.warmup, dev)
     tm = kernel_timing(ctx, step)
     ms = tm["fm_ms"] / max(1, tm["fm_launches"])
     steps_exec = int((d_ml.to(torch.int64) + (d_tag == 1).to(torch.int64) + (d_tag == 2).to(torch.int64)).sum().item())
     alg = float(n_q) * (P + 24) + 128.0 * steps_exec
-    leg = {"value": round(float(n_q) * args.steps / t, 1), "unit": "queries/s", "ms_per_step": round(t / args.steps * 1e3, 3),
-           "config": {"workload": f"FMIndex over {n_g} bp synthetic genome + '$', {n_q} x {P} bp backward_search, jump table off",
-                      "index_bytes": fm.device_bytes(), "suffix_array_host_s": round(sa_s, 1), "bwt_less_blocks_upload_s": round(idx_s, 1),
+    leg = {"value": round(world * float(n_q) * args.steps / t, 1), "unit": "queries/s", "ms_per_step": round(t / args.steps * 1e3, 3),
+           "scaling": "weak",
+           "config": {"workload": f"FMIndex over {n_g} bp synthetic genome + '$', {n_q} x {P} bp backward_search per GPU, "
+                                  "index beyond the Infinity Cache, jump table off",
+                      "index_bytes": fm.device_bytes(), "index_build_s": round(bt["total_s"], 2),
+                      "suffix_array_s": round(bt["suffix_array_s"], 3), "suffix_array_on": bt["where"],
+                      "blocks_from_bwt_s": round(bt["blocks_s"], 2),
                       "host_peak_rss_gb": round(resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6, 1)},
            "tags": {"complete": int((d_tag == 0).sum().item()), "partial": int((d_tag == 1).sum().item())},
            "roofline": {"bound": "hbm", "kernel": "fm_backward_search_kernel", "achieved": round(alg / (ms * 1e-3) / 1e9, 2),
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                        "traffic": pmc_traffic("fm_backward_search_kernel", "fm_big_queries_per_launch", n_q),
+                        "traffic": fm_big_traffic(n_q, fm.device_bytes()),
                         "launch_ms": round(ms, 4), "queries_per_launch": n_q, "alg_bytes_per_query": round(alg / n_q, 1)}}
     if do_cpu:
         occ = orc.Occ(b, 128, N_ALPHABET)
-        n_chk = min(n_q, 1_000_000)
+        n_chk = max(1, int(min(n_q, 1_000_000) * args.parity_frac))
         hp = pat[:n_chk * P].cpu().numpy()
         hoff = np.arange(n_chk + 1, dtype=np.uint64) * np.uint64(P)
         t0 = time.perf_counter()
@@ -595,13 +608,20 @@ def fm_big_leg(args, ctx, dev, stream, do_cpu, orc, threads, parity):
         ok = bool((d_tag[:n_chk].cpu().numpy() == otag).all() and (d_lo[:n_chk].cpu().numpy().astype(np.uint64) == olo).all() and
                   (d_hi[:n_chk].cpu().numpy().astype(np.uint64) == ohi).all() and
                   (d_ml[:n_chk].cpu().numpy().astype(np.uint64) == oml).all())
-        parity.update({"fm_big_queries_checked": n_chk, "fm_big_bit_exact": ok})
+        parity.update({"fm_big_queries_checked": n_chk, "fm_big_queries_total": n_q, "fm_big_bit_exact": ok})
         leg["cpu_baseline"] = {"value": round(n_chk / t_par, 1), "unit": "queries/s", "cores": threads, "kind": "port",
                                "sample": f"{n_chk} of the {n_q} queries (the parity pass), oracle backward_search"}
-    return leg
+        del occ
+    result["fm_big"] = leg
+    del pat, off, d_tag, d_lo, d_hi, d_ml
+    if not args.skip_pipeline:
+        result["seed_extend"] = seed_extend_leg(args, ctx, dev, stream, rank, world, do_cpu, orc, threads, parity,
+                                                fm, g_dev, g, sa, b, ls, n_g)
+    del sa, g_dev, fm
+    torch.cuda.empty_cache()
 
 
-def seed_extend_leg(args, ctx, dev, stream, rank, world, do_cpu, orc, threads, parity, fm, g_dev, g, sa, b, ls):
+def seed_extend_leg(args, ctx, dev, stream, rank, world, do_cpu, orc, threads, parity, fm, g_dev, g, sa, b, ls, n_genome):
     from rust_bio_amd.pipeline import SeedParams, attach_text, seed_extend_dev
     L, Rp = args.read_len, args.pipeline_reads
     reads, r_starts = synth_gpu.reads_from_genome(g_dev, Rp, L, seed=5 + 100003 * rank)
@@ -634,10 +654,11 @@ def seed_extend_leg(args, ctx, dev, stream, rank, world, do_cpu, orc, threads, p
         C * (L + (L + 2 * prm.pad) + 24 + 2.0 * (L + 1) * (L + 2 * prm.pad + 1)) + n_ops_total
     ms = pipe_t / args.steps * 1e3
     leg = {"value": round(world * Rp * args.steps / pipe_t, 1), "unit": "reads/s", "ms_per_step": round(ms, 3),
-           "config": {"workload": f"{Rp} x {L} bp reads per GPU (5% sub, 1% ins, 1% del) vs the {args.genome} bp genome through "
+           "config": {"workload": f"{Rp} x {L} bp reads per GPU (5% sub, 1% ins, 1% del) vs the {n_genome} bp genome through "
                                   "bg_seed_extend_batch_dev: 20-bp seeds at stride 10 -> backward_search -> Interval::occ (sampled SA, "
                                   "rate 32, intervals <= 16 rows) -> Aligner::semiglobal on +-25 bp windows -> best hit + its operations "
-                                  "(BASELINE configs[4] shape, genome scaled to the FM leg's)"},
+                                  "(BASELINE configs[4]: 10 M reads vs 3 Gbp over 8 GPUs; --fm-big-genome sets the genome)",
+                      "genome": n_genome},
            "seed_hits": int(tot[0]), "candidates": C,
            "mapped_frac": round(float(mapped.float().mean().item()), 4),
            "mapped_at_origin_frac": round(float(near.float().mean().item()), 4),
@@ -655,7 +676,7 @@ def seed_extend_leg(args, ctx, dev, stream, rank, world, do_cpu, orc, threads, p
         hr = reads[:n_chk * L].cpu().numpy()
         ho = np.arange(n_chk + 1, dtype=np.uint64) * np.uint64(L)
         t0 = time.perf_counter()
-        ohits, oops, ostride = orc.seed_extend_batch(b, ls, occ, sa, g, args.genome, osc, hr, ho, threads=threads)
+        ohits, oops, ostride = orc.seed_extend_batch(b, ls, occ, sa, g, n_genome, osc, hr, ho, threads=threads)
         t_par = time.perf_counter() - t0
         hits = d_hits[:n_chk * 96].cpu().numpy().view(_lib.SEED_HIT_DTYPE)
         ok = all((hits[f] == ohits[f]).all() for f in ("n_candidates", "n_seed_hits", "window_start", "ref_start", "ref_end"))
@@ -670,7 +691,7 @@ def seed_extend_leg(args, ctx, dev, stream, rank, world, do_cpu, orc, threads, p
             ok = bool((hops[dev_mask] == kind[or_mask]).all())
         parity.update({"seed_extend_reads_checked": n_chk, "seed_extend_reads_total": Rp, "seed_extend_bit_exact": bool(ok)})
         ns = min(n_chk, 2_000 * threads)
-        t_all = median_time(lambda: orc.seed_extend_batch(b, ls, occ, sa, g, args.genome, osc, hr[:ns * L], ho[:ns + 1],
+        t_all = median_time(lambda: orc.seed_extend_batch(b, ls, occ, sa, g, n_genome, osc, hr[:ns * L], ho[:ns + 1],
                                                           threads=threads, want_ops=False))
         leg["cpu_baseline"] = {"value": round(ns / t_all, 1), "unit": "reads/s", "cores": threads, "kind": "port",
                                "sample": f"{ns} of the {Rp} reads, median of 3 runs: the same composition out of the oracle's "

@@ -102,7 +102,7 @@ def test_bench_launches_its_own_ranks():
     env = dict(os.environ, BENCH_SINGLE_GPU="1")
     env.pop("WORLD_SIZE", None), env.pop("RANK", None), env.pop("LOCAL_RANK", None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--pairs", "20000",
-           "--genome", "300000", "--queries", "40000", "--skip-banded", "--skip-pipeline", "--skip-ingest", "--skip-k1"]
+           "--genome", "300000", "--fm-big-genome", "0", "--queries", "40000", "--skip-banded", "--skip-pipeline", "--skip-ingest", "--skip-k1"]
     out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert out.returncode == 0, out.stderr.decode()[-3000:]
     line = [ln for ln in out.stdout.decode().splitlines() if ln.startswith("{")][-1]

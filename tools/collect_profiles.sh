@@ -16,7 +16,9 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $R/bench.py --skip-cpu"
 # the counter passes keep one launch shape per kernel: the seed-and-extend leg reuses K2 / K5 on other batch sizes
-PMCBENCH="$BENCH --skip-pipeline --steps 2 --warmup 0"
+PMCBENCH="$BENCH --skip-pipeline --fm-big-genome 0 --steps 2 --warmup 0"
+# ... and the FM kernel on the 1 Gbp index gets passes of its own (same kernel name as the 100 Mbp leg)
+BIGBENCH="$BENCH --skip-fm --skip-k1 --skip-banded --skip-ingest --skip-pipeline --pairs 65536 --steps 2 --warmup 0"
 
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o bench -- $BENCH > "$OUT/${TAG}_bench.log" 2>&1
 cp "$OUT"/kt/bench_kernel_stats.csv "$OUT/${TAG}_bench_kernel_stats.csv" 2>/dev/null
@@ -27,6 +29,10 @@ for G in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES S
   rocprofv3 --kernel-trace --pmc $G --output-format csv -d "$OUT/pmc_$i" -o bench -- $PMCBENCH > "$OUT/pmc_$i.log" 2>&1
 done
 
+for C in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/big_$C" -o bench -- $BIGBENCH > "$OUT/big_$C.log" 2>&1
+done
+
 if [ -x "$R/tools/pmc_calib" ]; then
   for C in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/cal_$C" -o cal -- "$R/tools/pmc_calib" > "$OUT/cal_$C.log" 2>&1
@@ -34,4 +40,4 @@ if [ -x "$R/tools/pmc_calib" ]; then
 fi
 python "$R/tools/pmc_summary.py" "$OUT" "$TAG"
 # the raw traces are bulky (every torch kernel of the run): keep the summaries only
-rm -rf "$OUT"/kt "$OUT"/pmc_[0-9] "$OUT"/cal_FETCH_SIZE "$OUT"/cal_WRITE_SIZE
+rm -rf "$OUT"/kt "$OUT"/pmc_[0-9] "$OUT"/cal_FETCH_SIZE "$OUT"/cal_WRITE_SIZE "$OUT"/big_FETCH_SIZE "$OUT"/big_WRITE_SIZE

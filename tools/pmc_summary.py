@@ -61,6 +61,21 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
 # FASTQ ingest is many short kernels per call: bytes of all of them per bg_fastq_parse_dev call (the leg makes 4 calls)
 fq = sum(sum(v) * 1024.0 for c in ("FETCH_SIZE", "WRITE_SIZE") for k, v in counters.get(c, {}).items() if k.startswith("fq_"))
 res["ingest_bytes_per_call"] = fq / 4.0
+# the FM search kernel on the index beyond the Infinity Cache (its own passes)
+big = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    vals = [v for k, vs in per_kernel(os.path.join(out, "big_" + c)).get(c, {}).items() if "fm_backward_search_kernel" in k for v in vs]
+    if vals:
+        big[c] = {"launches": len(vals), "mean_bytes": sum(vals) * 1024.0 / len(vals)}
+logf = os.path.join(out, "big_FETCH_SIZE.log")
+if big and os.path.exists(logf):
+    for ln in open(logf):
+        if ln.startswith("{") and '"fm_big"' in ln:
+            fb = json.loads(ln)["fm_big"]
+            big["queries_per_launch"] = fb["roofline"]["queries_per_launch"]
+            big["index_bytes"] = fb["config"]["index_bytes"]
+            big["alg_bytes_per_launch"] = fb["roofline"]["alg_bytes_per_query"] * fb["roofline"]["queries_per_launch"]
+    res["fm_big"] = big
 json.dump(res, open(os.path.join(out, tag + "_pmc_traffic.json"), "w"), indent=1)
 
 # ---- issue counters
