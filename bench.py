@@ -368,7 +368,7 @@ def k1_legs(args, ctx, dev, stream, rank, world, do_cpu, orc, threads, parity):
               Scoring.from_scores(-500, -100, 100, -100), dict(match=100, mismatch=-100),
               f"{n} x {L} bp DNA pairs per GPU, Aligner::local, from_scores(-500,-100,100,-100): scores beyond K1p's 12 bits")]
     # template arguments <R, LP, SM, LOCAL, NARROW> of the instantiation each case runs (profile lookups go by name)
-    knames = {"blosum62_protein": "sw_fill_kernel<10, 16, 1, true, true>", "wide_scores_dna": "sw_fill_kernel<10, 16, 0, true, true>"}
+    knames = {"blosum62_protein": "sw_fill_kernel<10, 16, 1, true, true>", "wide_scores_dna": "sw_fill_kernel<10, 16, 0, true, true>"}  # R = 10 rows x 16 lanes, SM, LOCAL, NARROW
     for name, (x, xo, y, yo), scoring, okw, desc in cases:
         kname = knames[name]
         d_out = torch.empty(n * 64, dtype=torch.uint8, device=dev)

@@ -14,7 +14,7 @@
 namespace bgsw {
 sw_fill_fn get_fill_params_narrow(int lp, int r, bool local);
 sw_fill_fn get_fill_params_wide(int lp, int r, bool local);
-sw_fill_fn get_fill_matrix(int lp, int r, int sm, bool narrow);
+sw_fill_fn get_fill_matrix(int lp, int r, int sm, bool narrow, bool local);
 sw_fill_fn get_fill_pk16_local(int lp, int r, int which);
 sw_fill_fn get_fill_pk16_semiglobal(int lp, int r, int which);
 sw_fill_fn get_fill_pk16_global(int lp, int r, int which);
@@ -32,6 +32,8 @@ static Config pick_config(uint32_t m_cap, int sm) {
         return {64, 8};
     }
     if (m_cap <= 96) return {16, 6};
+    if (m_cap <= 128) return {16, 8};
+    if (m_cap <= 160) return {16, 10};
     if (m_cap <= 192) return {16, 12};
     if (m_cap <= 384) return {32, 12};
     return {64, 8};
@@ -284,7 +286,7 @@ static int align_batch_dev_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, u
     sw_fill_fn fill = sm == SCORE_PARAMS
                           ? (narrow ? get_fill_params_narrow(cfg.lp, cfg.r, all_zero_clips)
                                     : get_fill_params_wide(cfg.lp, cfg.r, all_zero_clips))
-                          : get_fill_matrix(cfg.lp, cfg.r, sm, narrow);
+                          : get_fill_matrix(cfg.lp, cfg.r, sm, narrow, all_zero_clips);
     // K1p: short reads whose scores fit 12 bits (sw_fill_pk16.inc) — two pairs per lane, one instantiation
     // unit per clip pattern.  Bound: no real DP value, nor the epilogue's go * i terms, may leave +-2040.
     sw_fill_fn fill_rest = nullptr, fill_second = nullptr;
