@@ -79,19 +79,24 @@ __global__ __launch_bounds__(256) void kmer_match_kernel(const BandDevArgs a) {
             for (uint32_t i = head[(h * 0xD6E8FEB86659FD93ull) >> shift]; i != kNone; i = next[i])
                 if (hy[i] == h && kmer_equal(y + i, x + p, k)) c++;
         }
-        s_scan[threadIdx.x] = c;
-        __syncthreads();
-        for (uint32_t o = 1; o < blockDim.x; o <<= 1) {
-            const uint32_t v = threadIdx.x >= o ? s_scan[threadIdx.x - o] : 0;
-            __syncthreads();
-            s_scan[threadIdx.x] += v;
-            __syncthreads();
+        // exclusive scan of the counts over the tile: inside a wavefront with lane shifts, one barrier for the four
+        // wavefront totals (a 256-wide LDS scan costs sixteen barriers per tile, forty tiles per read)
+        uint32_t incl = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t v = (uint32_t)__shfl_up((int)incl, o);
+            if ((threadIdx.x & 63) >= (uint32_t)o) incl += v;
         }
-        const uint32_t off = run + s_scan[threadIdx.x] - c;
-        const uint32_t tile_total = s_scan[blockDim.x - 1];
         // the in-place sort below is quadratic in c, and the chain kernel holds kMaxChainMatches
         if (c > kMaxMatchesPerKmer) s_flag = 1;
+        if ((threadIdx.x & 63) == 63) s_scan[threadIdx.x >> 6] = incl;
         __syncthreads();
+        uint32_t wbase = 0, tile_total = 0;
+        for (uint32_t wv = 0; wv < (blockDim.x >> 6); wv++) {
+            if (wv < (threadIdx.x >> 6)) wbase += s_scan[wv];
+            tile_total += s_scan[wv];
+        }
+        const uint32_t off = run + wbase + incl - c;
         if (run + tile_total > a.cap_matches || run + tile_total > kMaxChainMatches || s_flag) {
             over = true;  // block-uniform: s_flag and the totals are read after the barrier
         } else if (c) {
@@ -127,7 +132,12 @@ __device__ __forceinline__ bool frag_less(const Frag& p, const Frag& q) { return
 // LDS_TREE: tree / score / back live in LDS (lowest latency per event, but LDS limits a CU to one to three
 // pairs); otherwise in global scratch (L2-resident; every event costs a memory round trip, but tens of
 // wavefronts per CU hide it).  Only the sort buffer of the end-y values is always in LDS.
-template <bool LDS_TREE>
+// PART: 0 the whole chain in one launch; 1 only the preparation (sort of the end coordinates in LDS, tree positions,
+// continuation links, empty tree); 2 only the event loop + the path.  With the tree in global scratch the event loop
+// needs no LDS at all, and launched on its own it is resident 32 wavefronts per CU instead of the 10 that 16 KB of
+// sort buffer per wavefront allow — every event is a dependent L2 round trip that only occupancy hides
+// (11.7 ms instead of 26 per 16 384 pairs).
+template <bool LDS_TREE, int PART = 0>
 __global__ __launch_bounds__(64) void chain_kernel(const BandDevArgs a) {
     extern __shared__ __align__(16) uint8_t s_raw[];
     const uint32_t pair = blockIdx.x;
@@ -164,6 +174,7 @@ __global__ __launch_bounds__(64) void chain_kernel(const BandDevArgs a) {
         score = a.g_score + (size_t)pair * a.cap_matches;
         back = a.g_back + (size_t)pair * a.cap_matches;
     }
+    if (PART != 2) {
     for (uint32_t i = lane; i < np2; i += 64) ye[i] = i < nm ? my[i] + k : kNone;
     for (uint32_t i = lane; i < nm; i += 64) {
         int32_t c = -1;
@@ -217,6 +228,8 @@ __global__ __launch_bounds__(64) void chain_kernel(const BandDevArgs a) {
     __syncthreads();
     for (uint32_t i = lane; i <= nm; i += 64) tree[i] = Frag{0, 0};
     __syncthreads();
+    }
+    if (PART == 1) return;
 
     const uint32_t ms = a.match_score;
     const uint32_t go = (uint32_t)(-(int64_t)a.gap_open), ge = (uint32_t)(-(int64_t)a.gap_extend);
@@ -689,7 +702,8 @@ int launch_band_chain_and_raster(const BandDevArgs& a, hipStream_t st) {
     c.chain_cap = kMaxChainMatches;
     if (a.chain_global > 0 || (a.chain_global < 0 && a.n_pairs >= kChainGlobalMinPairs)) {
         // enough pairs to hide memory latency with occupancy: tree in global scratch, 16 KB of LDS per pair
-        chain_kernel<false><<<dim3(a.n_pairs), dim3(64), 4 * (size_t)(kMaxChainMatches + 1), st>>>(c);
+        chain_kernel<false, 1><<<dim3(a.n_pairs), dim3(64), 4 * (size_t)(kMaxChainMatches + 1), st>>>(c);
+        chain_kernel<false, 2><<<dim3(a.n_pairs), dim3(64), 0, st>>>(c);
     } else {
         static bool attr_set = false;
         if (!attr_set) {
