@@ -637,6 +637,9 @@ def seed_extend_leg(args, ctx, dev, stream, rank, world, do_cpu, orc, threads, p
     def pipe_step():
         seed_extend_dev(fm, sc, Rp, reads.data_ptr(), d_roff.data_ptr(), L, d_hits.data_ptr(), d_ops.data_ptr(), stride, prm,
                         stream, tot)
+        if world > 1:  # the single collective: score + reference span of every read (24-byte records)
+            h64 = d_hits.view(torch.int64).view(Rp, 12)
+            shard.gather_records(torch.stack((h64[:, 0] & 0xFFFFFFFF, h64[:, 9], h64[:, 10]), dim=1), counts=[Rp] * world)
 
     pipe_t = timed_steps(pipe_step, args.steps, args.warmup, dev)
     tm = kernel_timing(ctx, pipe_step, reps=1)
@@ -725,6 +728,8 @@ def banded_leg(args, ctx, dev, rank, world, do_cpu, orc, threads, parity):
     t0 = time.perf_counter()
     bal.align_dev(2, Pb, bx.data_ptr(), d_boff.data_ptr(), by.data_ptr(), d_boff.data_ptr(), d_bout.data_ptr(),
                   d_bops.data_ptr(), bstride)
+    if world > 1:  # the single collective: scores + coordinates of every pair
+        shard.gather_records(d_bout.view(torch.int32).view(Pb, 16)[:, :5].contiguous(), counts=[Pb] * world)
     torch.cuda.synchronize()
     bt_dev = shard.max_over_ranks(time.perf_counter() - t0, dev)
     dev_ok = bool((d_bout.view(torch.int32).view(Pb, 16)[:, 0].cpu().numpy() == bout["score"]).all())
