@@ -40,12 +40,46 @@ __device__ __forceinline__ bool kmer_equal(const uint8_t* a, const uint8_t* b, u
 }
 
 // ------------------------------------------------------------------------------------------- B1
+// STAGED: both sequences are copied to LDS first (16-byte loads) and every k-mer is hashed / compared from there.
+// With the sequences in global memory the hash loop (k is a run-time value) is a chain of k byte loads, each waited
+// for before the next — 16 L1/L2 round trips per hash, twice per position plus once per candidate comparison: that,
+// not the hash table, was where the kernel spent its time (18.6 ms per 16 384 x 10 kb pairs).
+constexpr uint32_t kStageMaxBytes = 40960;  // x + y: two blocks per CU keep their sequences in LDS
+template <bool STAGED>
 __global__ __launch_bounds__(256) void kmer_match_kernel(const BandDevArgs a) {
+    extern __shared__ __align__(16) uint8_t s_seq[];
     const uint32_t pair = blockIdx.x;
     const uint64_t xo = a.x_off[a.pair0 + pair], yo = a.y_off[a.pair0 + pair];
     const uint32_t m = (uint32_t)(a.x_off[a.pair0 + pair + 1] - xo), n = (uint32_t)(a.y_off[a.pair0 + pair + 1] - yo);
     const uint8_t* x = a.x + xo;
     const uint8_t* y = a.y + yo;
+    if (STAGED) {
+        uint8_t* sx = s_seq;
+        uint8_t* sy = s_seq + ((m + 15) & ~15u);
+        auto stage = [&](uint8_t* dst, const uint8_t* src, uint32_t len) {
+            const uint32_t mis = (uint32_t)((uintptr_t)src & 15u);  // bytes up to the first 16-byte boundary of src
+            const uint32_t headb = min(len, (16u - mis) & 15u);
+            for (uint32_t i = threadIdx.x; i < headb; i += blockDim.x) dst[i] = src[i];
+            const uint32_t nvec = (len - headb) / 16;
+            const uint4* s4 = (const uint4*)(src + headb);
+            for (uint32_t v = threadIdx.x; v < nvec; v += blockDim.x) {
+                const uint4 q = s4[v];
+                uint32_t* d = (uint32_t*)(dst + headb + 16 * v);  // dst + headb is only byte-aligned in general
+                if ((headb & 3u) == 0) {
+                    d[0] = q.x; d[1] = q.y; d[2] = q.z; d[3] = q.w;
+                } else {
+                    const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+                    for (int t = 0; t < 16; t++) dst[headb + 16 * v + t] = (uint8_t)(w[t >> 2] >> (8 * (t & 3)));
+                }
+            }
+            for (uint32_t i = headb + 16 * nvec + threadIdx.x; i < len; i += blockDim.x) dst[i] = src[i];
+        };
+        stage(sx, x, m);
+        stage(sy, y, n);
+        __syncthreads();
+        x = sx;
+        y = sy;
+    }
     const uint32_t k = a.k;
     BandDevPair* st = a.state + pair;
     uint32_t* head = a.head + (size_t)pair * a.table_size;
@@ -691,11 +725,15 @@ __global__ __launch_bounds__(256) void band_rows_kernel(const BandDevArgs a) {
 static size_t chain_lds_bytes(uint32_t cap) { return 16 * (size_t)(cap + 1) + 6 * (size_t)cap + 16; }
 
 int launch_band_match(const BandDevArgs& a, hipStream_t st) {
-    kmer_match_kernel<<<dim3(a.n_pairs), dim3(256), 0, st>>>(a);
+    const size_t stage_bytes = (size_t)((a.max_m + 15) & ~15u) + a.max_n + 16;
+    if (stage_bytes <= kStageMaxBytes)
+        kmer_match_kernel<true><<<dim3(a.n_pairs), dim3(256), stage_bytes, st>>>(a);
+    else
+        kmer_match_kernel<false><<<dim3(a.n_pairs), dim3(256), 0, st>>>(a);
     return hipGetLastError() == hipSuccess ? BG_OK : BG_ERR_HIP;
 }
 
-int launch_band_chain_and_raster(const BandDevArgs& a, hipStream_t st) {
+int launch_band_chain(const BandDevArgs& a, hipStream_t st) {
     // two LDS size classes: most pairs of a long-read batch sit just around 2k matches
     BandDevArgs c = a;
     c.chain_min = 0;
@@ -718,6 +756,10 @@ int launch_band_chain_and_raster(const BandDevArgs& a, hipStream_t st) {
         c.chain_cap = kMaxChainMatches;
         chain_kernel<true><<<dim3(a.n_pairs), dim3(64), chain_lds_bytes(c.chain_cap), st>>>(c);
     }
+    return hipGetLastError() == hipSuccess ? BG_OK : BG_ERR_HIP;
+}
+
+int launch_band_raster(const BandDevArgs& a, hipStream_t st) {
     band_kernel<<<dim3(a.n_pairs), dim3(256), 0, st>>>(a);
     band_rows_kernel<<<dim3(a.n_pairs), dim3(256), 0, st>>>(a);
     return hipGetLastError() == hipSuccess ? BG_OK : BG_ERR_HIP;

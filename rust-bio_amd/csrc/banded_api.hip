@@ -160,6 +160,8 @@ struct bg_band_scratch {
     void* h_ops = nullptr;  // pinned landing zone of the operations
     size_t h_ops_cap = 0;
     hipStream_t tb_stream = nullptr;
+    uint32_t* d_started = nullptr;  // blocks of the K3v2 launches of the current call that have started (see banded_fill2.hip)
+    uint32_t started_target = 0;    // ... and how many have been launched
 };
 
 void bg_band_scratch_free(bg_band_scratch* b) {
@@ -167,6 +169,8 @@ void bg_band_scratch_free(bg_band_scratch* b) {
     for (auto& s : b->set) {
         hipHostFree(s.h_pairs); hipHostFree(s.h_rowc); hipHostFree(s.h_roff);
         hipFree(s.d_pairs); hipFree(s.d_rowc); hipFree(s.d_roff); hipFree(s.d_tb); hipFree(s.d_aux);
+        hipFree(b->d_started);
+        b->d_started = nullptr;
         if (s.copied) hipEventDestroy(s.copied);
         if (s.filled) hipEventDestroy(s.filled);
         if (s.traced) hipEventDestroy(s.traced);
@@ -379,6 +383,9 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
         for (auto& s : B.set) BG_HIP(hipEventCreateWithFlags(&s.built, hipEventDisableTiming));
     }
     hipStream_t st_build = B.build_stream;
+    if (!B.d_started) BG_HIP(hipMalloc((void**)&B.d_started, 64));
+    BG_HIP(hipMemsetAsync(B.d_started, 0, 4, st));
+    B.started_target = 0;
     BG_HIP(hipEventRecord(B.seq_ready, st));
     BG_HIP(hipStreamWaitEvent(st_build, B.seq_ready, 0));
 
@@ -468,8 +475,16 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
             d.row_off = (uint32_t*)S.d_roff;
             if ((rc = pinned_reserve(&B.h_state, &B.h_state_cap, want * sizeof(BandDevPair)))) return rc;
             BG_HIP(hipMemcpyAsync(B.db[13], row0.data(), (want + 1) * 8, hipMemcpyHostToDevice, st_build));
+            // The k-mer join and the chaining of sub-batch c + 1 run UNDER the fill of c: they mostly wait on memory and
+            // fit the registers / LDS the fill leaves free — provided they start after every block of the fill is
+            // resident (launch_band_wait_started: the fill's grid is a single round of blocks, and a co-runner that is
+            // on a CU first delays the whole kernel: fill 57 -> 116 ms).  The raster kernels want 65 KB of LDS per block
+            // against the 130 KB per CU the fill holds: they start when that fill is done and overlap K4 of sub-batch c.
+            if (B.started_target) launch_band_wait_started(B.d_started, B.started_target, st_build);
             if ((rc = launch_band_match(d, st_build))) return rc;
-            if ((rc = launch_band_chain_and_raster(d, st_build))) return rc;
+            if ((rc = launch_band_chain(d, st_build))) return rc;
+            if (n_chunk >= 1 && B.set[(n_chunk - 1) & 1].busy) BG_HIP(hipStreamWaitEvent(st_build, B.set[(n_chunk - 1) & 1].filled, 0));
+            if ((rc = launch_band_raster(d, st_build))) return rc;
             BG_HIP(hipMemcpyAsync(B.h_state, d.state, want * sizeof(BandDevPair), hipMemcpyDeviceToHost, st_build));
             BG_HIP(hipEventRecord(S.built, st_build));
         } else {
@@ -583,8 +598,11 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
         a.n_pairs = (uint32_t)take;
         if (on_device) BG_HIP(hipStreamWaitEvent(st, S.built, 0));
         if (ctx->timing) BG_HIP(hipEventRecord(ctx->ev[0], st));
-        if (sm == SCORE_PARAMS && !ctx->band_fill_v1)
-            launch_band_fill2(a, narrow, st);  // K3v2: four pairs per wavefront + separate epilogue
+        if (sm == SCORE_PARAMS && !ctx->band_fill_v1) {
+            a.started = on_device ? B.d_started : nullptr;
+            if (on_device) B.started_target += band_fill2_blocks(a.n_pairs);
+            launch_band_fill2(a, narrow, st);  // K3v2: eight pairs per wavefront + separate epilogue
+        }
         else
             fill<<<dim3((unsigned)((take + 3) / 4)), dim3(256), 0, st>>>(a);
         BG_HIP(hipGetLastError());

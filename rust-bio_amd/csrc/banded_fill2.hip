@@ -21,6 +21,12 @@
 
 namespace bgband_dev {
 
+#ifndef BF2_LP
+#define BF2_LP 8  // measured on 16 384 x 10 kb pairs (fill ms): LP x R = 8x4 58.6, 8x5 58.8, 16x4 67.7, 16x2 76.6, 4x6 79.4, 8x6 85.8, 4x4 86.7, 8x8 88.2, 32x4 88.8
+#define BF2_R 4
+#endif
+#define BF2_LP_DEFAULT BF2_LP
+
 namespace {
 
 enum : uint32_t { IC_OPEN = 0, IC_EXT = 1, IC_YS = 2 };
@@ -67,6 +73,7 @@ __global__ __launch_bounds__(256) void banded_fill2_kernel(const BandArgs a) {
     constexpr int RS = LP * R;  // rows per strip
     const int lane = threadIdx.x & 63;
     const int g = lane / LP, ll = lane % LP;
+    if (a.started && threadIdx.x == 0) atomicAdd(a.started, 1u);  // see launch_band_wait_started
     const uint32_t job = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if ((uint64_t)job * PW >= a.n_pairs) return;  // wave-uniform
     const uint32_t pair = job * PW + g;
@@ -752,11 +759,28 @@ __global__ __launch_bounds__(256) void banded_epilogue_kernel(const BandArgs a) 
 
 }  // namespace
 
+// The fill's grid is ONE round of blocks (16 384 pairs = 512 blocks, two per CU, resident for the whole kernel), so
+// whatever holds LDS or registers on a CU at the moment the fill is dispatched delays some of its blocks by the full
+// co-runner's duration and with them the whole kernel.  A kernel that should run NEXT to the fill (the k-mer join of the
+// following sub-batch) therefore waits on its own stream until every fill block has counted itself in.
+__global__ void band_wait_started_kernel(const uint32_t* counter, uint32_t target) {
+    const uint64_t t0 = __builtin_readcyclecounter();
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        if (__builtin_readcyclecounter() - t0 > 50000000ull) break;  // ~20 ms: give up waiting, never hang the device
+        __builtin_amdgcn_s_sleep(64);
+    }
+}
+void launch_band_wait_started(const uint32_t* counter, uint32_t target, hipStream_t st) {
+    band_wait_started_kernel<<<dim3(1), dim3(1), 0, st>>>(counter, target);
+}
+uint32_t band_fill2_blocks(uint32_t n_pairs) {
+    constexpr int PW = 64 / BF2_LP_DEFAULT;
+    const uint32_t jobs = (n_pairs + PW - 1) / PW;
+    return (jobs + 3) / 4;
+}
+
 bool launch_band_fill2(const BandArgs& a, bool narrow, hipStream_t st) {
-#ifndef BF2_LP
-#define BF2_LP 8  // measured on 16 384 x 10 kb pairs (fill ms): LP x R = 8x4 58.6, 8x5 58.8, 16x4 67.7, 16x2 76.6, 4x6 79.4, 8x6 85.8, 4x4 86.7, 8x8 88.2, 32x4 88.8
-#define BF2_R 4
-#endif
+
     constexpr int LP = BF2_LP, R = BF2_R, PW = 64 / LP;
     const uint32_t jobs = (a.n_pairs + PW - 1) / PW;
     if (narrow)

@@ -79,6 +79,7 @@ struct BandArgs {
     uint8_t* ops;
     uint64_t ops_stride;
     int32_t mode, filter_clips;
+    uint32_t* started;  // K3v2: every block counts itself in when it starts (nullptr: nobody is waiting for that)
 };
 
 typedef void (*band_fill_fn)(const BandArgs);
@@ -86,6 +87,9 @@ band_fill_fn get_band_fill(int sm);
 // K3v2 (banded_fill2.hip): LP lanes per pair, R rows per lane, MatchParams scoring; the last-column
 // epilogue runs in its own kernel.  Returns false if the geometry is not instantiated.
 bool launch_band_fill2(const BandArgs& a, bool narrow, hipStream_t st);
+uint32_t band_fill2_blocks(uint32_t n_pairs);  // thread blocks launch_band_fill2 starts for n_pairs
+// holds `st` until *counter >= target (or ~20 ms have passed): "the fill kernel's blocks are all resident"
+void launch_band_wait_started(const uint32_t* counter, uint32_t target, hipStream_t st);
 void launch_band_traceback(const BandArgs& a, hipStream_t st);
 
 }  // namespace bgband_dev
