@@ -325,6 +325,8 @@ uint64_t bg_sparse_expand_kmer_matches(const uint8_t* x, uint64_t m, const uint8
  *   extension    Aligner::semiglobal(x = read, y = text[max(0, s - pad) .. min(n_text, s + read_len + pad)));
  *   best hit     per read the highest score, the smallest s among equal scores; a read without candidates
  *                reports score BG_MIN_SCORE, ref positions UINT64_MAX and no operations.
+ * A seed that reaches a byte outside the index's alphabet (where the reference's backward_search panics, fmindex.rs:229)
+ * does not vote; the call then returns BG_ERR_OUT_OF_ALPHABET with every read still answered.
  * The index handle needs the text (bg_fm_set_text[_dev]: all n bytes the index was built from, final sentinel
  * included) and a suffix array (bg_fm_set_suffix_array / bg_fm_set_sampled_suffix_array). */
 int bg_fm_set_text(bg_fm* fm, const uint8_t* text, uint64_t n);         /* host text, copied to the device */

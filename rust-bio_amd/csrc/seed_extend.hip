@@ -47,10 +47,12 @@ struct SeedPrm {
 
 // S2: votes of every seed slot
 __global__ __launch_bounds__(256) void se_votes_kernel(uint64_t n_q, const uint8_t* __restrict__ tag, const uint64_t* __restrict__ lower,
-                                                       const uint64_t* __restrict__ upper, uint32_t max_occ, uint32_t* __restrict__ cnt) {
+                                                       const uint64_t* __restrict__ upper, uint32_t max_occ, uint32_t* __restrict__ cnt,
+                                                       uint32_t* __restrict__ panics) {
     const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= n_q) return;
     uint32_t c = 0;
+    if (tag[q] == BG_FM_PANIC) atomicOr(panics, 1u);  // the seed reached a byte outside the alphabet: fmindex.rs:229 panics
     if (tag[q] == BG_FM_COMPLETE) {
         const uint64_t sz = upper[q] - lower[q];
         if (sz >= 1 && sz <= max_occ) c = (uint32_t)sz;
@@ -275,6 +277,7 @@ extern "C" int bg_seed_extend_batch_dev(bg_fm* fm, const bg_scoring_t* sc, const
     auto need = [&](int i, size_t bytes) -> int { return bg_reserve(&W.p[i], &W.cap[i], std::max<size_t>(bytes, 64)); };
 
     uint64_t done_hits = 0, done_cand = 0;
+    bool any_panic = false;
     const uint64_t chunk = 1u << 20;  // reads per pass: bounds the scratch (seed slots, proposals, candidate pairs)
     for (uint64_t r0 = 0; r0 < n_reads; r0 += chunk) {
         const uint64_t nr = std::min(chunk, n_reads - r0);
@@ -286,20 +289,24 @@ extern "C" int bg_seed_extend_batch_dev(bg_fm* fm, const bg_scoring_t* sc, const
         if ((rc = need(2, nq * 8))) return rc;          // upper
         if ((rc = need(3, nq * 4))) return rc;          // matched_len, then votes
         if ((rc = need(4, (nq + 1) * 8))) return rc;    // hit offsets
-        if ((rc = need(5, 2 * (nq / 2048 + 2) * 8 + 64))) return rc;  // scan partials
+        if ((rc = need(5, 2 * (nq / 2048 + 2) * 8 + 64))) return rc;  // scan partials (+ the panic flag behind them)
+        BG_HIP(hipMemsetAsync((uint8_t*)W.p[5] + 2 * (nq / 2048 + 2) * 8, 0, 8, st));
         uint8_t* d_tag = (uint8_t*)W.p[0];
         uint64_t *d_lo = (uint64_t*)W.p[1], *d_hi = (uint64_t*)W.p[2], *d_hoff = (uint64_t*)W.p[4], *d_sums = (uint64_t*)W.p[5];
         uint32_t* d_cnt = (uint32_t*)W.p[3];
         if (prm.S) {
             if ((rc = bg_fm_search_seeds_dev(fm, nr, d_reads, roff, prm.S, prm.stride, prm.seed_len, d_tag, d_lo, d_hi, d_cnt, st))) return rc;
-            se_votes_kernel<<<dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st>>>(nq, d_tag, d_lo, d_hi, prm.max_occ, d_cnt);
+            se_votes_kernel<<<dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st>>>(nq, d_tag, d_lo, d_hi, prm.max_occ, d_cnt,
+                                                                                      (uint32_t*)(d_sums + 2 * (nq / 2048 + 2)));
         } else {
             BG_HIP(hipMemsetAsync(d_cnt, 0, nq * 4, st));
         }
         if ((rc = bg_scan_u32(d_cnt, nq, d_hoff, d_sums, st))) return rc;
         BG_HIP(hipMemcpyAsync(&W.h_tot[0], d_hoff + nq, 8, hipMemcpyDeviceToHost, st));
+        BG_HIP(hipMemcpyAsync(&W.h_tot[4], d_sums + 2 * (nq / 2048 + 2), 8, hipMemcpyDeviceToHost, st));
         BG_HIP(hipStreamSynchronize(st));  // sizes the position array
         const uint64_t n_hits = W.h_tot[0];
+        if (W.h_tot[4] & 1) any_panic = true;
         // ---- S3: Interval::occ of the voting intervals
         if ((rc = need(6, n_hits * 8))) return rc;
         uint64_t* d_pos = (uint64_t*)W.p[6];
@@ -352,7 +359,9 @@ extern "C" int bg_seed_extend_batch_dev(bg_fm* fm, const bg_scoring_t* sc, const
         totals[0] = done_hits;
         totals[1] = done_cand;
     }
-    return BG_OK;
+    // a seed that reaches a byte outside the alphabet makes the reference's backward_search panic; here it does not
+    // vote, every read is still answered, and the call says so
+    return any_panic ? BG_ERR_OUT_OF_ALPHABET : BG_OK;
 }
 
 extern "C" int bg_seed_extend_batch(bg_fm* fm, const bg_scoring_t* sc, const bg_seed_params_t* prm, uint64_t n_reads,
@@ -372,6 +381,7 @@ extern "C" int bg_seed_extend_batch(bg_fm* fm, const bg_scoring_t* sc, const bg_
     uint64_t* d_off = nullptr;
     bg_seed_hit_t* d_hits = nullptr;
     std::vector<uint8_t> h_ops;
+    int panic_rc = BG_OK;
     auto run = [&]() -> int {
         hipStream_t st = ctx->stream;
         BG_HIP(hipMalloc((void**)&d_reads, std::max<uint64_t>(bytes, 16)));
@@ -381,7 +391,8 @@ extern "C" int bg_seed_extend_batch(bg_fm* fm, const bg_scoring_t* sc, const bg_
         if (bytes) BG_HIP(hipMemcpyAsync(d_reads, reads, bytes, hipMemcpyHostToDevice, st));
         BG_HIP(hipMemcpyAsync(d_off, read_off, (n_reads + 1) * 8, hipMemcpyHostToDevice, st));
         int rc = bg_seed_extend_batch_dev(fm, sc, prm, n_reads, d_reads, d_off, (uint32_t)max_len, d_hits, d_ops, stride, nullptr, st);
-        if (rc) return rc;
+        if (rc && rc != BG_ERR_OUT_OF_ALPHABET) return rc;
+        panic_rc = rc;
         BG_HIP(hipMemcpyAsync(hits, d_hits, n_reads * sizeof(bg_seed_hit_t), hipMemcpyDeviceToHost, st));
         if (stride) {
             h_ops.resize(n_reads * stride);
@@ -412,5 +423,5 @@ extern "C" int bg_seed_extend_batch(bg_fm* fm, const bg_scoring_t* sc, const bg_
         used += ops_buf ? a.n_ops : 0;
     }
     if (ops_used) *ops_used = used;
-    return status;
+    return status ? status : panic_rc;
 }

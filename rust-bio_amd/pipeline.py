@@ -32,8 +32,10 @@ def attach_text(fm, text=None, d_text=None):
         _lib.check(_lib.lib().bg_fm_set_text(fm.h, t.ctypes.data, len(t)), "bg_fm_set_text")
 
 
-def seed_extend_arrays(fm, scoring, reads, read_off, params=None, want_ops=True):
-    """Host-buffer batch: returns (hits: SEED_HIT_DTYPE[n], ops: uint8[], winners' operations back to back)."""
+def seed_extend_arrays(fm, scoring, reads, read_off, params=None, want_ops=True, allow_out_of_alphabet=False):
+    """Host-buffer batch: returns (hits: SEED_HIT_DTYPE[n], ops: uint8[], winners' operations back to back).
+    A seed that reaches a byte outside the index's alphabet raises AlphabetError (the reference's backward_search
+    panics there) unless allow_out_of_alphabet: such seeds simply do not vote."""
     params = params or SeedParams()
     rd = _lib.as_u8(reads)
     off = np.ascontiguousarray(read_off, dtype=np.uint64)
@@ -43,9 +45,10 @@ def seed_extend_arrays(fm, scoring, reads, read_off, params=None, want_ops=True)
     ops = np.zeros(max(cap, 1), dtype=np.uint8) if want_ops else None
     used = C.c_uint64(0)
     sc, pc = scoring.to_c(), params.to_c()
-    _lib.check(_lib.lib().bg_seed_extend_batch(fm.h, C.byref(sc), C.byref(pc), n, rd.ctypes.data, off.ctypes.data,
-                                               hits.ctypes.data, ops.ctypes.data if want_ops else None, cap, C.byref(used)),
-               "bg_seed_extend_batch")
+    rc = _lib.lib().bg_seed_extend_batch(fm.h, C.byref(sc), C.byref(pc), n, rd.ctypes.data, off.ctypes.data,
+                                         hits.ctypes.data, ops.ctypes.data if want_ops else None, cap, C.byref(used))
+    if not (rc == -7 and allow_out_of_alphabet):
+        _lib.check(rc, "bg_seed_extend_batch")
     return hits, (ops[:used.value] if want_ops else None)
 
 

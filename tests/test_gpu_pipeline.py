@@ -125,3 +125,22 @@ def test_seed_extend_needs_text_and_suffix_array():
     fm = FMIndex(b, ls, Occ(b, 64, ALPHA))
     with pytest.raises(_lib.BiogpuError):
         seed_extend_arrays(fm, Scoring.from_scores(-5, -1, 1, -1), reads, off)
+
+
+def test_seed_outside_the_alphabet_is_reported_and_does_not_vote():
+    """a byte the index's alphabet does not hold inside a seed: the reference's backward_search panics (fmindex.rs:229);
+    the call reports it, the seed does not vote, every read is still answered"""
+    g, text, reads, off, _ = make_case(n_text=60_000, R=200, L=100)
+    sa, b, ls, fm = build(text, 8)
+    attach_text(fm, text)
+    reads = reads.copy()
+    reads[5 * 100 + 37] = ord("X")          # read 5: two of its seeds cover the byte
+    sc = Scoring.from_scores(-5, -1, 1, -1)
+    with pytest.raises(_lib.AlphabetError):
+        seed_extend_arrays(fm, sc, reads, off)
+    hits, ops = seed_extend_arrays(fm, sc, reads, off, allow_out_of_alphabet=True)
+    clean, _ = seed_extend_arrays(fm, sc, np.where(np.arange(len(reads)) == 5 * 100 + 37, ord("A"), reads).astype(np.uint8), off)
+    keep = np.arange(200) != 5
+    for f in ("n_candidates", "ref_start", "ref_end"):
+        assert (hits[f][keep] == clean[f][keep]).all()
+    assert hits["n_seed_hits"][5] <= clean["n_seed_hits"][5] + 16 and hits["aln"]["score"][5] > MIN_SCORE
