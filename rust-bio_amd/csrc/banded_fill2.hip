@@ -324,12 +324,15 @@ __global__ __launch_bounds__(256) void banded_fill2_kernel(const BandArgs a) {
                     int32_t cmk = cm | 15;  // fold key: clean running maximum | row priority (15 = an earlier lane)
                     // LAST: some lane of the wavefront is at column n — only then the extra I candidate
                     // Sn[i-1] + go (banded.rs:590-596) and the last-column records exist
-                    auto rows = [&](auto last_tag) {
+                    // HASM: some lane of the wavefront owns row m in this strip (the last strip of a pair) — only then the
+                    // x-suffix-clip slot S[curr][m] is a candidate of a cell and row m is kept out of the fold
+                    auto rows = [&](auto last_tag, auto m_tag) {
                         constexpr bool LAST = decltype(last_tag)::value;
+                        constexpr bool HASM = decltype(m_tag)::value;
 #pragma unroll
                         for (int r = 0; r < R; r++) {
                             const bool inb = j >= cf[r] && j <= cl[r];
-                            const bool is_m = (r == mrow);
+                            const bool is_m = HASM && (r == mrow);
                             const int32_t left_S = Sl[r];
                             const int32_t m_key = diag + (px[r] == (uint32_t)q ? match_k : mismatch_k);
                             // banded.rs:580-607
@@ -352,15 +355,16 @@ __global__ __launch_bounds__(256) void banded_fill2_kernel(const BandArgs a) {
                             const int32_t best = kb & ~15;
                             Sl[r] = inb ? best : NEGS;
                             Dl[r] = inb ? Dv : NEGS;
-                            Il[r] = inb ? Iv : Il[r];
+                            if (LAST) Il[r] = inb ? Iv : Il[r];  // only I(i, n) is read again (the epilogue's records)
                             S_up = inb ? best : NEGS;
                             I_up = inb ? Iv : NEGS;
                             // banded.rs:648-653 (a no-op at i == m)
                             const int32_t fk = (int32_t)((uint32_t)(best + xs_s) | (uint32_t)(14 - r));
                             cmk = max(cmk, (inb && !is_m) ? fk : (int32_t)0x80000000);
                             // banded.rs:655-660
-                            const int32_t t1 = best + ys_s;
-                            const bool up = inb && t1 > Sn[r];
+                            // (outside the band S is NEGS and NEGS + ys_s <= NEGS <= Sn: no separate band test)
+                            const int32_t t1 = Sl[r] + ys_s;
+                            const bool up = t1 > Sn[r];
                             Ly[r] = up ? (uint32_t)nmj : Ly[r];
                             Sn[r] = up ? t1 : Sn[r];
                             // traceback byte: four cells per store
@@ -379,10 +383,10 @@ __global__ __launch_bounds__(256) void banded_fill2_kernel(const BandArgs a) {
                             Sn_prev = Sn[r];
                         }
                     };
-                    if (__any(last_col))
-                        rows(std::true_type{});
+                    if (__any(last_col) || __any(mrow >= 0 && mrow < R))
+                        rows(std::true_type{}, std::true_type{});
                     else
-                        rows(std::false_type{});
+                        rows(std::false_type{}, std::false_type{});
                     const int32_t lo = cmk & 15;
                     ca = lo == 15 ? ca_in : (mrow - 14 + lo);
                     cm = cmk & ~15;
