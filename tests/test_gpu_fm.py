@@ -148,3 +148,46 @@ def test_jump_table_does_not_change_results():
     assert fm.device_bytes() > 200_000_000  # the table exists
     for a_, b_ in zip(plain, fast):
         assert (a_ == b_).all()
+
+
+def test_one_index_searched_from_several_threads():
+    """`bg_fm` is immutable after construction: bg_fm_backward_search_batch_dev uses no shared scratch, so several host
+    threads may search one handle at once, each on its own stream (include/biogpu.h, "Streams and threads")."""
+    import threading
+    import torch
+    g = synth.genome(400_000, 13)
+    sa, b, ls, fm = build(g, b"ACGTNacgtn", 64)
+    occ = orc.Occ(b, 64, b"ACGTNacgtn")
+    dev = torch.device("cuda:0")
+    results, errors = {}, []
+
+    def worker(t):
+        try:
+            pat, off = synth.fm_patterns(g, 60_000, 50, seed=100 + t)
+            st = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(st):
+                d_pat = torch.from_numpy(pat).to(dev)
+                d_off = torch.from_numpy(off.astype(np.int64)).to(dev)
+                n = len(off) - 1
+                tag = torch.empty(n, dtype=torch.uint8, device=dev)
+                lo = torch.empty(n, dtype=torch.int64, device=dev)
+                hi = torch.empty(n, dtype=torch.int64, device=dev)
+                ml = torch.empty(n, dtype=torch.int32, device=dev)
+                for _ in range(5):
+                    fm.backward_search_dev(n, d_pat.data_ptr(), d_off.data_ptr(), tag.data_ptr(), lo.data_ptr(), hi.data_ptr(),
+                                           ml.data_ptr(), st.cuda_stream)
+                st.synchronize()
+            results[t] = (pat, off, tag.cpu().numpy(), lo.cpu().numpy(), hi.cpu().numpy(), ml.cpu().numpy())
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for t, (pat, off, tag, lo, hi, ml) in results.items():
+        otag, olo, ohi, oml = orc.backward_search_batch(b, ls, occ, pat, off, threads=4)
+        assert (tag == otag).all() and (lo.astype(np.uint64) == olo).all() and (hi.astype(np.uint64) == ohi).all()
+        assert (ml.astype(np.uint64) == oml).all()
