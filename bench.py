@@ -404,40 +404,51 @@ def k1_legs(args, ctx, dev, stream, rank, world, do_cpu, orc, threads, parity):
     return legs
 
 
-def build_index(args, ctx, dev, n_genome, seed, want_sa):
-    """Genome (SplitMix64, generated in HBM) -> suffix array -> BWT -> FM index + rate-32 suffix-array samples.  Every
-    rank builds its own replica on its own GPU: bg_suffix_array_dev / bg_bwt_dev / bg_sa_sample_dev (1 Gbp in well under
-    a second); `--host-sa` runs rust-bio's host-side order of things instead (bg_suffix_array: SA-IS on host cores, ~100 s
-    per Gbp).  The rank blocks themselves are still laid out by host threads from the BWT (bg_fm_build)."""
+def build_index(args, ctx, dev, n_genome, seed, want_sa, want_host):
+    """Genome (SplitMix64, generated in HBM) -> suffix array -> BWT -> FM index + rate-32 suffix-array samples, all on the
+    device and on every rank's own GPU: bg_suffix_array_dev / bg_bwt_dev / bg_sa_sample_dev / bg_fm_build_dev (1 Gbp in
+    well under a second, nothing text-sized crosses PCIe unless the oracle legs want host copies).  `--host-sa` runs
+    rust-bio's host-side order of things instead (bg_suffix_array: SA-IS on host cores, ~100 s per Gbp; bg_bwt; bg_less;
+    bg_fm_build laying the rank blocks out with host threads)."""
     from rust_bio_amd.suffix_array import SampledSuffixArray, bwt_dev, sample_dev, suffix_array_dev
     t = {}
     t0 = time.perf_counter()
     g_dev = synth_gpu.genome(n_genome, seed=seed, device=dev)
-    g = g_dev.cpu().numpy()
-    sa = None
+    torch.cuda.synchronize()
+    g = b = sa = None
     t1 = time.perf_counter()
     if args.host_sa:
+        g = g_dev.cpu().numpy()
+        t1 = time.perf_counter()
         sa = suffix_array(g)
         t["suffix_array_s"] = time.perf_counter() - t1
+        t2 = time.perf_counter()
         b = bwt(g, sa)
         ssa = SampledSuffixArray(sa, g, b, 32)
+        ls = less(b, N_ALPHABET)
+        fm = FMIndex(b, ls, Occ(b, 128, N_ALPHABET), ctx=ctx)
         if not want_sa:
             sa = None
     else:
         d_sa = suffix_array_dev(g_dev, ctx=ctx)
         torch.cuda.synchronize()
         t["suffix_array_s"] = time.perf_counter() - t1
+        t2 = time.perf_counter()
         d_b = bwt_dev(g_dev, d_sa, ctx=ctx)
-        ssa = sample_dev(d_sa, d_b, int(g[-1]), 32, ctx=ctx)
-        b = d_b.cpu().numpy()
-        if want_sa:  # the oracle's Interval::occ walks the raw array
-            sa = d_sa.cpu().numpy().view(np.uint32).astype(np.uint64)
+        ssa = sample_dev(d_sa, d_b, ord("$"), 32, ctx=ctx)
+        fm = FMIndex.from_device(d_b, 128, N_ALPHABET, ctx=ctx)
+        ls = fm._less
+        torch.cuda.synchronize()
+        t["bwt_samples_blocks_s"] = time.perf_counter() - t2
+        if want_host:  # the oracle legs search the BWT / walk the suffix array / cut windows on the host
+            g = g_dev.cpu().numpy()
+            b = d_b.cpu().numpy()
+            if want_sa:
+                sa = d_sa.cpu().numpy().view(np.uint32).astype(np.uint64)
+        fm._d_bwt = None
         del d_sa, d_b
-    t2 = time.perf_counter()
-    ls = less(b, N_ALPHABET)
-    fm = FMIndex(b, ls, Occ(b, 128, N_ALPHABET), ctx=ctx)
     ssa.attach(fm)
-    t["blocks_s"] = time.perf_counter() - t2
+    t.setdefault("bwt_samples_blocks_s", time.perf_counter() - t2)
     t["total_s"] = time.perf_counter() - t0
     t["where"] = "host (SA-IS, --host-sa)" if args.host_sa else "device (prefix doubling over radix sorts)"
     return g_dev, g, sa, b, ls, fm, t
@@ -446,7 +457,7 @@ def build_index(args, ctx, dev, n_genome, seed, want_sa):
 def fm_legs(args, ctx, dev, stream, rank, world, do_cpu, orc, threads, parity, result):
     L = args.read_len
     pipeline_here = not args.skip_pipeline and not args.fm_big_genome  # else the seed-and-extend leg runs on the big index
-    g_dev, g, sa, b, ls, fm, bt = build_index(args, ctx, dev, args.genome, 3, want_sa=do_cpu and pipeline_here)
+    g_dev, g, sa, b, ls, fm, bt = build_index(args, ctx, dev, args.genome, 3, want_sa=do_cpu and pipeline_here, want_host=do_cpu)
     n_q, P = args.queries, args.pattern_len
     pat, off = synth_gpu.fm_patterns(g_dev, n_q, P, seed=4 + 100003 * rank)
     d_tag = torch.empty(n_q, dtype=torch.uint8, device=dev)
@@ -474,8 +485,8 @@ def fm_legs(args, ctx, dev, stream, rank, world, do_cpu, orc, threads, parity, r
                                      f"{n_q} x {P} bp backward_search per GPU (BASELINE configs[2])",
                          "index_bytes": fm.device_bytes(), "index_build_s": round(bt["total_s"], 2),
                          "suffix_array_s": round(bt["suffix_array_s"], 3), "suffix_array_on": bt["where"],
-                         "index_build": "every rank builds its replica: genome, suffix array, BWT and SA samples on its GPU, "
-                                        "rank blocks by host threads from the BWT"},
+                         "index_build": "every rank builds its replica on its GPU: genome, suffix array, BWT, SA samples, rank "
+                                        "blocks (bg_suffix_array_dev, bg_bwt_dev, bg_sa_sample_dev, bg_fm_build_dev)"},
               "tags": {"complete": int((d_tag == 0).sum().item()), "partial": int((d_tag == 1).sum().item()),
                        "absent": int((d_tag == 2).sum().item())},
               "roofline": {"bound": "hbm", "kernel": "fm_backward_search_kernel", "achieved": round(fm_ach, 2),
@@ -566,7 +577,7 @@ def fm_big_leg(args, ctx, dev, stream, rank, world, do_cpu, orc, threads, parity
     import resource
     n_g, n_q, P = args.fm_big_genome, args.queries, args.pattern_len
     want_sa = do_cpu and not args.skip_pipeline
-    g_dev, g, sa, b, ls, fm, bt = build_index(args, ctx, dev, n_g, 33, want_sa=want_sa)
+    g_dev, g, sa, b, ls, fm, bt = build_index(args, ctx, dev, n_g, 33, want_sa=want_sa, want_host=do_cpu)
     pat, off = synth_gpu.fm_patterns(g_dev, n_q, P, seed=34 + 100003 * rank)
     d_tag = torch.empty(n_q, dtype=torch.uint8, device=dev)
     d_lo = torch.empty(n_q, dtype=torch.int64, device=dev)
@@ -590,7 +601,7 @@ def fm_big_leg(args, ctx, dev, stream, rank, world, do_cpu, orc, threads, parity
                                   "index beyond the Infinity Cache, jump table off",
                       "index_bytes": fm.device_bytes(), "index_build_s": round(bt["total_s"], 2),
                       "suffix_array_s": round(bt["suffix_array_s"], 3), "suffix_array_on": bt["where"],
-                      "blocks_from_bwt_s": round(bt["blocks_s"], 2),
+                      "bwt_samples_blocks_s": round(bt["bwt_samples_blocks_s"], 2),
                       "host_peak_rss_gb": round(resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6, 1)},
            "tags": {"complete": int((d_tag == 0).sum().item()), "partial": int((d_tag == 1).sum().item())},
            "roofline": {"bound": "hbm", "kernel": "fm_backward_search_kernel", "achieved": round(alg / (ms * 1e-3) / 1e9, 2),

@@ -102,6 +102,12 @@ int bg_sa_sample_dev(bg_ctx* ctx, const uint32_t* d_sa, const uint8_t* d_bwt, ui
 int bg_fm_build(bg_ctx* ctx, const uint8_t* bwt, uint64_t n, const uint64_t* less,
                 uint32_t less_len, uint32_t occ_k, const uint8_t* alphabet, uint32_t n_sym,
                 bg_fm** out);
+/* The same index from a BWT that lives in HBM (with bg_suffix_array_dev / bg_bwt_dev: text to searchable index
+ * without a host copy of anything text-sized).  `less(bwt, alphabet)` (bwt.rs:186-199) falls out of the byte
+ * histogram the layout needs anyway: it is computed here and, if less_out is given (max_symbol + 2 entries),
+ * returned.  Identical handle to bg_fm_build's on the same BWT.  Synchronous. */
+int bg_fm_build_dev(bg_ctx* ctx, const uint8_t* d_bwt, uint64_t n, uint32_t occ_k, const uint8_t* alphabet,
+                    uint32_t n_sym, uint64_t* less_out, bg_fm** out, void* stream);
 int bg_fm_free(bg_fm* fm);
 uint64_t bg_fm_device_bytes(const bg_fm* fm);
 

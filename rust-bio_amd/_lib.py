@@ -91,7 +91,7 @@ SYMBOLS = ["bg_device_count", "bg_init", "bg_free", "bg_strerror", "bg_last_erro
            "bg_align_banded_bands_batch", "bg_band_from_matches_batch", "bg_sparse_find_kmer_matches", "bg_sparse_sdpkpp",
            "bg_sparse_lcskpp", "bg_sparse_sdpkpp_union_lcskpp_path", "bg_sparse_expand_kmer_matches", "bg_fastq_parse",
            "bg_fastq_parse_dev", "bg_cigar_batch", "bg_cigar_batch_dev", "bg_get_timing", "bg_enable_timing",
-           "bg_pretty_batch", "bg_suffix_array_dev", "bg_bwt_dev", "bg_sa_sample_dev", "bg_fm_set_text", "bg_fm_set_text_dev", "bg_seed_extend_batch", "bg_seed_extend_batch_dev"]
+           "bg_pretty_batch", "bg_suffix_array_dev", "bg_bwt_dev", "bg_sa_sample_dev", "bg_fm_build_dev", "bg_fm_set_text", "bg_fm_set_text_dev", "bg_seed_extend_batch", "bg_seed_extend_batch_dev"]
 
 
 def build(force=False):
@@ -126,6 +126,7 @@ def lib():
         L.bg_less.argtypes = [vp, u64, vp, u32, vp, C.POINTER(u32)]
         L.bg_fm_build.argtypes = [vp, vp, u64, vp, u32, u32, vp, u32, C.POINTER(vp)]
         L.bg_fm_free.argtypes = [vp]
+        L.bg_fm_build_dev.argtypes = [vp, vp, u64, u32, vp, u32, vp, C.POINTER(vp), vp]
         L.bg_fm_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
         L.bg_fm_device_bytes.restype = u64
         L.bg_fm_device_bytes.argtypes = [vp]

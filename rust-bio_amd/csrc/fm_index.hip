@@ -25,6 +25,8 @@
 //     bits — so that Occ::get is still exactly one 64-byte line, whatever the symbol.  n / 7.5 bytes per such
 //     symbol (a 20-letter protein text: 2.7 bytes per symbol of index); the raw BWT is kept for K6 (bwt[pos]).
 // No MFMA: this is a latency/bandwidth-bound table walk (DESIGN.md §FM roofline).
+#include <hipcub/hipcub.hpp>
+
 #include <algorithm>
 #include <array>
 #include <numeric>
@@ -242,6 +244,62 @@ __global__ __launch_bounds__(256) void fm_jump_pack_kernel(const uint8_t* tag, c
 
 }  // namespace
 
+// How every byte value is ranked, decided from the BWT's histogram (shared by the host and the device builder).
+struct FmClasses {
+    bool gen = false;  // dense symbols exist: three coded bytes, code 0 = "something else"
+    int n_codes = 0;
+    int code_of[256], sparse_of[256], dense_of[256];
+    std::vector<int> sparse_syms, dense_syms;
+    uint16_t cls[256];
+};
+static void assign_classes(const uint64_t hist[256], const bool in_alpha[256], FmClasses& k) {
+    // the most frequent byte values get the 2-bit codes (ties: smaller byte first)
+    int order[256];
+    std::iota(order, order + 256, 0);
+    std::stable_sort(order, order + 256, [&](int a, int b) { return hist[a] > hist[b]; });
+    uint64_t beyond4 = 0;
+    for (int i = 4; i < 256; i++) beyond4 += hist[order[i]];
+    k.gen = beyond4 > kMaxExcLds;  // too many exceptions for the LDS list: dense symbols get bit vectors
+    std::fill(k.code_of, k.code_of + 256, -1);
+    std::fill(k.sparse_of, k.sparse_of + 256, -1);
+    std::fill(k.dense_of, k.dense_of + 256, -1);
+    k.n_codes = 0;
+    if (!k.gen) {
+        for (int i = 0; i < 4 && hist[order[i]] > 0; i++) k.code_of[order[i]] = k.n_codes++;
+        for (int c = 0; c < 256; c++)
+            if (hist[c] && k.code_of[c] < 0) k.sparse_syms.push_back(c);
+    } else {
+        for (int i = 0; i < 3; i++) k.code_of[order[i]] = 1 + k.n_codes++;  // code 0 = "none of the three"
+        uint64_t cum = 0;
+        for (int i = 255; i >= 3; i--) {  // ascending frequency: the rare ones stay lists while they fit
+            const int c = order[i];
+            if (!hist[c]) continue;
+            if (k.dense_syms.empty() && cum + hist[c] <= kMaxExcLds) {
+                cum += hist[c];
+                k.sparse_syms.push_back(c);
+            } else {
+                k.dense_syms.push_back(c);
+            }
+        }
+        std::sort(k.sparse_syms.begin(), k.sparse_syms.end());
+        std::sort(k.dense_syms.begin(), k.dense_syms.end());
+    }
+    for (size_t e = 0; e < k.sparse_syms.size(); e++) k.sparse_of[k.sparse_syms[e]] = (int)e;
+    for (size_t d = 0; d < k.dense_syms.size(); d++) k.dense_of[k.dense_syms[d]] = (int)d;
+    for (int c = 0; c < 256; c++) {
+        if (!in_alpha[c])
+            k.cls[c] = kClsPanic;
+        else if (k.code_of[c] >= 0)
+            k.cls[c] = (uint16_t)k.code_of[c];
+        else if (hist[c] == 0)
+            k.cls[c] = kClsZero;
+        else if (k.sparse_of[c] >= 0)
+            k.cls[c] = (uint16_t)(kClsSparse + k.sparse_of[c]);
+        else
+            k.cls[c] = (uint16_t)(kClsDense + k.dense_of[c]);
+    }
+}
+
 extern "C" int bg_fm_build(bg_ctx* ctx, const uint8_t* bwt, uint64_t n, const uint64_t* less,
                            uint32_t less_len, uint32_t occ_k, const uint8_t* alphabet,
                            uint32_t n_sym, bg_fm** out) {
@@ -285,55 +343,13 @@ extern "C" int bg_fm_build(bg_ctx* ctx, const uint8_t* bwt, uint64_t n, const ui
     for (uint32_t c = m; c < 256; c++)
         if (hist[c]) return BG_ERR_OUT_OF_ALPHABET;  // Occ::new: curr_occ[c] out of bounds
 
-    // the most frequent byte values get the 2-bit codes (ties: smaller byte first)
-    int order[256];
-    std::iota(order, order + 256, 0);
-    std::stable_sort(order, order + 256, [&](int a, int b) { return hist[a] > hist[b]; });
-    uint64_t beyond4 = 0;
-    for (int i = 4; i < 256; i++) beyond4 += hist[order[i]];
-    const bool gen = beyond4 > kMaxExcLds;  // too many exceptions for the LDS list: dense symbols get bit vectors
-    int code_of[256], sparse_of[256], dense_of[256];
-    std::fill(code_of, code_of + 256, -1);
-    std::fill(sparse_of, sparse_of + 256, -1);
-    std::fill(dense_of, dense_of + 256, -1);
-    int n_codes = 0;
-    std::vector<int> sparse_syms, dense_syms;
-    if (!gen) {
-        for (int i = 0; i < 4 && hist[order[i]] > 0; i++) code_of[order[i]] = n_codes++;
-        for (int c = 0; c < 256; c++)
-            if (hist[c] && code_of[c] < 0) sparse_syms.push_back(c);
-    } else {
-        for (int i = 0; i < 3; i++) code_of[order[i]] = 1 + n_codes++;  // code 0 = "none of the three"
-        uint64_t cum = 0;
-        for (int i = 255; i >= 3; i--) {  // ascending frequency: the rare ones stay lists while they fit
-            const int c = order[i];
-            if (!hist[c]) continue;
-            if (dense_syms.empty() && cum + hist[c] <= kMaxExcLds) {
-                cum += hist[c];
-                sparse_syms.push_back(c);
-            } else {
-                dense_syms.push_back(c);
-            }
-        }
-        std::sort(sparse_syms.begin(), sparse_syms.end());
-        std::sort(dense_syms.begin(), dense_syms.end());
-    }
-    for (size_t e = 0; e < sparse_syms.size(); e++) sparse_of[sparse_syms[e]] = (int)e;
-    for (size_t d = 0; d < dense_syms.size(); d++) dense_of[dense_syms[d]] = (int)d;
-
-    uint16_t cls[256];
-    for (int c = 0; c < 256; c++) {
-        if (!in_alpha[c])
-            cls[c] = kClsPanic;
-        else if (code_of[c] >= 0)
-            cls[c] = (uint16_t)code_of[c];
-        else if (hist[c] == 0)
-            cls[c] = kClsZero;
-        else if (sparse_of[c] >= 0)
-            cls[c] = (uint16_t)(kClsSparse + sparse_of[c]);
-        else
-            cls[c] = (uint16_t)(kClsDense + dense_of[c]);
-    }
+    FmClasses K;
+    assign_classes(hist, in_alpha, K);
+    const bool gen = K.gen;
+    const int n_codes = K.n_codes;
+    const int *code_of = K.code_of, *sparse_of = K.sparse_of, *dense_of = K.dense_of;
+    const std::vector<int>&sparse_syms = K.sparse_syms, &dense_syms = K.dense_syms;
+    const uint16_t* cls = K.cls;
 
     const uint64_t nblk = (n + kSymPerBlock - 1) / kSymPerBlock;
     const uint64_t nbv = (n + kBvBits - 1) / kBvBits;
@@ -417,7 +433,7 @@ extern "C" int bg_fm_build(bg_ctx* ctx, const uint8_t* bwt, uint64_t n, const ui
     if ((rc = upload(&fm->d_exc_sym_pos, exc_sym_pos.data(), exc_sym_pos.size() * 4))) return fail(rc);
     if ((rc = upload(&fm->d_sparse_off, sparse_off.data(), sparse_off.size() * 4))) return fail(rc);
     if ((rc = upload(&fm->d_exc_byte, exc_byte.data(), exc_byte.size()))) return fail(rc);
-    if ((rc = upload(&fm->d_class, cls, sizeof(cls)))) return fail(rc);
+    if ((rc = upload(&fm->d_class, cls, 256 * sizeof(uint16_t)))) return fail(rc);
     if ((rc = upload(&fm->d_less, less32, sizeof(less32)))) return fail(rc);
     if (gen && (rc = upload(&fm->d_bwt_raw, bwt, n))) return fail(rc);
     fm->dev.blocks = (const uint4*)fm->d_blocks;
@@ -432,6 +448,267 @@ extern "C" int bg_fm_build(bg_ctx* ctx, const uint8_t* bwt, uint64_t n, const ui
     fm->dev.n_exc = gen ? 0u : (uint32_t)exc_pos.size();
     fm->dev.nbv_blocks = (uint32_t)nbv;
     fm->dev.n_dense = (uint32_t)n_dense;
+    *out = fm;
+    return BG_OK;
+}
+
+// ---- the same index laid out on the device from a BWT that lives in HBM (bg_fm_build_dev) ---------------------------
+namespace {
+
+__global__ __launch_bounds__(256) void fmb_hist_kernel(const uint8_t* __restrict__ b, uint64_t n, unsigned long long* __restrict__ hist) {
+    __shared__ uint32_t s[256];
+    s[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) atomicAdd(&s[b[i]], 1u);
+    __syncthreads();
+    if (s[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (unsigned long long)s[threadIdx.x]);
+}
+
+struct ClsTab {
+    uint8_t code[256];   // 2-bit code of the byte in the packed stream (0 for everything without one)
+    uint8_t dense[256];  // 1 + dense id, 0: not dense
+    uint8_t sparse[256]; // 1: sparse exception
+};
+
+// one thread per 2-bit block: 192 symbols -> 12 words + how many of each code it holds
+__global__ __launch_bounds__(256) void fmb_blocks_kernel(const uint8_t* __restrict__ b, uint64_t n, uint64_t nblk, const ClsTab* __restrict__ tab,
+                                                         uint32_t* __restrict__ blocks, uint32_t* __restrict__ cnt /* [4][nblk] */) {
+    __shared__ uint8_t s_code[256];
+    s_code[threadIdx.x] = tab->code[threadIdx.x];
+    __syncthreads();
+    const uint64_t blk = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (blk >= nblk) return;
+    const uint64_t lo = blk * kSymPerBlock;
+    uint32_t c[4] = {0, 0, 0, 0};
+    for (uint32_t w = 0; w < 12; w++) {
+        uint32_t word = 0;
+        for (uint32_t t = 0; t < 16; t++) {
+            const uint64_t i = lo + 16 * w + t;
+            if (i < n) {
+                const uint32_t code = s_code[b[i]];
+                word |= code << (2 * t);
+                c[code]++;
+            }
+        }
+        blocks[blk * 16 + 4 + w] = word;
+    }
+    for (int k = 0; k < 4; k++) cnt[(uint64_t)k * nblk + blk] = c[k];
+}
+__global__ __launch_bounds__(256) void fmb_block_heads_kernel(uint64_t nblk, const uint32_t* __restrict__ scanned, uint32_t* __restrict__ blocks) {
+    const uint64_t blk = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (blk >= nblk) return;
+    for (int k = 0; k < 4; k++) blocks[blk * 16 + k] = scanned[(uint64_t)k * nblk + blk];
+}
+// one thread per (dense symbol, bit-vector block): 480 symbols -> 15 words + their population
+__global__ __launch_bounds__(256) void fmb_bitvec_kernel(const uint8_t* __restrict__ b, uint64_t n, uint64_t nbv, uint32_t n_dense,
+                                                         const uint8_t* __restrict__ dense_byte, uint32_t* __restrict__ bv,
+                                                         uint32_t* __restrict__ cnt /* [n_dense][nbv] */) {
+    const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (uint64_t)n_dense * nbv) return;
+    const uint32_t d = (uint32_t)(idx / nbv);
+    const uint64_t blk = idx - (uint64_t)d * nbv;
+    const uint32_t sym = dense_byte[d];
+    const uint64_t lo = blk * kBvBits;
+    uint32_t total = 0;
+    for (uint32_t w = 0; w < 15; w++) {
+        uint32_t word = 0;
+        for (uint32_t t = 0; t < 32; t++) {
+            const uint64_t i = lo + 32 * w + t;
+            if (i < n && b[i] == sym) word |= 1u << t;
+        }
+        bv[idx * 16 + 1 + w] = word;
+        total += (uint32_t)__popc(word);
+    }
+    cnt[idx] = total;
+}
+__global__ __launch_bounds__(256) void fmb_bitvec_heads_kernel(uint64_t total, const uint32_t* __restrict__ scanned, uint32_t* __restrict__ bv) {
+    const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < total) bv[idx * 16] = scanned[idx];
+}
+// sparse exceptions: (position, byte) appended in any order; the host sorts the few of them
+__global__ __launch_bounds__(256) void fmb_sparse_kernel(const uint8_t* __restrict__ b, uint64_t n, const ClsTab* __restrict__ tab,
+                                                         uint32_t cap, uint32_t* __restrict__ n_out, uint2* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t ch = b[i];
+    if (tab->sparse[ch]) {
+        const uint32_t k = atomicAdd(n_out, 1u);
+        if (k < cap) out[k] = make_uint2((uint32_t)i, ch);
+    }
+}
+
+}  // namespace
+
+extern "C" int bg_fm_build_dev(bg_ctx* ctx, const uint8_t* d_bwt, uint64_t n, uint32_t occ_k, const uint8_t* alphabet, uint32_t n_sym,
+                               uint64_t* less_out, bg_fm** out, void* stream) {
+    if (!ctx || !d_bwt || !alphabet || !out || n == 0 || n_sym == 0 || occ_k == 0) return BG_ERR_INVALID_ARG;
+    if (n >= 0xFFFFFFFFull) return BG_ERR_TOO_LARGE;
+    hipStream_t st = (hipStream_t)stream;
+    BG_HIP(hipSetDevice(ctx->device));
+    bool in_alpha[256] = {};
+    uint32_t max_symbol = 0;
+    for (uint32_t i = 0; i < n_sym; i++) {
+        in_alpha[alphabet[i]] = true;
+        max_symbol = std::max<uint32_t>(max_symbol, alphabet[i]);
+    }
+    const uint32_t m = max_symbol + 1;
+    if ((uint32_t)'$' < m) in_alpha['$'] = true;  // bwt.rs:101-104
+
+    std::vector<void*> tmp;  // device temporaries, freed on every exit
+    auto dalloc = [&](void** p, size_t bytes) -> int {
+        BG_HIP(hipMalloc(p, std::max<size_t>(bytes, 16)));
+        tmp.push_back(*p);
+        return BG_OK;
+    };
+    bg_fm* fm = nullptr;
+    auto body = [&]() -> int {
+        int rc;
+        unsigned long long* d_hist = nullptr;
+        if ((rc = dalloc((void**)&d_hist, 256 * 8))) return rc;
+        BG_HIP(hipMemsetAsync(d_hist, 0, 256 * 8, st));
+        fmb_hist_kernel<<<dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 8192)), dim3(256), 0, st>>>(d_bwt, n, d_hist);
+        uint64_t hist[256];
+        BG_HIP(hipMemcpyAsync(hist, d_hist, sizeof(hist), hipMemcpyDeviceToHost, st));
+        BG_HIP(hipStreamSynchronize(st));
+        for (uint32_t c = m; c < 256; c++)
+            if (hist[c]) return BG_ERR_OUT_OF_ALPHABET;  // Occ::new: curr_occ[c] out of bounds
+        // less(bwt, alphabet) (bwt.rs:186-199) falls out of the histogram
+        const uint32_t less_len = max_symbol + 2;
+        std::vector<uint64_t> less(less_len, 0);
+        {
+            uint64_t acc = 0;
+            for (uint32_t c = 0; c < less_len; c++) {
+                less[c] = acc;
+                if (c < 256) acc += hist[c];
+            }
+        }
+        if (less_out) memcpy(less_out, less.data(), less_len * 8);
+        FmClasses K;
+        assign_classes(hist, in_alpha, K);
+        ClsTab tab = {};
+        std::vector<uint8_t> dense_byte(K.dense_syms.size());
+        for (int c = 0; c < 256; c++) {
+            tab.code[c] = K.code_of[c] >= 0 ? (uint8_t)K.code_of[c] : 0;
+            tab.dense[c] = K.dense_of[c] >= 0 ? (uint8_t)(1 + K.dense_of[c]) : 0;
+            tab.sparse[c] = K.sparse_of[c] >= 0 && hist[c] ? 1 : 0;
+        }
+        for (size_t d = 0; d < K.dense_syms.size(); d++) dense_byte[d] = (uint8_t)K.dense_syms[d];
+
+        fm = new bg_fm;
+        fm->ctx = ctx;
+        fm->less_len = less_len;
+        fm->fmd_ok = true;
+        for (int c = 0; c < 256; c++)
+            if (hist[c] && (c == 0 || !strchr("ACGTNacgtn$", c))) fm->fmd_ok = false;
+        for (int c = 0; c < 256; c++)
+            if (K.code_of[c] >= 0) fm->code_byte[K.code_of[c]] = (uint8_t)c;
+        fm->n_codes = K.gen ? 3 : K.n_codes;
+
+        const uint64_t nblk = (n + kSymPerBlock - 1) / kSymPerBlock, nbv = (n + kBvBits - 1) / kBvBits;
+        const size_t n_dense = K.dense_syms.size();
+        ClsTab* d_tab = nullptr;
+        if ((rc = dalloc((void**)&d_tab, sizeof(ClsTab)))) return rc;
+        BG_HIP(hipMemcpyAsync(d_tab, &tab, sizeof(tab), hipMemcpyHostToDevice, st));
+        auto keep = [&](void** p, size_t bytes) -> int {  // device memory the handle owns
+            const size_t alloc = std::max<size_t>(bytes, 16);
+            BG_HIP(hipMalloc(p, alloc));
+            fm->bytes += alloc;
+            return BG_OK;
+        };
+        // ---- 2-bit blocks
+        uint32_t *d_cnt = nullptr, *d_scan = nullptr;
+        void* d_cub = nullptr;
+        const uint64_t n_cnt = std::max<uint64_t>(4 * nblk, (uint64_t)n_dense * nbv);
+        if ((rc = keep(&fm->d_blocks, nblk * 64))) return rc;
+        if ((rc = dalloc((void**)&d_cnt, n_cnt * 4))) return rc;
+        if ((rc = dalloc((void**)&d_scan, n_cnt * 4))) return rc;
+        size_t cub_bytes = 0;
+        BG_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, cub_bytes, d_cnt, d_scan, std::max<uint64_t>(nblk, nbv), st));
+        if ((rc = dalloc(&d_cub, cub_bytes))) return rc;
+        fmb_blocks_kernel<<<dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, st>>>(d_bwt, n, nblk, d_tab, (uint32_t*)fm->d_blocks, d_cnt);
+        BG_HIP(hipGetLastError());
+        for (int k = 0; k < 4; k++)
+            BG_HIP(hipcub::DeviceScan::ExclusiveSum(d_cub, cub_bytes, d_cnt + (uint64_t)k * nblk, d_scan + (uint64_t)k * nblk, nblk, st));
+        fmb_block_heads_kernel<<<dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, st>>>(nblk, d_scan, (uint32_t*)fm->d_blocks);
+        // ---- one-hot bit vectors of the dense symbols
+        if ((rc = keep(&fm->d_bitvecs, n_dense * nbv * 64))) return rc;
+        if (n_dense) {
+            uint8_t* d_db = nullptr;
+            if ((rc = dalloc((void**)&d_db, n_dense))) return rc;
+            BG_HIP(hipMemcpyAsync(d_db, dense_byte.data(), n_dense, hipMemcpyHostToDevice, st));
+            const uint64_t tot = (uint64_t)n_dense * nbv;
+            fmb_bitvec_kernel<<<dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st>>>(d_bwt, n, nbv, (uint32_t)n_dense, d_db,
+                                                                                      (uint32_t*)fm->d_bitvecs, d_cnt);
+            BG_HIP(hipGetLastError());
+            for (size_t d = 0; d < n_dense; d++)
+                BG_HIP(hipcub::DeviceScan::ExclusiveSum(d_cub, cub_bytes, d_cnt + d * nbv, d_scan + d * nbv, nbv, st));
+            fmb_bitvec_heads_kernel<<<dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st>>>(tot, d_scan, (uint32_t*)fm->d_bitvecs);
+        }
+        // ---- sparse exceptions (at most kMaxExcLds positions by construction of the classes)
+        uint32_t* d_ns = nullptr;
+        uint2* d_sp = nullptr;
+        if ((rc = dalloc((void**)&d_ns, 4))) return rc;
+        if ((rc = dalloc((void**)&d_sp, (size_t)(kMaxExcLds + 8) * 8))) return rc;
+        BG_HIP(hipMemsetAsync(d_ns, 0, 4, st));
+        fmb_sparse_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(d_bwt, n, d_tab, kMaxExcLds + 8, d_ns, d_sp);
+        BG_HIP(hipGetLastError());
+        uint32_t ns = 0;
+        BG_HIP(hipMemcpyAsync(&ns, d_ns, 4, hipMemcpyDeviceToHost, st));
+        BG_HIP(hipStreamSynchronize(st));
+        if (ns > kMaxExcLds) return BG_ERR_HIP;  // cannot happen: the classes were cut so that they fit
+        std::vector<uint2> sp(ns);
+        if (ns) BG_HIP(hipMemcpy(sp.data(), d_sp, (size_t)ns * 8, hipMemcpyDeviceToHost));
+        std::sort(sp.begin(), sp.end(), [](const uint2& a, const uint2& b) { return a.x < b.x; });
+        std::vector<uint32_t> exc_pos(ns), exc_sym_pos, sparse_off(K.sparse_syms.size() + 1, 0);
+        std::vector<uint8_t> exc_byte(ns);
+        for (uint32_t e = 0; e < ns; e++) {
+            exc_pos[e] = sp[e].x;
+            exc_byte[e] = (uint8_t)sp[e].y;
+        }
+        for (size_t e = 0; e < K.sparse_syms.size(); e++) {
+            for (uint32_t q = 0; q < ns; q++)
+                if ((int)sp[q].y == K.sparse_syms[e]) exc_sym_pos.push_back(sp[q].x);
+            sparse_off[e + 1] = (uint32_t)exc_sym_pos.size();
+        }
+        uint32_t less32[256] = {};
+        for (uint32_t i = 0; i < less_len && i < 256; i++) less32[i] = (uint32_t)less[i];
+        auto upload = [&](void** dptr, const void* src, size_t bytes) -> int {
+            int r2 = keep(dptr, bytes);
+            if (r2) return r2;
+            if (bytes) BG_HIP(hipMemcpy(*dptr, src, bytes, hipMemcpyHostToDevice));
+            return BG_OK;
+        };
+        if ((rc = upload(&fm->d_exc_pos, exc_pos.data(), exc_pos.size() * 4))) return rc;
+        if ((rc = upload(&fm->d_exc_sym_pos, exc_sym_pos.data(), exc_sym_pos.size() * 4))) return rc;
+        if ((rc = upload(&fm->d_sparse_off, sparse_off.data(), sparse_off.size() * 4))) return rc;
+        if ((rc = upload(&fm->d_exc_byte, exc_byte.data(), exc_byte.size()))) return rc;
+        if ((rc = upload(&fm->d_class, K.cls, 256 * sizeof(uint16_t)))) return rc;
+        if ((rc = upload(&fm->d_less, less32, sizeof(less32)))) return rc;
+        if (K.gen) {
+            if ((rc = keep(&fm->d_bwt_raw, n))) return rc;
+            BG_HIP(hipMemcpyAsync(fm->d_bwt_raw, d_bwt, n, hipMemcpyDeviceToDevice, st));
+        }
+        BG_HIP(hipStreamSynchronize(st));
+        fm->dev.blocks = (const uint4*)fm->d_blocks;
+        fm->dev.bitvecs = (const uint4*)fm->d_bitvecs;
+        fm->dev.exc_pos = (const uint32_t*)fm->d_exc_pos;
+        fm->dev.exc_sym_pos = (const uint32_t*)fm->d_exc_sym_pos;
+        fm->dev.sparse_off = (const uint32_t*)fm->d_sparse_off;
+        fm->dev.sym_class = (const uint16_t*)fm->d_class;
+        fm->dev.less = (const uint32_t*)fm->d_less;
+        fm->dev.bwt_raw = (const uint8_t*)fm->d_bwt_raw;
+        fm->dev.n = (uint32_t)n;
+        fm->dev.n_exc = K.gen ? 0u : ns;
+        fm->dev.nbv_blocks = (uint32_t)nbv;
+        fm->dev.n_dense = (uint32_t)n_dense;
+        return BG_OK;
+    };
+    const int rc = body();
+    for (void* p : tmp) hipFree(p);
+    if (rc) {
+        bg_fm_free(fm);
+        return rc;
+    }
     *out = fm;
     return BG_OK;
 }

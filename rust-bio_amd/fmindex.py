@@ -52,7 +52,26 @@ class FMIndex:
                                           alpha.ctypes.data, len(alpha), C.byref(self.h)),
                    "FMIndex::new")
 
+    @classmethod
+    def from_device(cls, d_bwt, k, alphabet, ctx=None, stream=0):
+        """bg_fm_build_dev: the index from a BWT that lives in HBM (a uint8 cuda tensor, e.g. bwt_dev's); `less` is
+        computed on the way and kept in `self._less`."""
+        self = cls.__new__(cls)
+        self.ctx = ctx or _lib.default_context()
+        if k < 1:
+            raise ValueError("k must be >= 1")
+        alpha = _lib.as_u8(bytes(alphabet))
+        self._less = np.zeros(int(alpha.max()) + 2, dtype=np.uint64)
+        self._bwt = None
+        self._d_bwt = d_bwt
+        self.h = C.c_void_p()
+        _lib.check(_lib.lib().bg_fm_build_dev(self.ctx.h, d_bwt.data_ptr(), d_bwt.numel(), k, alpha.ctypes.data, len(alpha),
+                                              self._less.ctypes.data, C.byref(self.h), stream), "FMIndex::new (device)")
+        return self
+
     def bwt(self):
+        if self._bwt is None:
+            self._bwt = self._d_bwt.cpu().numpy()
         return self._bwt
 
     def set_option(self, key, value):

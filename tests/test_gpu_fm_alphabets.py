@@ -125,3 +125,40 @@ def test_fmd_smems_on_a_genome_with_many_n():
         want = ofmd.all_smems(p, 8)
         assert [(iv.lower, iv.lower_rev, iv.size, iv.match_size, pos, ln) for iv, pos, ln in r] == \
                [(*w[0], w[1], w[2]) for w in want], p
+
+
+@pytest.mark.parametrize("kind", ["dna", "dna_n", "protein", "tiny"])
+def test_index_built_on_the_device_equals_the_host_built_one(kind):
+    """bg_fm_build_dev (blocks, bit vectors, exception lists and `less` from a BWT in HBM) against bg_fm_build: same
+    searches, same located positions, same `less`."""
+    import torch
+    from rust_bio_amd.suffix_array import bwt_dev, suffix_array_dev
+    rng = np.random.default_rng(17)
+    if kind == "dna":
+        t, alpha, pal = synth.genome(500_000, 5), b"ACGTNacgtn", b"ACGT"
+    elif kind == "dna_n":
+        t, alpha, pal = text_with_n(500_000, seed=6), b"ACGTNacgtn", b"ACGTN"
+    elif kind == "protein":
+        t = np.append(np.frombuffer(PROTEIN, dtype=np.uint8)[rng.integers(0, 20, size=300_000)], np.uint8(ord("$")))
+        alpha, pal = bytes(sorted(PROTEIN)), PROTEIN
+    else:
+        t, alpha, pal = np.frombuffer(b"GCCTTAACATTATTACGCCTA$", dtype=np.uint8), b"ACGTNacgtn", b"ACGT"
+    sa = suffix_array(t)
+    b = bwt(t, sa)
+    ls = less(b, alpha)
+    host = FMIndex(b, ls, Occ(b, 64, alpha))
+    d_text = torch.from_numpy(np.array(t)).to("cuda:0")
+    d_sa = suffix_array_dev(d_text)
+    d_b = bwt_dev(d_text, d_sa)
+    dev = FMIndex.from_device(d_b, 64, alpha)
+    assert (dev._less == ls).all() and (dev.bwt() == b).all()
+    plen = 8 if kind != "tiny" else 3
+    pat, off = patterns_from(t, 20_000 if kind != "tiny" else 50, plen, 3, pal)
+    for a_, b_ in zip(host.backward_search_arrays(pat, off), dev.backward_search_arrays(pat, off)):
+        assert (a_ == b_).all()
+    for fm in (host, dev):
+        SampledSuffixArray(sa, t, b, 4, fmindex=fm)
+    rows = rng.integers(0, len(sa), size=min(5000, len(sa))).astype(np.uint64)
+    lo, hi = rows, rows + np.uint64(1)
+    assert (host.interval_occ_arrays(lo, hi)[1] == dev.interval_occ_arrays(lo, hi)[1]).all()
+    assert (dev.interval_occ_arrays(lo, hi)[1] == sa[rows.astype(np.intp)]).all()
