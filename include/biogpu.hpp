@@ -109,6 +109,34 @@ struct Alignment {
         out.resize(off[1]);
         return out;
     }
+    // Alignment::pretty(x, y, ncol) of bio-types (restated from the crate: parity unpinned): rows x / marks / y in
+    // blocks of ncol columns; panics where the crate's row-length assert fires (a non-ASCII byte)
+    std::string pretty(const Text& x, const Text& y, size_t ncol) const {
+        bg_alignment_t rec = {};
+        rec.score = score;
+        rec.xstart = (uint32_t)xstart;
+        rec.xend = (uint32_t)xend;
+        rec.ystart = (uint32_t)ystart;
+        rec.yend = (uint32_t)yend;
+        rec.xlen = (uint32_t)xlen;
+        rec.ylen = (uint32_t)ylen;
+        rec.n_ops = (uint32_t)operations.size();
+        rec.mode = (uint8_t)mode;
+        std::vector<uint8_t> ops(operations.size() + 1);
+        for (size_t i = 0; i < operations.size(); i++) {
+            ops[i] = (uint8_t)operations[i].kind;
+            if (operations[i].kind >= AlignmentOperation::Xclip && rec.n_clips < 4) rec.clip_len[rec.n_clips++] = (uint32_t)operations[i].len;
+        }
+        const uint64_t xo[2] = {0, x.size()}, yo[2] = {0, y.size()};
+        std::string out(3 * (x.size() + y.size()) + 5 * ((x.size() + y.size()) / std::max<size_t>(ncol, 1) + 2) + 16, '\0');
+        uint64_t off[2] = {0, 0};
+        const int rc = bg_pretty_batch(Context::shared_default()->raw(), 1, &rec, ops.data(), operations.size(), x.data(), xo, y.data(), yo,
+                                       (uint32_t)ncol, &out[0], out.size(), off);
+        if (rc == BG_ERR_UNSUPPORTED) throw Panic("assertion failed: x_pretty.len() == inb_pretty.len()");
+        check(rc, "bg_pretty_batch");
+        out.resize(off[1]);
+        return out;
+    }
 };
 
 // alignment::sparse (sparse.rs): the pieces the banded aligner's entry points take or produce
@@ -585,6 +613,41 @@ public:
         std::vector<std::optional<size_t>> res(rows.size());
         for (size_t i = 0; i < rows.size(); i++)
             if (pos[i] != BG_SA_NONE) res[i] = (size_t)pos[i];
+        return res;
+    }
+    // Seed-and-extend in one call (bg_seed_extend_batch): the loop rust-bio's callers write from backward_search,
+    // Interval::occ and Aligner::semiglobal (src/lib.rs:129-165, benches/fmindex.rs:20-38); definition in biogpu.h.
+    // Needs attach_text() and a suffix array.
+    void attach_text(const Text& text) { check(bg_fm_set_text(h_, text.data(), text.size()), "bg_fm_set_text"); }
+    struct SeedHit {
+        std::optional<alignment::Alignment> alignment;  // Aligner::semiglobal(read, window) of the best candidate
+        size_t ref_start = 0, ref_end = 0;              // text coordinates of its y span
+        uint32_t n_candidates = 0;
+    };
+    std::vector<SeedHit> seed_extend_batch(const alignment::pairwise::Scoring& scoring, const std::vector<Text>& reads, uint32_t seed_len = 20,
+                                           uint32_t stride = 10, uint32_t max_occ = 16, uint32_t pad = 25) const {
+        std::vector<int32_t> table;
+        const bg_scoring_t sc = scoring.to_c(table);
+        const bg_seed_params_t prm = {seed_len, stride, max_occ, pad};
+        Text buf;
+        std::vector<uint64_t> off{0};
+        for (auto& r : reads) {
+            buf.insert(buf.end(), r.begin(), r.end());
+            off.push_back(buf.size());
+        }
+        std::vector<bg_seed_hit_t> hits(reads.size());
+        std::vector<uint8_t> ops(2 * buf.size() + (2 * (size_t)pad + 4) * reads.size() + 8);
+        uint64_t used = 0;
+        const int rc = bg_seed_extend_batch(h_, &sc, &prm, reads.size(), buf.data(), off.data(), hits.data(), ops.data(), ops.size(), &used);
+        if (rc == BG_ERR_OUT_OF_ALPHABET) throw Panic("index out of bounds: a seed holds a byte outside the index's alphabet");
+        check(rc, "bg_seed_extend_batch");
+        std::vector<SeedHit> res(reads.size());
+        for (size_t r = 0; r < reads.size(); r++) {
+            if (hits[r].aln.score != BG_MIN_SCORE) res[r].alignment = alignment::pairwise::detail::to_alignment(hits[r].aln, ops.data());
+            res[r].ref_start = (size_t)hits[r].ref_start;
+            res[r].ref_end = (size_t)hits[r].ref_end;
+            res[r].n_candidates = hits[r].n_candidates;
+        }
         return res;
     }
     bg_fm* raw() const { return h_; }

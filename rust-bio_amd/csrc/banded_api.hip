@@ -600,11 +600,14 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
         if (ctx->timing) BG_HIP(hipEventRecord(ctx->ev[0], st));
         if (sm == SCORE_PARAMS && !ctx->band_fill_v1) {
             a.started = on_device ? B.d_started : nullptr;
+            a.tb_flip = kTbFlip;
             if (on_device) B.started_target += band_fill2_blocks(a.n_pairs);
             launch_band_fill2(a, narrow, st);  // K3v2: eight pairs per wavefront + separate epilogue
         }
-        else
+        else {
+            a.tb_flip = 0;
             fill<<<dim3((unsigned)((take + 3) / 4)), dim3(256), 0, st>>>(a);
+        }
         BG_HIP(hipGetLastError());
         if (ctx->timing) {
             BG_HIP(hipEventRecord(ctx->ev[1], st));

@@ -13,6 +13,8 @@
 //     hand the 16-byte groups that have become complete (plus the last, partial group of a finished row) to HBM as
 //     dwordx4 stores.  Every group is written exactly once, whole: WRITE_SIZE = the traceback bytes (+ the padding of
 //     rows to 16 bytes), where per-row dword streams used to be evicted from L2 half-filled (11x, round 1).
+//     Byte layout: bits 0-2 the S candidate that won (C_*), bit 3 / bit 4 "the I / D value opened a gap" — the inverse of
+//     K3's "extended" flags: K4 XORs kTbFlip onto what it reads (BandArgs::tb_flip); bits 5-7 are not read.
 //
 // MatchParams scoring only (Scoring::from_scores); tabulated match functions keep using K3.
 #include <type_traits>
@@ -30,6 +32,15 @@ namespace bgband_dev {
 namespace {
 
 enum : uint32_t { IC_OPEN = 0, IC_EXT = 1, IC_YS = 2 };
+
+// (MASK & a) | (~MASK & b) as one v_bfi_b32 (the compiler splits the C expression into and / and / or)
+template <int MASK>
+__device__ __forceinline__ uint32_t bfi(uint32_t a, uint32_t b) {
+    static_assert(MASK >= 0 && MASK <= 64, "inline constant");
+    uint32_t r;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "n"(MASK), "v"(a), "v"(b));
+    return r;
+}
 
 // first-maximum scan over the 64 lanes: combine(earlier, later) = later.v > earlier.v ? later : earlier
 __device__ __forceinline__ void wave_scan_first_max(int lane, int64_t& v, uint32_t& idx) {
@@ -53,6 +64,7 @@ template <int R, int LP, bool NARROW>
 __global__ __launch_bounds__(256) void banded_fill2_kernel(const BandArgs a) {
     constexpr int RING = R <= 2 ? 128 : R <= 4 ? 64 : 32;  // bytes of LDS per row: twice the flush interval (+ a group) stays intact
     constexpr int FLUSH = RING / 2;    // steps between two hand-overs of complete 16-byte groups
+    static_assert(FLUSH % (2 * LP) == 0, "hand-overs fall on chunk-pair boundaries");
     constexpr int LANE_LDS = R * RING + 4;   // + 4: consecutive lanes start one bank apart — the 64 byte writes of a step hit
                                              // 64 different banks when the lanes sit at the same ring position (78.9 % of the
                                              // LDS cycles were bank conflicts with a 16-byte pad: four lanes per bank)
@@ -155,6 +167,7 @@ __global__ __launch_bounds__(256) void banded_fill2_kernel(const BandArgs a) {
     uint32_t nstrips_w = nstrips;
 #pragma unroll
     for (int o = 32; o; o >>= 1) nstrips_w = max(nstrips_w, (uint32_t)__shfl_xor((int)nstrips_w, o));
+    nstrips_w = (uint32_t)__builtin_amdgcn_readfirstlane((int)nstrips_w);
 
     for (uint32_t strip = 0; strip < nstrips_w; strip++) {
         const uint32_t rb = (strip * LP + ll) * R;
@@ -187,7 +200,7 @@ __global__ __launch_bounds__(256) void banded_fill2_kernel(const BandArgs a) {
                         const Col0 c = col0_cell(sc, i, m, fold0);
                         Sl[r] = to_s(c.S);
                         Il[r] = to_s(c.I);
-                        s_row[r * RING] = (uint8_t)(c.sbits | (c.ibits << 4));  // column 0 keeps whole nibbles
+                        s_row[r * RING] = (uint8_t)((c.sbits | (c.ibits << 4)) ^ kTbFlip);  // column 0 keeps whole nibbles
                     }
                     jlo = min(jlo, max(1, rc.x));
                     jhi = max(jhi, rc.y);
@@ -209,6 +222,7 @@ __global__ __launch_bounds__(256) void banded_fill2_kernel(const BandArgs a) {
         int nsteps_w = nsteps;
 #pragma unroll
         for (int o = 32; o; o >>= 1) nsteps_w = max(nsteps_w, __shfl_xor(nsteps_w, o));
+        nsteps_w = __builtin_amdgcn_readfirstlane(nsteps_w);  // the same in every lane: loop control on the scalar unit
         // Hand the traceback bytes that became complete 16-byte groups since the previous hand-over to HBM (see the
         // header).  j_now / j_prev: this lane's column after the current / the previous hand-over step.
         auto flush_tb = [&](int j_now, int j_prev, bool final_pass) {
@@ -234,17 +248,21 @@ __global__ __launch_bounds__(256) void banded_fill2_kernel(const BandArgs a) {
             continue;
         }
 
-        // row above this lane's first row, for the first lane of the pair
+        // the row above the strip's first row: the pair's first lane takes its upper neighbours from it.  Every lane of
+        // the pair holds its extent — each of them prepares one column of a chunk (below)
         int2 rc_above = make_int2(1, 0);
+        if (live) {
+            if (strip == 0)
+                rc_above = rc0;
+            else if (strip * RS <= m)
+                rc_above = rowc[strip * RS];
+        }
         int32_t Sn_above = NEGS;
         if (live && ll == 0) {
-            if (strip == 0) {
-                rc_above = rc0;
+            if (strip == 0)
                 Sn_above = to_s(Sn0);
-            } else if (rb <= m) {
-                rc_above = rowc[rb];
+            else if (rb <= m)
                 Sn_above = to_s(gSn[rb]);
-            }
         }
         // S(rb, 0): the diagonal of this lane's first row at column 1
         int32_t diag0 = NEGS;
@@ -257,58 +275,59 @@ __global__ __launch_bounds__(256) void banded_fill2_kernel(const BandArgs a) {
         // next strip) publishes the column's fold instead of this one
         int2 rc_below = make_int2(1, 0);
         if (live && rb + R + 1 <= m) rc_below = rowc[rb + R + 1];
+        uint32_t wn[R];  // cells of the row (0: none): (j - cf) < wn is the band test
+#pragma unroll
+        for (int r = 0; r < R; r++) wn[r] = (uint32_t)max(cl[r] - cf[r] + 1, 0);
 
-        int32_t S_out = NEGS, I_out = NEGS, cm_out = NEGS, Snl_out = NEGS;
-        int32_t ca_out = 0, q_out = 0;
-        int32_t ychunk = 0, ychunk_nx = 0;
-        int4 bch = make_int4(NEGS, NEGS, NEGS, 0), bch_nx = bch;
-        {
-            const int jj = jlo + ll;  // column of chunk 0 for this lane
-            if (jj <= jhi && jj >= 1) {
-                ychunk_nx = y[jj - 1];
-                if (strip) bch_nx = bnd[jj];
-            }
-        }
-        for (int t = 0; t < nsteps_w; t++) {
-            if ((t & (LP - 1)) == 0) {
-                ychunk = ychunk_nx;
-                bch = bch_nx;
-                const int jj = jlo + t + LP + ll;
-                if (jj <= jhi && jj >= 1) {
-                    ychunk_nx = y[jj - 1];
-                    if (strip) bch_nx = bnd[jj];
-                }
-            }
-            int32_t S_up = wave_shr1(S_out), I_up = wave_shr1(I_out), cm = wave_shr1(cm_out);
-            int32_t ca = wave_shr1(ca_out), q = wave_shr1(q_out), Sn_prev = wave_shr1(Snl_out);
-            const int j = jlo + t - ll;
-            const bool col_ok = j >= jlo && j <= jhi;
-            if (ll == 0) {
-                q = ychunk;
-                Sn_prev = Sn_above;
-                const bool above_in = rc_above.y >= rc_above.x && j >= rc_above.x && j <= rc_above.y;
-                S_up = I_up = cm = NEGS;
-                ca = 0;
-                if (above_in) {
+        // What the pair's first lane needs at column j, prepared LP columns at a time: lane ll of the pair prepares column
+        // jlo + t0 + ll — the y symbol, the x-prefix-clip candidate of the column (banded.rs:564-572) and the cell above the
+        // strip: (S, I, fold, fold row) as the previous strip's last lane left them, or row 0's closed form — and the
+        // chunk moves one lane down per step.  Two chunks alternate so that the loads of one are in flight during the
+        // LP steps that consume the other.
+        struct Chunk {
+            int32_t q, xk, S, I, cm, ca;
+        };
+        auto load_chunk = [&](int t0) -> Chunk {
+            Chunk c = {0, NEGS, NEGS, NEGS, NEGS, 0};
+            const int jj = jlo + t0 + ll;
+            if (jj >= 1 && jj <= jhi) {
+                c.q = y[jj - 1];
+                const bool last_col = (uint32_t)jj == n;
+                const int32_t xclip_j = sc.xp + max(last_col ? max(sc.yp, Sn0) : sc.yp, sc.go + sc.ge * (jj - 1));
+                c.xk = NARROW ? (int32_t)((uint32_t)to_s(xclip_j) | C_XP) : xclip_j;
+                if (rc_above.y >= rc_above.x && jj >= rc_above.x && jj <= rc_above.y) {
                     if (strip) {
-                        S_up = bch.x;
-                        I_up = bch.y;
-                        cm = bch.z;
-                        ca = bch.w;
+                        const int4 b4 = bnd[jj];
+                        c.S = b4.x;
+                        c.I = b4.y;
+                        c.cm = b4.z;
+                        c.ca = b4.w;
                     } else {
-                        S_up = to_s(row0_cell(sc, (uint32_t)j).S);  // banded.rs:518-546 (I[curr][0] = MIN)
+                        c.S = to_s(row0_cell(sc, (uint32_t)jj).S);  // banded.rs:518-546 (I[curr][0] = MIN)
                     }
                 }
             }
-            ychunk = wave_shl1(ychunk);
-            bch.x = wave_shl1(bch.x);
-            bch.y = wave_shl1(bch.y);
-            bch.z = wave_shl1(bch.z);
-            bch.w = wave_shl1(bch.w);
+            return c;
+        };
+
+        int32_t S_out = NEGS, I_out = NEGS, cm_out = NEGS, Snl_out = NEGS;
+        int32_t ca_out = 0, q_out = 0, xk_out = NEGS;
+        auto step = [&](const int t, Chunk& c) {
+            int32_t S_up = wave_shr1z(S_out), I_up = wave_shr1z(I_out), cm = wave_shr1z(cm_out);
+            int32_t ca = wave_shr1z(ca_out), q = wave_shr1z(q_out), xk = wave_shr1z(xk_out), Sn_prev = wave_shr1z(Snl_out);
+            if (ll == 0) {
+                S_up = c.S;
+                I_up = c.I;
+                cm = c.cm;
+                ca = c.ca;
+                q = c.q;
+                xk = c.xk;
+                Sn_prev = Sn_above;
+            }
+            const int j = jlo + t - ll;
+            const bool col_ok = j >= jlo && j <= jhi;
             if (col_ok) {
                 const bool last_col = (uint32_t)j == n;
-                // banded.rs:564-572
-                const int32_t xclip_j = sc.xp + max(last_col ? max(sc.yp, Sn0) : sc.yp, sc.go + sc.ge * (j - 1));
                 int32_t diag = diag0;
                 diag0 = S_up;
                 bool any_in = false;
@@ -318,7 +337,7 @@ __global__ __launch_bounds__(256) void banded_fill2_kernel(const BandArgs a) {
                     const int32_t go_s = sc.go * 16, ge_s = sc.ge * 16, go_t = go_s + 8;  // open candidates carry bit 3
                     const int32_t xs_s = to_s(sc.xs), ys_s = to_s(sc.ys);
                     const int32_t match_k = (sc.match * 16) | (int32_t)C_MATCH, mismatch_k = (sc.mismatch * 16) | (int32_t)C_SUBST;
-                    const int32_t xkey_j = (int32_t)((uint32_t)to_s(xclip_j) | C_XP);
+                    const int32_t xkey_j = xk;
                     const int32_t nmj = (int32_t)(n - (uint32_t)j);
                     const int32_t ca_in = ca;
                     int32_t cmk = cm | 15;  // fold key: clean running maximum | row priority (15 = an earlier lane)
@@ -331,7 +350,8 @@ __global__ __launch_bounds__(256) void banded_fill2_kernel(const BandArgs a) {
                         constexpr bool HASM = decltype(m_tag)::value;
 #pragma unroll
                         for (int r = 0; r < R; r++) {
-                            const bool inb = j >= cf[r] && j <= cl[r];
+                            const int32_t jc = j - cf[r];
+                            const bool inb = (uint32_t)jc < wn[r];
                             const bool is_m = HASM && (r == mrow);
                             const int32_t left_S = Sl[r];
                             const int32_t m_key = diag + (px[r] == (uint32_t)q ? match_k : mismatch_k);
@@ -356,27 +376,34 @@ __global__ __launch_bounds__(256) void banded_fill2_kernel(const BandArgs a) {
                             Sl[r] = inb ? best : NEGS;
                             Dl[r] = inb ? Dv : NEGS;
                             if (LAST) Il[r] = inb ? Iv : Il[r];  // only I(i, n) is read again (the epilogue's records)
-                            S_up = inb ? best : NEGS;
+                            S_up = Sl[r];
                             I_up = inb ? Iv : NEGS;
-                            // banded.rs:648-653 (a no-op at i == m)
-                            const int32_t fk = (int32_t)((uint32_t)(best + xs_s) | (uint32_t)(14 - r));
-                            cmk = max(cmk, (inb && !is_m) ? fk : (int32_t)0x80000000);
+                            // banded.rs:648-653 (a no-op at i == m).  Without row m in sight the band test is in Sl already:
+                            // outside the band the key is NEGS + xs_s + (14 - r) <= NEGS + 14 (clip penalties are <= 0, the
+                            // API refuses others) and the running key is >= NEGS + 15
+                            if (HASM) {
+                                const int32_t fk = (int32_t)((uint32_t)(best + xs_s) | (uint32_t)(14 - r));
+                                cmk = max(cmk, (inb && !is_m) ? fk : (int32_t)0x80000000);
+                            } else {
+                                cmk = max(cmk, Sl[r] + (xs_s + (14 - r)));
+                            }
                             // banded.rs:655-660
                             // (outside the band S is NEGS and NEGS + ys_s <= NEGS <= Sn: no separate band test)
                             const int32_t t1 = Sl[r] + ys_s;
                             const bool up = t1 > Sn[r];
                             Ly[r] = up ? (uint32_t)nmj : Ly[r];
                             Sn[r] = up ? t1 : Sn[r];
-                            // traceback byte: four cells per store
-                            const uint32_t cell = (((uint32_t)kb & 7u) | (((uint32_t)Dv_t & 8u) << 1) | ((uint32_t)Iv_t & 8u)) ^ 24u;
-                            // unconditional: outside the band the byte lands on a ring slot that is rewritten before its
-                            // group is handed over (left of the band) or never handed over (right of it)
-                            s_row[r * RING + ((uint32_t)(j - cf[r]) & (uint32_t)(RING - 1))] = (uint8_t)cell;
+                            // traceback byte, I/D flags as the keys carry them (1 = opened: kTbFlip turns them into K4's
+                            // "1 = extended").  Unconditional: outside the band the byte lands on a ring slot that is
+                            // rewritten before its group is handed over (left of the band) or never handed over (right of it)
+                            // (bits 5-7 of the byte carry score bits: K4 reads bits 0-4 only)
+                            const uint32_t cell = bfi<16>((uint32_t)Dv_t << 1, bfi<8>((uint32_t)Iv_t, (uint32_t)kb));
+                            s_row[r * RING + ((uint32_t)jc & (uint32_t)(RING - 1))] = (uint8_t)cell;
                             any_in = any_in || inb;
                             m_here = m_here || (inb && is_m);
                             v_best_m = (inb && is_m) ? best : v_best_m;
                             if (LAST) {
-                                celln[r] = (inb && last_col) ? cell : celln[r];
+                                celln[r] = (inb && last_col) ? ((cell & 31u) ^ kTbFlip) : celln[r];
                                 icase[r] = (inb && last_col) ? ic : icase[r];
                             }
                             diag = left_S;
@@ -423,7 +450,7 @@ __global__ __launch_bounds__(256) void banded_fill2_kernel(const BandArgs a) {
                         if (m_sc > best) { best = m_sc; code = eq ? C_MATCH : C_SUBST; }
                         if (Iv > best) { best = Iv; code = C_INS; }
                         if (Dv > best) { best = Dv; code = C_DEL; }
-                        if (xclip_j > best) { best = xclip_j; code = C_XP; }
+                        if (xk > best) { best = xk; code = C_XP; }
                         const int32_t yclip_i = sc.yp + sc.go + sc.ge * ((int32_t)i - 1);
                         if (yclip_i > best) { best = yclip_i; code = C_YP; }
                         Sl[r] = best;
@@ -436,7 +463,7 @@ __global__ __launch_bounds__(256) void banded_fill2_kernel(const BandArgs a) {
                         // banded.rs:655-660
                         if (best + sc.ys > Sn[r]) { Sn[r] = best + sc.ys; Ly[r] = n - (uint32_t)j; }
                         const uint32_t cell = code | (iext ? 8u : 0u) | (dext ? 16u : 0u);
-                        s_row[r * RING + ((uint32_t)(j - cf[r]) & (uint32_t)(RING - 1))] = (uint8_t)cell;
+                        s_row[r * RING + ((uint32_t)(j - cf[r]) & (uint32_t)(RING - 1))] = (uint8_t)(cell ^ kTbFlip);
                         if (last_col) {
                             celln[r] = cell;
                             icase[r] = ic;
@@ -465,10 +492,28 @@ __global__ __launch_bounds__(256) void banded_fill2_kernel(const BandArgs a) {
                 cm_out = cm;
                 ca_out = ca;
                 q_out = q;
+                xk_out = xk;
                 Snl_out = Sn_prev;
                 if (ll == LP - 1 && strip + 1 < nstrips) bnd[j] = make_int4(S_up, I_up, cm, ca);
             }
-            if (((t + 1) & (FLUSH - 1)) == 0) flush_tb(jlo + t - ll, jlo + t - ll - FLUSH, false);  // wave-uniform
+            // the chunk moves on (all lanes active again; its old values are dead: the moves are in place)
+            c.q = wave_shl1z(c.q);
+            c.xk = wave_shl1z(c.xk);
+            c.S = wave_shl1z(c.S);
+            c.I = wave_shl1z(c.I);
+            c.cm = wave_shl1z(c.cm);
+            c.ca = wave_shl1z(c.ca);
+        };
+        Chunk c_even = load_chunk(0), c_odd;
+        for (int t0 = 0; t0 < nsteps_w; t0 += 2 * LP) {
+            c_odd = load_chunk(t0 + LP);
+#pragma unroll 1
+            for (int t = t0; t < min(t0 + LP, nsteps_w); t++) step(t, c_even);
+            c_even = load_chunk(t0 + 2 * LP);
+#pragma unroll 1
+            for (int t = t0 + LP; t < min(t0 + 2 * LP, nsteps_w); t++) step(t, c_odd);
+            const int t_done = min(t0 + 2 * LP, nsteps_w);  // wave-uniform; FLUSH is a multiple of 2 * LP
+            if ((t_done & (FLUSH - 1)) == 0) flush_tb(jlo + t_done - 1 - ll, jlo + t_done - 1 - ll - FLUSH, false);
         }
         {
             const int t_last = (nsteps_w & ~(FLUSH - 1)) - 1;  // step of the last hand-over inside the loop (-1: none)

@@ -59,6 +59,8 @@ struct BandAux {
     __host__ __device__ uint64_t words() const { return off_endc() + (m + 4) / 4; }
 };
 
+constexpr uint32_t kTbFlip = 24;  // bits 3 (I) and 4 (D) of a traceback byte
+
 struct BandArgs {
     const uint8_t* x;
     const uint64_t* x_off;
@@ -79,6 +81,7 @@ struct BandArgs {
     uint8_t* ops;
     uint64_t ops_stride;
     int32_t mode, filter_clips;
+    uint32_t tb_flip;   // XORed onto every traceback byte K4 reads (kTbFlip after K3v2, 0 after K3)
     uint32_t* started;  // K3v2: every block counts itself in when it starts (nullptr: nobody is waiting for that)
 };
 

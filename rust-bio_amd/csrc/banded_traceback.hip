@@ -110,7 +110,8 @@ __global__ __launch_bounds__(256) void banded_traceback_kernel(const BandArgs a)
         const int2 rc = rowc[i];
         return rc.y >= rc.x && (int)j >= rc.x && (int)j <= rc.y;
     };
-    auto cellb = [&](uint32_t i, uint32_t j) -> uint32_t { return tb[roff[i] + j - (uint32_t)rowc[i].x]; };
+    // K3v2 leaves the I/D flags as its keys carry them (1 = opened): a.tb_flip turns them into 1 = extended
+    auto cellb = [&](uint32_t i, uint32_t j) -> uint32_t { return (uint32_t)tb[roff[i] + j - (uint32_t)rowc[i].x] ^ a.tb_flip; };
     // S nibble a cell carried while the matrix was being filled (what "open" I/D moves copied)
     auto s_fill = [&](uint32_t i, uint32_t j) -> uint32_t {
         if (i == 0) {

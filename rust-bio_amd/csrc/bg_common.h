@@ -106,6 +106,9 @@ __device__ __forceinline__ int wave_shr1(int v, int old = 0) {
 __device__ __forceinline__ int wave_shl1(int v, int old = 0) {
     return __builtin_amdgcn_update_dpp(old, v, 0x130 /*wave_shl:1*/, 0xf, 0xf, false);
 }
+// ... with 0 in lane 0 (resp. 63): no register has to be initialised for the lane without a source
+__device__ __forceinline__ int wave_shr1z(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, true); }
+__device__ __forceinline__ int wave_shl1z(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, true); }
 // sum over the 4 lanes of a quad, result in all 4
 __device__ __forceinline__ unsigned quad_sum(unsigned v) {
     v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1 /*quad_perm:[1,0,3,2]*/, 0xf, 0xf, true);

@@ -287,6 +287,12 @@ static int align_batch_dev_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, u
                           ? (narrow ? get_fill_params_narrow(cfg.lp, cfg.r, all_zero_clips)
                                     : get_fill_params_wide(cfg.lp, cfg.r, all_zero_clips))
                           : get_fill_matrix(cfg.lp, cfg.r, sm, narrow, all_zero_clips);
+    if (!fill && sm != SCORE_PARAMS && cfg.lp == 16 && cfg.r < 12) {
+        // 8 and 10 rows per lane exist for the LDS table with narrow scores only (the protein case they were measured
+        // on); a table beyond 64 classes or wide scores take the 12-row geometry that is instantiated for everything
+        cfg.r = 12;
+        fill = get_fill_matrix(cfg.lp, cfg.r, sm, narrow, all_zero_clips);
+    }
     // K1p: short reads whose scores fit 12 bits (sw_fill_pk16.inc) — two pairs per lane, one instantiation
     // unit per clip pattern.  Bound: no real DP value, nor the epilogue's go * i terms, may leave +-2040.
     sw_fill_fn fill_rest = nullptr, fill_second = nullptr;

@@ -234,6 +234,59 @@ static void kat_fastq_reader_and_cigar() {
     }
 }
 
+// Alignment::pretty on the bio-types documentation pair, and the seed-and-extend loop of src/lib.rs:129-165 in one call
+static void kat_pretty_and_seed_extend() {
+    using namespace bio::alignment;
+    const Text x = text("CCGTCCGGCAAGGG"), y = text("AAAAACCGTTGACGGCCAA");
+    auto aligner = pairwise::Aligner::new_(-5, -1, [](uint8_t a, uint8_t b) { return a == b ? 1 : -1; });
+    CHECK_EQ(aligner.local(x, y).pretty(x, y, 100), std::string("     CCGTCCGGCAAGGG          \n"
+                                                                "     ||||                    \n"
+                                                                "AAAAACCGT          TGACGGCCAA\n\n\n"));
+    CHECK_EQ(aligner.global(x, y).pretty(x, y, 100), std::string("-----CCGTCCGGCAAGGG\n"
+                                                                 "xxxxx||||\\\\\\\\\\\\\\\\\\\\\n"
+                                                                 "AAAAACCGTTGACGGCCAA\n\n\n"));
+    {
+        // a pseudo-random text without long repeats; reads are substrings (one with a substitution) or foreign
+        Text g;
+        uint64_t s = 0x9E3779B97F4A7C15ull;
+        for (int i = 0; i < 4000; i++) {
+            s = s * 6364136223846793005ull + 1442695040888963407ull;
+            g.push_back("ACGT"[(s >> 33) & 3]);
+        }
+        Text t = g;
+        t.push_back('$');
+        const auto alphabet = alphabets::dna::n_alphabet();
+        const auto sa = suffix_array::suffix_array(t);
+        const auto b = bwt::bwt(t, sa);
+        fmindex::FMIndex fm(b, bwt::less(b, alphabet), bwt::Occ(b, 3, alphabet));
+        fm.attach(sa);
+        fm.attach_text(t);
+        Text r0(g.begin() + 1000, g.begin() + 1100), r1(g.begin() + 2500, g.begin() + 2600), r2(100, 'A');
+        r1[50] = r1[50] == 'A' ? 'C' : 'A';
+        for (size_t i = 0; i < r2.size(); i += 2) r2[i] = 'C';
+        const auto scoring = pairwise::Scoring::from_scores(-5, -1, 1, -1);
+        const auto hits = fm.seed_extend_batch(scoring, {r0, r1, r2});
+        CHECK_EQ(hits.size(), (size_t)3);
+        CHECK(hits[0].alignment && hits[0].alignment->score == 100);
+        CHECK_EQ(hits[0].ref_start, (size_t)1000);
+        CHECK_EQ(hits[0].ref_end, (size_t)1100);
+        CHECK(hits[1].alignment && hits[1].alignment->score == 98);
+        CHECK_EQ(hits[1].ref_start, (size_t)2500);
+        CHECK(!hits[2].alignment && hits[2].n_candidates == 0);
+        // the same placement through the reference's own loop: backward_search -> occ -> semiglobal on the window
+        const auto iv = fm.backward_search(Text(r0.begin(), r0.begin() + 20));
+        CHECK(iv.kind == fmindex::BackwardSearchResult::Complete);
+        const auto pos = iv.interval.occ(sa);
+        CHECK(pos == (std::vector<size_t>{1000}));
+        auto semi = pairwise::Aligner::with_scoring(scoring);
+        const Text window(g.begin() + 975, g.begin() + 1125);
+        const auto a = semi.semiglobal(r0, window);
+        CHECK_EQ(a.score, hits[0].alignment->score);
+        CHECK(a.operations == hits[0].alignment->operations);
+        CHECK_EQ(975 + a.ystart, hits[0].ref_start);
+    }
+}
+
 int main(int argc, char** argv) {
     const char* filter = argc > 1 ? argv[1] : "";
     int ran = 0;
@@ -256,6 +309,7 @@ int main(int argc, char** argv) {
     run("kat_banded_with_matches_and_prehash", kat_banded_with_matches_and_prehash);
     run("kat_fmdindex_smems", kat_fmdindex_smems);
     run("kat_fastq_reader_and_cigar", kat_fastq_reader_and_cigar);
+    run("kat_pretty_and_seed_extend", kat_pretty_and_seed_extend);
     std::printf("%d tests, %d failed\n", ran, g_failed);
     return g_failed ? 1 : 0;
 }

@@ -181,6 +181,27 @@ def test_closure_with_many_classes_uses_global_table():
     differential(kw, "global", xs, ys)
 
 
+@pytest.mark.parametrize("m_len", [97, 128, 129, 160, 161, 192, 193, 384, 400])
+def test_tabulated_scoring_at_every_row_geometry(m_len):
+    """K1's rows-per-lane choice follows the longest x; every choice must exist for the LDS table (protein), the
+    table beyond 64 classes (a closure over all bytes) and wide scores — 101-160 bases once had no instantiation for
+    the last two (the reference's banded-vs-full tests run 100-base pairs through a closure)."""
+    rng = np.random.default_rng(m_len)
+    fn = np.fromfunction(lambda a, b: np.where(a == b, 1, -1), (256, 256), dtype=np.int64).astype(np.int32)
+    xs = [bytes(rng.integers(65, 69, size=m_len).astype(np.uint8)) for _ in range(6)] + [b"A" * m_len]
+    ys = [bytes(rng.integers(65, 69, size=int(rng.integers(1, m_len + 30))).astype(np.uint8)) for _ in range(7)]
+    clips = dict(xclip_prefix=MIN_SCORE, xclip_suffix=MIN_SCORE, yclip_prefix=MIN_SCORE, yclip_suffix=MIN_SCORE)
+    for mode in ("local", "global", "semiglobal"):
+        differential(dict(gap_open=-5, gap_extend=-1, matrix=fn, **clips), mode, xs, ys)
+        differential(dict(gap_open=-5, gap_extend=-1, matrix=fn, **clips), mode, xs, ys, ctx_opts={"force_wide": 1})
+    aa = b"ARNDCQEGHILKMFPSTWYVBZX"
+    px = [bytes(rng.choice(list(aa), size=m_len).astype(np.uint8)) for _ in range(4)]
+    py = [bytes(rng.choice(list(aa), size=int(rng.integers(1, m_len + 30))).astype(np.uint8)) for _ in range(4)]
+    for mode in ("local", "semiglobal"):
+        differential(dict(gap_open=-10, gap_extend=-1, matrix=blosum62_matrix(), **clips), mode, px, py)
+        differential(dict(gap_open=-10, gap_extend=-1, matrix=blosum62_matrix(), **clips), mode, px, py, ctx_opts={"force_wide": 1})
+
+
 def test_positive_penalty_is_rejected_like_the_reference_asserts():
     s = Scoring.from_scores(-5, -1, 1, -1)
     s.xclip_prefix = 3
