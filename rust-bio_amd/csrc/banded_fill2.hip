@@ -42,6 +42,14 @@ __device__ __forceinline__ uint32_t bfi(uint32_t a, uint32_t b) {
     return r;
 }
 
+// NARROW values back to the reference's integers (the inverse of the fill's to_s; identity for !NARROW)
+template <bool NARROW>
+__device__ __forceinline__ int32_t from_scaled(int32_t v) {
+    if (!NARROW) return v;
+    constexpr int32_t NEGS = kNarrowFloor * 16;
+    return v < -(1 << 29) ? NEG + ((v - NEGS) >> 4) : (v >> 4);
+}
+
 // first-maximum scan over the 64 lanes: combine(earlier, later) = later.v > earlier.v ? later : earlier
 __device__ __forceinline__ void wave_scan_first_max(int lane, int64_t& v, uint32_t& idx) {
 #pragma unroll
@@ -60,8 +68,12 @@ __device__ __forceinline__ void wave_scan_first_max(int lane, int64_t& v, uint32
 // (banded.rs:609-642, strict '>') is one integer max, "open" gap candidates carry bit 3, and the cell
 // update is branch-free (cells outside the band are computed and discarded).  MIN_SCORE maps to
 // NEGS = -2^30 with offsets preserved, which is all the reference's arithmetic on it needs.
-template <int R, int LP, bool NARROW>
+// XP: the scoring has an x-prefix clip (xclip_prefix != MIN_SCORE).  Without one the column's clip candidate is
+// MIN_SCORE + (something <= 0), which never beats the x-suffix-clip slot every cell starts from (banded.rs:609-642 test
+// with a strict '>'): the NARROW path then neither prepares nor passes it along.
+template <int R, int LP, bool NARROW, bool XP>
 __global__ __launch_bounds__(256) void banded_fill2_kernel(const BandArgs a) {
+    static_assert(NARROW || XP, "the generic path always carries the candidate");
     constexpr int RING = R <= 2 ? 128 : R <= 4 ? 64 : 32;  // bytes of LDS per row: twice the flush interval (+ a group) stays intact
     constexpr int FLUSH = RING / 2;    // steps between two hand-overs of complete 16-byte groups
     static_assert(FLUSH % (2 * LP) == 0, "hand-overs fall on chunk-pair boundaries");
@@ -77,10 +89,10 @@ __global__ __launch_bounds__(256) void banded_fill2_kernel(const BandArgs a) {
         if (v <= NEG / 2) return NEGS + (int32_t)((uint32_t)(max(v, NEG - (1 << 20)) - NEG) << 4);
         return (int32_t)((uint32_t)v << 4);
     };
-    auto from_s = [](int32_t v) -> int32_t {
-        if (!NARROW) return v;
-        return v < -(1 << 29) ? NEG + ((v - NEGS) >> 4) : (v >> 4);
-    };
+    auto from_s = [](int32_t v) -> int32_t { return from_scaled<NARROW>(v); };
+    // NARROW keeps Sn[] (banded.rs:655-660) without its constant term: Sn[r] holds max_j S(i, j) over the band cells seen so
+    // far, started at NEGS - ys so that "S + ys > Sn" is "S > Sn[r]"; the true value is Sn[r] + ys wherever it is read
+    const int32_t sn_bias = NARROW ? to_s(a.sc.ys) : 0;
     constexpr int PW = 64 / LP;
     constexpr int RS = LP * R;  // rows per strip
     const int lane = threadIdx.x & 63;
@@ -120,7 +132,8 @@ __global__ __launch_bounds__(256) void banded_fill2_kernel(const BandArgs a) {
     uint8_t* gEndC = (uint8_t*)(aux + L.off_endc());
 
     if (live)
-        for (uint32_t j = ll; j <= n; j += LP) gV[j] = NEG;  // S[curr][m] of a column without band rows
+        for (uint32_t j = ll; j <= n; j += LP) gV[j] = NEGS;  // S[curr][m] of a column without band rows (gV keeps the fill's
+                                                              // domain: the epilogue converts what it reads)
 
     // ---- row 0 (banded.rs:501-508, 518-554): Sn[0] / Ly[0] depend on closed forms only
     const int2 rc0 = live ? rowc[0] : make_int2(1, 0);
@@ -158,7 +171,7 @@ __global__ __launch_bounds__(256) void banded_fill2_kernel(const BandArgs a) {
     if (live && ll == 0) {
         const bool m_in_col0 = bp.start_0 <= m && m < bp.end_0;
         gLx[0] = (int32_t)lx0;
-        gV[0] = m_in_col0 ? col0_cell(sc, m, m, fold0).S : NEG;  // banded.rs:497-499
+        gV[0] = to_s(m_in_col0 ? col0_cell(sc, m, m, fold0).S : NEG);  // banded.rs:497-499
         gSn[0] = Sn0;
         gLy[0] = (int32_t)Ly0;
     }
@@ -180,7 +193,8 @@ __global__ __launch_bounds__(256) void banded_fill2_kernel(const BandArgs a) {
         for (int r = 0; r < R; r++) {
             const uint32_t i = rb + r + 1;
             px[r] = 0;
-            Sl[r] = Dl[r] = Il[r] = Sn[r] = NEGS;
+            Sl[r] = Dl[r] = Il[r] = NEGS;
+            Sn[r] = NEGS - sn_bias;
             ycl[r] = NEGS;
             Ly[r] = 0;
             celln[r] = 0;
@@ -292,9 +306,11 @@ __global__ __launch_bounds__(256) void banded_fill2_kernel(const BandArgs a) {
             const int jj = jlo + t0 + ll;
             if (jj >= 1 && jj <= jhi) {
                 c.q = y[jj - 1];
-                const bool last_col = (uint32_t)jj == n;
-                const int32_t xclip_j = sc.xp + max(last_col ? max(sc.yp, Sn0) : sc.yp, sc.go + sc.ge * (jj - 1));
-                c.xk = NARROW ? (int32_t)((uint32_t)to_s(xclip_j) | C_XP) : xclip_j;
+                if (XP) {
+                    const bool last_col = (uint32_t)jj == n;
+                    const int32_t xclip_j = sc.xp + max(last_col ? max(sc.yp, Sn0) : sc.yp, sc.go + sc.ge * (jj - 1));
+                    c.xk = NARROW ? (int32_t)((uint32_t)to_s(xclip_j) | C_XP) : xclip_j;
+                }
                 if (rc_above.y >= rc_above.x && jj >= rc_above.x && jj <= rc_above.y) {
                     if (strip) {
                         const int4 b4 = bnd[jj];
@@ -310,18 +326,19 @@ __global__ __launch_bounds__(256) void banded_fill2_kernel(const BandArgs a) {
             return c;
         };
 
-        int32_t S_out = NEGS, I_out = NEGS, cm_out = NEGS, Snl_out = NEGS;
+        int32_t S_out = NEGS, I_out = NEGS, cm_out = NEGS;
         int32_t ca_out = 0, q_out = 0, xk_out = NEGS;
         auto step = [&](const int t, Chunk& c) {
             int32_t S_up = wave_shr1z(S_out), I_up = wave_shr1z(I_out), cm = wave_shr1z(cm_out);
-            int32_t ca = wave_shr1z(ca_out), q = wave_shr1z(q_out), xk = wave_shr1z(xk_out), Sn_prev = wave_shr1z(Snl_out);
+            int32_t ca = wave_shr1z(ca_out), q = wave_shr1z(q_out), xk = XP ? wave_shr1z(xk_out) : NEGS;
+            int32_t Sn_prev = wave_shr1z(Sn[R - 1]) + sn_bias;  // Sn of the row above this lane's first one, columns <= j folded in
             if (ll == 0) {
                 S_up = c.S;
                 I_up = c.I;
                 cm = c.cm;
                 ca = c.ca;
                 q = c.q;
-                xk = c.xk;
+                if (XP) xk = c.xk;
                 Sn_prev = Sn_above;
             }
             const int j = jlo + t - ll;
@@ -360,7 +377,7 @@ __global__ __launch_bounds__(256) void banded_fill2_kernel(const BandArgs a) {
                             uint32_t ic = IC_OPEN;
                             if (LAST) {
                                 ic = (Iv_t & 8) ? IC_OPEN : IC_EXT;
-                                const int32_t clipk = Sn_prev + go_s;
+                                const int32_t clipk = Sn_prev + go_s;  // (Sn_prev: a true Sn, see below)
                                 const bool ys = last_col && clipk > (Iv_t & ~15);
                                 Iv_t = ys ? clipk : Iv_t;
                                 ic = ys ? (uint32_t)IC_YS : ic;
@@ -370,7 +387,8 @@ __global__ __launch_bounds__(256) void banded_fill2_kernel(const BandArgs a) {
                             // banded.rs:609-642: first maximum wins == max over (score | priority)
                             const int32_t k_init = is_m ? (int32_t)(((uint32_t)cmk & ~15u) | C_XS) : (int32_t)((uint32_t)NEGS | C_XS);
                             int32_t kb = max(max(k_init, m_key), (int32_t)((uint32_t)Iv | C_INS));
-                            kb = max(max(kb, (int32_t)((uint32_t)Dv | C_DEL)), xkey_j);
+                            kb = max(kb, (int32_t)((uint32_t)Dv | C_DEL));
+                            if (XP) kb = max(kb, xkey_j);
                             kb = max(kb, ycl[r]);
                             const int32_t best = kb & ~15;
                             Sl[r] = inb ? best : NEGS;
@@ -388,11 +406,10 @@ __global__ __launch_bounds__(256) void banded_fill2_kernel(const BandArgs a) {
                                 cmk = max(cmk, Sl[r] + (xs_s + (14 - r)));
                             }
                             // banded.rs:655-660
-                            // (outside the band S is NEGS and NEGS + ys_s <= NEGS <= Sn: no separate band test)
-                            const int32_t t1 = Sl[r] + ys_s;
-                            const bool up = t1 > Sn[r];
+                            // (outside the band S is NEGS <= NEGS - ys <= Sn[r]: no separate band test)
+                            const bool up = Sl[r] > Sn[r];
                             Ly[r] = up ? (uint32_t)nmj : Ly[r];
-                            Sn[r] = up ? t1 : Sn[r];
+                            Sn[r] = max(Sn[r], Sl[r]);
                             // traceback byte, I/D flags as the keys carry them (1 = opened: kTbFlip turns them into K4's
                             // "1 = extended").  Unconditional: outside the band the byte lands on a ring slot that is
                             // rewritten before its group is handed over (left of the band) or never handed over (right of it)
@@ -407,7 +424,7 @@ __global__ __launch_bounds__(256) void banded_fill2_kernel(const BandArgs a) {
                                 icase[r] = (inb && last_col) ? ic : icase[r];
                             }
                             diag = left_S;
-                            Sn_prev = Sn[r];
+                            if (LAST) Sn_prev = Sn[r] + ys_s;
                         }
                     };
                     if (__any(last_col) || __any(mrow >= 0 && mrow < R))
@@ -484,7 +501,7 @@ __global__ __launch_bounds__(256) void banded_fill2_kernel(const BandArgs a) {
                 }
                 // only the last band row of the column publishes (rows of a column's band are contiguous)
                 if (any_in && !(j >= rc_below.x && j <= rc_below.y)) {
-                    gV[j] = from_s(m_here ? v_best_m : cm);
+                    gV[j] = m_here ? v_best_m : cm;
                     gLx[j] = ca;
                 }
                 S_out = S_up;
@@ -492,13 +509,12 @@ __global__ __launch_bounds__(256) void banded_fill2_kernel(const BandArgs a) {
                 cm_out = cm;
                 ca_out = ca;
                 q_out = q;
-                xk_out = xk;
-                Snl_out = Sn_prev;
+                if (XP) xk_out = xk;
                 if (ll == LP - 1 && strip + 1 < nstrips) bnd[j] = make_int4(S_up, I_up, cm, ca);
             }
             // the chunk moves on (all lanes active again; its old values are dead: the moves are in place)
             c.q = wave_shl1z(c.q);
-            c.xk = wave_shl1z(c.xk);
+            if (XP) c.xk = wave_shl1z(c.xk);
             c.S = wave_shl1z(c.S);
             c.I = wave_shl1z(c.I);
             c.cm = wave_shl1z(c.cm);
@@ -523,7 +539,7 @@ __global__ __launch_bounds__(256) void banded_fill2_kernel(const BandArgs a) {
         for (int r = 0; r < R; r++) {
             const uint32_t i = rb + r + 1;
             if (live && i <= m && cl[r] >= cf[r]) {
-                gSn[i] = from_s(Sn[r]);
+                gSn[i] = from_s(Sn[r] + sn_bias);
                 gLy[i] = (int32_t)Ly[r];
                 if (cl[r] == (int)n && cf[r] <= (int)n) {  // inside the band of the last column
                     gEndV[i] = make_int2(from_s(Sl[r]), from_s(Il[r]));
@@ -537,7 +553,7 @@ __global__ __launch_bounds__(256) void banded_fill2_kernel(const BandArgs a) {
 
 // Last-column epilogue (banded.rs:683-723) + Sn[m] / Ly[m] (665-670) for one pair per wavefront, from the
 // per-row values the fill left in aux.  The arithmetic is K3's (banded_fill.hip), fed from memory.
-template <int R>
+template <int R, bool NARROW>
 __global__ __launch_bounds__(256) void banded_epilogue_kernel(const BandArgs a) {
     constexpr int RS = 64 * R;
     const int lane = threadIdx.x & 63;
@@ -753,7 +769,7 @@ __global__ __launch_bounds__(256) void banded_epilogue_kernel(const BandArgs a) 
         int64_t v = INT64_MIN;
         uint32_t vj = j;
         if (j <= n) {
-            const int32_t V = gV[j];
+            const int32_t V = from_scaled<NARROW>(gV[j]);
             if (V + sc.ys > NEG) v = (int64_t)(V + sc.ys);
         }
         wave_scan_first_max(lane, v, vj);
@@ -832,11 +848,16 @@ bool launch_band_fill2(const BandArgs& a, bool narrow, hipStream_t st) {
 
     constexpr int LP = BF2_LP, R = BF2_R, PW = 64 / LP;
     const uint32_t jobs = (a.n_pairs + PW - 1) / PW;
-    if (narrow)
-        banded_fill2_kernel<R, LP, true><<<dim3((jobs + 3) / 4), dim3(256), 0, st>>>(a);
-    else
-        banded_fill2_kernel<R, LP, false><<<dim3((jobs + 3) / 4), dim3(256), 0, st>>>(a);
-    banded_epilogue_kernel<2><<<dim3((a.n_pairs + 3) / 4), dim3(256), 0, st>>>(a);
+    if (narrow) {
+        if (a.sc.xp > NEG / 2)
+            banded_fill2_kernel<R, LP, true, true><<<dim3((jobs + 3) / 4), dim3(256), 0, st>>>(a);
+        else
+            banded_fill2_kernel<R, LP, true, false><<<dim3((jobs + 3) / 4), dim3(256), 0, st>>>(a);
+        banded_epilogue_kernel<2, true><<<dim3((a.n_pairs + 3) / 4), dim3(256), 0, st>>>(a);
+    } else {
+        banded_fill2_kernel<R, LP, false, true><<<dim3((jobs + 3) / 4), dim3(256), 0, st>>>(a);
+        banded_epilogue_kernel<2, false><<<dim3((a.n_pairs + 3) / 4), dim3(256), 0, st>>>(a);
+    }
     return true;
 }
 
