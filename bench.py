@@ -58,6 +58,7 @@ def parse_args():
     ap.add_argument("--k1-pairs", type=int, default=262_144, help="int32-kernel legs: pairs per GPU")
     ap.add_argument("--skip-banded", action="store_true")
     ap.add_argument("--banded-pairs", type=int, default=32768, help="banded leg: 10 kb pairs per GPU (configs[3] is 100k over 8 GPUs)")
+    ap.add_argument("--banded-chunk", type=int, default=0, help="banded leg: pairs per sub-batch (0 = the library's default)")
     ap.add_argument("--skip-pipeline", action="store_true")
     ap.add_argument("--pipeline-reads", type=int, default=1_000_000, help="seed-and-extend leg: reads per GPU")
     ap.add_argument("--skip-ingest", action="store_true")
@@ -717,6 +718,8 @@ def seed_extend_leg(args, ctx, dev, stream, rank, world, do_cpu, orc, threads, p
 def banded_leg(args, ctx, dev, rank, world, do_cpu, orc, threads, parity):
     from rust_bio_amd.banded import Aligner as BandedAligner
     Pb, Lb, kb, wb = args.banded_pairs, 10_000, 16, 32
+    if args.banded_chunk:
+        ctx.set_option("chunk_pairs", args.banded_chunk)
     bx, bxo, by, byo = synth_gpu.sw_pairs_big(Pb, Lb, seed=4 + 100003 * rank, device=dev, sub=0.06, ins=0.02,
                                                dele=0.02, chunk=64)
     hx, hy = bx.cpu().numpy(), by.cpu().numpy()
@@ -797,6 +800,9 @@ def banded_leg(args, ctx, dev, rank, world, do_cpu, orc, threads, parity):
                                   "sample": f"{nt} of the {Pb} pairs, median of 3 runs, C++ restatement of rust-bio 4.0.1 "
                                             "banded::Aligner::semiglobal incl. band construction (oracle/)",
                                   "full_parity_pass_value": round(float(ocells.sum()) / t_par / 1e9, 4)}
+    if args.banded_chunk:
+        ctx.set_option("chunk_pairs", 0)
+        banded["config"]["pairs_per_sub_batch"] = args.banded_chunk
     return banded
 
 
