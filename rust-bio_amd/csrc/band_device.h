@@ -54,7 +54,7 @@ struct BandDevArgs {
 };
 
 int launch_band_match(const BandDevArgs& a, hipStream_t st);
-int launch_band_chain(const BandDevArgs& a, hipStream_t st);   // B2: sdpkpp
+int launch_band_chain(const BandDevArgs& a, hipStream_t st, int part = 0);   // B2: sdpkpp (part: see band_device.hip)
 int launch_band_raster(const BandDevArgs& a, hipStream_t st);  // B3 + B4: Band::create_from_match_path, per-row ranges
 
 }  // namespace bgband_dev

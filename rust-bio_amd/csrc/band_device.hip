@@ -417,9 +417,14 @@ __global__ __launch_bounds__(64) void chain_kernel(const BandDevArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------- B3
-// One tile of the per-column ranges in LDS: columns [j0, j0 + kBandTile).  Every operation only
+// One tile of the per-column ranges in LDS: columns [j0, j0 + kBandTile) — 2048 columns, 16 KB: measured per 16 384
+// 10 kb pairs 12.2 ms with 8192 columns (two blocks per CU), 7.6 ms with 4096, 7.4 ms with 2048 (the path is walked once
+// per tile; what costs is the LDS atomics of a block, and more blocks per CU hide them).  Every operation only
 // lowers start[j] or raises end[j]; columns outside the tile are skipped (another pass owns them).
-constexpr uint32_t kBandTile = 8192;
+#ifndef BG_BAND_TILE
+#define BG_BAND_TILE 2048
+#endif
+constexpr uint32_t kBandTile = BG_BAND_TILE;
 struct BandCols {
     uint32_t* start;  // LDS, indexed by j - j0
     uint32_t* end;
@@ -597,9 +602,8 @@ __device__ __forceinline__ uint64_t block_sum(uint64_t v, uint64_t* s_tmp) {
 
 // Column ranges -> per-row column ranges.  The band Band::create rasterises has no empty column between
 // its first and last one, and starts / ends never decrease: then the first column of row i is the first
-// one whose end exceeds i, its last column the last one whose start does not — two binary searches per
-// row, rows spread over the threads (coalesced), instead of a sequential sweep.  Anything else goes back
-// to the host builder.
+// one whose end exceeds i, its last column the last one whose start does not — every column hands its index to
+// the rows it is the first / the last column of.  Anything else goes back to the host builder.
 __global__ __launch_bounds__(256) void band_rows_kernel(const BandDevArgs a) {
     const uint32_t pair = blockIdx.x;
     BandDevPair* st = a.state + pair;
@@ -652,34 +656,27 @@ __global__ __launch_bounds__(256) void band_rows_kernel(const BandDevArgs a) {
     }
     uint64_t tb_bytes = 0;
     if (flags == BP_OK) {
+        // Both column arrays are non-decreasing here, so the rows whose first column is j are those from
+        // min(end[j-1], m+1) up to min(end[j], m+1), and the rows whose last column is j those from start[j] up to
+        // start[j+1] (up to m for the last column): two scatters from the columns instead of two searches per row.
+        for (uint32_t i = threadIdx.x; i <= m; i += blockDim.x) rowc[i] = make_int2((int)(j_last + 1), -1);
+        __syncthreads();
+        for (uint32_t j = j_first + threadIdx.x; j <= j_last; j += blockDim.x) {
+            const uint32_t e0 = j == j_first ? 0u : min(end[j - 1], m + 1), e1 = min(end[j], m + 1);
+            for (uint32_t i = e0; i < e1; i++) rowc[i].x = (int)j;
+            const uint32_t s0 = start[j], s1 = j == j_last ? m + 1 : min(start[j + 1], m + 1);
+            for (uint32_t i = s0; i < s1; i++) rowc[i].y = (int)j;
+        }
+        __syncthreads();
         uint64_t covered = 0, run = 0;
         for (uint32_t i0 = 0; i0 <= m; i0 += blockDim.x) {  // tiles of 256 rows
             const uint32_t i = i0 + threadIdx.x;
             uint32_t width = 0;
             int2 rc = make_int2(1, 0);
             if (i <= m) {
-                // first column whose end exceeds i
-                uint32_t lo = j_first, hi = j_last + 1;
-                while (lo < hi) {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    if (min(end[mid], m + 1) > i)
-                        hi = mid;
-                    else
-                        lo = mid + 1;
-                }
-                const uint32_t cf = lo;
-                // last column whose start is at most i
-                lo = j_first;
-                hi = j_last + 1;
-                while (lo < hi) {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    if (start[mid] <= i)
-                        lo = mid + 1;
-                    else
-                        hi = mid;
-                }
-                if (cf <= j_last && lo > j_first && cf <= lo - 1) {
-                    rc = make_int2((int)cf, (int)(lo - 1));
+                const int2 got = rowc[i];  // {first column whose end exceeds i, last column whose start is at most i}
+                if ((uint32_t)got.x <= j_last && got.y >= 0 && got.x <= got.y) {
+                    rc = got;
                     covered += (uint64_t)(rc.y - rc.x + 1);
                     if (i >= 1) width = ((uint32_t)(rc.y - rc.x + 1) + (kTbRowAlign - 1)) & ~(kTbRowAlign - 1);  // row 0 is not stored
                 }
@@ -733,16 +730,18 @@ int launch_band_match(const BandDevArgs& a, hipStream_t st) {
     return hipGetLastError() == hipSuccess ? BG_OK : BG_ERR_HIP;
 }
 
-int launch_band_chain(const BandDevArgs& a, hipStream_t st) {
+// part 1: what of the chaining wants LDS (the event preparation of the global-tree flavour); part 2: the rest (its event
+// loop: 24 VGPRs, no LDS — the one builder kernel that runs well next to a K3v2 fill); 0: both
+int launch_band_chain(const BandDevArgs& a, hipStream_t st, int part) {
     // two LDS size classes: most pairs of a long-read batch sit just around 2k matches
     BandDevArgs c = a;
     c.chain_min = 0;
     c.chain_cap = kMaxChainMatches;
     if (a.chain_global > 0 || (a.chain_global < 0 && a.n_pairs >= kChainGlobalMinPairs)) {
         // enough pairs to hide memory latency with occupancy: tree in global scratch, 16 KB of LDS per pair
-        chain_kernel<false, 1><<<dim3(a.n_pairs), dim3(64), 4 * (size_t)(kMaxChainMatches + 1), st>>>(c);
-        chain_kernel<false, 2><<<dim3(a.n_pairs), dim3(64), 0, st>>>(c);
-    } else {
+        if (part != 2) chain_kernel<false, 1><<<dim3(a.n_pairs), dim3(64), 4 * (size_t)(kMaxChainMatches + 1), st>>>(c);
+        if (part != 1) chain_kernel<false, 2><<<dim3(a.n_pairs), dim3(64), 0, st>>>(c);
+    } else if (part != 1) {
         static bool attr_set = false;
         if (!attr_set) {
             hipFuncSetAttribute((const void*)chain_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -145,7 +145,7 @@ struct bg_band_scratch {
         // device
         void *d_pairs = nullptr, *d_rowc = nullptr, *d_roff = nullptr, *d_tb = nullptr, *d_aux = nullptr;
         size_t dc_pairs = 0, dc_rowc = 0, dc_roff = 0, dc_tb = 0, dc_aux = 0;
-        hipEvent_t copied = nullptr, filled = nullptr, traced = nullptr, built = nullptr;
+        hipEvent_t copied = nullptr, filled = nullptr, traced = nullptr, built = nullptr, matched = nullptr;
         bool busy = false;
     } set[2];
     // device band builder (band_device.hip): scratch slices per pair + its per-pair state
@@ -175,6 +175,7 @@ void bg_band_scratch_free(bg_band_scratch* b) {
         if (s.filled) hipEventDestroy(s.filled);
         if (s.traced) hipEventDestroy(s.traced);
         if (s.built) hipEventDestroy(s.built);
+        if (s.matched) hipEventDestroy(s.matched);
     }
     for (void* p : b->io) hipFree(p);
     for (void* p : b->db) hipFree(p);
@@ -373,14 +374,18 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
     // by band_device.hip on its own stream, or by the host threads.
     struct Plan {
         uint64_t p0 = 0, want = 0;
-        bool on_device = false;
+        bool on_device = false, matched = false;  // matched: the k-mer join of this sub-batch has been launched (issue_match)
+        BandDevArgs d = {};
         std::vector<HostPair> hp;
         std::vector<uint64_t> row0;
     } plan[2];
     if (!B.build_stream) {
         BG_HIP(hipStreamCreateWithFlags(&B.build_stream, hipStreamNonBlocking));
         BG_HIP(hipEventCreateWithFlags(&B.seq_ready, hipEventDisableTiming));
-        for (auto& s : B.set) BG_HIP(hipEventCreateWithFlags(&s.built, hipEventDisableTiming));
+        for (auto& s : B.set) {
+            BG_HIP(hipEventCreateWithFlags(&s.built, hipEventDisableTiming));
+            BG_HIP(hipEventCreateWithFlags(&s.matched, hipEventDisableTiming));
+        }
     }
     hipStream_t st_build = B.build_stream;
     if (!B.d_started) BG_HIP(hipMalloc((void**)&B.d_started, 64));
@@ -389,12 +394,91 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
     BG_HIP(hipEventRecord(B.seq_ready, st));
     BG_HIP(hipStreamWaitEvent(st_build, B.seq_ready, 0));
 
+    const bool build_on_device = dev_kw != nullptr && !ctx->band_on_host;
+    // First half of the device builder for the sub-batch that starts at p0: the k-mer join (B1) and the event
+    // preparation of the chaining.  They get along badly with a running fill (65 VGPRs and 20 KB of LDS per block, 16 KB
+    // of LDS per wavefront, against the 86 VGPRs per SIMD and 30 KB per CU two fill wavefronts leave: 10.7 + 3.2 ms alone,
+    // 40 + 35 ms under the fill), while the chaining's event loop (24 VGPRs, no LDS) loses little there.  So these two
+    // run for sub-batch c + 1 on the idle device just before fill c is launched — finish(c) calls this once it knows
+    // where c + 1 starts and lets the fill wait for it — and the event loop of c + 1 then has the whole fill to itself.  It touches nothing of the scratch set (K4 of c - 1
+    // may still be reading that), only the builder's own arrays, which raster c has finished with.
+    auto issue_match = [&](uint64_t p0, uint64_t n_chunk) -> int {
+        Plan& P = plan[n_chunk & 1];
+        int rc = BG_OK;
+        P.matched = false;
+        if (!build_on_device) return BG_OK;
+        const uint64_t want = std::min<uint64_t>(chunk_pairs, n_pairs - p0);
+        uint32_t max_m = 0, max_n = 0;
+        for (uint64_t q = 0; q < want; q++) {
+            max_m = std::max<uint32_t>(max_m, (uint32_t)(x_off[p0 + q + 1] - x_off[p0 + q]));
+            max_n = std::max<uint32_t>(max_n, (uint32_t)(y_off[p0 + q + 1] - y_off[p0 + q]));
+        }
+        BandDevArgs d = {};
+        d.x = d_x;
+        d.x_off = d_xo;
+        d.y = d_y;
+        d.y_off = d_yo;
+        d.pair0 = p0;
+        d.n_pairs = (uint32_t)want;
+        d.k = dev_kw[0];
+        d.w = dev_kw[1];
+        d.gap_open = cs.gap_open;
+        d.gap_extend = cs.gap_extend;
+        d.xclip_prefix = cs.xclip_prefix;
+        d.xclip_suffix = cs.xclip_suffix;
+        d.yclip_prefix = cs.yclip_prefix;
+        d.yclip_suffix = cs.yclip_suffix;
+        d.match_score = (uint32_t)(cs.match_scores_some ? cs.match_score : 2);  // banded.rs:105,1315-1318
+        d.max_m = max_m;
+        d.max_n = std::max<uint32_t>(max_n, 1);
+        d.table_bits = 4;
+        while ((1u << d.table_bits) < 2 * d.max_n) d.table_bits++;
+        d.table_size = 1u << d.table_bits;
+        d.cap_matches = kMaxChainMatches + 1;
+        d.chain_global = ctx->band_chain_global;
+        const size_t need[17] = {(size_t)want * d.table_size * 4, (size_t)want * d.max_n * 4, (size_t)want * d.max_n * 8,
+                                 (size_t)64 /* (unused) */, (size_t)want * d.cap_matches * 4,
+                                 (size_t)want * d.cap_matches * 4, (size_t)want * d.cap_matches * 4,
+                                 (size_t)want * d.cap_matches * 4, (size_t)want * d.cap_matches * 4,
+                                 (size_t)want * d.cap_matches * 4, (size_t)want * (d.max_n + 1) * 4,
+                                 (size_t)want * (d.max_n + 1) * 4, (size_t)want * sizeof(BandDevPair), (size_t)(want + 1) * 8,
+                                 (size_t)want * (d.cap_matches + 1) * 16, (size_t)want * d.cap_matches * 4, (size_t)want * d.cap_matches * 2};
+        for (int i = 0; i < 17; i++)
+            if ((rc = bg_reserve(&B.db[i], &B.db_cap[i], std::max<size_t>(need[i], 64)))) return rc;
+        d.head = (uint32_t*)B.db[0];
+        d.next = (uint32_t*)B.db[1];
+        d.hy = (uint64_t*)B.db[2];
+        d.mx = (uint32_t*)B.db[4];
+        d.my = (uint32_t*)B.db[5];
+        d.path = (uint32_t*)B.db[6];
+        d.qpos = (uint32_t*)B.db[7];
+        d.upos = (uint32_t*)B.db[8];
+        d.cont = (int32_t*)B.db[9];
+        d.col_start = (uint32_t*)B.db[10];
+        d.col_end = (uint32_t*)B.db[11];
+        d.state = (BandDevPair*)B.db[12];
+        d.row0 = (const uint64_t*)B.db[13];
+        d.g_tree = B.db[14];
+        d.g_score = (uint32_t*)B.db[15];
+        d.g_back = (int16_t*)B.db[16];
+        if ((rc = launch_band_match(d, st_build))) return rc;
+        if ((rc = launch_band_chain(d, st_build, 1))) return rc;
+        BG_HIP(hipEventRecord(B.set[n_chunk & 1].matched, st_build));
+        P.d = d;
+        P.p0 = p0;
+        P.want = want;
+        P.matched = true;
+        return BG_OK;
+    };
+
     auto issue = [&](uint64_t p0, uint64_t n_chunk) -> int {
         Plan& P = plan[n_chunk & 1];
         std::vector<HostPair>& hp = P.hp;
         std::vector<uint64_t>& row0 = P.row0;
         int rc = BG_OK;
         bg_band_scratch::Set& S = B.set[n_chunk & 1];
+        if (build_on_device && !(P.matched && P.p0 == p0))
+            if ((rc = issue_match(p0, n_chunk))) return rc;
         P.p0 = p0;
         if (S.busy) {  // its staging and device buffers were last used two sub-batches ago
             BG_HIP(hipEventSynchronize(S.traced));
@@ -412,77 +496,25 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
         int2* h_rowc = (int2*)S.h_rowc;
         uint32_t* h_roff = (uint32_t*)S.h_roff;
         (void)S.h_pairs;
-        const bool on_device = dev_kw != nullptr && !ctx->band_on_host;
+        const bool on_device = build_on_device;
         P.on_device = on_device;
         if (on_device) {
-            // ---- Band::create on the device (band_device.hip); the few pairs it hands back are built below
-            uint32_t max_m = 0, max_n = 0;
-            for (uint64_t q = 0; q < want; q++) {
-                max_m = std::max<uint32_t>(max_m, (uint32_t)(x_off[p0 + q + 1] - x_off[p0 + q]));
-                max_n = std::max<uint32_t>(max_n, (uint32_t)(y_off[p0 + q + 1] - y_off[p0 + q]));
-            }
-            BandDevArgs d = {};
-            d.x = d_x;
-            d.x_off = d_xo;
-            d.y = d_y;
-            d.y_off = d_yo;
-            d.pair0 = p0;
-            d.n_pairs = (uint32_t)want;
-            d.k = dev_kw[0];
-            d.w = dev_kw[1];
-            d.gap_open = cs.gap_open;
-            d.gap_extend = cs.gap_extend;
-            d.xclip_prefix = cs.xclip_prefix;
-            d.xclip_suffix = cs.xclip_suffix;
-            d.yclip_prefix = cs.yclip_prefix;
-            d.yclip_suffix = cs.yclip_suffix;
-            d.match_score = (uint32_t)(cs.match_scores_some ? cs.match_score : 2);  // banded.rs:105,1315-1318
-            d.max_m = max_m;
-            d.max_n = std::max<uint32_t>(max_n, 1);
-            d.table_bits = 4;
-            while ((1u << d.table_bits) < 2 * d.max_n) d.table_bits++;
-            d.table_size = 1u << d.table_bits;
-            d.cap_matches = kMaxChainMatches + 1;
-            d.chain_global = ctx->band_chain_global;
-            const size_t need[17] = {(size_t)want * d.table_size * 4, (size_t)want * d.max_n * 4, (size_t)want * d.max_n * 8,
-                                     (size_t)64 /* (unused) */, (size_t)want * d.cap_matches * 4,
-                                     (size_t)want * d.cap_matches * 4, (size_t)want * d.cap_matches * 4,
-                                     (size_t)want * d.cap_matches * 4, (size_t)want * d.cap_matches * 4,
-                                     (size_t)want * d.cap_matches * 4, (size_t)want * (d.max_n + 1) * 4,
-                                     (size_t)want * (d.max_n + 1) * 4, (size_t)want * sizeof(BandDevPair), (size_t)(want + 1) * 8,
-                                     (size_t)want * (d.cap_matches + 1) * 16, (size_t)want * d.cap_matches * 4, (size_t)want * d.cap_matches * 2};
-            for (int i = 0; i < 17; i++)
-                if ((rc = bg_reserve(&B.db[i], &B.db_cap[i], std::max<size_t>(need[i], 64)))) return rc;
-            d.head = (uint32_t*)B.db[0];
-            d.next = (uint32_t*)B.db[1];
-            d.hy = (uint64_t*)B.db[2];
-            d.mx = (uint32_t*)B.db[4];
-            d.my = (uint32_t*)B.db[5];
-            d.path = (uint32_t*)B.db[6];
-            d.qpos = (uint32_t*)B.db[7];
-            d.upos = (uint32_t*)B.db[8];
-            d.cont = (int32_t*)B.db[9];
-            d.col_start = (uint32_t*)B.db[10];
-            d.col_end = (uint32_t*)B.db[11];
-            d.state = (BandDevPair*)B.db[12];
-            d.row0 = (const uint64_t*)B.db[13];
-            d.g_tree = B.db[14];
-            d.g_score = (uint32_t*)B.db[15];
-            d.g_back = (int16_t*)B.db[16];
+            // ---- Band::create on the device (band_device.hip); the few pairs it hands back are built below.
+            // The k-mer join is already on its way (issue_match)
+            BandDevArgs d = P.d;
             if ((rc = bg_reserve(&S.d_rowc, &S.dc_rowc, std::max<size_t>(row0[want] * sizeof(int2), 64)))) return rc;
             if ((rc = bg_reserve(&S.d_roff, &S.dc_roff, std::max<size_t>(row0[want] * 4, 64)))) return rc;
             d.rowc = (int2*)S.d_rowc;
             d.row_off = (uint32_t*)S.d_roff;
             if ((rc = pinned_reserve(&B.h_state, &B.h_state_cap, want * sizeof(BandDevPair)))) return rc;
             BG_HIP(hipMemcpyAsync(B.db[13], row0.data(), (want + 1) * 8, hipMemcpyHostToDevice, st_build));
-            // The k-mer join and the chaining of sub-batch c + 1 run UNDER the fill of c: they mostly wait on memory and
-            // fit the registers / LDS the fill leaves free — provided they start after every block of the fill is
-            // resident (launch_band_wait_started: the fill's grid is a single round of blocks, and a co-runner that is
-            // on a CU first delays the whole kernel: fill 57 -> 116 ms).  The raster kernels want 65 KB of LDS per block
-            // against the 130 KB per CU the fill holds: they start when that fill is done and overlap K4 of sub-batch c.
+            // The chaining of sub-batch c + 1 runs UNDER the fill of c: it mostly waits on memory and fits the registers
+            // the fill leaves free — provided it starts after every block of the fill is resident
+            // (launch_band_wait_started: the fill's grid is a single round of blocks, and a co-runner that is on a CU
+            // first delays the whole kernel: fill 57 -> 116 ms).  The raster kernels start when that fill is done and
+            // overlap K4 of sub-batch c.
             if (B.started_target) launch_band_wait_started(B.d_started, B.started_target, st_build);
-            if ((rc = launch_band_match(d, st_build))) return rc;
-            if ((rc = launch_band_chain(d, st_build))) return rc;
+            if ((rc = launch_band_chain(d, st_build, 2))) return rc;
             if (n_chunk >= 1 && B.set[(n_chunk - 1) & 1].busy) BG_HIP(hipStreamWaitEvent(st_build, B.set[(n_chunk - 1) & 1].filled, 0));
             if ((rc = launch_band_raster(d, st_build))) return rc;
             BG_HIP(hipMemcpyAsync(B.h_state, d.state, want * sizeof(BandDevPair), hipMemcpyDeviceToHost, st_build));
@@ -597,6 +629,10 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
         a.pair0 = p0;
         a.n_pairs = (uint32_t)take;
         if (on_device) BG_HIP(hipStreamWaitEvent(st, S.built, 0));
+        if (on_device && p0 + take < n_pairs) {  // the next sub-batch's k-mer join goes first (see issue_match)
+            if ((rc = issue_match(p0 + take, n_chunk + 1))) return rc;
+            BG_HIP(hipStreamWaitEvent(st, B.set[(n_chunk + 1) & 1].matched, 0));
+        }
         if (ctx->timing) BG_HIP(hipEventRecord(ctx->ev[0], st));
         if (sm == SCORE_PARAMS && !ctx->band_fill_v1) {
             a.started = on_device ? B.d_started : nullptr;
