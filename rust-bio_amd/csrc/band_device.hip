@@ -39,6 +39,26 @@ __device__ __forceinline__ bool kmer_equal(const uint8_t* a, const uint8_t* b, u
     return true;
 }
 
+// global -> LDS copy of a sequence by the whole block: 16-byte loads from the first 16-byte boundary of src on
+__device__ __forceinline__ void stage_bytes(uint8_t* dst, const uint8_t* src, uint32_t len) {
+    const uint32_t mis = (uint32_t)((uintptr_t)src & 15u);  // bytes up to the first 16-byte boundary of src
+    const uint32_t headb = min(len, (16u - mis) & 15u);
+    for (uint32_t i = threadIdx.x; i < headb; i += blockDim.x) dst[i] = src[i];
+    const uint32_t nvec = (len - headb) / 16;
+    const uint4* s4 = (const uint4*)(src + headb);
+    for (uint32_t v = threadIdx.x; v < nvec; v += blockDim.x) {
+        const uint4 q = s4[v];
+        uint32_t* d = (uint32_t*)(dst + headb + 16 * v);  // dst + headb is only byte-aligned in general
+        if ((headb & 3u) == 0) {
+            d[0] = q.x; d[1] = q.y; d[2] = q.z; d[3] = q.w;
+        } else {
+            const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+            for (int t = 0; t < 16; t++) dst[headb + 16 * v + t] = (uint8_t)(w[t >> 2] >> (8 * (t & 3)));
+        }
+    }
+    for (uint32_t i = headb + 16 * nvec + threadIdx.x; i < len; i += blockDim.x) dst[i] = src[i];
+}
+
 // ------------------------------------------------------------------------------------------- B1
 // STAGED: both sequences are copied to LDS first (16-byte loads) and every k-mer is hashed / compared from there.
 // With the sequences in global memory the hash loop (k is a run-time value) is a chain of k byte loads, each waited
@@ -56,26 +76,8 @@ __global__ __launch_bounds__(256) void kmer_match_kernel(const BandDevArgs a) {
     if (STAGED) {
         uint8_t* sx = s_seq;
         uint8_t* sy = s_seq + ((m + 15) & ~15u);
-        auto stage = [&](uint8_t* dst, const uint8_t* src, uint32_t len) {
-            const uint32_t mis = (uint32_t)((uintptr_t)src & 15u);  // bytes up to the first 16-byte boundary of src
-            const uint32_t headb = min(len, (16u - mis) & 15u);
-            for (uint32_t i = threadIdx.x; i < headb; i += blockDim.x) dst[i] = src[i];
-            const uint32_t nvec = (len - headb) / 16;
-            const uint4* s4 = (const uint4*)(src + headb);
-            for (uint32_t v = threadIdx.x; v < nvec; v += blockDim.x) {
-                const uint4 q = s4[v];
-                uint32_t* d = (uint32_t*)(dst + headb + 16 * v);  // dst + headb is only byte-aligned in general
-                if ((headb & 3u) == 0) {
-                    d[0] = q.x; d[1] = q.y; d[2] = q.z; d[3] = q.w;
-                } else {
-                    const uint32_t w[4] = {q.x, q.y, q.z, q.w};
-                    for (int t = 0; t < 16; t++) dst[headb + 16 * v + t] = (uint8_t)(w[t >> 2] >> (8 * (t & 3)));
-                }
-            }
-            for (uint32_t i = headb + 16 * nvec + threadIdx.x; i < len; i += blockDim.x) dst[i] = src[i];
-        };
-        stage(sx, x, m);
-        stage(sy, y, n);
+        stage_bytes(sx, x, m);
+        stage_bytes(sy, y, n);
         __syncthreads();
         x = sx;
         y = sy;
@@ -151,6 +153,161 @@ __global__ __launch_bounds__(256) void kmer_match_kernel(const BandDevArgs a) {
     }
     if (threadIdx.x == 0) {
         st->n_matches = over ? 0 : run;
+        st->flags = over ? BP_HOST_FALLBACK : BP_OK;
+    }
+}
+
+// ------------------------------------------------------------------------------------------- B1 (LDS)
+// The whole join of a pair in LDS: both sequences, a table of 16 384 first positions, the per-position chain links and
+// a 16-bit tag per y k-mer — 20 + 64 + 20 + 20 KB for 10 kb reads, one block of 512 threads per CU.  kmer_match_kernel
+// keeps table, links and hashes in global memory (a 128 KB table per pair: 28 GB of HBM traffic per 16 384 pairs for
+// 164 MB of sequences, every probe a chain of dependent L2 / HBM round trips); it had to fit next to a running fill
+// (20 KB of LDS), which the join no longer does (banded_api.hip).  Every thread owns a contiguous run of positions and
+// rolls a polynomial hash along it (one byte in, one byte out per position); what is hashed how is ours to choose —
+// candidates are compared byte for byte — and the matches come out exactly as kmer_match_kernel leaves them: in x
+// order, the y positions of one x position ascending.
+constexpr uint32_t kLdsJoinTable = 16384;
+constexpr uint32_t kLdsJoinThreads = 512;
+constexpr uint32_t kRollBase = 0x9E3779B1u;
+__host__ __device__ inline size_t lds_join_bytes(uint32_t m, uint32_t n) {
+    return (size_t)((m + 15) & ~15u) + ((n + 15) & ~15u) + 4 * (size_t)kLdsJoinTable + 2 * (size_t)((n + 7) & ~7u) * 2 + 64;
+}
+__global__ __launch_bounds__(512) void kmer_match_lds_kernel(const BandDevArgs a) {
+    extern __shared__ __align__(16) uint8_t s_seq[];
+    const uint32_t pair = blockIdx.x;
+    const uint32_t tid = threadIdx.x, nth = blockDim.x;
+    const uint64_t xo = a.x_off[a.pair0 + pair], yo = a.y_off[a.pair0 + pair];
+    const uint32_t m = (uint32_t)(a.x_off[a.pair0 + pair + 1] - xo), n = (uint32_t)(a.y_off[a.pair0 + pair + 1] - yo);
+    uint8_t* sx = s_seq;
+    uint8_t* sy = sx + ((m + 15) & ~15u);
+    uint32_t* head = (uint32_t*)(sy + ((n + 15) & ~15u));
+    uint16_t* next = (uint16_t*)(head + kLdsJoinTable);
+    uint16_t* tag = next + ((n + 7) & ~7u);
+    __shared__ uint32_t s_wsum[kLdsJoinThreads / 64];
+    __shared__ uint32_t s_flag;
+    if (tid == 0) s_flag = 0;
+    {
+        stage_bytes(sx, a.x + xo, m);
+        stage_bytes(sy, a.y + yo, n);
+        for (uint32_t i = tid; i < kLdsJoinTable / 4; i += nth) ((uint4*)head)[i] = make_uint4(kNone, kNone, kNone, kNone);
+    }
+    const uint32_t k = a.k;
+    BandDevPair* st = a.state + pair;
+    uint32_t* mx = a.mx + (size_t)pair * a.cap_matches;
+    uint32_t* my = a.my + (size_t)pair * a.cap_matches;
+    const uint32_t nky = n >= k && k ? n - k + 1 : 0, nkx = m >= k && k ? m - k + 1 : 0;
+    uint32_t bk1 = 1;  // kRollBase^(k-1)
+    for (uint32_t t = 1; t < k; t++) bk1 *= kRollBase;
+    auto first_hash = [&](const uint8_t* q) {
+        uint32_t h = 0;
+        for (uint32_t t = 0; t < k; t++) h = h * kRollBase + q[t];
+        return h;
+    };
+    auto slot_of = [](uint32_t h) { return (h * 0x85EBCA6Bu) >> 18; };  // 14 bits
+    auto tag_of = [](uint32_t h) { return (uint16_t)(h ^ (h >> 16)); };
+    __syncthreads();
+    {  // y positions into the table: a contiguous run per thread, the hash rolled along it
+        const uint32_t per = (nky + nth - 1) / nth, i0 = min(nky, tid * per), i1 = min(nky, i0 + per);
+        uint32_t h = i0 < i1 ? first_hash(sy + i0) : 0;
+        for (uint32_t i = i0; i < i1; i++) {
+            tag[i] = tag_of(h);
+            next[i] = (uint16_t)atomicExch(&head[slot_of(h)], i);  // kNone truncates to 0xFFFF: no position is that large
+            if (i + 1 < i1) h = (h - sy[i] * bk1) * kRollBase + sy[i + k];
+        }
+    }
+    __syncthreads();
+    const bool too_long = (k == 0 || m + k >= (1u << 20));
+    const uint32_t per = (nkx + nth - 1) / nth, p0 = min(nkx, tid * per), p1 = min(nkx, p0 + per);
+    // The first 16 bytes of the x k-mer ride along in four registers (one byte out, one byte in per position); a
+    // candidate's first 16 bytes come as five aligned LDS words shifted into place; both are compared under the masks of
+    // the bytes below k — no loop, no branch.  Bytes from the 17th on (k > 16) take the byte loop.
+    uint32_t kmask[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) kmask[j] = k >= 4u * (j + 1) ? 0xFFFFFFFFu : (k > 4u * j ? (1u << (8 * (k - 4 * j))) - 1 : 0u);
+    auto window_at = [&](uint32_t p, uint32_t* w) {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            w[j] = (uint32_t)sx[p + 4 * j] | ((uint32_t)sx[p + 4 * j + 1] << 8) | ((uint32_t)sx[p + 4 * j + 2] << 16) | ((uint32_t)sx[p + 4 * j + 3] << 24);
+    };
+    auto window_roll = [&](uint32_t p, uint32_t* w) {  // p: the position being left
+        const uint32_t in = sx[p + 16];
+        w[0] = __builtin_amdgcn_alignbyte(w[1], w[0], 1);
+        w[1] = __builtin_amdgcn_alignbyte(w[2], w[1], 1);
+        w[2] = __builtin_amdgcn_alignbyte(w[3], w[2], 1);
+        w[3] = __builtin_amdgcn_alignbyte(in, w[3], 1);
+    };
+    const uint32_t* sy32 = (const uint32_t*)sy;
+    auto walk = [&](uint32_t p, uint32_t h, const uint32_t* w, auto&& hit) {
+        const uint16_t tg = tag_of(h);
+        for (uint32_t i = head[slot_of(h)] & 0xFFFFu; i != 0xFFFFu; i = next[i]) {
+            if (tag[i] != tg) continue;
+            const uint32_t q = i >> 2, sh = i & 3u;
+            const uint32_t d0 = sy32[q], d1 = sy32[q + 1], d2 = sy32[q + 2], d3 = sy32[q + 3], d4 = sy32[q + 4];
+            uint32_t diff = (__builtin_amdgcn_alignbyte(d1, d0, sh) ^ w[0]) & kmask[0];
+            diff |= (__builtin_amdgcn_alignbyte(d2, d1, sh) ^ w[1]) & kmask[1];
+            diff |= (__builtin_amdgcn_alignbyte(d3, d2, sh) ^ w[2]) & kmask[2];
+            diff |= (__builtin_amdgcn_alignbyte(d4, d3, sh) ^ w[3]) & kmask[3];
+            for (uint32_t t = 16; t < k; t++) diff |= (uint32_t)(sy[i + t] ^ sx[p + t]);
+            if (diff == 0) hit(i);
+        }
+    };
+    // pass 1: matches per thread (and the longest list of one x position)
+    uint32_t mine = 0, longest = 0;
+    uint32_t w[4] = {0, 0, 0, 0};
+    if (!too_long && p0 < p1) {
+        uint32_t h = first_hash(sx + p0);
+        window_at(p0, w);
+        for (uint32_t p = p0; p < p1; p++) {
+            uint32_t c = 0;
+            walk(p, h, w, [&](uint32_t) { c++; });
+            mine += c;
+            longest = max(longest, c);
+            if (p + 1 < p1) {
+                h = (h - sx[p] * bk1) * kRollBase + sx[p + k];
+                window_roll(p, w);
+            }
+        }
+    }
+    // the in-place sort below is quadratic in the list length, and the chain kernel holds kMaxChainMatches
+    if (longest > kMaxMatchesPerKmer) s_flag = 1;
+    uint32_t incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = (uint32_t)__shfl_up((int)incl, o);
+        if ((tid & 63) >= (uint32_t)o) incl += v;
+    }
+    if ((tid & 63) == 63) s_wsum[tid >> 6] = incl;
+    __syncthreads();
+    uint32_t wbase = 0, total = 0;
+    for (uint32_t wv = 0; wv < (nth >> 6); wv++) {
+        if (wv < (tid >> 6)) wbase += s_wsum[wv];
+        total += s_wsum[wv];
+    }
+    const bool over = too_long || total > a.cap_matches || total > kMaxChainMatches || s_flag;
+    if (!over && mine) {  // pass 2: the same walk, now writing
+        uint32_t off = wbase + incl - mine;
+        uint32_t h = first_hash(sx + p0);
+        window_at(p0, w);
+        for (uint32_t p = p0; p < p1; p++) {
+            uint32_t nw = 0;
+            walk(p, h, w, [&](uint32_t i) {  // insertion sort by y (the lists are in arbitrary order)
+                uint32_t t = nw++;
+                while (t > 0 && my[off + t - 1] > i) {
+                    my[off + t] = my[off + t - 1];
+                    t--;
+                }
+                my[off + t] = i;
+            });
+            for (uint32_t t = 0; t < nw; t++) mx[off + t] = p;
+            off += nw;
+            if (p + 1 < p1) {
+                h = (h - sx[p] * bk1) * kRollBase + sx[p + k];
+                window_roll(p, w);
+            }
+        }
+    }
+    if (tid == 0) {
+        st->n_matches = over ? 0 : total;
         st->flags = over ? BP_HOST_FALLBACK : BP_OK;
     }
 }
@@ -722,6 +879,17 @@ __global__ __launch_bounds__(256) void band_rows_kernel(const BandDevArgs a) {
 static size_t chain_lds_bytes(uint32_t cap) { return 16 * (size_t)(cap + 1) + 6 * (size_t)cap + 16; }
 
 int launch_band_match(const BandDevArgs& a, hipStream_t st) {
+    // positions are 16-bit in the LDS flavour, and everything of a pair has to fit 160 KB
+    const size_t lds_bytes = lds_join_bytes(a.max_m, a.max_n);
+    if (a.max_n < 0xFFFFu && lds_bytes <= 150 * 1024 && !a.join_global) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipFuncSetAttribute((const void*)kmer_match_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+            attr_set = true;
+        }
+        kmer_match_lds_kernel<<<dim3(a.n_pairs), dim3(kLdsJoinThreads), lds_bytes, st>>>(a);
+        return hipGetLastError() == hipSuccess ? BG_OK : BG_ERR_HIP;
+    }
     const size_t stage_bytes = (size_t)((a.max_m + 15) & ~15u) + a.max_n + 16;
     if (stage_bytes <= kStageMaxBytes)
         kmer_match_kernel<true><<<dim3(a.n_pairs), dim3(256), stage_bytes, st>>>(a);

@@ -252,7 +252,7 @@ def test_device_band_builder_equals_host_builder():
     for mode, sc in [(2, Scoring.from_scores(-5, -1, 1, -1)), (3, Scoring.from_scores(-4, -2, 2, -3)),
                      (0, Scoring.from_scores(-5, -1, 1, -1).xclip(-7).yclip_prefix_(-3).yclip_suffix_(0)),
                      (1, Scoring.new(-6, -1, lambda a, b: 2 if a == b else -2))]:
-        for k, w in [(8, 6), (11, 20), (5, 3)]:
+        for k, w in [(8, 6), (11, 20), (5, 3), (20, 12)]:  # (k beyond 16: the LDS join compares its tail byte by byte)
             al = BAligner.with_scoring(sc, k, w)
             x, xo = _lib.concat(xs)
             y, yo = _lib.concat(ys)
@@ -263,8 +263,9 @@ def test_device_band_builder_equals_host_builder():
             except Exception as e:  # noqa: BLE001 - statuses are compared below
                 out_h, ops_h, cells_h = al.last_out.copy(), al.last_ops.copy(), al.last_cells.copy()
             al.ctx.set_option("band_on_host", 0)
-            for chain_global in (0, 1):  # both placements of the chaining kernel's tree
+            for chain_global, join_global in ((0, 0), (1, 0), (1, 1)):  # both placements of the chaining kernel's tree, both k-mer joins
                 al.ctx.set_option("band_chain_global", chain_global)
+                al.ctx.set_option("band_join_global", join_global)
                 try:
                     out_d, ops_d = al.align_arrays(mode, x, xo, y, yo)
                 except Exception as e:  # noqa: BLE001
@@ -276,6 +277,7 @@ def test_device_band_builder_equals_host_builder():
                     if out_h["status"][p] == 0:
                         assert decode_ops(out_d[p], ops_d) == decode_ops(out_h[p], ops_h), (mode, k, w, p, chain_global)
             al.ctx.set_option("band_chain_global", -1)
+            al.ctx.set_option("band_join_global", 0)
 
 
 def test_device_band_builder_large_batch_10kb():
@@ -289,11 +291,14 @@ def test_device_band_builder_large_batch_10kb():
     out_h, ops_h = al.align_arrays(2, x, off, y, off)
     cells_h = al.last_cells.copy()
     al.ctx.set_option("band_on_host", 0)
-    out_d, ops_d = al.align_arrays(2, x, off, y, off)
-    assert (al.last_cells == cells_h).all()
-    for f in ("score", "xstart", "xend", "ystart", "yend", "n_ops", "status", "ops_off"):
-        assert (out_d[f] == out_h[f]).all(), f
-    assert (ops_d[:int(out_d["n_ops"].sum())] == ops_h[:int(out_h["n_ops"].sum())]).all()
+    for join_global in (0, 1):  # k-mer join in LDS (what a 10 kb batch gets) and with its table in global memory
+        al.ctx.set_option("band_join_global", join_global)
+        out_d, ops_d = al.align_arrays(2, x, off, y, off)
+        assert (al.last_cells == cells_h).all(), join_global
+        for f in ("score", "xstart", "xend", "ystart", "yend", "n_ops", "status", "ops_off"):
+            assert (out_d[f] == out_h[f]).all(), (f, join_global)
+        assert (ops_d[:int(out_d["n_ops"].sum())] == ops_h[:int(out_h["n_ops"].sum())]).all(), join_global
+    al.ctx.set_option("band_join_global", 0)
 
 
 def test_fill_kernel_variants_agree():
