@@ -7,6 +7,8 @@
 #include <map>
 #include <type_traits>
 
+#include <condition_variable>
+#include <mutex>
 #include <thread>
 
 #include "sw_kernels.h"
@@ -559,9 +561,53 @@ int align_batch_pipelined(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint64_
         used = dst[np];
         return BG_OK;
     };
+    // The stages are drained by a second host thread, in order, while this one packs and launches the following ones:
+    // per stage the host's share is max(pack, drain) instead of their sum (the host side, not PCIe or the kernels, is
+    // what bounds this entry point).  `used` / `status` belong to the drainer until it is joined.
+    std::mutex mu;
+    std::condition_variable cv;
+    uint64_t submitted = 0, drained = 0;
+    bool abort_drain = false;
+    int drain_rc = BG_OK;
+    const int device = ctx->device;
+    std::thread drainer([&] {
+        if (hipSetDevice(device) != hipSuccess) {
+            std::lock_guard<std::mutex> lk(mu);
+            drain_rc = BG_ERR_HIP;
+            drained = nch;
+            cv.notify_all();
+            return;
+        }
+        for (uint64_t c = 0; c < nch; c++) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return submitted > c || abort_drain; });
+                if (submitted <= c) break;  // aborted before this stage was launched
+            }
+            const int r = drain(c);
+            std::lock_guard<std::mutex> lk(mu);
+            if (r && drain_rc == BG_OK) drain_rc = r;
+            drained = c + 1;
+            cv.notify_all();
+        }
+        std::lock_guard<std::mutex> lk(mu);
+        drained = nch;
+        cv.notify_all();
+    });
+    auto stop_drainer = [&] {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            abort_drain = true;
+        }
+        cv.notify_all();
+        drainer.join();
+    };
     int rc;
     for (uint64_t c = 0; c < nch; c++) {
-        if (c >= bg_host_pipe::NSET && (rc = drain(c - bg_host_pipe::NSET))) return rc;  // frees this stage's set
+        if (c >= bg_host_pipe::NSET) {  // this stage's set is free once stage c - NSET has been drained
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return drained >= c - bg_host_pipe::NSET + 1; });
+        }
         bg_host_pipe::Set& S = P.set[c % bg_host_pipe::NSET];
         const uint64_t p0 = c * chunk, np = std::min(n_pairs, p0 + chunk) - p0;
         const uint64_t xb = x_off[p0 + np] - x_off[p0], yb = y_off[p0 + np] - y_off[p0];
@@ -572,26 +618,32 @@ int align_batch_pipelined(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint64_
             hxo[p] = x_off[p0 + p] - x_off[p0];
             hyo[p] = y_off[p0 + p] - y_off[p0];
         }
-        if (xb) BG_HIP(hipMemcpyAsync(S.d_in, S.h_in, xb, hipMemcpyHostToDevice, P.s_in));
-        if (yb) BG_HIP(hipMemcpyAsync(S.d_in + o_y, S.h_in + o_y, yb, hipMemcpyHostToDevice, P.s_in));
-        BG_HIP(hipMemcpyAsync(S.d_in + o_xo, S.h_in + o_xo, 2 * (chunk + 1) * 8, hipMemcpyHostToDevice, P.s_in));
-        BG_HIP(hipEventRecord(S.in_done, P.s_in));
-        BG_HIP(hipStreamWaitEvent(s_k, S.in_done, 0));
+        bool in_ok = true;
+        if (xb) in_ok = in_ok && hipMemcpyAsync(S.d_in, S.h_in, xb, hipMemcpyHostToDevice, P.s_in) == hipSuccess;
+        if (yb) in_ok = in_ok && hipMemcpyAsync(S.d_in + o_y, S.h_in + o_y, yb, hipMemcpyHostToDevice, P.s_in) == hipSuccess;
+        in_ok = in_ok && hipMemcpyAsync(S.d_in + o_xo, S.h_in + o_xo, 2 * (chunk + 1) * 8, hipMemcpyHostToDevice, P.s_in) == hipSuccess;
+        in_ok = in_ok && hipEventRecord(S.in_done, P.s_in) == hipSuccess && hipStreamWaitEvent(s_k, S.in_done, 0) == hipSuccess;
         bool uniform = true;  // the host knows the lengths: no reduction + synchronisation on the device
         for (uint64_t p = 1; p < np && uniform; p++) uniform = hxo[p + 1] - hxo[p] == hxo[1] && hyo[p + 1] - hyo[p] == hyo[1];
-        rc = align_batch_dev_impl(ctx, sc, mode, np, S.d_in, (const uint64_t*)(S.d_in + o_xo), S.d_in + o_y, (const uint64_t*)(S.d_in + o_yo),
+        rc = !in_ok ? BG_ERR_HIP : align_batch_dev_impl(ctx, sc, mode, np, S.d_in, (const uint64_t*)(S.d_in + o_xo), S.d_in + o_y, (const uint64_t*)(S.d_in + o_yo),
                                   max_x, max_y, (bg_alignment_t*)S.d_out, stride ? S.d_out + o_ops : nullptr, stride, s_k, uniform ? 1 : 0);
+        if (rc == BG_OK && (hipEventRecord(S.k_done, s_k) != hipSuccess || hipStreamWaitEvent(P.s_out, S.k_done, 0) != hipSuccess ||
+                            hipMemcpyAsync(S.h_out, S.d_out, o_ops + np * stride, hipMemcpyDeviceToHost, P.s_out) != hipSuccess ||
+                            hipEventRecord(S.out_done, P.s_out) != hipSuccess))
+            rc = BG_ERR_HIP;
         if (rc) {
             hipDeviceSynchronize();
+            stop_drainer();
             return rc;
         }
-        BG_HIP(hipEventRecord(S.k_done, s_k));
-        BG_HIP(hipStreamWaitEvent(P.s_out, S.k_done, 0));
-        BG_HIP(hipMemcpyAsync(S.h_out, S.d_out, o_ops + np * stride, hipMemcpyDeviceToHost, P.s_out));
-        BG_HIP(hipEventRecord(S.out_done, P.s_out));
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            submitted = c + 1;
+        }
+        cv.notify_all();
     }
-    for (uint64_t c = nch > bg_host_pipe::NSET ? nch - bg_host_pipe::NSET : 0; c < nch; c++)
-        if ((rc = drain(c))) return rc;
+    drainer.join();
+    if (drain_rc) return drain_rc;
     if (ops_used) *ops_used = used;
     return status;
 }
