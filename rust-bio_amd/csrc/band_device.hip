@@ -888,17 +888,23 @@ __global__ __launch_bounds__(256) void band_rows_kernel(const BandDevArgs a) {
                 }
                 rowc[i] = rc;
             }
-            // exclusive scan of the widths inside the tile
-            s_scan[threadIdx.x] = width;
-            __syncthreads();
-            for (uint32_t o = 1; o < blockDim.x; o <<= 1) {
-                const uint32_t v = threadIdx.x >= o ? s_scan[threadIdx.x - o] : 0;
-                __syncthreads();
-                s_scan[threadIdx.x] += v;
-                __syncthreads();
+            // exclusive scan of the widths inside the tile: lane shifts inside a wavefront, one barrier for the four
+            // wavefront totals (a 256-wide LDS scan is sixteen barriers per tile, forty tiles per 10 kb read)
+            uint32_t incl = width;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t v = (uint32_t)__shfl_up((int)incl, o);
+                if ((threadIdx.x & 63) >= (uint32_t)o) incl += v;
             }
-            if (i <= m) roff[i] = (uint32_t)(run + s_scan[threadIdx.x] - width);
-            run += s_scan[blockDim.x - 1];
+            if ((threadIdx.x & 63) == 63) s_scan[threadIdx.x >> 6] = incl;
+            __syncthreads();
+            uint32_t wbase = 0, tile_total = 0;
+            for (uint32_t wv = 0; wv < (blockDim.x >> 6); wv++) {
+                if (wv < (threadIdx.x >> 6)) wbase += s_scan[wv];
+                tile_total += s_scan[wv];
+            }
+            if (i <= m) roff[i] = (uint32_t)(run + wbase + incl - width);
+            run += tile_total;
             __syncthreads();
         }
         const uint64_t cov = block_sum(covered, s_tmp);
