@@ -146,7 +146,8 @@ struct bg_band_scratch {
         void *d_pairs = nullptr, *d_rowc = nullptr, *d_roff = nullptr, *d_tb = nullptr, *d_aux = nullptr;
         size_t dc_pairs = 0, dc_rowc = 0, dc_roff = 0, dc_tb = 0, dc_aux = 0;
         hipEvent_t copied = nullptr, filled = nullptr, traced = nullptr, built = nullptr, matched = nullptr;
-        bool busy = false;
+        hipEvent_t fill_gone = nullptr;  // the fill kernel itself is off the device (its epilogue may still run)
+        bool busy = false, fill_gone_valid = false;
     } set[2];
     // device band builder (band_device.hip): scratch slices per pair + its per-pair state
     void* db[17] = {};
@@ -176,6 +177,7 @@ void bg_band_scratch_free(bg_band_scratch* b) {
         if (s.traced) hipEventDestroy(s.traced);
         if (s.built) hipEventDestroy(s.built);
         if (s.matched) hipEventDestroy(s.matched);
+        if (s.fill_gone) hipEventDestroy(s.fill_gone);
     }
     for (void* p : b->io) hipFree(p);
     for (void* p : b->db) hipFree(p);
@@ -385,6 +387,7 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
         for (auto& s : B.set) {
             BG_HIP(hipEventCreateWithFlags(&s.built, hipEventDisableTiming));
             BG_HIP(hipEventCreateWithFlags(&s.matched, hipEventDisableTiming));
+            BG_HIP(hipEventCreateWithFlags(&s.fill_gone, hipEventDisableTiming));
         }
     }
     hipStream_t st_build = B.build_stream;
@@ -516,7 +519,10 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
             // overlap K4 of sub-batch c.
             if (B.started_target) launch_band_wait_started(B.d_started, B.started_target, st_build);
             if ((rc = launch_band_chain(d, st_build, 2))) return rc;
-            if (n_chunk >= 1 && B.set[(n_chunk - 1) & 1].busy) BG_HIP(hipStreamWaitEvent(st_build, B.set[(n_chunk - 1) & 1].filled, 0));
+            if (n_chunk >= 1 && B.set[(n_chunk - 1) & 1].busy) {  // (the raster does not have to wait for the fill's epilogue)
+                bg_band_scratch::Set& prev = B.set[(n_chunk - 1) & 1];
+                BG_HIP(hipStreamWaitEvent(st_build, prev.fill_gone_valid ? prev.fill_gone : prev.filled, 0));
+            }
             if ((rc = launch_band_raster(d, st_build))) return rc;
             BG_HIP(hipMemcpyAsync(B.h_state, d.state, want * sizeof(BandDevPair), hipMemcpyDeviceToHost, st_build));
             BG_HIP(hipEventRecord(S.built, st_build));
@@ -639,11 +645,13 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
             a.started = on_device ? B.d_started : nullptr;
             a.tb_flip = kTbFlip;
             if (on_device) B.started_target += band_fill2_blocks(a.n_pairs);
-            launch_band_fill2(a, narrow, st);  // K3v2: eight pairs per wavefront + separate epilogue
+            launch_band_fill2(a, narrow, st, S.fill_gone);  // K3v2: eight pairs per wavefront + separate epilogue
+            S.fill_gone_valid = true;
         }
         else {
             a.tb_flip = 0;
             fill<<<dim3((unsigned)((take + 3) / 4)), dim3(256), 0, st>>>(a);
+            S.fill_gone_valid = false;
         }
         BG_HIP(hipGetLastError());
         if (ctx->timing) {

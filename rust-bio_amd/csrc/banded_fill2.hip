@@ -844,7 +844,7 @@ uint32_t band_fill2_blocks(uint32_t n_pairs) {
     return (jobs + 3) / 4;
 }
 
-bool launch_band_fill2(const BandArgs& a, bool narrow, hipStream_t st) {
+bool launch_band_fill2(const BandArgs& a, bool narrow, hipStream_t st, hipEvent_t after_fill) {
 
     constexpr int LP = BF2_LP, R = BF2_R, PW = 64 / LP;
     const uint32_t jobs = (a.n_pairs + PW - 1) / PW;
@@ -853,9 +853,11 @@ bool launch_band_fill2(const BandArgs& a, bool narrow, hipStream_t st) {
             banded_fill2_kernel<R, LP, true, true><<<dim3((jobs + 3) / 4), dim3(256), 0, st>>>(a);
         else
             banded_fill2_kernel<R, LP, true, false><<<dim3((jobs + 3) / 4), dim3(256), 0, st>>>(a);
+        if (after_fill) (void)hipEventRecord(after_fill, st);
         banded_epilogue_kernel<2, true><<<dim3((a.n_pairs + 3) / 4), dim3(256), 0, st>>>(a);
     } else {
         banded_fill2_kernel<R, LP, false, true><<<dim3((jobs + 3) / 4), dim3(256), 0, st>>>(a);
+        if (after_fill) (void)hipEventRecord(after_fill, st);
         banded_epilogue_kernel<2, false><<<dim3((a.n_pairs + 3) / 4), dim3(256), 0, st>>>(a);
     }
     return true;

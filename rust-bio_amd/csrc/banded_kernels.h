@@ -89,7 +89,7 @@ typedef void (*band_fill_fn)(const BandArgs);
 band_fill_fn get_band_fill(int sm);
 // K3v2 (banded_fill2.hip): LP lanes per pair, R rows per lane, MatchParams scoring; the last-column
 // epilogue runs in its own kernel.  Returns false if the geometry is not instantiated.
-bool launch_band_fill2(const BandArgs& a, bool narrow, hipStream_t st);
+bool launch_band_fill2(const BandArgs& a, bool narrow, hipStream_t st, hipEvent_t after_fill = nullptr);  // after_fill: recorded between the fill and its epilogue
 uint32_t band_fill2_blocks(uint32_t n_pairs);  // thread blocks launch_band_fill2 starts for n_pairs
 // holds `st` until *counter >= target (or ~20 ms have passed): "the fill kernel's blocks are all resident"
 void launch_band_wait_started(const uint32_t* counter, uint32_t target, hipStream_t st);
