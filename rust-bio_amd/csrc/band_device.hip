@@ -370,18 +370,20 @@ __global__ __launch_bounds__(64) void chain_kernel(const BandDevArgs a) {
     for (uint32_t i = lane; i < nm; i += 64) {
         int32_t c = -1;
         const uint32_t cx = mx[i], cy = my[i];
-        if (cx > 0 && cy > 0) {  // sparse.rs:265-267: binary search for (x - 1, y - 1)
-            uint32_t lo = 0, hi = nm;
+        if (cx > 0 && cy > 0) {
+            // sparse.rs:265-267 looks (x - 1, y - 1) up by binary search.  The matches are sorted by (x, y), so if it
+            // exists it sits among the few matches of x - 1 and x just before this one: walk back over them (one or
+            // two steps on ordinary reads, at most 2 kMaxMatchesPerKmer) instead of eleven dependent probes
             const uint32_t kx = cx - 1, ky = cy - 1;
-            while (lo < hi) {
-                const uint32_t mid = (lo + hi) >> 1;
-                const uint32_t vx = mx[mid], vy = my[mid];
-                if (vx < kx || (vx == kx && vy < ky))
-                    lo = mid + 1;
-                else
-                    hi = mid;
+            for (uint32_t j = i; j-- > 0;) {
+                const uint32_t vx = mx[j];
+                if (vx < kx) break;
+                if (vx == kx) {
+                    const uint32_t vy = my[j];
+                    if (vy == ky) c = (int32_t)j;
+                    if (vy <= ky) break;
+                }
             }
-            if (lo < nm && mx[lo] == kx && my[lo] == ky) c = (int32_t)lo;
         }
         cont[i] = c;
     }
