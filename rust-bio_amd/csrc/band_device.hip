@@ -593,9 +593,10 @@ struct BandCols {
 __device__ __forceinline__ uint32_t ssub(uint32_t p, uint32_t q) { return p > q ? p - q : 0; }
 
 // banded.rs:1111-1120
-__device__ void add_entry(const BandCols& b, uint32_t r, uint32_t c, uint32_t w) {
+// (sub, nsub): the columns of the box are shared by nsub cooperating lanes
+__device__ void add_entry(const BandCols& b, uint32_t r, uint32_t c, uint32_t w, uint32_t sub = 0, uint32_t nsub = 1) {
     const uint32_t lo = ssub(r, w), hi = (uint32_t)min((uint64_t)r + w + 1, (uint64_t)b.rows);
-    for (uint64_t j = max((uint64_t)ssub(c, w), (uint64_t)b.j0), je = min(min((uint64_t)c + w + 1, (uint64_t)b.cols), (uint64_t)b.j1); j < je; j++) {
+    for (uint64_t j = max((uint64_t)ssub(c, w), (uint64_t)b.j0) + sub, je = min(min((uint64_t)c + w + 1, (uint64_t)b.cols), (uint64_t)b.j1); j < je; j += nsub) {
         atomicMin(&b.start[j - b.j0], lo);
         atomicMax(&b.end[j - b.j0], hi);
     }
@@ -633,6 +634,17 @@ __device__ void add_gap(const BandCols& b, uint32_t r0, uint32_t c0, uint32_t r1
         const uint32_t ca = max(c0, ssub(b.j0, w)), cb = (uint32_t)min((uint64_t)c1, (uint64_t)b.j1 + w);
         for (uint64_t c = (uint64_t)ca + tid; c < cb; c += nth)
             add_entry(b, r0 + (r1 - r0) * ((uint32_t)c - c0) / (c1 - c0), (uint32_t)c, w);
+    }
+}
+// add_gap for a group of nsub lanes that share the columns of every entry (gaps between chained matches are a few
+// points long: sharing the points would leave most of the group idle)
+__device__ void add_gap_cols(const BandCols& b, uint32_t r0, uint32_t c0, uint32_t r1, uint32_t c1, uint32_t w, uint32_t sub, uint32_t nsub) {
+    const uint32_t nr = r1 - r0, nc = c1 - c0;
+    if (nr > nc) {
+        for (uint64_t r = r0; r < r1; r++) add_entry(b, (uint32_t)r, c0 + (c1 - c0) * ((uint32_t)r - r0) / (r1 - r0), w, sub, nsub);
+    } else {
+        const uint32_t ca = max(c0, ssub(b.j0, w)), cb = (uint32_t)min((uint64_t)c1, (uint64_t)b.j1 + w);
+        for (uint64_t c = ca; c < cb; c++) add_entry(b, r0 + (r1 - r0) * ((uint32_t)c - c0) / (c1 - c0), (uint32_t)c, w, sub, nsub);
     }
 }
 // banded.rs:1150-1276
@@ -694,10 +706,10 @@ __device__ void set_boundaries(const BandCols& b, uint32_t fx, uint32_t fy, uint
 // Entries (r0 + s, c0 + s), s < len — what a run of diagonal continuations of the match path adds (banded.rs:1352-1357:
 // one add_entry per continuation) — as one lower / raise per column: column j sees the entries max(0, j - w - c0) ..
 // min(len - 1, j + w - c0), its start comes from the first of them, its end from the last.
-__device__ void add_diag_run(const BandCols& b, uint32_t r0, uint32_t c0, uint32_t len, uint32_t w) {
+__device__ void add_diag_run(const BandCols& b, uint32_t r0, uint32_t c0, uint32_t len, uint32_t w, uint32_t sub = 0, uint32_t nsub = 1) {
     const uint64_t jlo = max((uint64_t)ssub(c0, w), (uint64_t)b.j0);
     const uint64_t jhi = min(min((uint64_t)c0 + len + w, (uint64_t)b.cols), (uint64_t)b.j1);
-    for (uint64_t j = jlo; j < jhi; j++) {
+    for (uint64_t j = jlo + sub; j < jhi; j += nsub) {
         const uint64_t s_min = j > (uint64_t)c0 + w ? j - w - c0 : 0, s_max = min((uint64_t)len - 1, j + w - c0);
         atomicMin(&b.start[j - b.j0], ssub((uint32_t)(r0 + s_min), w));
         atomicMax(&b.end[j - b.j0], (uint32_t)min((uint64_t)r0 + s_max + w + 1, (uint64_t)b.rows));
@@ -711,7 +723,8 @@ __global__ __launch_bounds__(256) void band_kernel(const BandDevArgs a) {
     // with anchors and continuations interleaved over the lanes every wavefront walked both code paths at a tenth of
     // its width (7.4 -> 2.x ms per 16 384 pairs).
     __shared__ uint16_t s_anchor[kMaxChainMatches + 2];
-    __shared__ uint32_t s_wtot[4], s_nanchor;
+    __shared__ uint32_t s_wtot[4], s_nanchor, s_lo, s_hi;
+    constexpr uint32_t G = 4;  // lanes per anchor: they share the columns of its gap, its k-mer and its run
     const uint32_t pair = blockIdx.x;
     const BandDevPair* st = a.state + pair;
     if (st->flags != BP_OK) return;
@@ -723,6 +736,9 @@ __global__ __launch_bounds__(256) void band_kernel(const BandDevArgs a) {
     const uint32_t* mx = a.mx + (size_t)pair * a.cap_matches;
     const uint32_t* my = a.my + (size_t)pair * a.cap_matches;
     const uint32_t* path = a.path + (size_t)pair * a.cap_matches;
+    // anchor coordinates, read by every tile pass without going through path[] (the chaining's tree positions are dead)
+    uint32_t* acx = a.qpos + (size_t)pair * a.cap_matches;
+    uint32_t* acy = a.upos + (size_t)pair * a.cap_matches;
     const uint32_t len = st->n_path, k = a.k, w = a.w;
     if (!full) {
         // every thread looks at a contiguous stretch of the path: anchors counted, scanned over the block, written in order
@@ -747,7 +763,11 @@ __global__ __launch_bounds__(256) void band_kernel(const BandDevArgs a) {
         }
         uint32_t o = base + incl - mine;
         for (uint32_t t = t0; t < t1; t++)
-            if (is_anchor(t)) s_anchor[o++] = (uint16_t)t;
+            if (is_anchor(t)) {
+                acx[o] = mx[path[t]];
+                acy[o] = my[path[t]];
+                s_anchor[o++] = (uint16_t)t;
+            }
         if (threadIdx.x == 0) {
             s_anchor[total] = (uint16_t)len;  // end of the last run
             s_nanchor = total;
@@ -767,23 +787,40 @@ __global__ __launch_bounds__(256) void band_kernel(const BandDevArgs a) {
             s_start[j] = full ? 0u : m + 1;  // empty range m+1..0 (banded.rs:1061-1067)
             s_end[j] = full ? m + 1 : 0u;
         }
+        if (threadIdx.x == 0) {
+            s_lo = 0xFFFFFFFFu;
+            s_hi = 0;
+        }
         __syncthreads();
         if (!full) {
             set_boundaries(b, mx[path[0]], my[path[0]], mx[path[len - 1]], my[path[len - 1]], k, w, a, threadIdx.x, blockDim.x);
-            for (uint32_t ai = threadIdx.x; ai < n_anchor; ai += blockDim.x) {  // banded.rs:1352-1365
+            // the anchors whose columns (gap, k-mer, run: [gap start - w, run end + w]) touch the tile are a contiguous
+            // range of the list: every thread tests its share, the range comes out of two LDS atomics
+            for (uint32_t ai = threadIdx.x; ai < n_anchor; ai += blockDim.x) {
                 const uint32_t t = s_anchor[ai], run = (uint32_t)s_anchor[ai + 1] - t - 1;  // continuations behind the anchor
-                const uint32_t cx = mx[path[t]], cy = my[path[t]];
+                const uint32_t cy = acy[ai];
                 if ((uint64_t)cy + k + run + w < j0) continue;  // entirely left of the tile
-                if (t > 0) {
-                    const uint32_t px = mx[path[t - 1]], py = my[path[t - 1]];
-                    if (ssub(py + k - 1, w) >= b.j1) continue;  // entirely right of it
-                    add_gap(b, px + (k - 1), py + (k - 1), cx, cy, w);
-                } else if (ssub(cy, w) >= b.j1) {
-                    continue;
+                // the path element before the anchor: the last continuation of the previous anchor
+                const uint32_t first_col = ai > 0 ? ssub(acy[ai - 1] + ((uint32_t)s_anchor[ai] - (uint32_t)s_anchor[ai - 1] - 1) + k - 1, w) : ssub(cy, w);
+                if (first_col >= b.j1) continue;  // entirely right of it
+                atomicMin(&s_lo, ai);
+                atomicMax(&s_hi, ai + 1);
+            }
+            __syncthreads();
+            const uint32_t a_lo = s_lo, a_hi = s_hi;
+            // banded.rs:1352-1365, G lanes per anchor
+            for (uint32_t ai = a_lo < a_hi ? a_lo + threadIdx.x / G : a_hi; ai < a_hi; ai += blockDim.x / G) {
+                const uint32_t sub = threadIdx.x % G;
+                const uint32_t t = s_anchor[ai], run = (uint32_t)s_anchor[ai + 1] - t - 1;
+                const uint32_t cx = acx[ai], cy = acy[ai];
+                if (ai > 0) {
+                    const uint32_t prun = (uint32_t)s_anchor[ai] - (uint32_t)s_anchor[ai - 1] - 1;
+                    const uint32_t px = acx[ai - 1] + prun, py = acy[ai - 1] + prun;
+                    add_gap_cols(b, px + (k - 1), py + (k - 1), cx, cy, w, sub, G);
                 }
-                add_kmer(b, cx, cy, k, w);
+                add_kmer(b, cx, cy, k, w, sub, G);
                 // continuation s of the anchor is add_entry((cx + s) + k, (cy + s) + k)
-                if (run) add_diag_run(b, cx + k, cy + k, run, w);
+                if (run) add_diag_run(b, cx + k, cy + k, run, w, sub, G);
             }
         }
         __syncthreads();
