@@ -914,19 +914,34 @@ __global__ __launch_bounds__(256) void band_rows_kernel(const BandDevArgs a) {
         }
         __syncthreads();
         uint64_t covered = 0, run = 0;
-        for (uint32_t i0 = 0; i0 <= m; i0 += blockDim.x) {  // tiles of 256 rows
-            const uint32_t i = i0 + threadIdx.x;
-            uint32_t width = 0;
+        if (threadIdx.x == 0) {  // row 0: a closed form, not stored
+            const int2 got = rowc[0];
+            int2 rc = make_int2(1, 0);
+            if ((uint32_t)got.x <= j_last && got.y >= 0 && got.x <= got.y) {
+                rc = got;
+                covered += (uint64_t)(rc.y - rc.x + 1);
+            }
+            rowc[0] = rc;
+            roff[0] = 0;
+        }
+        for (uint32_t q0 = 0; q0 < m; q0 += blockDim.x) {  // tiles of 256 rows 1 + q0 ..: eight-row groups are eight lanes
+            const uint32_t q = q0 + threadIdx.x, i = q + 1;
+            uint32_t groups = 0;
             int2 rc = make_int2(1, 0);
             if (i <= m) {
                 const int2 got = rowc[i];  // {first column whose end exceeds i, last column whose start is at most i}
                 if ((uint32_t)got.x <= j_last && got.y >= 0 && got.x <= got.y) {
                     rc = got;
                     covered += (uint64_t)(rc.y - rc.x + 1);
-                    if (i >= 1) width = ((uint32_t)(rc.y - rc.x + 1) + (kTbRowAlign - 1)) & ~(kTbRowAlign - 1);  // row 0 is not stored
+                    groups = ((uint32_t)(rc.y - rc.x + 1) + (kTbRowAlign - 1)) / kTbRowAlign;
                 }
                 rowc[i] = rc;
             }
+            // the eight rows of a line have as many group slots as the longest of them (banded_kernels.h)
+            groups = max(groups, (uint32_t)__shfl_xor((int)groups, 1));
+            groups = max(groups, (uint32_t)__shfl_xor((int)groups, 2));
+            groups = max(groups, (uint32_t)__shfl_xor((int)groups, 4));
+            const uint32_t width = (threadIdx.x & 7u) == 0 ? groups * kTbGroupStride : 0u;  // the line group's bytes, once
             // exclusive scan of the widths inside the tile: lane shifts inside a wavefront, one barrier for the four
             // wavefront totals (a 256-wide LDS scan is sixteen barriers per tile, forty tiles per 10 kb read)
             uint32_t incl = width;
@@ -942,7 +957,8 @@ __global__ __launch_bounds__(256) void band_rows_kernel(const BandDevArgs a) {
                 if (wv < (threadIdx.x >> 6)) wbase += s_scan[wv];
                 tile_total += s_scan[wv];
             }
-            if (i <= m) roff[i] = (uint32_t)(run + wbase + incl - width);
+            // (incl is the same in the eight lanes of a line group: only its first lane contributes)
+            if (i <= m) roff[i] = (uint32_t)(run + wbase + incl - groups * kTbGroupStride + (q & (kTbLineRows - 1)) * kTbRowAlign);
             run += tile_total;
             __syncthreads();
         }

@@ -75,14 +75,20 @@ void rows_from_columns(const bgband::Band& b, HostPair& hp, int2* rowc, uint32_t
         lim = std::min(lim, b.start[j]);
     }
     uint64_t off = 0, covered = 0;
-    for (uint32_t i = 0; i <= m; i++) {
-        row_off[i] = (uint32_t)off;
-        const int2 rc = rowc[i];
-        if (rc.y >= rc.x) {
-            covered += (uint64_t)(rc.y - rc.x + 1);
-            // row 0 is a closed form, not stored; rows start 16-byte aligned (K3v2 stores complete 16-byte groups)
-            if (i >= 1) off += ((uint64_t)(rc.y - rc.x + 1) + (kTbRowAlign - 1)) & ~(uint64_t)(kTbRowAlign - 1);
+    row_off[0] = 0;  // row 0 is a closed form, not stored
+    if (rowc[0].y >= rowc[0].x) covered += (uint64_t)(rowc[0].y - rowc[0].x + 1);
+    // rows 1..m in line groups of eight: 16-cell groups, the groups of the eight rows interleaved (banded_kernels.h)
+    for (uint32_t q0 = 0; q0 < m; q0 += kTbLineRows) {
+        uint64_t groups = 0;
+        for (uint32_t q = q0; q < std::min(m, q0 + kTbLineRows); q++) {
+            const int2 rc = rowc[q + 1];
+            if (rc.y >= rc.x) {
+                covered += (uint64_t)(rc.y - rc.x + 1);
+                groups = std::max<uint64_t>(groups, ((uint64_t)(rc.y - rc.x + 1) + (kTbRowAlign - 1)) / kTbRowAlign);
+            }
         }
+        for (uint32_t q = q0; q < std::min(m, q0 + kTbLineRows); q++) row_off[q + 1] = (uint32_t)(off + (q - q0) * kTbRowAlign);
+        off += groups * kTbGroupStride;
     }
     hp.tb_bytes = (off + 15) & ~15ull;
     // every row's band columns must form ONE interval (no holes) for the device layout

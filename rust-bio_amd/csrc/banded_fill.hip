@@ -309,7 +309,7 @@ __global__ __launch_bounds__(256) void banded_fill_kernel(const BandArgs a) {
                         {  // four cells per store: single-byte stores cost 6x their size in HBM write traffic
                             const uint32_t cj = (uint32_t)(j - cf[r]);
                             acc[r] = (cj & 3u) ? (acc[r] | (cell << (8 * (cj & 3u)))) : cell;
-                            if ((cj & 3u) == 3u || j == cl[r]) tbr[r][cj >> 2] = acc[r];
+                            if ((cj & 3u) == 3u || j == cl[r]) tbr[r][tb_cell_off(cj & ~3u) >> 2] = acc[r];
                         }
                         if (last_col) {
                             celln[r] = cell;

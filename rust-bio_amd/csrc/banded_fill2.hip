@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256) void banded_fill2_kernel(const BandArgs a) {
                     const int gk = g0 + k;
                     if (gk < g1) {
                         const uint32_t* src = (const uint32_t*)(s_row + r * RING + ((gk * 16) & (RING - 1)));  // 4-byte aligned only
-                        *(uint4*)(tb + trow[r] + (uint32_t)gk * 16u) = make_uint4(src[0], src[1], src[2], src[3]);
+                        *(uint4*)(tb + trow[r] + (uint32_t)gk * kTbGroupStride) = make_uint4(src[0], src[1], src[2], src[3]);
                     }
                 }
             }

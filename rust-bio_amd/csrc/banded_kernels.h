@@ -26,9 +26,16 @@ namespace bgband_dev {
 using namespace bgsw;
 
 enum : uint32_t { BP_OK = 0, BP_TOO_MANY_CELLS = 1, BP_UNSUPPORTED = 2 };
-// every row's traceback bytes start on a 16-byte boundary of the pair's block: K3v2 hands them over in complete
-// 16-byte groups (banded_fill2.hip)
-constexpr uint32_t kTbRowAlign = 16;
+// Traceback bytes of a pair (one per band cell, rows 1..m; row 0 is a closed form): a row's cells cf..cl in groups of
+// 16 — K3v2 hands them over in complete 16-byte groups (banded_fill2.hip) — and the groups of eight consecutive rows
+// interleaved: group g of row i sits at row_off[i] + g * 128, row_off[i] = (base of the rows (i-1)/8*8+1 ..) +
+// ((i-1) % 8) * 16.  A traceback path that runs down a diagonal stays inside one 128-byte line for eight rows (with the
+// rows' bytes back to back it touched a new line on every row: K4 fetched 1.4 MB per 10 kb pair, 23 GB per launch).
+constexpr uint32_t kTbRowAlign = 16;   // cells per group
+constexpr uint32_t kTbLineRows = 8;    // rows whose groups share a line
+constexpr uint32_t kTbGroupStride = kTbRowAlign * kTbLineRows;
+// byte offset of cell c (= j - cf) of a row behind its row_off
+__host__ __device__ inline uint32_t tb_cell_off(uint32_t c) { return (c >> 4) * kTbGroupStride + (c & 15u); }
 
 // One pair of a banded batch (device copy, built on the host)
 struct BandPair {

@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void banded_traceback_kernel(const BandArgs a)
         return rc.y >= rc.x && (int)j >= rc.x && (int)j <= rc.y;
     };
     // K3v2 leaves the I/D flags as its keys carry them (1 = opened): a.tb_flip turns them into 1 = extended
-    auto cellb = [&](uint32_t i, uint32_t j) -> uint32_t { return (uint32_t)tb[roff[i] + j - (uint32_t)rowc[i].x] ^ a.tb_flip; };
+    auto cellb = [&](uint32_t i, uint32_t j) -> uint32_t { return (uint32_t)tb[roff[i] + tb_cell_off(j - (uint32_t)rowc[i].x)] ^ a.tb_flip; };
     // S nibble a cell carried while the matrix was being filled (what "open" I/D moves copied)
     auto s_fill = [&](uint32_t i, uint32_t j) -> uint32_t {
         if (i == 0) {
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void banded_traceback_kernel(const BandArgs a)
                 const uint32_t ii = i - lane, jj = j - lane;
                 const int2 rc = rowc[ii];
                 if (rc.y >= rc.x && (int)jj >= rc.x && (int)jj <= rc.y) {
-                    st = s_nibble_of_code((uint32_t)tb[roff[ii] + jj - (uint32_t)rc.x] & 7u);
+                    st = s_nibble_of_code((uint32_t)tb[roff[ii] + tb_cell_off(jj - (uint32_t)rc.x)] & 7u);
                     ok = st == TB_MATCH || st == TB_SUBST;
                 }
             }
