@@ -8,7 +8,7 @@
 //   * the last-column epilogue (banded.rs:683-723) needs scans over all rows of a pair; it runs afterwards
 //     in banded_epilogue_kernel (one wavefront per pair) from what the fill stored per row.
 //
-//   * traceback bytes (one per band cell, row-major per row: the layout K4 walks) are staged in LDS: every lane owns a
+//   * traceback bytes (one per band cell, 16-cell groups of a row, eight rows to a 128-byte line: banded_kernels.h) are staged in LDS: every lane owns a
 //     ring of RING bytes per row, a cell is one ds_write_b8, and every FLUSH steps — a wave-uniform moment — all lanes
 //     hand the 16-byte groups that have become complete (plus the last, partial group of a finished row) to HBM as
 //     dwordx4 stores.  Every group is written exactly once, whole: WRITE_SIZE = the traceback bytes (+ the padding of
