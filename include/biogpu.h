@@ -61,7 +61,17 @@ int bg_init(int device, bg_ctx** out);
 int bg_free(bg_ctx* ctx);
 const char* bg_strerror(int status);
 const char* bg_last_error(void); /* text of the last HIP failure on this thread */
-/* Tunables (0 keeps the default): pairs per sub-batch of the SW pipeline. */
+/* Tunables (0 keeps the default) and the switches the tests use to reach every kernel variant:
+ *   chunk_pairs        pairs per sub-batch of bg_align_batch_dev (default 2^20) and of the banded pipeline (16384)
+ *   host_chunk_pairs   pairs per stage of bg_align_batch's pipelined host path (131072)
+ *   force_wide = 1     scores kept as plain int32 even where they fit the 24-bit keys of the fast kernels
+ *   no_pk16 = 1        no packed-int16 fill (K1p): the int32 kernel K1 runs for every batch
+ *   no_couples = 1     K1p without the (m, n) slot order on ragged batches
+ *   band_on_host = 1   bands built by the host threads instead of the device builder
+ *   band_fill_v1 = 1   banded fill with one pair per wavefront (K3) even where K3v2 applies
+ *   band_chain_global  chaining tree placement: 0 LDS, 1 global scratch, -1 by batch size (default)
+ *   band_join_global = 1  k-mer join with its table in global memory even where the LDS flavour applies
+ * Unknown keys return BG_ERR_INVALID_ARG. */
 int bg_set_option(bg_ctx* ctx, const char* key, int64_t value);
 
 /* ------------------------------------------------------------------ host table builders
