@@ -206,16 +206,13 @@ void parallel_for(uint64_t n, uint64_t grain, F&& fn) {
         return;
     }
     std::atomic<uint64_t> next{0};
-    std::vector<std::thread> th;
-    for (unsigned t = 0; t < nt; t++)
-        th.emplace_back([&, t] {
-            for (;;) {
-                const uint64_t lo = next.fetch_add(grain);
-                if (lo >= n) break;
-                fn(t, lo, std::min<uint64_t>(n, lo + grain));
-            }
-        });
-    for (auto& t : th) t.join();
+    bg_pool_run(nt, [&](unsigned t) {
+        for (;;) {
+            const uint64_t lo = next.fetch_add(grain);
+            if (lo >= n) break;
+            fn(t, lo, std::min<uint64_t>(n, lo + grain));
+        }
+    });
 }
 
 int check_scoring(const bg_scoring_t* sc) {

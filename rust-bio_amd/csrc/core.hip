@@ -2,6 +2,9 @@
 #include <sched.h>
 
 #include <algorithm>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
 #include <thread>
 
 #include "bg_common.h"
@@ -33,6 +36,61 @@ unsigned bg_host_threads() {
         fclose(f);
     }
     return nt;
+}
+
+namespace {
+struct PoolJob {
+    const std::function<void(unsigned)>* fn;
+    unsigned next = 0, total = 0, done = 0;
+};
+struct Pool {
+    std::mutex mu;
+    std::condition_variable work, finished;
+    std::deque<PoolJob*> jobs;  // jobs that still have indices to hand out
+    bool started = false;
+    void start() {
+        const unsigned nw = std::max(1u, bg_host_threads()) - 1;
+        for (unsigned w = 0; w < nw; w++) std::thread([this] { loop(); }).detach();
+        started = true;
+    }
+    // runs one index of the front job; lk is held on entry and on return
+    void run_one(std::unique_lock<std::mutex>& lk, PoolJob* job) {
+        const unsigned idx = job->next++;
+        if (job->next == job->total) jobs.erase(std::find(jobs.begin(), jobs.end(), job));
+        lk.unlock();
+        (*job->fn)(idx);
+        lk.lock();
+        if (++job->done == job->total) finished.notify_all();
+    }
+    void loop() {
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            work.wait(lk, [this] { return !jobs.empty(); });
+            run_one(lk, jobs.front());
+        }
+    }
+};
+Pool& pool() {
+    static Pool* p = new Pool();  // never destroyed: its detached workers outlive static destruction
+    return *p;
+}
+}  // namespace
+
+void bg_pool_run(unsigned nt, const std::function<void(unsigned)>& fn) {
+    if (nt <= 1) {
+        if (nt) fn(0);
+        return;
+    }
+    Pool& P = pool();
+    PoolJob job;
+    job.fn = &fn;
+    job.total = nt;
+    std::unique_lock<std::mutex> lk(P.mu);
+    if (!P.started) P.start();
+    P.jobs.push_back(&job);
+    P.work.notify_all();
+    while (job.next < job.total) P.run_one(lk, &job);  // the caller works on its own job
+    P.finished.wait(lk, [&] { return job.done == job.total; });
 }
 
 extern "C" int bg_device_count(void) {

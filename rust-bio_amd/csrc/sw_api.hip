@@ -7,6 +7,7 @@
 #include <map>
 #include <type_traits>
 
+#include <atomic>
 #include <condition_variable>
 #include <mutex>
 #include <thread>
@@ -481,9 +482,7 @@ void parallel_for(uint64_t n, uint64_t grain, F&& f) {  // f(begin, end) on the 
         f((uint64_t)0, n);
         return;
     }
-    std::vector<std::thread> th;
-    for (unsigned t = 0; t < nt; t++) th.emplace_back([&, t] { f(n * t / nt, n * (t + 1) / nt); });
-    for (auto& t : th) t.join();
+    bg_pool_run(nt, [&](unsigned t) { f(n * t / nt, n * (t + 1) / nt); });
 }
 void parallel_memcpy(uint8_t* dst, const uint8_t* src, uint64_t n) {
     parallel_for(n, 1 << 20, [&](uint64_t a, uint64_t b) { memcpy(dst + a, src + a, b - a); });
@@ -614,17 +613,23 @@ int align_batch_pipelined(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint64_
         parallel_memcpy(S.h_in, x + x_off[p0], xb);
         parallel_memcpy(S.h_in + o_y, y + y_off[p0], yb);
         uint64_t *hxo = (uint64_t*)(S.h_in + o_xo), *hyo = (uint64_t*)(S.h_in + o_yo);
-        for (uint64_t p = 0; p <= np; p++) {
-            hxo[p] = x_off[p0 + p] - x_off[p0];
-            hyo[p] = y_off[p0 + p] - y_off[p0];
-        }
+        std::atomic<bool> ragged{false};  // the host knows the lengths: no reduction + synchronisation on the device
+        const uint64_t len_x = np ? x_off[p0 + 1] - x_off[p0] : 0, len_y = np ? y_off[p0 + 1] - y_off[p0] : 0;
+        parallel_for(np + 1, 16384, [&](uint64_t a, uint64_t b) {
+            bool rag = false;
+            for (uint64_t p = a; p < b; p++) {
+                hxo[p] = x_off[p0 + p] - x_off[p0];
+                hyo[p] = y_off[p0 + p] - y_off[p0];
+                if (p < np) rag = rag || x_off[p0 + p + 1] - x_off[p0 + p] != len_x || y_off[p0 + p + 1] - y_off[p0 + p] != len_y;
+            }
+            if (rag) ragged = true;
+        });
         bool in_ok = true;
         if (xb) in_ok = in_ok && hipMemcpyAsync(S.d_in, S.h_in, xb, hipMemcpyHostToDevice, P.s_in) == hipSuccess;
         if (yb) in_ok = in_ok && hipMemcpyAsync(S.d_in + o_y, S.h_in + o_y, yb, hipMemcpyHostToDevice, P.s_in) == hipSuccess;
         in_ok = in_ok && hipMemcpyAsync(S.d_in + o_xo, S.h_in + o_xo, 2 * (chunk + 1) * 8, hipMemcpyHostToDevice, P.s_in) == hipSuccess;
         in_ok = in_ok && hipEventRecord(S.in_done, P.s_in) == hipSuccess && hipStreamWaitEvent(s_k, S.in_done, 0) == hipSuccess;
-        bool uniform = true;  // the host knows the lengths: no reduction + synchronisation on the device
-        for (uint64_t p = 1; p < np && uniform; p++) uniform = hxo[p + 1] - hxo[p] == hxo[1] && hyo[p + 1] - hyo[p] == hyo[1];
+        const bool uniform = !ragged;
         rc = !in_ok ? BG_ERR_HIP : align_batch_dev_impl(ctx, sc, mode, np, S.d_in, (const uint64_t*)(S.d_in + o_xo), S.d_in + o_y, (const uint64_t*)(S.d_in + o_yo),
                                   max_x, max_y, (bg_alignment_t*)S.d_out, stride ? S.d_out + o_ops : nullptr, stride, s_k, uniform ? 1 : 0);
         if (rc == BG_OK && (hipEventRecord(S.k_done, s_k) != hipSuccess || hipStreamWaitEvent(P.s_out, S.k_done, 0) != hipSuccess ||
