@@ -1,6 +1,7 @@
 """Long differential fuzz (run by hand on a GPU box: python tests/fuzz_banded.py SEED SECONDS): banded engine
 (device band builder + K3v2/K3 + K4) vs the CPU oracle over random k, w, modes, clips and sequences.
-Round 1: 126 473 pairs in 1817 configurations, 0 mismatches."""
+Round 1: 126 473 pairs in 1817 configurations, 0 mismatches; round 2 (K3v2 chunks, 8-row traceback lines, LDS k-mer
+join, compacted raster): 181 875 pairs in 2624 configurations (seed 20260924, 150 s), 0 mismatches."""
 import sys, time
 import numpy as np
 import os
