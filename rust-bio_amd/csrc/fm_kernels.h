@@ -64,11 +64,11 @@ __device__ __forceinline__ uint32_t block_part(const uint4 v, uint32_t t, uint32
     uint64_t e0 = ~(w0 ^ pat), e1 = ~(w1 ^ pat);
     e0 = e0 & (e0 >> 1) & 0x5555555555555555ull;
     e1 = e1 & (e1 >> 1) & 0x5555555555555555ull;
-    const int t0 = have >= 32 ? 32 : have;
-    const int t1 = have >= 64 ? 32 : (have > 32 ? have - 32 : 0);
-    const uint64_t m0 = t0 == 32 ? ~0ull : ((1ull << (2 * t0)) - 1);
-    const uint64_t m1 = t1 == 32 ? ~0ull : ((1ull << (2 * t1)) - 1);
-    return (uint32_t)(__popcll(e0 & m0) + __popcll(e1 & m1));
+    // matches among the first t0 / t1 symbols of the two halves: the others are shifted out at the top (e has even
+    // bits only; t0 >= 1, t1 may be 0: its shift goes in two halves) instead of being masked off — no select, no
+    // 64-bit subtract
+    const int t0 = min(have, 32), t1 = min(max(have - 32, 0), 32);
+    return (uint32_t)(__popcll(e0 << (64 - 2 * t0)) + __popcll((e1 << (32 - t1)) << (32 - t1)));
 }
 
 // this lane's share of rank1(o) inside one bit-vector block: lane 0 holds the counter and bits 0..95, lane t >= 1
@@ -89,10 +89,9 @@ __device__ __forceinline__ uint32_t bv_part(const uint4 v, uint32_t t, uint32_t 
         if (have <= 0) return 0;
         have = min(have, 128);
     }
-    const int h0 = min(have, 64), h1 = have - h0;
-    const uint64_t m0 = h0 == 64 ? ~0ull : ((1ull << h0) - 1);
-    const uint64_t m1 = h1 >= 64 ? ~0ull : ((1ull << h1) - 1);
-    return acc + (uint32_t)(__popcll(lo & m0) + __popcll(hi & m1));
+    const int h0 = min(have, 64), h1 = have - h0;  // h0 >= 1, 0 <= h1 <= 64: unwanted bits leave at the top
+    const int s1 = 64 - h1, s1a = min(s1, 32);
+    return acc + (uint32_t)(__popcll(lo << (64 - h0)) + __popcll((hi << s1a) << (s1 - s1a)));
 }
 // Occ::get(r, dense symbol d) for the quad: one 64-byte block
 __device__ __forceinline__ uint4 bv_load(const FmDev& fm, uint32_t d, uint32_t r, uint32_t t, uint32_t& o) {
