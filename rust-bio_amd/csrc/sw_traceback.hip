@@ -127,11 +127,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
     uint32_t xstart = 0, ystart = 0, xend = m, yend = n;
     uint32_t layer = s_nib(m, n);
     const uint32_t guard = 2 * (m + n) + 16;
+    // Moves between interior cells (1 <= i, 1 <= j < n, target i', j' >= 1) — nearly all of a path — take one common
+    // sequence instead of the per-move cases below, which a wavefront whose 64 paths are at different moves walks one
+    // after the other: the packed cell of the position is kept from the step that arrived there, the target's cell is
+    // looked up once per step whatever the move (mod.rs:857-877: INS / DEL continue in their layer while the cell says
+    // "extended", everything else continues with the S move of the cell it steps to).
+    uint32_t c_here = 0;
+    bool have_c = false;
     for (uint32_t steps = 0; layer != TB_START; steps++) {
         if (steps > guard || (ops_end && n_ops + 1 > a.ops_stride)) {
             status = BG_ERR_TRACEBACK;
             break;
         }
+        if (layer >= TB_INS && layer <= TB_MATCH && i >= 1 && i <= m && j >= 1 && j < n) {
+            const bool is_ins = layer == TB_INS, is_del = layer == TB_DEL;
+            const uint32_t ti = i - (is_del ? 0u : 1u), tj = j - (is_ins ? 0u : 1u);
+            if (ti >= 1 && tj >= 1) {
+                if (!have_c && (is_ins || is_del)) c_here = cell(i, j);
+                const bool ext = (is_ins && (c_here & 8u)) || (is_del && (c_here & 16u));
+                push(is_ins ? (uint32_t)BG_OP_INS : is_del ? (uint32_t)BG_OP_DEL : layer == TB_MATCH ? (uint32_t)BG_OP_MATCH : (uint32_t)BG_OP_SUBST);
+                c_here = cell(ti, tj);
+                have_c = true;
+                if (!ext) layer = s_nibble_of_code(c_here & 7u);
+                i = ti;
+                j = tj;
+                continue;
+            }
+        }
+        have_c = false;
         uint32_t next;
         switch (layer) {
             case TB_INS:
