@@ -13,10 +13,14 @@ One "step" = one pass of the hot path over one batch of synthetic input that is 
   * `fm`: BASELINE configs[2] — FMIndex over a 100 Mbp synthetic genome, 10 M x 100 bp backward_search per GPU
     (weak), and `fm.strong`: the same 10 M queries in total split over the ranks (strong), both with the single
     all-gather of the result records inside the timed step;
-  * `fm_big`: the same searches on a 1 Gbp index (333 MB of rank blocks: beyond the 256 MiB Infinity Cache);
-  * `seed_extend` (configs[4]): reads vs that 1 Gbp genome through bg_seed_extend_batch_dev (3 Gbp: --fm-big-genome);
-  * `k1_int32`: the general int32 kernel (BLOSUM62 protein pairs; DNA with scores beyond 12 bits);
-  * `banded` (configs[3] shape), `ingest` (FASTQ text -> records).
+  * `value_int32` / `int32`: the headline workload, same pairs, through the int32 kernel K1 (the reference's width);
+  * `fm_big`: the same searches on the 3 Gbp index of configs[4] (1 GB of rank blocks: four times the Infinity Cache);
+  * `seed_extend` (configs[4]): 1.25 M reads per GPU vs that 3 Gbp genome through bg_seed_extend_batch_dev (weak), and
+    `seed_extend.strong`: 10 M reads in total split over the ranks, record all-gather inside the step;
+  * `banded` (configs[3]): 100 000 x 10 kb pairs per GPU, banded::Aligner::semiglobal (weak), `banded.strong`: the 100 000
+    pairs in total split over the ranks; oracle parity on >= 1 % of the pairs (records + every operation);
+  * `k1_int32`: the general int32 kernel at 1 M pairs (BLOSUM62 protein pairs; DNA with scores beyond 12 bits);
+  * `ingest` (FASTQ text -> records).
 Units (pairs / queries / reads) shard across ranks; every rank builds its own replica of the index on its GPU
 (suffix array, BWT and SA samples on the device).  Rank 0 prints ONE JSON line.  The CPU legs (oracle parity over the whole workload +
 `cpu_baseline`, median of 3) run on rank 0 of the single-GPU run only.
@@ -29,7 +33,7 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-for p in (ROOT, os.path.join(ROOT, "oracle")):
+for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tools")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
@@ -49,18 +53,22 @@ def parse_args():
     ap.add_argument("--queries", type=int, default=10_000_000, help="FM leg: patterns per GPU (configs[2]: 10M)")
     ap.add_argument("--pattern-len", type=int, default=100)
     ap.add_argument("--skip-fm", action="store_true")
-    ap.add_argument("--fm-big-genome", type=int, default=1_000_000_000,
-                    help="genome of the second FM leg and of the seed-and-extend leg: an index that cannot sit in the 256 MiB "
-                         "Infinity Cache (1 Gbp: 333 MB of rank blocks; configs[4] names 3000000000); 0: skip, seed-and-extend "
-                         "then runs on --genome")
+    ap.add_argument("--fm-big-genome", type=int, default=3_000_000_000,
+                    help="genome of the second FM leg and of the seed-and-extend leg (BASELINE configs[4]: 3 Gbp; 1 GB of rank "
+                         "blocks, four times the 256 MiB Infinity Cache); 0: skip, seed-and-extend then runs on --genome")
     ap.add_argument("--host-sa", action="store_true", help="build suffix arrays with the host SA-IS instead of the device builder")
     ap.add_argument("--skip-k1", action="store_true")
-    ap.add_argument("--k1-pairs", type=int, default=262_144, help="int32-kernel legs: pairs per GPU")
+    ap.add_argument("--k1-pairs", type=int, default=1_000_000, help="int32-kernel legs: pairs per GPU (configs[1]'s 1M)")
     ap.add_argument("--skip-banded", action="store_true")
-    ap.add_argument("--banded-pairs", type=int, default=32768, help="banded leg: 10 kb pairs per GPU (configs[3] is 100k over 8 GPUs)")
+    ap.add_argument("--banded-pairs", type=int, default=100_000,
+                    help="banded leg: 10 kb pairs per GPU, and in total for banded.strong (configs[3]: 100k, split over the GPUs)")
+    ap.add_argument("--banded-parity-pairs", type=int, default=1024, help="banded leg: pairs compared with the oracle (>= 1 %)")
     ap.add_argument("--banded-chunk", type=int, default=0, help="banded leg: pairs per sub-batch (0 = the library's default)")
     ap.add_argument("--skip-pipeline", action="store_true")
-    ap.add_argument("--pipeline-reads", type=int, default=1_000_000, help="seed-and-extend leg: reads per GPU")
+    ap.add_argument("--pipeline-reads", type=int, default=1_250_000,
+                    help="seed-and-extend leg: reads per GPU (configs[4]: 10 M reads over 8 GPUs = 1.25 M each)")
+    ap.add_argument("--pipeline-reads-total", type=int, default=10_000_000,
+                    help="seed_extend.strong: reads in total, split over the GPUs (configs[4]: 10 M); 0: skip")
     ap.add_argument("--skip-ingest", action="store_true")
     ap.add_argument("--ingest-reads", type=int, default=1_000_000, help="FASTQ ingest leg: four-line records per GPU")
     ap.add_argument("--skip-cpu", action="store_true", help="no oracle parity / cpu_baseline legs")
@@ -109,10 +117,22 @@ def host_cores():
     return n
 
 
+_CSRC_SHA = None
+
+
 def _newest_profile(pattern):
+    """newest committed counter summary — only if it was collected with the kernel sources that run now (the files carry
+    tools/csrc_hash.py's hash of rust-bio_amd/csrc): counters of edited kernels are reported as null, not as stale numbers"""
     import glob
+    global _CSRC_SHA
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
-    return json.load(open(files[-1])) if files else None
+    if not files:
+        return None
+    d = json.load(open(files[-1]))
+    if _CSRC_SHA is None:
+        from csrc_hash import csrc_sha
+        _CSRC_SHA = csrc_sha(ROOT)
+    return d if d.get("csrc_sha") == _CSRC_SHA else None
 
 
 def pmc_traffic(kernel, shape_key, shape_val):
@@ -321,6 +341,39 @@ def main():
               "roofline": roofline}
     if host_api:
         result["host_api"] = host_api
+    # the same workload at the reference's arithmetic width: K1 (int32 recurrence) on the very same pairs
+    if not args.skip_k1:
+        ctx.set_option("no_pk16", 1)
+        d_out32, d_ops32 = torch.empty_like(d_out), torch.empty_like(d_ops)
+
+        def sw32_step():
+            aligner.align_dev(3, n_pairs, x.data_ptr(), xo.data_ptr(), y.data_ptr(), yo.data_ptr(),
+                              L, L, d_out32.data_ptr(), d_ops32.data_ptr(), stride, stream)
+
+        t32 = timed_steps(sw32_step, args.steps, args.warmup, dev)
+        tm32 = kernel_timing(ctx, sw32_step)
+        ctx.set_option("no_pk16", 0)
+        # every record byte and every operation byte equal to the int16 run (which the oracle pass above covers pair by pair)
+        same = bool(torch.equal(d_out, d_out32))
+        kq = rec[:, 7].to(torch.int64)
+        for c0 in range(0, n_pairs, 1 << 18):
+            k = min(1 << 18, n_pairs - c0)
+            m = torch.arange(stride, device=dev)[None, :] >= (stride - kq[c0:c0 + k])[:, None]
+            same = same and bool((d_ops.view(n_pairs, stride)[c0:c0 + k][m] == d_ops32.view(n_pairs, stride)[c0:c0 + k][m]).all())
+        f32 = tm32["fill_ms"] / max(1, tm32["fill_launches"])
+        result["value_int32"] = round(world * float(n_pairs) * L * L * args.steps / t32 / 1e9, 3)
+        result["int32"] = {"value": result["value_int32"], "unit": "GCUPS", "dtype": "int32",
+                           "ms_per_step": round(t32 / args.steps * 1e3, 3),
+                           "config": {"workload": "the headline workload (same pairs, same scoring) through K1, the int32 kernel: "
+                                                  "ctx option no_pk16 = 1"},
+                           "records_and_ops_equal_int16_run": same,
+                           "roofline": sw_roofline("sw_fill_kernel<10, 16, 0, true, true>", f32,
+                                                   tm32["traceback_ms"] / max(1, tm32["traceback_launches"]),
+                                                   n_pairs / (tm32["fill_launches"] / 2), L, n_ops_mean,
+                                                   "K1 (int32): VALU-bound", shape_key="k1_pairs_per_launch")}
+        if parity is not None:
+            parity["sw_int32_equals_int16_all_pairs"] = same
+        del d_out32, d_ops32
     del x, y, d_ops, d_out
     torch.cuda.empty_cache()
 
@@ -445,7 +498,7 @@ def build_index(args, ctx, dev, n_genome, seed, want_sa, want_host):
             g = g_dev.cpu().numpy()
             b = d_b.cpu().numpy()
             if want_sa:
-                sa = d_sa.cpu().numpy().view(np.uint32).astype(np.uint64)
+                sa = d_sa.cpu().numpy().view(np.uint32)  # the oracle walks it as it is (orc_seed_extend_batch_sa32)
         fm._d_bwt = None
         del d_sa, d_b
     ssa.attach(fm)
@@ -684,27 +737,75 @@ def seed_extend_leg(args, ctx, dev, stream, rank, world, do_cpu, orc, threads, p
                         "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
                         "alg_bytes_per_read": round(alg / Rp, 1),
                         "note": "dominated by the candidates' semiglobal fill (VALU-bound like the headline kernel)"}}
+    # strong scaling on configs[4]: the SAME reads in total (10 M), split over the ranks, one all-gather of 24-byte
+    # records {score, ref_start, ref_end} inside the step; the index is a replica on every GPU
+    Rt = args.pipeline_reads_total
+    if Rt:
+        s_steps, s_warm = max(2, args.steps // 4), 1
+        r_lo, r_hi = shard.partition(Rt, rank, world)
+        my = r_hi - r_lo
+        counts = [shard.partition(Rt, r, world)[1] - shard.partition(Rt, r, world)[0] for r in range(world)]
+        # every rank draws the global read set from rank 0's seed (chunked generator) and keeps its contiguous share
+        g_reads, _ = synth_gpu.reads_from_genome(g_dev, Rt, L, seed=5)
+        s_reads = g_reads[r_lo * L:r_hi * L].contiguous() if world > 1 else g_reads
+        s_roff = torch.arange(my + 1, dtype=torch.int64, device=dev) * L
+        s_hits = torch.empty(max(my, 1) * 96, dtype=torch.uint8, device=dev)
+        s_ops = torch.empty(max(my, 1) * stride, dtype=torch.uint8, device=dev)  # same work as the weak leg: operations included
+        holder = {}
+
+        def strong_step():
+            seed_extend_dev(fm, sc, my, s_reads.data_ptr(), s_roff.data_ptr(), L, s_hits.data_ptr(), s_ops.data_ptr(), stride, prm, stream, None)
+            h64 = s_hits.view(torch.int64).view(-1, 12)[:my]
+            holder["all"] = shard.gather_records(torch.stack((h64[:, 0] & 0xFFFFFFFF, h64[:, 9], h64[:, 10]), dim=1), counts=counts)
+
+        st_t = timed_steps(strong_step, s_steps, s_warm, dev)
+        leg["strong"] = {"value": round(float(Rt) * s_steps / st_t, 1), "unit": "reads/s", "scaling": "strong",
+                         "ms_per_step": round(st_t / s_steps * 1e3, 3), "steps": s_steps, "reads_total": Rt, "reads_per_gpu": my,
+                         "collective": "one all-gather of 24-byte records per step (RCCL)" if world > 1 else "none (1 GPU)",
+                         "gathered_records": int(holder["all"].shape[0]),
+                         "note": "records only (score + reference span); the winners' operations stay on the rank that "
+                                 "computed them (INTEGRATION.md section 3)"}
+        if world > 1:  # the gathered records of the sharded run must be the unsharded answer
+            f_roff = torch.arange(Rt + 1, dtype=torch.int64, device=dev) * L
+            f_hits = torch.empty(Rt * 96, dtype=torch.uint8, device=dev)
+            seed_extend_dev(fm, sc, Rt, g_reads.data_ptr(), f_roff.data_ptr(), L, f_hits.data_ptr(), 0, 0, prm, stream, None)
+            f64 = f_hits.view(torch.int64).view(Rt, 12)
+            full = torch.stack((f64[:, 0] & 0xFFFFFFFF, f64[:, 9], f64[:, 10]), dim=1)
+            leg["strong"]["sharded_equals_unsharded"] = bool((full == holder["all"]).all().item())
+            del f_roff, f_hits, f64, full
+        del g_reads, s_reads, s_roff, s_hits, s_ops, holder
+        torch.cuda.empty_cache()
     if do_cpu:
         occ = orc.Occ(b, 128, N_ALPHABET)
         osc = orc.make_scoring(-5, -1, 1, -1)
-        n_chk = max(1, int(min(Rp, 100_000) * args.parity_frac))
+        n_chk = max(2, int(min(Rp, 100_000) * args.parity_frac))
+        # the first and the LAST reads of the batch: the call walks the reads in passes of 2^20, the tail belongs to the last pass
+        segs = [(0, n_chk // 2), (Rp - (n_chk - n_chk // 2), n_chk - n_chk // 2)]
+        hv64 = d_hits.view(torch.int64).view(Rp, 12)
+        # every read's operations end at the end of its own slot of the caller's buffer (biogpu.h)
+        ok = bool((hv64[:, 4] == (torch.arange(Rp, device=dev) + 1) * stride - hv[:, 7].to(torch.int64)).all().item())
+        t_par = 0.0
+        for r0, k in segs:
+            hr = reads[r0 * L:(r0 + k) * L].cpu().numpy()
+            ho = np.arange(k + 1, dtype=np.uint64) * np.uint64(L)
+            t0 = time.perf_counter()
+            ohits, oops, ostride = orc.seed_extend_batch(b, ls, occ, sa, g, n_genome, osc, hr, ho, threads=threads)
+            t_par += time.perf_counter() - t0
+            hits = d_hits[r0 * 96:(r0 + k) * 96].cpu().numpy().view(_lib.SEED_HIT_DTYPE)
+            ok = ok and all((hits[f] == ohits[f]).all() for f in ("n_candidates", "n_seed_hits", "window_start", "ref_start", "ref_end"))
+            ok = ok and all((hits["aln"][f].astype(np.int64) == ohits["aln"][f].astype(np.int64)).all()
+                            for f in ("score", "xstart", "xend", "ystart", "yend", "n_ops"))
+            if ok:  # the winners' operations (right-aligned in their slot)
+                hops = d_ops[r0 * stride:(r0 + k) * stride].cpu().numpy().reshape(k, stride)
+                kq = hits["aln"]["n_ops"].astype(np.int64)
+                dev_mask = np.arange(stride)[None, :] >= (stride - kq)[:, None]
+                or_mask = np.arange(ostride)[None, :] < kq[:, None]
+                kind = (oops.reshape(k, ostride) & np.uint64(0xFF)).astype(np.uint8)
+                ok = bool((hops[dev_mask] == kind[or_mask]).all())
+        parity.update({"seed_extend_reads_checked": n_chk, "seed_extend_reads_total": Rp, "seed_extend_bit_exact": bool(ok),
+                       "seed_extend_sample": "first and last n/2 reads (the last pass of 2^20 included) + ops_off of every read"})
         hr = reads[:n_chk * L].cpu().numpy()
         ho = np.arange(n_chk + 1, dtype=np.uint64) * np.uint64(L)
-        t0 = time.perf_counter()
-        ohits, oops, ostride = orc.seed_extend_batch(b, ls, occ, sa, g, n_genome, osc, hr, ho, threads=threads)
-        t_par = time.perf_counter() - t0
-        hits = d_hits[:n_chk * 96].cpu().numpy().view(_lib.SEED_HIT_DTYPE)
-        ok = all((hits[f] == ohits[f]).all() for f in ("n_candidates", "n_seed_hits", "window_start", "ref_start", "ref_end"))
-        ok = ok and all((hits["aln"][f].astype(np.int64) == ohits["aln"][f].astype(np.int64)).all()
-                        for f in ("score", "xstart", "xend", "ystart", "yend", "n_ops"))
-        if ok:  # the winners' operations (right-aligned in their slot)
-            hops = d_ops[:n_chk * stride].cpu().numpy().reshape(n_chk, stride)
-            kq = hits["aln"]["n_ops"].astype(np.int64)
-            dev_mask = np.arange(stride)[None, :] >= (stride - kq)[:, None]
-            or_mask = np.arange(ostride)[None, :] < kq[:, None]
-            kind = (oops.reshape(n_chk, ostride) & np.uint64(0xFF)).astype(np.uint8)
-            ok = bool((hops[dev_mask] == kind[or_mask]).all())
-        parity.update({"seed_extend_reads_checked": n_chk, "seed_extend_reads_total": Rp, "seed_extend_bit_exact": bool(ok)})
         ns = min(n_chk, 2_000 * threads)
         t_all = median_time(lambda: orc.seed_extend_batch(b, ls, occ, sa, g, n_genome, osc, hr[:ns * L], ho[:ns + 1],
                                                           threads=threads, want_ops=False))
@@ -713,6 +814,10 @@ def seed_extend_leg(args, ctx, dev, stream, rank, world, do_cpu, orc, threads, p
                                          "backward_search, Interval::occ (raw suffix array) and Aligner::semiglobal (oracle/pipeline.cpp)",
                                "full_parity_pass_value": round(n_chk / t_par, 1)}
     return leg
+
+
+def bcells_of(bal):
+    return float(bal.last_cells.sum())
 
 
 def banded_leg(args, ctx, dev, rank, world, do_cpu, orc, threads, parity):
@@ -747,6 +852,44 @@ def banded_leg(args, ctx, dev, rank, world, do_cpu, orc, threads, parity):
     torch.cuda.synchronize()
     bt_dev = shard.max_over_ranks(time.perf_counter() - t0, dev)
     dev_ok = bool((d_bout.view(torch.int32).view(Pb, 16)[:, 0].cpu().numpy() == bout["score"]).all())
+    # strong scaling on configs[3]: the SAME Pb pairs in total (100 k), split over the ranks, one all-gather of the
+    # 20-byte records {score, xstart, xend, ystart, yend} inside the step.  With one GPU the split is the whole batch:
+    # the device-resident run above is that measurement.
+    strong = {"value": round(bcells_of(bal) / bt_dev / 1e9, 3), "unit": "GCUPS (band cells)", "scaling": "strong",
+              "pairs_total": Pb, "pairs_per_gpu": Pb, "pairs_per_s": round(Pb / bt_dev, 1), "collective": "none (1 GPU)",
+              "note": "1 GPU: the same run as device_resident"}
+    if world > 1:
+        gx, _, gy, _ = (bx, None, by, None) if rank == 0 else synth_gpu.sw_pairs_big(Pb, Lb, seed=4, device=dev, sub=0.06, ins=0.02,
+                                                                                     dele=0.02, chunk=64)[:4]
+        p_lo, p_hi = shard.partition(Pb, rank, world)
+        my = p_hi - p_lo
+        counts = [shard.partition(Pb, r, world)[1] - shard.partition(Pb, r, world)[0] for r in range(world)]
+        sx, sy = gx[p_lo * Lb:p_hi * Lb].contiguous(), gy[p_lo * Lb:p_hi * Lb].contiguous()
+        holder = {}
+
+        def strong_step():
+            holder["cells"] = bal.align_dev(2, my, sx.data_ptr(), d_boff.data_ptr(), sy.data_ptr(), d_boff.data_ptr(),
+                                            d_bout.data_ptr(), d_bops.data_ptr(), bstride, want_cells=True)
+            holder["all"] = shard.gather_records(d_bout.view(torch.int32).view(Pb, 16)[:my, :5].contiguous(), counts=counts)
+
+        strong_step()
+        my_cells = torch.tensor([float(holder["cells"].sum())], dtype=torch.float64, device=dev)
+        tot_cells = float(shard.gather_records(my_cells.view(1, 1)).sum().item())
+        shard.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        strong_step()
+        torch.cuda.synchronize()
+        st_t = shard.max_over_ranks(time.perf_counter() - t0, dev)
+        sharded = holder["all"].clone()
+        bal.align_dev(2, Pb, gx.data_ptr(), d_boff.data_ptr(), gy.data_ptr(), d_boff.data_ptr(), d_bout.data_ptr(),
+                      d_bops.data_ptr(), bstride)
+        torch.cuda.synchronize()
+        strong = {"value": round(tot_cells / st_t / 1e9, 3), "unit": "GCUPS (band cells)", "scaling": "strong",
+                  "pairs_total": Pb, "pairs_per_gpu": my, "pairs_per_s": round(Pb / st_t, 1),
+                  "collective": "one all-gather of 20-byte records per step (RCCL)",
+                  "sharded_equals_unsharded": bool((sharded == d_bout.view(torch.int32).view(Pb, 16)[:, :5]).all().item())}
+        del gx, gy, sx, sy
     del d_bout, d_bops, bx, by
     # kernel durations from a second, event-timed pass (timing serialises the K3/K4/host pipeline)
     ctx.enable_timing(True)
@@ -765,8 +908,9 @@ def banded_leg(args, ctx, dev, rank, world, do_cpu, orc, threads, parity):
               "device_resident": {"value": round(world * bcells / bt_dev / 1e9, 3), "unit": "GCUPS (band cells)",
                                   "pairs_per_s": round(world * Pb / bt_dev, 1), "scores_equal_host_api": dev_ok},
               "config": {"workload": f"{Pb} x 10 kb read pairs per GPU (6% sub, 2% ins, 2% del), banded::Aligner::"
-                                     f"semiglobal, k-mer {kb}, w {wb} (BASELINE configs[3] shape)",
+                                     f"semiglobal, k-mer {kb}, w {wb} (BASELINE configs[3]: 100k x 10 kb)",
                          "mean_band_cells": round(bcells / Pb, 1)},
+              "strong": strong,
               "kernel_ms": {"fill": round(tm["fill_ms"], 2), "traceback": round(tm["traceback_ms"], 2)},
               "dp_only_gcups": round(bcells / ((tm["fill_ms"] + tm["traceback_ms"]) * 1e-3) / 1e9, 2),
               "host_threads": host_cores(),
@@ -778,7 +922,7 @@ def banded_leg(args, ctx, dev, rank, world, do_cpu, orc, threads, parity):
                            "alg_bytes_per_pair": round(balg / Pb, 1)},
               "pairs_per_launch": Pb_launch}
     if do_cpu:
-        nsb = min(Pb, max(8, int(512 * args.parity_frac)))  # >= 1 % of the 32 768 pairs
+        nsb = min(Pb, max(8, int(args.banded_parity_pairs * args.parity_frac)))  # >= 1 % of the 100 000 pairs
         osc = orc.make_scoring(-5, -1, 1, -1)
         t0 = time.perf_counter()
         oout, oops, ostride, ocells = orc.banded_align_batch(osc, "semiglobal", kb, wb, hx[:nsb * Lb], hoff[:nsb + 1],

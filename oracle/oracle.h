@@ -175,6 +175,12 @@ int orc_seed_extend_batch(const uint8_t* bwt, uint64_t n, const uint64_t* less, 
                           const orc_scoring_t* sc, uint64_t n_reads, const uint8_t* reads,
                           const uint64_t* read_off, uint32_t seed_len, uint32_t stride, uint32_t max_occ,
                           uint32_t pad, orc_seed_hit_t* out, uint64_t* ops, uint64_t ops_stride, int threads);
+/* the same with a 32-bit suffix array (texts below 2^32 symbols: half the host memory) */
+int orc_seed_extend_batch_sa32(const uint8_t* bwt, uint64_t n, const uint64_t* less, uint64_t less_len,
+                               const orc_occ* occ, const uint32_t* sa, const uint8_t* text, uint64_t n_text,
+                               const orc_scoring_t* sc, uint64_t n_reads, const uint8_t* reads,
+                               const uint64_t* read_off, uint32_t seed_len, uint32_t stride, uint32_t max_occ,
+                               uint32_t pad, orc_seed_hit_t* out, uint64_t* ops, uint64_t ops_stride, int threads);
 
 #ifdef __cplusplus
 }

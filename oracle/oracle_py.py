@@ -128,6 +128,10 @@ def lib():
              [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
               C.POINTER(Scoring), C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
               C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]),
+            ("orc_seed_extend_batch_sa32", C.c_int,
+             [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
+              C.POINTER(Scoring), C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+              C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]),
             ("orc_pretty", C.c_int64, [C.POINTER(AlignmentRec), C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
                                        C.c_uint64, C.c_void_p, C.c_uint64]),
             ("orc_cigar", C.c_int64, [C.POINTER(AlignmentRec), C.c_void_p, C.c_int, C.c_void_p, C.c_uint64]),
@@ -587,7 +591,8 @@ def seed_extend_batch(bwt_arr, less_arr, occ, sa, text, n_text, scoring, reads, 
     sc = scoring[0] if isinstance(scoring, tuple) else scoring
     b, tx, rd = _buf(bwt_arr), _buf(text), _buf(reads)
     ls = np.ascontiguousarray(less_arr, dtype=np.uint64)
-    sa = np.ascontiguousarray(sa, dtype=np.uint64)
+    sa32 = getattr(sa, "dtype", None) == np.uint32  # a suffix array downloaded from the device: not widened
+    sa = np.ascontiguousarray(sa, dtype=np.uint32 if sa32 else np.uint64)
     off = np.ascontiguousarray(read_off, dtype=np.uint64)
     n = len(off) - 1
     out = np.zeros(n, dtype=SEED_HIT_DTYPE)
@@ -597,10 +602,10 @@ def seed_extend_batch(bwt_arr, less_arr, occ, sa, text, n_text, scoring, reads, 
     if want_ops and n:
         stride_ops = 2 * int(np.diff(off).max()) + 2 * pad + 8
         ops = np.zeros(n * stride_ops, dtype=np.uint64)
-    rc = lib().orc_seed_extend_batch(b.ctypes.data, len(b), ls.ctypes.data, len(ls), occ.h, sa.ctypes.data,
-                                     tx.ctypes.data, n_text, C.byref(sc), n, rd.ctypes.data, off.ctypes.data,
-                                     seed_len, stride, max_occ, pad, out.ctypes.data,
-                                     ops.ctypes.data if ops is not None else None, stride_ops, threads)
+    fn = lib().orc_seed_extend_batch_sa32 if sa32 else lib().orc_seed_extend_batch
+    rc = fn(b.ctypes.data, len(b), ls.ctypes.data, len(ls), occ.h, sa.ctypes.data, tx.ctypes.data, n_text, C.byref(sc), n,
+            rd.ctypes.data, off.ctypes.data, seed_len, stride, max_occ, pad, out.ctypes.data,
+            ops.ctypes.data if ops is not None else None, stride_ops, threads)
     if rc:
         raise RuntimeError(f"oracle seed_extend_batch failed rc={rc}")
     return out, ops, stride_ops

@@ -23,12 +23,15 @@
 #include "oracle.h"
 #include "pairwise_impl.h"
 
-extern "C" int orc_seed_extend_batch(const uint8_t* bwt, uint64_t n, const uint64_t* less, uint64_t less_len,
-                                     const orc_occ* occ, const uint64_t* sa, const uint8_t* text, uint64_t n_text,
-                                     const orc_scoring_t* sc, uint64_t n_reads, const uint8_t* reads,
-                                     const uint64_t* read_off, uint32_t seed_len, uint32_t stride, uint32_t max_occ,
-                                     uint32_t pad, orc_seed_hit_t* out, uint64_t* ops, uint64_t ops_stride,
-                                     int threads) {
+// SaT: the suffix array's element type (uint64_t as `RawSuffixArray = Vec<usize>`, or uint32_t so that a 3 Gbp
+// array downloaded from the device need not be widened to 24 GB of host memory)
+template <typename SaT>
+static int seed_extend_impl(const uint8_t* bwt, uint64_t n, const uint64_t* less, uint64_t less_len,
+                            const orc_occ* occ, const SaT* sa, const uint8_t* text, uint64_t n_text,
+                            const orc_scoring_t* sc, uint64_t n_reads, const uint8_t* reads,
+                            const uint64_t* read_off, uint32_t seed_len, uint32_t stride, uint32_t max_occ,
+                            uint32_t pad, orc_seed_hit_t* out, uint64_t* ops, uint64_t ops_stride,
+                            int threads) {
     if (threads < 1) threads = 1;
     std::vector<int> rc(threads, 0);
     auto work = [&](int t) {
@@ -95,4 +98,24 @@ extern "C" int orc_seed_extend_batch(const uint8_t* bwt, uint64_t n, const uint6
     for (int r : rc)
         if (r) return r;
     return 0;
+}
+
+extern "C" int orc_seed_extend_batch(const uint8_t* bwt, uint64_t n, const uint64_t* less, uint64_t less_len,
+                                     const orc_occ* occ, const uint64_t* sa, const uint8_t* text, uint64_t n_text,
+                                     const orc_scoring_t* sc, uint64_t n_reads, const uint8_t* reads,
+                                     const uint64_t* read_off, uint32_t seed_len, uint32_t stride, uint32_t max_occ,
+                                     uint32_t pad, orc_seed_hit_t* out, uint64_t* ops, uint64_t ops_stride,
+                                     int threads) {
+    return seed_extend_impl<uint64_t>(bwt, n, less, less_len, occ, sa, text, n_text, sc, n_reads, reads, read_off, seed_len, stride,
+                                      max_occ, pad, out, ops, ops_stride, threads);
+}
+
+extern "C" int orc_seed_extend_batch_sa32(const uint8_t* bwt, uint64_t n, const uint64_t* less, uint64_t less_len,
+                                          const orc_occ* occ, const uint32_t* sa, const uint8_t* text, uint64_t n_text,
+                                          const orc_scoring_t* sc, uint64_t n_reads, const uint8_t* reads,
+                                          const uint64_t* read_off, uint32_t seed_len, uint32_t stride, uint32_t max_occ,
+                                          uint32_t pad, orc_seed_hit_t* out, uint64_t* ops, uint64_t ops_stride,
+                                          int threads) {
+    return seed_extend_impl<uint32_t>(bwt, n, less, less_len, occ, sa, text, n_text, sc, n_reads, reads, read_off, seed_len, stride,
+                                      max_occ, pad, out, ops, ops_stride, threads);
 }

@@ -51,6 +51,7 @@ struct bg_ctx {
     bg_seed_scratch* seed = nullptr;  // persistent scratch of the seed-and-extend pipeline
     int64_t host_chunk_pairs = 0;     // pairs per pipeline stage of bg_align_batch (0 = default)
     int64_t chunk_pairs = 0;  // 0 = default
+    int64_t seed_chunk_reads = 0;  // reads per pass of bg_seed_extend_batch_dev (0 = 2^20)
     bool force_wide = false;  // tests: disable the NARROW (28-bit key) kernels
     bool no_pk16 = false;     // tests: disable K1p (two pairs per lane in packed int16 halves)
     bool no_couples = false;  // tests: K1p without the (m, n) slot order on ragged batches

@@ -172,6 +172,10 @@ extern "C" int bg_set_option(bg_ctx* ctx, const char* key, int64_t value) {
         ctx->chunk_pairs = value;
         return BG_OK;
     }
+    if (!strcmp(key, "seed_chunk_reads")) {
+        ctx->seed_chunk_reads = value;
+        return BG_OK;
+    }
     if (!strcmp(key, "band_join_global")) {
         ctx->band_join_global = value != 0;
         return BG_OK;

@@ -180,7 +180,10 @@ __global__ __launch_bounds__(64) void se_gather_kernel(SeedPrm prm, uint64_t n_r
 }
 
 // S7: 16 lanes per read: best candidate (highest score, first = smallest start among equals), record + operations
-__global__ __launch_bounds__(256) void se_best_kernel(uint64_t n_reads, const uint64_t* __restrict__ coff, const uint32_t* __restrict__ n_hits,
+// `hits` / `ops` are the caller's whole arrays, `r0` the first read of this pass: read r0 + r of the call owns
+// ops[(r0 + r) * ops_stride, (r0 + r + 1) * ops_stride) and its ops_off is relative to the caller's `ops`
+__global__ __launch_bounds__(256) void se_best_kernel(uint64_t n_reads, uint64_t r0, const uint64_t* __restrict__ coff,
+                                                      const uint32_t* __restrict__ n_hits,
                                                       const bg_alignment_t* __restrict__ aln, const uint8_t* __restrict__ c_ops,
                                                       const uint32_t* __restrict__ w_lo, bg_seed_hit_t* __restrict__ hits,
                                                       uint8_t* __restrict__ ops, uint64_t ops_stride) {
@@ -207,19 +210,19 @@ __global__ __launch_bounds__(256) void se_best_kernel(uint64_t n_reads, const ui
     h.window_start = h.ref_start = h.ref_end = ~0ull;
     h.n_candidates = nc;
     h.n_seed_hits = n_hits[r];
-    h.aln.ops_off = (r + 1) * ops_stride;
+    h.aln.ops_off = (r0 + r + 1) * ops_stride;
     if (nc) {
         const uint32_t c = ~(uint32_t)best;
         const bg_alignment_t a = aln[c0 + c];
         h.aln = a;
-        h.aln.ops_off = (r + 1) * ops_stride - a.n_ops;
+        h.aln.ops_off = (r0 + r + 1) * ops_stride - a.n_ops;
         h.window_start = w_lo[c0 + c];
         h.ref_start = (uint64_t)w_lo[c0 + c] + a.ystart;
         h.ref_end = (uint64_t)w_lo[c0 + c] + a.yend;
         if (ops && c_ops)
             for (uint32_t i = l16; i < a.n_ops; i += 16) ops[h.aln.ops_off + i] = c_ops[a.ops_off + i];
     }
-    if (l16 == 0) hits[r] = h;
+    if (l16 == 0) hits[r0 + r] = h;
 }
 
 }  // namespace
@@ -262,6 +265,7 @@ extern "C" int bg_seed_extend_batch_dev(bg_fm* fm, const bg_scoring_t* sc, const
     bg_ctx* ctx = fm->ctx;
     hipStream_t st = (hipStream_t)stream;
     BG_HIP(hipSetDevice(ctx->device));
+    bg_scratch_guard guard(ctx, st);  // ctx->seed is one scratch set: calls on other streams wait for this one's last kernel
     SeedPrm prm;
     prm.S = max_read_len >= prm_in->seed_len ? (max_read_len - prm_in->seed_len) / prm_in->stride + 1 : 0;
     prm.stride = prm_in->stride;
@@ -278,7 +282,8 @@ extern "C" int bg_seed_extend_batch_dev(bg_fm* fm, const bg_scoring_t* sc, const
 
     uint64_t done_hits = 0, done_cand = 0;
     bool any_panic = false;
-    const uint64_t chunk = 1u << 20;  // reads per pass: bounds the scratch (seed slots, proposals, candidate pairs)
+    // reads per pass: bounds the scratch (seed slots, proposals, candidate pairs); bg_set_option("seed_chunk_reads") for tests
+    const uint64_t chunk = ctx->seed_chunk_reads > 0 ? (uint64_t)ctx->seed_chunk_reads : (1u << 20);
     for (uint64_t r0 = 0; r0 < n_reads; r0 += chunk) {
         const uint64_t nr = std::min(chunk, n_reads - r0);
         const uint64_t nq = nr * std::max<uint32_t>(prm.S, 1);
@@ -349,8 +354,8 @@ extern "C" int bg_seed_extend_batch_dev(bg_fm* fm, const bg_scoring_t* sc, const
                                                d_cops, cstride, st, -1)))
             return rc;
         // ---- S7: best hit per read
-        se_best_kernel<<<dim3((unsigned)((nr * 16 + 255) / 256)), dim3(256), 0, st>>>(nr, d_coff, d_nh, d_aln, d_cops, d_wlo, d_hits + r0,
-                                                                                      d_ops ? d_ops + r0 * ops_stride : nullptr, ops_stride);
+        se_best_kernel<<<dim3((unsigned)((nr * 16 + 255) / 256)), dim3(256), 0, st>>>(nr, r0, d_coff, d_nh, d_aln, d_cops, d_wlo, d_hits,
+                                                                                      d_ops, ops_stride);
         BG_HIP(hipGetLastError());
         done_hits += n_hits;
         done_cand += C;

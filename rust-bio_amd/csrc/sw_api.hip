@@ -568,6 +568,7 @@ int align_batch_pipelined(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint64_
     uint64_t submitted = 0, drained = 0;
     bool abort_drain = false;
     int drain_rc = BG_OK;
+    std::string drain_err;  // the drainer's thread-local HIP error text, handed to the caller's bg_last_error()
     const int device = ctx->device;
     std::thread drainer([&] {
         if (hipSetDevice(device) != hipSuccess) {
@@ -585,7 +586,10 @@ int align_batch_pipelined(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint64_
             }
             const int r = drain(c);
             std::lock_guard<std::mutex> lk(mu);
-            if (r && drain_rc == BG_OK) drain_rc = r;
+            if (r && drain_rc == BG_OK) {
+                drain_rc = r;
+                drain_err = bg_tls_error;
+            }
             drained = c + 1;
             cv.notify_all();
         }
@@ -648,7 +652,10 @@ int align_batch_pipelined(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint64_
         cv.notify_all();
     }
     drainer.join();
-    if (drain_rc) return drain_rc;
+    if (drain_rc) {
+        bg_tls_error = drain_err;
+        return drain_rc;
+    }
     if (ops_used) *ops_used = used;
     return status;
 }

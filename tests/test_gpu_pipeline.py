@@ -144,3 +144,35 @@ def test_seed_outside_the_alphabet_is_reported_and_does_not_vote():
     for f in ("n_candidates", "ref_start", "ref_end"):
         assert (hits[f][keep] == clean[f][keep]).all()
     assert hits["n_seed_hits"][5] <= clean["n_seed_hits"][5] + 16 and hits["aln"]["score"][5] > MIN_SCORE
+
+
+@pytest.mark.parametrize("chunk", [256, 999])
+def test_seed_extend_in_several_passes_keeps_global_operation_offsets(chunk):
+    """bg_seed_extend_batch_dev walks the reads in passes (2^20 by default; `seed_chunk_reads` here): a read of a later pass
+    owns ops[(r, r + 1) * ops_stride) of the CALLER's buffer and its ops_off is relative to that buffer — both flavours"""
+    g, text, reads, off, _ = make_case(n_text=120_000, R=1500, L=150)
+    sa, b, ls, fm = build(text, 8)
+    dev = torch.device("cuda:0")
+    d_text = torch.from_numpy(text).to(dev)
+    attach_text(fm, d_text=d_text)
+    sc = Scoring.from_scores(-5, -1, 1, -1)
+    occ = orc.Occ(b, 64, ALPHA)
+    ohits, oops, ostride = orc.seed_extend_batch(b, ls, occ, sa, text, len(g), orc.make_scoring(-5, -1, 1, -1), reads, off, threads=8)
+    fm.ctx.set_option("seed_chunk_reads", chunk)
+    try:
+        hits, ops = seed_extend_arrays(fm, sc, reads, off)  # host flavour: compacts by ops_off
+        compare(hits, ops, ohits, oops, ostride)
+        R, L, prm = len(off) - 1, 150, SeedParams()
+        stride = 2 * L + 2 * prm.pad + 4
+        d_reads = torch.from_numpy(reads).to(dev)
+        d_off = torch.from_numpy(off.astype(np.int64)).to(dev)
+        d_hits = torch.zeros(R * 96, dtype=torch.uint8, device=dev)
+        d_ops = torch.zeros(R * stride, dtype=torch.uint8, device=dev)
+        seed_extend_dev(fm, sc, R, d_reads.data_ptr(), d_off.data_ptr(), L, d_hits.data_ptr(), d_ops.data_ptr(), stride, prm,
+                        torch.cuda.current_stream().cuda_stream, None)
+        torch.cuda.synchronize()
+    finally:
+        fm.ctx.set_option("seed_chunk_reads", 0)
+    dh = d_hits.cpu().numpy().view(_lib.SEED_HIT_DTYPE)
+    assert (dh["aln"]["ops_off"] == (np.arange(R) + 1) * stride - dh["aln"]["n_ops"]).all()
+    compare(dh, d_ops.cpu().numpy(), ohits, oops, ostride)

@@ -102,7 +102,8 @@ def test_bench_launches_its_own_ranks():
     env = dict(os.environ, BENCH_SINGLE_GPU="1")
     env.pop("WORLD_SIZE", None), env.pop("RANK", None), env.pop("LOCAL_RANK", None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--pairs", "20000",
-           "--genome", "300000", "--fm-big-genome", "0", "--queries", "40000", "--skip-banded", "--skip-pipeline", "--skip-ingest", "--skip-k1"]
+           "--genome", "300000", "--fm-big-genome", "0", "--queries", "40000", "--banded-pairs", "97", "--pipeline-reads", "3000",
+           "--pipeline-reads-total", "5001", "--skip-ingest", "--skip-k1"]
     out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert out.returncode == 0, out.stderr.decode()[-3000:]
     line = [ln for ln in out.stdout.decode().splitlines() if ln.startswith("{")][-1]
@@ -110,3 +111,7 @@ def test_bench_launches_its_own_ranks():
     assert d["n_gpus"] == 2 and d["fm"]["strong"]["queries_total"] == 40000
     assert d["fm"]["strong"]["sharded_equals_unsharded"] is True
     assert d["fm"]["strong"]["gathered_records"] == 40000
+    # configs[3] and configs[4] as strong legs: the same pairs / reads in total, split over the two ranks (ragged shards)
+    bs, ss = d["banded"]["strong"], d["seed_extend"]["strong"]
+    assert bs["pairs_total"] == 97 and bs["pairs_per_gpu"] == 48 and bs["sharded_equals_unsharded"] is True
+    assert ss["reads_total"] == 5001 and ss["gathered_records"] == 5001 and ss["sharded_equals_unsharded"] is True

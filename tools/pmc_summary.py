@@ -14,7 +14,11 @@ import json
 import os
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from csrc_hash import csrc_sha  # noqa: E402
+
 out, tag = sys.argv[1], sys.argv[2]
+SHA = csrc_sha()  # the kernel sources these counters were collected with: bench.py reports them only while they match
 OURS = ("bgsw", "bgband", "bgfm", "fm_backward", "fq_", "se_", "sa_", "fmd_", "cigar_kernel", "pretty_kernel", "interval_rows")
 
 
@@ -54,7 +58,7 @@ for p in passes:
 shape = launch_shape(os.path.join(out, "pmc_1.log")) if passes else {}
 
 # ---- HBM traffic
-res = {"unit": "bytes per launch (mean over launches)", "kernels": {}, "launch_shape": shape}
+res = {"unit": "bytes per launch (mean over launches)", "csrc_sha": SHA, "kernels": {}, "launch_shape": shape}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for k, v in counters.get(c, {}).items():
         res["kernels"].setdefault(k, {})[c] = {"launches": len(v), "mean_bytes": sum(v) * 1024.0 / len(v)}
@@ -79,14 +83,14 @@ if big and os.path.exists(logf):
 json.dump(res, open(os.path.join(out, tag + "_pmc_traffic.json"), "w"), indent=1)
 
 # ---- issue counters
-sq = {"unit": "events per launch (mean over launches)", "kernels": {}, "launch_shape": shape}
+sq = {"unit": "events per launch (mean over launches)", "csrc_sha": SHA, "kernels": {}, "launch_shape": shape}
 for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES"):
     for k, v in counters.get(c, {}).items():
         sq["kernels"].setdefault(k, {})[c] = sum(v) / len(v)
 json.dump(sq, open(os.path.join(out, tag + "_sq_counters.json"), "w"), indent=1)
 
 # ---- LDS bank conflicts
-lds = {"unit": "events per launch (mean over launches)", "kernels": {}, "launch_shape": shape}
+lds = {"unit": "events per launch (mean over launches)", "csrc_sha": SHA, "kernels": {}, "launch_shape": shape}
 for c in ("SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_INSTS_LDS", "SQ_ACTIVE_INST_LDS"):
     for k, v in counters.get(c, {}).items():
         lds["kernels"].setdefault(k, {})[c] = sum(v) / len(v)
