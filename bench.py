@@ -58,6 +58,7 @@ def parse_args():
                          "blocks, four times the 256 MiB Infinity Cache); 0: skip, seed-and-extend then runs on --genome")
     ap.add_argument("--host-sa", action="store_true", help="build suffix arrays with the host SA-IS instead of the device builder")
     ap.add_argument("--skip-k1", action="store_true")
+    ap.add_argument("--skip-packed", action="store_true", help="no 2-bit packed A/B legs (packed2)")
     ap.add_argument("--k1-pairs", type=int, default=1_000_000, help="int32-kernel legs: pairs per GPU (configs[1]'s 1M)")
     ap.add_argument("--skip-banded", action="store_true")
     ap.add_argument("--banded-pairs", type=int, default=100_000,
@@ -172,6 +173,49 @@ def valu_frac(kernel, launch_ms, shape_key, shape_val):
     if not hits:
         return None
     return round(max(hits) * 64.0 / (launch_ms * 1e-3) / VALU_PEAK_LANE_OPS, 4)
+
+
+_GATHER = {}
+
+
+def gather_ceiling(footprint_bytes):
+    """The chip's measured rate for K5's access shape — quads reading two dependent random 64-byte lines per step at full
+    occupancy — over a table of `footprint_bytes`: tools/microbench/ub_gather64 (built by __graft_entry__.build()), run here,
+    on this GPU, next to the leg it is compared with.  Returns G lines/s or None when the binary is missing."""
+    import subprocess
+    exe = os.path.join(ROOT, "tools", "microbench", "ub_gather64")
+    mb = round(footprint_bytes / 1e6, 1)
+    if mb in _GATHER:
+        return _GATHER[mb]
+    val = None
+    if os.path.exists(exe):
+        try:
+            env = dict(os.environ, HIP_VISIBLE_DEVICES=str(torch.cuda.current_device()))
+            out = subprocess.run([exe, "1000", str(mb)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=120, env=env)
+            for ln in out.stdout.decode().splitlines():
+                if ln.startswith("{"):
+                    d = json.loads(ln)
+                    if d["dep"] == 1 and d["lines_per_step"] == 2:
+                        val = d["glines_per_s"]
+        except (OSError, subprocess.SubprocessError, ValueError):
+            val = None
+    _GATHER[mb] = val
+    return val
+
+
+def fm_gather_fields(fm, n_q, pat, off, bufs, stream, launch_ms, block_bytes):
+    """requested 64-byte block loads of one launch (the counting instantiation of K5, outside the timed region) against
+    the gather ceiling at the index's footprint"""
+    d_tag, d_lo, d_hi, d_ml = bufs
+    lines = fm.backward_search_count_lines_dev(n_q, pat.data_ptr(), off.data_ptr(), d_tag.data_ptr(), d_lo.data_ptr(), d_hi.data_ptr(),
+                                               d_ml.data_ptr(), stream)
+    ceil_g = gather_ceiling(block_bytes)
+    rate = lines / (launch_ms * 1e-3) / 1e9
+    return {"requested_lines_per_launch": lines, "glines_per_s": round(rate, 2),
+            "gather_ceiling_glines_per_s": ceil_g,
+            "frac_of_gather_ceiling": round(rate / ceil_g, 4) if ceil_g else None,
+            "gather_ceiling_source": "tools/microbench/ub_gather64 (two dependent random 64-B lines per quad-step, 8 waves/SIMD) "
+                                     f"on a {round(block_bytes / 1e6)} MB table, run beside this leg"}
 
 
 def timed_steps(fn, steps, warmup, device):
@@ -341,6 +385,40 @@ def main():
               "roofline": roofline}
     if host_api:
         result["host_api"] = host_api
+    # A/B: the same pairs as 2-bit streams (bg_pack2_dev + bg_align_batch_packed_dev: K1p loads codes instead of bytes)
+    if not args.skip_packed:
+        from rust_bio_amd import pack2
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        xpk, bad_x = pack2.pack_dev(x, ctx=ctx, stream=stream)
+        ypk, bad_y = pack2.pack_dev(y, ctx=ctx, stream=stream)
+        torch.cuda.synchronize()
+        pack_ms = (time.perf_counter() - t0) * 1e3
+        d_outp, d_opsp = torch.empty_like(d_out), torch.empty_like(d_ops)
+
+        def swp_step():
+            aligner.align_packed_dev(3, n_pairs, xpk.data_ptr(), xo.data_ptr(), ypk.data_ptr(), yo.data_ptr(), L, L,
+                                     d_outp.data_ptr(), d_opsp.data_ptr(), stride, stream=stream)
+
+        tp = timed_steps(swp_step, args.steps, args.warmup, dev)
+        tmp_ = kernel_timing(ctx, swp_step)
+        same = bool(torch.equal(d_out, d_outp)) and bad_x == 0 and bad_y == 0
+        kq = rec[:, 7].to(torch.int64)
+        for c0 in range(0, n_pairs, 1 << 18):
+            k = min(1 << 18, n_pairs - c0)
+            m = torch.arange(stride, device=dev)[None, :] >= (stride - kq[c0:c0 + k])[:, None]
+            same = same and bool((d_ops.view(n_pairs, stride)[c0:c0 + k][m] == d_opsp.view(n_pairs, stride)[c0:c0 + k][m]).all())
+        result["packed2"] = {"value": round(world * float(n_pairs) * L * L * args.steps / tp / 1e9, 3), "unit": "GCUPS",
+                             "ms_per_step": round(tp / args.steps * 1e3, 3),
+                             "fill_launch_ms": round(tmp_["fill_ms"] / max(1, tmp_["fill_launches"]), 4),
+                             "byte_flavour_ms_per_step": round(sw_t / args.steps * 1e3, 3),
+                             "pack_ms_both_streams": round(pack_ms, 3),
+                             "records_and_ops_equal_byte_run": same,
+                             "config": {"workload": "the headline pairs as 2-bit streams (16 symbols per dword) through "
+                                                    "bg_align_batch_packed_dev: A/B against the byte flavour above"}}
+        if parity is not None:
+            parity["sw_packed2_equals_bytes_all_pairs"] = same
+        del xpk, ypk, d_outp, d_opsp
     # the same workload at the reference's arithmetic width: K1 (int32 recurrence) on the very same pairs
     if not args.skip_k1:
         ctx.set_option("no_pk16", 1)
@@ -551,6 +629,35 @@ def fm_legs(args, ctx, dev, stream, rank, world, do_cpu, orc, threads, parity, r
                            "note": "the 33 MB block index of a 100 Mbp text sits in the 256 MiB Infinity Cache: see fm_big "
                                    "for an index that cannot"}}
 
+    block_bytes = (args.genome + 1 + 191) // 192 * 64
+    if rank == 0:
+        fm_res["roofline"].update(fm_gather_fields(fm, n_q, pat, off, (d_tag, d_lo, d_hi, d_ml), stream, fm_ms, block_bytes))
+    if not args.skip_packed:  # A/B: the same patterns as a 2-bit stream (dword load per 16 steps, no class lookups)
+        from rust_bio_amd import pack2
+        ref = (d_tag.clone(), d_lo.clone(), d_hi.clone(), d_ml.clone())
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ppk, bad = pack2.pack_dev(pat, codes=fm.pattern_codes(), ctx=ctx, stream=stream)
+        torch.cuda.synchronize()
+        pack_ms = (time.perf_counter() - t0) * 1e3
+
+        def fm_packed_step():
+            fm.backward_search_packed_dev(n_q, ppk.data_ptr(), off.data_ptr(), d_tag.data_ptr(), d_lo.data_ptr(), d_hi.data_ptr(),
+                                          d_ml.data_ptr(), stream)
+
+        tpk = timed_steps(fm_packed_step, args.steps, args.warmup, dev)
+        tmk = kernel_timing(ctx, fm_packed_step)
+        same = bad == 0 and all(bool(torch.equal(a_, b_)) for a_, b_ in zip(ref, (d_tag, d_lo, d_hi, d_ml)))
+        fm_res["packed2"] = {"value": round(world * float(n_q) * args.steps / tpk, 1), "unit": "queries/s",
+                             "ms_per_step": round(tpk / args.steps * 1e3, 3),
+                             "launch_ms": round(tmk["fm_ms"] / max(1, tmk["fm_launches"]), 4),
+                             "byte_flavour_launch_ms": round(fm_ms, 4), "pack_ms": round(pack_ms, 3),
+                             "results_equal_byte_run": same,
+                             "config": {"workload": "the same patterns as a 2-bit stream (bg_pack2_dev with bg_fm_pattern_codes, "
+                                                    "bg_fm_backward_search_packed_dev): A/B against the byte flavour"}}
+        if parity is not None:
+            parity["fm_packed2_equals_bytes_all_queries"] = same
+        del ppk, ref
     # strong scaling on configs[2]: the SAME n_q queries in total, split over the ranks, gathered inside the step
     q_lo, q_hi = shard.partition(n_q, rank, world)
     if world > 1:  # every rank must search the same global query set: regenerate it from rank 0's seed
@@ -662,6 +769,8 @@ def fm_big_leg(args, ctx, dev, stream, rank, world, do_cpu, orc, threads, parity
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                         "traffic": fm_big_traffic(n_q, fm.device_bytes()),
                         "launch_ms": round(ms, 4), "queries_per_launch": n_q, "alg_bytes_per_query": round(alg / n_q, 1)}}
+    if rank == 0:
+        leg["roofline"].update(fm_gather_fields(fm, n_q, pat, off, (d_tag, d_lo, d_hi, d_ml), stream, ms, (n_g + 1 + 191) // 192 * 64))
     if do_cpu:
         occ = orc.Occ(b, 128, N_ALPHABET)
         n_chk = max(1, int(min(n_q, 1_000_000) * args.parity_frac))

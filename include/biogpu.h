@@ -145,6 +145,37 @@ int bg_fm_backward_search_batch_dev(bg_fm* fm, uint64_t n_q, const uint8_t* d_pa
                                     const uint64_t* d_pat_off, uint8_t* d_tag, uint64_t* d_lower,
                                     uint64_t* d_upper, uint32_t* d_matched_len, void* stream);
 
+/* ---- 2-bit packed sequences (pack2.hip) ---------------------------------------------------------
+ * rust-bio's Aligner and FMIndex take `&[u8]` (pairwise/mod.rs:591, fmindex.rs:144); the engine also accepts its own
+ * 2-bit wire format, what BASELINE's north_star calls "packed 2-bit reads".  A byte buffer — any concatenation of
+ * sequences, e.g. the `seq` buffer bg_fastq_parse_dev fills — is packed as ONE stream: symbol s sits in bits
+ * 2 (s % 16) .. + 1 of little-endian dword s / 16, `codes[c]` is the byte value of code c (four distinct bytes).
+ * Sequence boundaries do not matter to the packing: the offset arrays of the byte flavours (x_off / pat_off /
+ * seq_off, in symbols) address the packed stream unchanged.  d_packed must hold (n + 15) / 16 + 1 dwords (consumers
+ * may read one dword past the last symbol; its content is never interpreted).  A byte that is none of the four
+ * codes is stored as code 0 and counted in *d_n_invalid (a device counter the caller zeroes; may be NULL): a buffer
+ * with a non-zero count must take the byte entry points.  Asynchronous on `stream`. */
+int bg_pack2_dev(bg_ctx* ctx, const uint8_t* d_bytes, uint64_t n, const uint8_t* codes, uint32_t* d_packed,
+                 uint64_t* d_n_invalid, void* stream);
+int bg_unpack2_dev(bg_ctx* ctx, const uint32_t* d_packed, uint64_t n, const uint8_t* codes, uint8_t* d_bytes,
+                   void* stream);
+/* The byte values of the index's four 2-bit codes — the `codes` to pack its patterns with.  BG_ERR_UNSUPPORTED when
+ * the text has fewer than four frequent letters or symbols ranked by bit vectors: such an
+ * index takes byte patterns only. */
+int bg_fm_pattern_codes(const bg_fm* fm, uint8_t* codes);
+/* bg_fm_backward_search_batch_dev on patterns packed with bg_fm_pattern_codes' codes; d_sym_off[q] is the SYMBOL
+ * offset of pattern q in the stream (n_q + 1 entries).  Same outputs.  (A dword load per 16 steps instead of a byte
+ * load per step, no symbol-class lookups: measured against the byte flavour in bench.py's `fm.packed2`.) */
+int bg_fm_backward_search_packed_dev(bg_fm* fm, uint64_t n_q, const uint32_t* d_packed, const uint64_t* d_sym_off,
+                                     uint8_t* d_tag, uint64_t* d_lower, uint64_t* d_upper, uint32_t* d_matched_len,
+                                     void* stream);
+/* Measurement aid: bg_fm_backward_search_batch_dev with the 64-byte block loads it issues counted (*lines_out, host
+ * memory; synchronous).  bench.py sets the count against the chip's measured ceiling for such gathers
+ * (tools/microbench/ub_gather64.hip). */
+int bg_fm_backward_search_count_lines_dev(bg_fm* fm, uint64_t n_q, const uint8_t* d_pat, const uint64_t* d_pat_off,
+                                          uint8_t* d_tag, uint64_t* d_lower, uint64_t* d_upper, uint32_t* d_matched_len,
+                                          uint64_t* lines_out, void* stream);
+
 /* ---- suffix-array lookups for FM-index hits (kernel K6) ------------------------------------
  * Attach the suffix array the FM index was built from, then resolve rows to text positions.
  * The index handle must come from bg_fm_build over the same text (n rows). */
@@ -256,6 +287,14 @@ int bg_align_batch_dev(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint64_t n
                        const uint8_t* d_x, const uint64_t* d_x_off, const uint8_t* d_y,
                        const uint64_t* d_y_off, uint32_t max_xlen, uint32_t max_ylen,
                        bg_alignment_t* d_out, uint8_t* d_ops, uint64_t ops_stride, void* stream);
+/* The same on 2-bit streams (bg_pack2_dev above): d_x / d_y hold 16 symbols per dword, the offsets count symbols,
+ * `codes` are the bytes the four codes stand for.  Short reads under MatchParams scoring (the packed-int16 kernel) read
+ * the codes as they are; every other case unpacks the streams into ctx scratch first (one stream synchronisation) and
+ * runs the byte kernels — same results either way. */
+int bg_align_batch_packed_dev(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint64_t n_pairs, const uint32_t* d_x,
+                              const uint64_t* d_x_off, const uint32_t* d_y, const uint64_t* d_y_off,
+                              const uint8_t* codes, uint32_t max_xlen, uint32_t max_ylen, bg_alignment_t* d_out,
+                              uint8_t* d_ops, uint64_t ops_stride, void* stream);
 
 /* banded::Aligner::{custom,global,semiglobal,local} (banded.rs:282,872,901,972) with k-mer
  * length k and window w.  The band (k-mer matching, sparse DP chaining, Band construction,

@@ -91,7 +91,9 @@ SYMBOLS = ["bg_device_count", "bg_init", "bg_free", "bg_strerror", "bg_last_erro
            "bg_align_banded_bands_batch", "bg_band_from_matches_batch", "bg_sparse_find_kmer_matches", "bg_sparse_sdpkpp",
            "bg_sparse_lcskpp", "bg_sparse_sdpkpp_union_lcskpp_path", "bg_sparse_expand_kmer_matches", "bg_fastq_parse",
            "bg_fastq_parse_dev", "bg_cigar_batch", "bg_cigar_batch_dev", "bg_get_timing", "bg_enable_timing",
-           "bg_pretty_batch", "bg_suffix_array_dev", "bg_bwt_dev", "bg_sa_sample_dev", "bg_fm_build_dev", "bg_fm_set_text", "bg_fm_set_text_dev", "bg_seed_extend_batch", "bg_seed_extend_batch_dev"]
+           "bg_pretty_batch", "bg_suffix_array_dev", "bg_bwt_dev", "bg_sa_sample_dev", "bg_fm_build_dev", "bg_fm_set_text", "bg_fm_set_text_dev", "bg_seed_extend_batch", "bg_seed_extend_batch_dev",
+           "bg_pack2_dev", "bg_unpack2_dev", "bg_fm_pattern_codes", "bg_fm_backward_search_packed_dev",
+           "bg_fm_backward_search_count_lines_dev", "bg_align_batch_packed_dev"]
 
 
 def build(force=False):
@@ -172,6 +174,12 @@ def lib():
         L.bg_fm_set_text_dev.argtypes = [vp, vp, u64]
         L.bg_seed_extend_batch.argtypes = [vp, C.POINTER(ScoringC), C.POINTER(SeedParamsC), u64, vp, vp, vp, vp, u64, C.POINTER(u64)]
         L.bg_seed_extend_batch_dev.argtypes = [vp, C.POINTER(ScoringC), C.POINTER(SeedParamsC), u64, vp, vp, u32, vp, vp, u64, vp, vp]
+        L.bg_pack2_dev.argtypes = [vp, vp, u64, vp, vp, vp, vp]
+        L.bg_unpack2_dev.argtypes = [vp, vp, u64, vp, vp, vp]
+        L.bg_fm_pattern_codes.argtypes = [vp, vp]
+        L.bg_fm_backward_search_packed_dev.argtypes = [vp, u64, vp, vp, vp, vp, vp, vp, vp]
+        L.bg_fm_backward_search_count_lines_dev.argtypes = [vp, u64, vp, vp, vp, vp, vp, vp, C.POINTER(u64), vp]
+        L.bg_align_batch_packed_dev.argtypes = [vp, C.POINTER(ScoringC), i32, u64, vp, vp, vp, vp, vp, u32, u32, vp, vp, u64, vp]
         L.bg_get_timing.argtypes = [vp, C.POINTER(TimingC)]
         L.bg_enable_timing.argtypes = [vp, i32]
         for s in SYMBOLS:

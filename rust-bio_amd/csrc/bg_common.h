@@ -44,6 +44,8 @@ struct bg_ctx {
     size_t io_cap[6] = {};
     void* h_ops = nullptr;  // ... and the pinned landing zone of the operations
     size_t h_ops_cap = 0;
+    void* unpk[2] = {};     // bg_align_batch_packed_dev: byte copies of the 2-bit streams for the kernels that take bytes
+    size_t unpk_cap[2] = {};
     void* table = nullptr;  // compacted scoring table + code map
     size_t table_bytes = 0;
     bg_band_scratch* band = nullptr;  // persistent scratch of the banded pipeline

@@ -132,6 +132,8 @@ extern "C" int bg_free(bg_ctx* ctx) {
     hipFree(ctx->aux);
     hipFree(ctx->bnd);
     hipFree(ctx->table);
+    hipFree(ctx->unpk[0]);
+    hipFree(ctx->unpk[1]);
     for (void* p : ctx->io) hipFree(p);
     if (ctx->h_ops) hipHostFree(ctx->h_ops);
     bg_band_scratch_free(ctx->band);

@@ -49,21 +49,34 @@ namespace {
 // pattern: Absent), so overlapping windows need no copy of the reads.
 struct SeedSrc {
     uint32_t S, stride, seed_len;
+    uint32_t code_bytes;            // PACKED: the byte value of each 2-bit code (code c in bits 8c..8c+7)
+    unsigned long long* lines;      // COUNT: receives the number of 64-byte block loads the launch issued
 };
-template <bool JUMP, bool SEEDS>
+// PACKED: `pat` is a 2-bit stream (16 symbols per little-endian dword, symbol s in bits 2 (s % 16) of dword s / 16, the
+// codes being the index's own: bg_fm_pattern_codes / bg_pack2_dev) and `pat_off` counts SYMBOLS: a pattern costs a dword
+// load every 16 steps instead of a byte load per step, its symbols are codes already (no class lookup, none of the
+// sparse / dense / panic arms).  Only for indexes whose four codes are all symbols (DNA-like BWTs).
+// COUNT: the block loads of the launch are counted (bench.py: requested lines against the gather ceiling of
+// tools/microbench/ub_gather64.hip); the results are the same.
+template <bool JUMP, bool SEEDS, bool PACKED = false, bool COUNT = false>
 __global__ __launch_bounds__(256) void fm_backward_search_kernel(
     FmDev fm, uint64_t n_q, const uint8_t* __restrict__ pat, const uint64_t* __restrict__ pat_off,
     uint8_t* __restrict__ tag, uint64_t* __restrict__ lower, uint64_t* __restrict__ upper,
     uint32_t* __restrict__ matched_len, const uint4* __restrict__ jump, const SeedSrc seeds) {
+    static_assert(!(PACKED && (JUMP || SEEDS)), "packed patterns: plain searches only");
     __shared__ uint16_t s_class[256];
     __shared__ uint32_t s_less[256];
     __shared__ uint32_t s_exc[kMaxExcLds];
     for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) {
         s_class[i] = fm.sym_class[i];
-        s_less[i] = fm.less[i];
+        // PACKED: entry c (< 4) is less[] of the byte that code c stands for
+        s_less[i] = (PACKED && i < 4) ? fm.less[(seeds.code_bytes >> (8 * i)) & 0xFFu] : fm.less[i];
     }
     for (uint32_t i = threadIdx.x; i < fm.n_exc; i += blockDim.x) s_exc[i] = fm.exc_pos[i];  // n_exc <= kMaxExcLds
     __syncthreads();
+    const uint32_t* __restrict__ pk = (const uint32_t*)pat;
+    uint32_t pk_cur = 0;      // PACKED: the dword that holds the next symbol
+    uint32_t n_lines = 0;     // COUNT
 
     const uint32_t t = threadIdx.x & 3;
     const uint64_t n_quads = (uint64_t)gridDim.x * (blockDim.x >> 2);
@@ -132,7 +145,13 @@ __global__ __launch_bounds__(256) void fm_backward_search_kernel(
                         }
                     }
                 }
-                a_next = pat[off + pos - 1];
+                if (PACKED) {
+                    const uint64_t gs = off + pos - 1;
+                    pk_cur = pk[gs >> 4];
+                    a_next = (pk_cur >> (2 * ((uint32_t)gs & 15u))) & 3u;
+                } else {
+                    a_next = pat[off + pos - 1];
+                }
                 active = true;
                 return;
             }
@@ -147,16 +166,24 @@ __global__ __launch_bounds__(256) void fm_backward_search_kernel(
             // one iteration of the loop at fmindex.rs:160-182
             const uint32_t a = a_next;
             pos -= 1;
-            if (pos) a_next = pat[off + pos - 1];  // prefetch; address independent of the ranks
-            const uint32_t cls = s_class[a];
+            if (PACKED) {
+                if (pos) {  // the next symbol: a new dword every 16 steps
+                    const uint64_t gs = off + pos - 1;
+                    if (((uint32_t)gs & 15u) == 15u) pk_cur = pk[gs >> 4];
+                    a_next = (pk_cur >> (2 * ((uint32_t)gs & 15u))) & 3u;
+                }
+            } else if (pos) {
+                a_next = pat[off + pos - 1];  // prefetch; address independent of the ranks
+            }
+            const uint32_t cls = PACKED ? a : (uint32_t)s_class[a];
             const uint32_t less_a = s_less[a];
             uint32_t occ_r = 0, occ_l = 0;
             bool stop = false;
             uint32_t stop_tag = BG_FM_PARTIAL;
-            if (cls == kClsPanic) {
+            if (!PACKED && cls == kClsPanic) {
                 stop = true;
                 stop_tag = BG_FM_PANIC;
-            } else if (cls < 4) {
+            } else if (PACKED || cls < 4) {
                 const uint32_t br = r / kSymPerBlock, orr = r - br * kSymPerBlock;
                 const uint4 vr = fm.blocks[(uint64_t)br * 4 + t];
                 uint4 vl = vr;
@@ -164,14 +191,25 @@ __global__ __launch_bounds__(256) void fm_backward_search_kernel(
                 if (l > 0) {
                     const uint32_t bl = (l - 1) / kSymPerBlock;
                     ol = (l - 1) - bl * kSymPerBlock;
-                    if (bl != br) vl = fm.blocks[(uint64_t)bl * 4 + t];
+                    if (bl != br) {
+                        vl = fm.blocks[(uint64_t)bl * 4 + t];
+                        if (COUNT) n_lines += 1;
+                    }
                 }
+                if (COUNT) n_lines += 1;
                 occ_r = quad_sum(block_part(vr, t, orr, cls));
                 if (l > 0) occ_l = quad_sum(block_part(vl, t, ol, cls));
                 if (cls == 0 && fm.n_exc) {  // sparse exceptions sit in the stream as code 0
-                    occ_r -= count_le(s_exc, 0u, fm.n_exc, r);
-                    if (l > 0) occ_l -= count_le(s_exc, 0u, fm.n_exc, l - 1);
+                    if (fm.n_exc == 1) {     // a text with one sentinel and nothing else outside its four letters: no search loop
+                        const uint32_t e0 = s_exc[0];
+                        occ_r -= e0 <= r ? 1u : 0u;
+                        if (l > 0) occ_l -= e0 <= l - 1 ? 1u : 0u;
+                    } else {
+                        occ_r -= count_le(s_exc, 0u, fm.n_exc, r);
+                        if (l > 0) occ_l -= count_le(s_exc, 0u, fm.n_exc, l - 1);
+                    }
                 }
+            } else if (PACKED) {
             } else if (cls >= kClsDense) {  // one-hot bit vector of this symbol: one 64-byte block per rank
                 const uint32_t d = cls - kClsDense;
                 uint32_t orr, ol = 0;
@@ -220,6 +258,7 @@ __global__ __launch_bounds__(256) void fm_backward_search_kernel(
             }
         }
     }
+    if (COUNT && t == 0 && n_lines) atomicAdd(seeds.lines, (unsigned long long)n_lines);
 }
 
 // jump-table construction: every kJumpK-mer over the four coded bytes as a pattern ...
@@ -836,6 +875,72 @@ int bg_fm_search_seeds_dev(bg_fm* fm, uint64_t n_reads, const uint8_t* d_reads, 
         fm->dev, n_q, d_reads, d_read_off, d_tag, d_lower, d_upper, d_matched_len, nullptr, SeedSrc{S, stride, seed_len});
     BG_HIP(hipGetLastError());
     return BG_OK;
+}
+
+// ---- 2-bit packed patterns (north_star: "coalesced HBM loads of packed 2-bit reads") -------------------------------
+extern "C" int bg_fm_pattern_codes(const bg_fm* fm, uint8_t codes[4]) {
+    if (!fm || !codes) return BG_ERR_INVALID_ARG;
+    // the four 2-bit codes must all stand for symbols of the text (a DNA-like BWT): with dense symbols code 0 means
+    // "something else", and an index over fewer than four letters has codes no pattern symbol may use
+    if (fm->dev.n_dense || fm->n_codes != 4) return BG_ERR_UNSUPPORTED;
+    for (int c = 0; c < 4; c++) codes[c] = fm->code_byte[c];
+    return BG_OK;
+}
+
+extern "C" int bg_fm_backward_search_packed_dev(bg_fm* fm, uint64_t n_q, const uint32_t* d_packed, const uint64_t* d_sym_off,
+                                                uint8_t* d_tag, uint64_t* d_lower, uint64_t* d_upper, uint32_t* d_matched_len,
+                                                void* stream) {
+    if (!fm || (n_q && (!d_packed || !d_sym_off || !d_tag || !d_lower || !d_upper || !d_matched_len))) return BG_ERR_INVALID_ARG;
+    if (fm->dev.n_dense || fm->n_codes != 4) return BG_ERR_UNSUPPORTED;
+    if (n_q == 0) return BG_OK;
+    bg_ctx* ctx = fm->ctx;
+    hipStream_t st = (hipStream_t)stream;
+    const uint64_t blocks = std::min<uint64_t>((n_q + 63) / 64, 256 * 8);
+    SeedSrc ex{};
+    ex.code_bytes = (uint32_t)fm->code_byte[0] | (uint32_t)fm->code_byte[1] << 8 | (uint32_t)fm->code_byte[2] << 16 |
+                    (uint32_t)fm->code_byte[3] << 24;
+    if (ctx->timing) BG_HIP(hipEventRecord(ctx->ev[0], st));
+    fm_backward_search_kernel<false, false, true, false><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(
+        fm->dev, n_q, (const uint8_t*)d_packed, d_sym_off, d_tag, d_lower, d_upper, d_matched_len, nullptr, ex);
+    BG_HIP(hipGetLastError());
+    if (ctx->timing) {
+        BG_HIP(hipEventRecord(ctx->ev[1], st));
+        BG_HIP(hipEventSynchronize(ctx->ev[1]));
+        float ms = 0;
+        BG_HIP(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+        ctx->last.fm_ms += ms;
+        ctx->last.fm_launches += 1;
+    }
+    return BG_OK;
+}
+
+// measurement aid: the same search with its 64-byte block loads counted (synchronous; *lines_out on the host)
+extern "C" int bg_fm_backward_search_count_lines_dev(bg_fm* fm, uint64_t n_q, const uint8_t* d_pat, const uint64_t* d_pat_off,
+                                                     uint8_t* d_tag, uint64_t* d_lower, uint64_t* d_upper,
+                                                     uint32_t* d_matched_len, uint64_t* lines_out, void* stream) {
+    if (!fm || !lines_out || (n_q && (!d_pat_off || !d_tag || !d_lower || !d_upper || !d_matched_len))) return BG_ERR_INVALID_ARG;
+    *lines_out = 0;
+    if (n_q == 0) return BG_OK;
+    hipStream_t st = (hipStream_t)stream;
+    BG_HIP(hipSetDevice(fm->ctx->device));
+    unsigned long long* d_cnt = nullptr;
+    BG_HIP(hipMalloc((void**)&d_cnt, 8));
+    int rc = BG_OK;
+    auto run = [&]() -> int {
+        BG_HIP(hipMemsetAsync(d_cnt, 0, 8, st));
+        const uint64_t blocks = std::min<uint64_t>((n_q + 63) / 64, 256 * 8);
+        SeedSrc ex{};
+        ex.lines = d_cnt;
+        fm_backward_search_kernel<false, false, false, true><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(
+            fm->dev, n_q, d_pat, d_pat_off, d_tag, d_lower, d_upper, d_matched_len, nullptr, ex);
+        BG_HIP(hipGetLastError());
+        BG_HIP(hipMemcpyAsync(lines_out, d_cnt, 8, hipMemcpyDeviceToHost, st));
+        BG_HIP(hipStreamSynchronize(st));
+        return BG_OK;
+    };
+    rc = run();
+    hipFree(d_cnt);
+    return rc;
 }
 
 extern "C" int bg_fm_backward_search_batch(bg_fm* fm, uint64_t n_q, const uint8_t* pat,

@@ -224,7 +224,7 @@ static int align_batch_dev_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, u
                                 const uint8_t* d_x, const uint64_t* d_x_off, const uint8_t* d_y,
                                 const uint64_t* d_y_off, uint32_t max_xlen, uint32_t max_ylen,
                                 bg_alignment_t* d_out, uint8_t* d_ops, uint64_t ops_stride,
-                                void* stream, int len_hint) {
+                                void* stream, int len_hint, const uint8_t* packed_codes = nullptr) {
     if (!ctx || !sc || mode < BG_MODE_CUSTOM || mode > BG_MODE_LOCAL) return BG_ERR_INVALID_ARG;
     int rc = check_scoring(sc);
     if (rc) return rc;
@@ -326,6 +326,23 @@ static int align_batch_dev_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, u
         }
     }
     if (!fill) return BG_ERR_UNSUPPORTED;
+    if (packed_codes) {
+        if (pk16) {
+            a.packed = 1;  // K1p reads the 2-bit streams as they are
+        } else {
+            // every other kernel takes bytes: the streams are unpacked into ctx scratch (two totals come back to the host)
+            uint64_t tot[2] = {0, 0};
+            BG_HIP(hipMemcpyAsync(&tot[0], d_x_off + n_pairs, 8, hipMemcpyDeviceToHost, st));
+            BG_HIP(hipMemcpyAsync(&tot[1], d_y_off + n_pairs, 8, hipMemcpyDeviceToHost, st));
+            BG_HIP(hipStreamSynchronize(st));
+            for (int k = 0; k < 2; k++)
+                if ((rc = bg_reserve(&ctx->unpk[k], &ctx->unpk_cap[k], std::max<uint64_t>(tot[k], 16)))) return rc;
+            if ((rc = bg_unpack2_dev(ctx, (const uint32_t*)d_x, tot[0], packed_codes, (uint8_t*)ctx->unpk[0], st))) return rc;
+            if ((rc = bg_unpack2_dev(ctx, (const uint32_t*)d_y, tot[1], packed_codes, (uint8_t*)ctx->unpk[1], st))) return rc;
+            a.x = (const uint8_t*)ctx->unpk[0];
+            a.y = (const uint8_t*)ctx->unpk[1];
+        }
+    }
     const int nw = tb_words(cfg.r);
     const uint32_t pw = 64 / cfg.lp;
     SwGeom& g = a.g;
@@ -441,6 +458,21 @@ extern "C" int bg_align_batch_dev(bg_ctx* ctx, const bg_scoring_t* sc, int mode,
                                   bg_alignment_t* d_out, uint8_t* d_ops, uint64_t ops_stride,
                                   void* stream) {
     return align_batch_dev_impl(ctx, sc, mode, n_pairs, d_x, d_x_off, d_y, d_y_off, max_xlen, max_ylen, d_out, d_ops, ops_stride, stream, -1);
+}
+
+// Aligner::{custom, global, semiglobal, local} on 2-bit streams (pack2.hip): x / y hold 16 symbols per dword, the offsets
+// count symbols.  K1p loads the codes directly; whatever K1p does not take (long reads, wide scores, a tabulated match
+// function — which sees the bytes `codes` stand for) is unpacked into ctx scratch first.
+extern "C" int bg_align_batch_packed_dev(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint64_t n_pairs, const uint32_t* d_x,
+                                         const uint64_t* d_x_off, const uint32_t* d_y, const uint64_t* d_y_off,
+                                         const uint8_t codes[4], uint32_t max_xlen, uint32_t max_ylen, bg_alignment_t* d_out,
+                                         uint8_t* d_ops, uint64_t ops_stride, void* stream) {
+    if (!codes || (n_pairs && (!d_x || !d_y))) return BG_ERR_INVALID_ARG;
+    for (int a = 0; a < 4; a++)
+        for (int b = a + 1; b < 4; b++)
+            if (codes[a] == codes[b]) return BG_ERR_INVALID_ARG;
+    return align_batch_dev_impl(ctx, sc, mode, n_pairs, (const uint8_t*)d_x, d_x_off, (const uint8_t*)d_y, d_y_off, max_xlen, max_ylen,
+                                d_out, d_ops, ops_stride, stream, -1, codes);
 }
 
 // ---- pipelined host-buffer path ------------------------------------------------------------------------------

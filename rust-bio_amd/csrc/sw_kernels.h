@@ -127,7 +127,13 @@ struct SwArgs {
     uint64_t ops_stride;
     int32_t mode;         // BG_MODE_* recorded in the result
     int32_t filter_clips; // semiglobal/local drop Xclip/Yclip ops (mod.rs:974,1006)
+    // x / y are 2-bit streams (pack2.hip: 16 symbols per dword, offsets in symbols) instead of bytes — K1p only
+    int32_t packed;
 };
+// symbol s of a 2-bit stream
+__device__ __forceinline__ uint32_t sym2(const uint8_t* stream, uint64_t s) {
+    return (((const uint32_t*)stream)[s >> 4] >> (2 * ((uint32_t)s & 15u))) & 3u;
+}
 
 // ---- closed forms of the matrix borders (mod.rs:622-671 column 0, 678-717 row 0) -------------
 struct Col0 {

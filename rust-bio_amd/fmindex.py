@@ -112,6 +112,24 @@ class FMIndex:
                                                               d_lo, d_hi, d_ml, stream),
                    "backward_search_dev")
 
+    def pattern_codes(self):
+        """the byte value of each 2-bit code of this index (what its patterns are packed with: pack2.pack_dev)"""
+        cb = (C.c_uint8 * 4)()
+        _lib.check(_lib.lib().bg_fm_pattern_codes(self.h, cb), "bg_fm_pattern_codes")
+        return bytes(cb)
+
+    def backward_search_packed_dev(self, n_q, d_packed, d_sym_off, d_tag, d_lo, d_hi, d_ml, stream=0):
+        """backward_search_dev on a 2-bit pattern stream (pack2.py); d_sym_off: symbol offsets (n_q + 1)"""
+        _lib.check(_lib.lib().bg_fm_backward_search_packed_dev(self.h, n_q, d_packed, d_sym_off, d_tag, d_lo, d_hi, d_ml, stream),
+                   "backward_search_packed_dev")
+
+    def backward_search_count_lines_dev(self, n_q, d_pat, d_off, d_tag, d_lo, d_hi, d_ml, stream=0):
+        """the same search with its 64-byte block loads counted (synchronous) -> lines"""
+        lines = C.c_uint64(0)
+        _lib.check(_lib.lib().bg_fm_backward_search_count_lines_dev(self.h, n_q, d_pat, d_off, d_tag, d_lo, d_hi, d_ml,
+                                                                    C.byref(lines), stream), "backward_search_count_lines_dev")
+        return int(lines.value)
+
     def interval_occ_arrays(self, lower, upper):
         """Interval::occ for a batch: returns (out_off, positions); needs an attached suffix array."""
         lo = np.ascontiguousarray(lower, dtype=np.uint64)

@@ -287,6 +287,15 @@ class Aligner:
                                                  d_x_off, d_y, d_y_off, max_xlen, max_ylen, d_out,
                                                  d_ops, ops_stride, stream), "bg_align_batch_dev")
 
+    def align_packed_dev(self, mode, n_pairs, d_xpk, d_x_off, d_ypk, d_y_off, max_xlen, max_ylen, d_out, d_ops, ops_stride,
+                         codes=b"ACGT", stream=0):
+        """align_dev on 2-bit streams (pack2.py): d_xpk / d_ypk hold 16 symbols per dword, offsets count symbols."""
+        sc = self.scoring.to_c()
+        cb = (C.c_uint8 * 4)(*bytes(codes))
+        _lib.check(_lib.lib().bg_align_batch_packed_dev(self.ctx.h, C.byref(sc), mode, n_pairs, d_xpk, d_x_off, d_ypk, d_y_off,
+                                                        cb, max_xlen, max_ylen, d_out, d_ops, ops_stride, stream),
+                   "bg_align_batch_packed_dev")
+
     def custom_batch(self, xs, ys): return self.align_batch(MODE_CUSTOM, xs, ys)
     def global_batch(self, xs, ys): return self.align_batch(MODE_GLOBAL, xs, ys)
     def semiglobal_batch(self, xs, ys): return self.align_batch(MODE_SEMIGLOBAL, xs, ys)
