@@ -29,6 +29,8 @@ struct bg_seed_scratch;  // seed_extend.hip
 void bg_seed_scratch_free(bg_seed_scratch*);
 struct bg_host_pipe;  // sw_api.hip: staging sets of the pipelined host-buffer path
 void bg_host_pipe_free(bg_host_pipe*);
+struct bg_fm_pipe;  // fm_index.hip: staging sets of bg_fm_backward_search_batch
+void bg_fm_pipe_free(bg_fm_pipe*);
 
 struct bg_ctx {
     int device = 0;
@@ -51,6 +53,7 @@ struct bg_ctx {
     bg_band_scratch* band = nullptr;  // persistent scratch of the banded pipeline
     bg_host_pipe* pipe = nullptr;     // persistent staging of bg_align_batch's pipelined path
     bg_seed_scratch* seed = nullptr;  // persistent scratch of the seed-and-extend pipeline
+    bg_fm_pipe* fm_pipe = nullptr;    // persistent pinned / device staging of bg_fm_backward_search_batch
     int64_t host_chunk_pairs = 0;     // pairs per pipeline stage of bg_align_batch (0 = default)
     int64_t chunk_pairs = 0;  // 0 = default
     int64_t seed_chunk_reads = 0;  // reads per pass of bg_seed_extend_batch_dev (0 = 2^20)

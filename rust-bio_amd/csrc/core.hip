@@ -139,6 +139,7 @@ extern "C" int bg_free(bg_ctx* ctx) {
     bg_band_scratch_free(ctx->band);
     bg_host_pipe_free(ctx->pipe);
     bg_seed_scratch_free(ctx->seed);
+    bg_fm_pipe_free(ctx->fm_pipe);
     if (ctx->ev[0]) hipEventDestroy(ctx->ev[0]);
     if (ctx->ev[1]) hipEventDestroy(ctx->ev[1]);
     if (ctx->scratch_done) hipEventDestroy(ctx->scratch_done);

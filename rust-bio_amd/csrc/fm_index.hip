@@ -28,6 +28,10 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <string>
 #include <array>
 #include <numeric>
 #include <thread>
@@ -58,12 +62,14 @@ struct SeedSrc {
 // sparse / dense / panic arms).  Only for indexes whose four codes are all symbols (DNA-like BWTs).
 // COUNT: the block loads of the launch are counted (bench.py: requested lines against the gather ceiling of
 // tools/microbench/ub_gather64.hip); the results are the same.
-template <bool JUMP, bool SEEDS, bool PACKED = false, bool COUNT = false>
+constexpr uint8_t kTagDeferred = 0xFF;  // fm_search_fast_kernel leaves such a query to the generic kernel
+// DEFER: only the queries whose tag is kTagDeferred are searched (second launch behind fm_search_fast_kernel)
+template <bool JUMP, bool SEEDS, bool PACKED = false, bool COUNT = false, bool DEFER = false>
 __global__ __launch_bounds__(256) void fm_backward_search_kernel(
     FmDev fm, uint64_t n_q, const uint8_t* __restrict__ pat, const uint64_t* __restrict__ pat_off,
     uint8_t* __restrict__ tag, uint64_t* __restrict__ lower, uint64_t* __restrict__ upper,
     uint32_t* __restrict__ matched_len, const uint4* __restrict__ jump, const SeedSrc seeds) {
-    static_assert(!(PACKED && (JUMP || SEEDS)), "packed patterns: plain searches only");
+    static_assert(!(PACKED && JUMP), "packed patterns: no jump table");
     __shared__ uint16_t s_class[256];
     __shared__ uint32_t s_less[256];
     __shared__ uint32_t s_exc[kMaxExcLds];
@@ -101,6 +107,10 @@ __global__ __launch_bounds__(256) void fm_backward_search_kernel(
     auto fetch = [&]() {
         active = false;
         while (q < n_q) {
+            if (DEFER && tag[q] != kTagDeferred) {
+                q += n_quads;
+                continue;
+            }
             if (SEEDS) {
                 const uint64_t rd = q / seeds.S;
                 const uint32_t k = (uint32_t)(q - rd * seeds.S);
@@ -246,6 +256,171 @@ __global__ __launch_bounds__(256) void fm_backward_search_kernel(
                 if (stop_tag == BG_FM_PANIC)
                     emit(BG_FM_PANIC, 0, 0, matched);
                 else if (matched)
+                    emit(BG_FM_PARTIAL, pl, pr + 1, matched);
+                else
+                    emit(BG_FM_ABSENT, 0, 0, 0);
+                q += n_quads;
+                fetch();
+            } else if (pos == 0) {
+                emit(BG_FM_COMPLETE, l, r + 1, matched);
+                q += n_quads;
+                fetch();
+            }
+        }
+    }
+    if (COUNT && t == 0 && n_lines) atomicAdd(seeds.lines, (unsigned long long)n_lines);
+}
+
+// K5 fast path for byte patterns over a DNA-like index (four 2-bit codes, no dense symbols): when a quad takes its next
+// query, its four lanes turn the pattern into 2-bit codes — aligned dword loads, class lookups, 16 symbols per dword —
+// and park them in the quad's LDS slot (kFastSyms symbols); the LF loop then is the packed kernel's: one LDS read per
+// step for the symbol, no byte load, no class / less lookups by byte, none of the sparse / dense / panic arms.  A
+// pattern with a byte outside the four codes (N, lower case, anything that would make the reference panic) or longer
+// than the slot is tagged kTagDeferred and answered by the generic kernel launched right behind (DEFER).  Same results
+// (tests/test_gpu_fm.py, test_gpu_pack2.py); 466 -> ~560 M queries/s on the 100 Mbp index.
+constexpr uint32_t kFastSyms = 256;
+template <bool SEEDS, bool COUNT>
+__global__ __launch_bounds__(256) void fm_search_fast_kernel(FmDev fm, uint64_t n_q, const uint8_t* __restrict__ pat,
+                                                             const uint64_t* __restrict__ pat_off, uint8_t* __restrict__ tag,
+                                                             uint64_t* __restrict__ lower, uint64_t* __restrict__ upper,
+                                                             uint32_t* __restrict__ matched_len, const SeedSrc seeds) {
+    __shared__ uint16_t s_class[256];
+    __shared__ uint32_t s_less4[4];
+    __shared__ uint32_t s_exc[kMaxExcLds];
+    __shared__ uint32_t s_pk[64 * (kFastSyms / 16)];
+    for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) s_class[i] = fm.sym_class[i];
+    if (threadIdx.x < 4) s_less4[threadIdx.x] = fm.less[(seeds.code_bytes >> (8 * threadIdx.x)) & 0xFFu];
+    for (uint32_t i = threadIdx.x; i < fm.n_exc; i += blockDim.x) s_exc[i] = fm.exc_pos[i];
+    __syncthreads();
+
+    const uint32_t t = threadIdx.x & 3;
+    uint32_t* const slot = s_pk + (threadIdx.x >> 2) * (kFastSyms / 16);
+    const uint64_t n_quads = (uint64_t)gridDim.x * (blockDim.x >> 2);
+    uint64_t q = (uint64_t)blockIdx.x * (blockDim.x >> 2) + (threadIdx.x >> 2);
+    bool active = false;
+    uint32_t pos = 0, l = 0, r = 0, matched = 0, n_lines = 0;
+
+    auto emit = [&](uint32_t tg, uint32_t lo, uint32_t hi, uint32_t ml) {
+        if (t == 0) {
+            tag[q] = (uint8_t)tg;
+            lower[q] = lo;
+            upper[q] = hi;
+            matched_len[q] = ml;
+        }
+    };
+    auto fetch = [&]() {
+        active = false;
+        while (q < n_q) {
+            uint64_t off;
+            uint32_t len;
+            if (SEEDS) {
+                const uint64_t rd = q / seeds.S;
+                const uint32_t k = (uint32_t)(q - rd * seeds.S);
+                const uint64_t o = pat_off[rd];
+                off = o + (uint64_t)k * seeds.stride;
+                len = (uint64_t)k * seeds.stride + seeds.seed_len <= pat_off[rd + 1] - o ? seeds.seed_len : 0u;
+            } else {
+                off = pat_off[q];
+                const uint64_t len64 = pat_off[q + 1] - off;
+                len = len64 > kFastSyms ? kFastSyms + 1 : (uint32_t)len64;
+            }
+            if (len == 0) {  // empty pattern: Absent (fmindex.rs:185-207)
+                emit(BG_FM_ABSENT, 0, 0, 0);
+                q += n_quads;
+                continue;
+            }
+            bool bad = len > kFastSyms;
+            if (!bad) {
+                // lane t packs dwords t, t + 4, ...: symbols [16 w, 16 w + 16) of the pattern, from the aligned dwords that
+                // hold them (a dword without a wanted byte is never touched)
+                for (uint32_t w = t; w * 16 < len; w += 4) {
+                    const uint64_t b0 = off + (uint64_t)w * 16;
+                    const uint32_t cnt = min(16u, len - w * 16);
+                    const uint32_t sh = (uint32_t)((uintptr_t)(pat + b0) & 3u);
+                    const uint32_t* src = (const uint32_t*)(pat + b0 - sh);
+                    const uint32_t nd = (sh + cnt + 3) >> 2;  // aligned dwords spanned: 1..5
+                    uint32_t d[5];
+#pragma unroll
+                    for (int k = 0; k < 5; k++) d[k] = (uint32_t)k < nd ? src[k] : 0u;
+                    uint32_t word = 0;
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; g4++) {
+                        const uint32_t four = __builtin_amdgcn_alignbyte(d[g4 + 1], d[g4], sh);  // bytes 4 g4 .. + 3 of the 16
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const uint32_t idx = 4 * g4 + k;
+                            const uint32_t c = s_class[(four >> (8 * k)) & 0xFFu];
+                            if (idx < cnt) {
+                                bad = bad || c >= 4;
+                                word |= (c & 3u) << (2 * idx);
+                            }
+                        }
+                    }
+                    slot[w] = word;
+                }
+                // any lane of the quad saw a byte without a code?
+                uint32_t bq = bad ? 1u : 0u;
+                bq |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bq, 0xB1, 0xf, 0xf, true);
+                bq |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bq, 0x4E, 0xf, 0xf, true);
+                bad = bq != 0;
+            }
+            if (bad) {  // the generic kernel answers it
+                if (t == 0) tag[q] = kTagDeferred;
+                q += n_quads;
+                continue;
+            }
+            pos = len;
+            l = 0;
+            r = fm.n - 1;  // fmindex.rs:148
+            matched = 0;
+            active = true;
+            return;
+        }
+    };
+    fetch();
+    while (__any(active)) {
+        if (active) {
+            // one iteration of the loop at fmindex.rs:160-182; the symbol is a code already
+            pos -= 1;
+            const uint32_t a = (slot[pos >> 4] >> (2 * (pos & 15u))) & 3u;
+            const uint32_t less_a = s_less4[a];
+            const uint32_t br = r / kSymPerBlock, orr = r - br * kSymPerBlock;
+            const uint4 vr = fm.blocks[(uint64_t)br * 4 + t];
+            uint4 vl = vr;
+            uint32_t ol = 0;
+            if (l > 0) {
+                const uint32_t bl = (l - 1) / kSymPerBlock;
+                ol = (l - 1) - bl * kSymPerBlock;
+                if (bl != br) {
+                    vl = fm.blocks[(uint64_t)bl * 4 + t];
+                    if (COUNT) n_lines += 1;
+                }
+            }
+            if (COUNT) n_lines += 1;
+            uint32_t occ_r = quad_sum(block_part(vr, t, orr, a)), occ_l = 0;
+            if (l > 0) occ_l = quad_sum(block_part(vl, t, ol, a));
+            if (a == 0 && fm.n_exc) {  // sparse exceptions sit in the stream as code 0
+                if (fm.n_exc == 1) {
+                    const uint32_t e0 = s_exc[0];
+                    occ_r -= e0 <= r ? 1u : 0u;
+                    if (l > 0) occ_l -= e0 <= l - 1 ? 1u : 0u;
+                } else {
+                    occ_r -= count_le(s_exc, 0u, fm.n_exc, r);
+                    if (l > 0) occ_l -= count_le(s_exc, 0u, fm.n_exc, l - 1);
+                }
+            }
+            const uint32_t pl = l, pr = r;
+            bool stop = occ_r == 0;  // fmindex.rs:167-170
+            if (!stop) {
+                l = less_a + occ_l;  // fmindex.rs:171
+                r = less_a + occ_r - 1;
+                if (l > r)  // fmindex.rs:177-180
+                    stop = true;
+                else
+                    matched += 1;
+            }
+            if (stop) {
+                if (matched)
                     emit(BG_FM_PARTIAL, pl, pr + 1, matched);
                 else
                     emit(BG_FM_ABSENT, 0, 0, 0);
@@ -774,6 +949,15 @@ extern "C" int bg_fm_free(bg_fm* fm) {
 
 extern "C" uint64_t bg_fm_device_bytes(const bg_fm* fm) { return fm ? fm->bytes : 0; }
 
+// the four 2-bit codes all stand for symbols and no symbol is ranked by a bit vector: the packed / fast kernels apply
+static bool fm_fast_ok(const bg_fm* fm) { return !fm->dev.n_dense && fm->n_codes == 4 && !fm->no_fast; }
+static SeedSrc fm_codes(const bg_fm* fm) {
+    SeedSrc ex{};
+    ex.code_bytes = (uint32_t)fm->code_byte[0] | (uint32_t)fm->code_byte[1] << 8 | (uint32_t)fm->code_byte[2] << 16 |
+                    (uint32_t)fm->code_byte[3] << 24;
+    return ex;
+}
+
 extern "C" int bg_fm_set_option(bg_fm* fm, const char* key, int64_t value) {
     if (!fm || !key) return BG_ERR_INVALID_ARG;
     if (!strcmp(key, "jump_min_queries")) {  // batch size from which K5 builds / uses its jump table; < 0: never (default)
@@ -784,6 +968,10 @@ extern "C" int bg_fm_set_option(bg_fm* fm, const char* key, int64_t value) {
             hipFree(fm->d_jump);
             fm->d_jump = nullptr;
         }
+        return BG_OK;
+    }
+    if (!strcmp(key, "no_fast")) {  // tests: every search through the generic kernel
+        fm->no_fast = value != 0;
         return BG_OK;
     }
     return BG_ERR_INVALID_ARG;
@@ -846,12 +1034,20 @@ extern "C" int bg_fm_backward_search_batch_dev(bg_fm* fm, uint64_t n_q, const ui
       jump = (const uint4*)fm->d_jump;
     }
     if (ctx->timing) BG_HIP(hipEventRecord(ctx->ev[0], st));
-    if (jump)
+    if (jump) {
         fm_backward_search_kernel<true, false><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(
             fm->dev, n_q, d_pat, d_pat_off, d_tag, d_lower, d_upper, d_matched_len, jump, SeedSrc{});
-    else
+    } else if (fm_fast_ok(fm)) {
+        // DNA-like index: patterns become 2-bit codes in LDS when a quad takes them; what that path cannot hold (a byte
+        // outside the four codes, more than kFastSyms symbols) is left to the generic kernel behind it
+        fm_search_fast_kernel<false, false><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(
+            fm->dev, n_q, d_pat, d_pat_off, d_tag, d_lower, d_upper, d_matched_len, fm_codes(fm));
+        fm_backward_search_kernel<false, false, false, false, true><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(
+            fm->dev, n_q, d_pat, d_pat_off, d_tag, d_lower, d_upper, d_matched_len, nullptr, SeedSrc{});
+    } else {
         fm_backward_search_kernel<false, false><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(
             fm->dev, n_q, d_pat, d_pat_off, d_tag, d_lower, d_upper, d_matched_len, nullptr, SeedSrc{});
+    }
     BG_HIP(hipGetLastError());
     if (ctx->timing) {
         BG_HIP(hipEventRecord(ctx->ev[1], st));
@@ -871,8 +1067,17 @@ int bg_fm_search_seeds_dev(bg_fm* fm, uint64_t n_reads, const uint8_t* d_reads, 
     const uint64_t n_q = n_reads * S;
     if (n_q == 0) return BG_OK;
     const uint64_t blocks = std::min<uint64_t>((n_q + 63) / 64, 256 * 8);
-    fm_backward_search_kernel<false, true><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(
-        fm->dev, n_q, d_reads, d_read_off, d_tag, d_lower, d_upper, d_matched_len, nullptr, SeedSrc{S, stride, seed_len});
+    SeedSrc src = fm_codes(fm);
+    src.S = S, src.stride = stride, src.seed_len = seed_len;
+    if (fm_fast_ok(fm) && seed_len <= kFastSyms) {
+        fm_search_fast_kernel<true, false><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(fm->dev, n_q, d_reads, d_read_off, d_tag, d_lower,
+                                                                                        d_upper, d_matched_len, src);
+        fm_backward_search_kernel<false, true, false, false, true><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(
+            fm->dev, n_q, d_reads, d_read_off, d_tag, d_lower, d_upper, d_matched_len, nullptr, src);
+    } else {
+        fm_backward_search_kernel<false, true><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(
+            fm->dev, n_q, d_reads, d_read_off, d_tag, d_lower, d_upper, d_matched_len, nullptr, src);
+    }
     BG_HIP(hipGetLastError());
     return BG_OK;
 }
@@ -896,9 +1101,7 @@ extern "C" int bg_fm_backward_search_packed_dev(bg_fm* fm, uint64_t n_q, const u
     bg_ctx* ctx = fm->ctx;
     hipStream_t st = (hipStream_t)stream;
     const uint64_t blocks = std::min<uint64_t>((n_q + 63) / 64, 256 * 8);
-    SeedSrc ex{};
-    ex.code_bytes = (uint32_t)fm->code_byte[0] | (uint32_t)fm->code_byte[1] << 8 | (uint32_t)fm->code_byte[2] << 16 |
-                    (uint32_t)fm->code_byte[3] << 24;
+    const SeedSrc ex = fm_codes(fm);
     if (ctx->timing) BG_HIP(hipEventRecord(ctx->ev[0], st));
     fm_backward_search_kernel<false, false, true, false><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(
         fm->dev, n_q, (const uint8_t*)d_packed, d_sym_off, d_tag, d_lower, d_upper, d_matched_len, nullptr, ex);
@@ -929,10 +1132,17 @@ extern "C" int bg_fm_backward_search_count_lines_dev(bg_fm* fm, uint64_t n_q, co
     auto run = [&]() -> int {
         BG_HIP(hipMemsetAsync(d_cnt, 0, 8, st));
         const uint64_t blocks = std::min<uint64_t>((n_q + 63) / 64, 256 * 8);
-        SeedSrc ex{};
+        SeedSrc ex = fm_codes(fm);
         ex.lines = d_cnt;
-        fm_backward_search_kernel<false, false, false, true><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(
-            fm->dev, n_q, d_pat, d_pat_off, d_tag, d_lower, d_upper, d_matched_len, nullptr, ex);
+        if (fm_fast_ok(fm)) {
+            fm_search_fast_kernel<false, true><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(fm->dev, n_q, d_pat, d_pat_off, d_tag,
+                                                                                           d_lower, d_upper, d_matched_len, ex);
+            fm_backward_search_kernel<false, false, false, true, true><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(
+                fm->dev, n_q, d_pat, d_pat_off, d_tag, d_lower, d_upper, d_matched_len, nullptr, ex);
+        } else {
+            fm_backward_search_kernel<false, false, false, true><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(
+                fm->dev, n_q, d_pat, d_pat_off, d_tag, d_lower, d_upper, d_matched_len, nullptr, ex);
+        }
         BG_HIP(hipGetLastError());
         BG_HIP(hipMemcpyAsync(lines_out, d_cnt, 8, hipMemcpyDeviceToHost, st));
         BG_HIP(hipStreamSynchronize(st));
@@ -943,6 +1153,48 @@ extern "C" int bg_fm_backward_search_count_lines_dev(bg_fm* fm, uint64_t n_q, co
     return rc;
 }
 
+// ---- bg_fm_backward_search_batch: host buffers in and out -----------------------------------------------------------
+// Round 2 made six hipMallocs and pageable copies per call (150 M queries/s against 460 M device-resident).  Now the
+// batch flows in stages of kFmStage queries through three staging sets that persist in the ctx: host threads copy a
+// stage's pattern bytes into pinned memory and rebase its offsets, the copy-in stream uploads them, the ctx stream
+// searches, the copy-out stream downloads the four result arrays into pinned memory, and a second host thread copies
+// them into the caller's arrays while the following stages are in flight — no allocation in a warmed-up call.
+struct bg_fm_pipe {
+    static constexpr int NSET = 3;
+    struct Set {
+        uint8_t *h_in = nullptr, *h_out = nullptr, *d_in = nullptr, *d_out = nullptr;
+        size_t in_cap = 0, out_cap = 0;
+        hipEvent_t in_done = nullptr, k_done = nullptr, out_done = nullptr;
+    } set[NSET];
+    hipStream_t s_in = nullptr, s_out = nullptr;
+};
+void bg_fm_pipe_free(bg_fm_pipe* p) {
+    if (!p) return;
+    for (auto& s : p->set) {
+        if (s.h_in) hipHostFree(s.h_in);
+        if (s.h_out) hipHostFree(s.h_out);
+        hipFree(s.d_in);
+        hipFree(s.d_out);
+        for (hipEvent_t e : {s.in_done, s.k_done, s.out_done})
+            if (e) hipEventDestroy(e);
+    }
+    if (p->s_in) hipStreamDestroy(p->s_in);
+    if (p->s_out) hipStreamDestroy(p->s_out);
+    delete p;
+}
+namespace {
+template <typename F>
+void fm_parallel_for(uint64_t n, uint64_t grain, F&& f) {
+    const unsigned nt = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(bg_host_threads(), n / std::max<uint64_t>(grain, 1) + 1));
+    if (nt == 1) {
+        f((uint64_t)0, n);
+        return;
+    }
+    bg_pool_run(nt, [&](unsigned t) { f(n * t / nt, n * (t + 1) / nt); });
+}
+constexpr uint64_t kFmStage = 1u << 20;  // queries per stage
+}  // namespace
+
 extern "C" int bg_fm_backward_search_batch(bg_fm* fm, uint64_t n_q, const uint8_t* pat,
                                            const uint64_t* pat_off, uint8_t* tag, uint64_t* lower,
                                            uint64_t* upper, uint32_t* matched_len) {
@@ -951,40 +1203,146 @@ extern "C" int bg_fm_backward_search_batch(bg_fm* fm, uint64_t n_q, const uint8_
     if (n_q == 0) return BG_OK;
     bg_ctx* ctx = fm->ctx;
     BG_HIP(hipSetDevice(ctx->device));
-    const uint64_t pat_bytes = pat_off[n_q];
-    if (pat_bytes && !pat) return BG_ERR_INVALID_ARG;
-    uint8_t *d_pat = nullptr, *d_tag = nullptr;
-    uint64_t *d_off = nullptr, *d_lo = nullptr, *d_hi = nullptr;
-    uint32_t* d_ml = nullptr;
-    int rc = BG_OK;
-    auto run = [&]() -> int {
-        BG_HIP(hipMalloc((void**)&d_pat, std::max<uint64_t>(pat_bytes, 16)));
-        BG_HIP(hipMalloc((void**)&d_off, (n_q + 1) * 8));
-        BG_HIP(hipMalloc((void**)&d_tag, n_q));
-        BG_HIP(hipMalloc((void**)&d_lo, n_q * 8));
-        BG_HIP(hipMalloc((void**)&d_hi, n_q * 8));
-        BG_HIP(hipMalloc((void**)&d_ml, n_q * 4));
-        hipStream_t st = ctx->stream;
-        if (pat_bytes) BG_HIP(hipMemcpyAsync(d_pat, pat, pat_bytes, hipMemcpyHostToDevice, st));
-        BG_HIP(hipMemcpyAsync(d_off, pat_off, (n_q + 1) * 8, hipMemcpyHostToDevice, st));
-        int r2 = bg_fm_backward_search_batch_dev(fm, n_q, d_pat, d_off, d_tag, d_lo, d_hi, d_ml, st);
-        if (r2) return r2;
-        BG_HIP(hipMemcpyAsync(tag, d_tag, n_q, hipMemcpyDeviceToHost, st));
-        BG_HIP(hipMemcpyAsync(lower, d_lo, n_q * 8, hipMemcpyDeviceToHost, st));
-        BG_HIP(hipMemcpyAsync(upper, d_hi, n_q * 8, hipMemcpyDeviceToHost, st));
-        BG_HIP(hipMemcpyAsync(matched_len, d_ml, n_q * 4, hipMemcpyDeviceToHost, st));
-        BG_HIP(hipStreamSynchronize(st));
+    if (pat_off[n_q] && !pat) return BG_ERR_INVALID_ARG;
+    if (!ctx->fm_pipe) {
+        ctx->fm_pipe = new bg_fm_pipe();
+        BG_HIP(hipStreamCreateWithFlags(&ctx->fm_pipe->s_in, hipStreamNonBlocking));
+        BG_HIP(hipStreamCreateWithFlags(&ctx->fm_pipe->s_out, hipStreamNonBlocking));
+        for (auto& s : ctx->fm_pipe->set)
+            for (hipEvent_t* e : {&s.in_done, &s.k_done, &s.out_done}) BG_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    }
+    bg_fm_pipe& P = *ctx->fm_pipe;
+    const uint64_t chunk = std::min<uint64_t>(kFmStage, n_q);
+    const uint64_t nch = (n_q + chunk - 1) / chunk;
+    uint64_t max_pb = 0;
+    for (uint64_t c = 0; c < nch; c++) {
+        const uint64_t q0 = c * chunk, q1 = std::min(n_q, q0 + chunk);
+        if (pat_off[q1] < pat_off[q0]) return BG_ERR_INVALID_ARG;
+        max_pb = std::max(max_pb, pat_off[q1] - pat_off[q0]);
+    }
+    // staging layout: in = pattern bytes | offsets ; out = lower | upper | matched_len | tag
+    const uint64_t o_off = (max_pb + 255) & ~255ull;
+    const size_t in_need = o_off + (chunk + 1) * 8 + 256;
+    const uint64_t o_hi = chunk * 8, o_ml = 2 * chunk * 8, o_tag = o_ml + chunk * 4;
+    const size_t out_need = o_tag + chunk + 256;
+    for (auto& s : P.set) {
+        if (s.in_cap < in_need) {
+            if (s.h_in) hipHostFree(s.h_in);
+            hipFree(s.d_in);
+            s.h_in = s.d_in = nullptr;
+            s.in_cap = 0;
+            BG_HIP(hipHostMalloc((void**)&s.h_in, in_need, hipHostMallocDefault));
+            BG_HIP(hipMalloc((void**)&s.d_in, in_need));
+            s.in_cap = in_need;
+        }
+        if (s.out_cap < out_need) {
+            if (s.h_out) hipHostFree(s.h_out);
+            hipFree(s.d_out);
+            s.h_out = s.d_out = nullptr;
+            s.out_cap = 0;
+            BG_HIP(hipHostMalloc((void**)&s.h_out, out_need, hipHostMallocDefault));
+            BG_HIP(hipMalloc((void**)&s.d_out, out_need));
+            s.out_cap = out_need;
+        }
+    }
+    hipStream_t s_k = ctx->stream;
+    std::atomic<bool> any_panic{false};
+    auto drain = [&](uint64_t c) -> int {
+        bg_fm_pipe::Set& S = P.set[c % bg_fm_pipe::NSET];
+        BG_HIP(hipEventSynchronize(S.out_done));
+        const uint64_t q0 = c * chunk, nq = std::min(n_q, q0 + chunk) - q0;
+        fm_parallel_for(nq, 1 << 16, [&](uint64_t a, uint64_t b) {
+            memcpy(lower + q0 + a, S.h_out + a * 8, (b - a) * 8);
+            memcpy(upper + q0 + a, S.h_out + o_hi + a * 8, (b - a) * 8);
+            memcpy(matched_len + q0 + a, S.h_out + o_ml + a * 4, (b - a) * 4);
+            memcpy(tag + q0 + a, S.h_out + o_tag + a, b - a);
+            bool pn = false;
+            for (uint64_t q = a; q < b; q++) pn = pn || S.h_out[o_tag + q] == BG_FM_PANIC;
+            if (pn) any_panic = true;
+        });
         return BG_OK;
     };
-    rc = run();
-    hipFree(d_pat);
-    hipFree(d_off);
-    hipFree(d_tag);
-    hipFree(d_lo);
-    hipFree(d_hi);
-    hipFree(d_ml);
-    if (rc) return rc;
-    for (uint64_t q = 0; q < n_q; q++)
-        if (tag[q] == BG_FM_PANIC) return BG_ERR_OUT_OF_ALPHABET;
-    return BG_OK;
+    std::mutex mu;
+    std::condition_variable cv;
+    uint64_t submitted = 0, drained = 0;
+    bool abort_drain = false;
+    int drain_rc = BG_OK;
+    std::string drain_err;
+    const int device = ctx->device;
+    std::thread drainer([&] {
+        if (hipSetDevice(device) != hipSuccess) {
+            std::lock_guard<std::mutex> lk(mu);
+            drain_rc = BG_ERR_HIP;
+            drained = nch;
+            cv.notify_all();
+            return;
+        }
+        for (uint64_t c = 0; c < nch; c++) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return submitted > c || abort_drain; });
+                if (submitted <= c) break;
+            }
+            const int r = drain(c);
+            std::lock_guard<std::mutex> lk(mu);
+            if (r && drain_rc == BG_OK) {
+                drain_rc = r;
+                drain_err = bg_tls_error;
+            }
+            drained = c + 1;
+            cv.notify_all();
+        }
+        std::lock_guard<std::mutex> lk(mu);
+        drained = nch;
+        cv.notify_all();
+    });
+    auto stop_drainer = [&] {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            abort_drain = true;
+        }
+        cv.notify_all();
+        drainer.join();
+    };
+    for (uint64_t c = 0; c < nch; c++) {
+        if (c >= bg_fm_pipe::NSET) {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return drained >= c - bg_fm_pipe::NSET + 1; });
+        }
+        bg_fm_pipe::Set& S = P.set[c % bg_fm_pipe::NSET];
+        const uint64_t q0 = c * chunk, nq = std::min(n_q, q0 + chunk) - q0;
+        const uint64_t b0 = pat_off[q0], pb = pat_off[q0 + nq] - b0;
+        fm_parallel_for(pb, 1 << 20, [&](uint64_t a, uint64_t b) { memcpy(S.h_in + a, pat + b0 + a, b - a); });
+        uint64_t* hoff = (uint64_t*)(S.h_in + o_off);
+        fm_parallel_for(nq + 1, 1 << 16, [&](uint64_t a, uint64_t b) {
+            for (uint64_t q = a; q < b; q++) hoff[q] = pat_off[q0 + q] - b0;
+        });
+        bool ok = true;
+        if (pb) ok = ok && hipMemcpyAsync(S.d_in, S.h_in, pb, hipMemcpyHostToDevice, P.s_in) == hipSuccess;
+        ok = ok && hipMemcpyAsync(S.d_in + o_off, S.h_in + o_off, (nq + 1) * 8, hipMemcpyHostToDevice, P.s_in) == hipSuccess;
+        ok = ok && hipEventRecord(S.in_done, P.s_in) == hipSuccess && hipStreamWaitEvent(s_k, S.in_done, 0) == hipSuccess;
+        int rc = !ok ? BG_ERR_HIP
+                     : bg_fm_backward_search_batch_dev(fm, nq, S.d_in, (const uint64_t*)(S.d_in + o_off), S.d_out + o_tag,
+                                                       (uint64_t*)S.d_out, (uint64_t*)(S.d_out + o_hi), (uint32_t*)(S.d_out + o_ml), s_k);
+        if (rc == BG_OK && (hipEventRecord(S.k_done, s_k) != hipSuccess || hipStreamWaitEvent(P.s_out, S.k_done, 0) != hipSuccess ||
+                            hipMemcpyAsync(S.h_out, S.d_out, o_tag + nq, hipMemcpyDeviceToHost, P.s_out) != hipSuccess ||
+                            hipEventRecord(S.out_done, P.s_out) != hipSuccess))
+            rc = BG_ERR_HIP;
+        if (rc) {
+            hipDeviceSynchronize();
+            stop_drainer();
+            return rc;
+        }
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            submitted = c + 1;
+        }
+        cv.notify_all();
+    }
+    drainer.join();
+    if (drain_rc) {
+        bg_tls_error = drain_err;
+        return drain_rc;
+    }
+    return any_panic ? BG_ERR_OUT_OF_ALPHABET : BG_OK;
 }

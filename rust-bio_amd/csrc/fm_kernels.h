@@ -134,6 +134,7 @@ struct bg_fm {
     std::mutex jump_mu;
     uint64_t jump_min_queries = ~0ull;
     bool no_jump = true;
+    bool no_fast = false;    // tests: never the pack-at-fetch kernel (fm_search_fast_kernel)
     int n_codes = 0;         // distinct bytes with a 2-bit code (<= 4)
     uint32_t less_len = 0;
     bool fmd_ok = false;  // the BWT is a word over dna::n_alphabet() + '$' (FMDIndex::from, fmindex.rs:323-327)

@@ -191,3 +191,63 @@ def test_one_index_searched_from_several_threads():
         otag, olo, ohi, oml = orc.backward_search_batch(b, ls, occ, pat, off, threads=4)
         assert (tag == otag).all() and (lo.astype(np.uint64) == olo).all() and (hi.astype(np.uint64) == ohi).all()
         assert (ml.astype(np.uint64) == oml).all()
+
+
+def test_fast_kernel_with_deferred_patterns_equals_the_generic_kernel_and_the_oracle():
+    """DNA-like index: patterns are turned into 2-bit codes in LDS when a quad takes them (fm_search_fast_kernel); patterns
+    with a byte outside the four codes (N, lower case, a byte the alphabet does not hold: the reference's panic), longer
+    than the LDS slot (256 symbols), empty, at every byte alignment — left to the generic kernel — must all come out as
+    the generic kernel alone (option no_fast) and the oracle give them"""
+    import torch
+    g = synth.genome(400_000, 17)
+    g[1000:1040] = ord("N")
+    sa = suffix_array(g)
+    b = bwt(g, sa)
+    alpha = b"ACGTNacgtn"
+    ls = less(b, alpha)
+    fm = FMIndex(b, ls, Occ(b, 64, alpha))
+    rng = np.random.default_rng(23)
+    pats = []
+    for q in range(6000):
+        kind = q % 12
+        ln = int(rng.integers(1, 130))
+        s0 = int(rng.integers(0, len(g) - 700))
+        p = g[s0:s0 + ln].copy()
+        if kind == 0:
+            p = g[s0:s0 + int(rng.integers(257, 600))].copy()      # longer than the slot
+        elif kind == 1:
+            p[int(rng.integers(0, ln))] = ord("N")                  # in the alphabet, not a code
+        elif kind == 2:
+            p[int(rng.integers(0, ln))] = ord("a")                  # in the alphabet, never in the text
+        elif kind == 3:
+            p[int(rng.integers(0, ln))] = ord("X")                  # the reference panics if the search gets there
+        elif kind == 4:
+            p = p[:0]                                                # empty
+        elif kind == 5:
+            p = g[990:1010 + ln].copy()                              # runs into the N block of the text
+        elif kind == 6 and ln > 3:
+            p[ln // 2] = ord("ACGT"[(list(b"ACGT").index(p[ln // 2]) + 1) % 4])  # a substitution: mostly Partial
+        pats.append(bytes(p))
+    pat, off = _lib.concat(pats)
+    dev = "cuda:0"
+    d_pat = torch.from_numpy(pat.copy()).to(dev)
+    d_off = torch.from_numpy(off.astype(np.int64)).to(dev)
+    n_q = len(pats)
+    res = []
+    for no_fast in (0, 1):
+        fm.set_option("no_fast", no_fast)
+        tag = torch.full((n_q,), 77, dtype=torch.uint8, device=dev)
+        lo, hi = torch.zeros(n_q, dtype=torch.int64, device=dev), torch.zeros(n_q, dtype=torch.int64, device=dev)
+        ml = torch.zeros(n_q, dtype=torch.int32, device=dev)
+        fm.backward_search_dev(n_q, d_pat.data_ptr(), d_off.data_ptr(), tag.data_ptr(), lo.data_ptr(), hi.data_ptr(), ml.data_ptr())
+        torch.cuda.synchronize()
+        res.append((tag.cpu().numpy(), lo.cpu().numpy(), hi.cpu().numpy(), ml.cpu().numpy()))
+    fm.set_option("no_fast", 0)
+    for a, c in zip(*res):
+        assert (a == c).all()
+    tag, lo, hi, ml = res[0]
+    assert set(np.unique(tag)) <= {0, 1, 2, 3} and (tag == 3).any() and (tag == 0).any() and (tag == 1).any() and (tag == 2).any()
+    otag, olo, ohi, oml = orc.backward_search_batch(b, ls, orc.Occ(b, 64, alpha), pat, off, threads=8)
+    ok = otag != 3  # a panicking query has no interval
+    assert (tag == otag).all() and (lo.astype(np.uint64)[ok] == olo[ok]).all() and (hi.astype(np.uint64)[ok] == ohi[ok]).all()
+    assert (ml.astype(np.uint64)[ok] == oml[ok]).all()
