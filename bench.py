@@ -586,6 +586,34 @@ def build_index(args, ctx, dev, n_genome, seed, want_sa, want_host):
     return g_dev, g, sa, b, ls, fm, t
 
 
+def fm_packed_leg(args, ctx, dev, stream, world, fm, n_q, pat, off, bufs, byte_ms, parity, key):
+    """A/B: the same patterns as a 2-bit stream (bg_pack2_dev with the index's codes, bg_fm_backward_search_packed_dev: a dword
+    load per 16 steps, symbols are codes already) against the byte flavour whose results sit in `bufs`"""
+    from rust_bio_amd import pack2
+    d_tag, d_lo, d_hi, d_ml = bufs
+    ref = (d_tag.clone(), d_lo.clone(), d_hi.clone(), d_ml.clone())
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ppk, bad = pack2.pack_dev(pat, codes=fm.pattern_codes(), ctx=ctx, stream=stream)
+    torch.cuda.synchronize()
+    pack_ms = (time.perf_counter() - t0) * 1e3
+
+    def step():
+        fm.backward_search_packed_dev(n_q, ppk.data_ptr(), off.data_ptr(), d_tag.data_ptr(), d_lo.data_ptr(), d_hi.data_ptr(),
+                                      d_ml.data_ptr(), stream)
+
+    tpk = timed_steps(step, args.steps, args.warmup, dev)
+    tmk = kernel_timing(ctx, step)
+    same = bad == 0 and all(bool(torch.equal(a_, b_)) for a_, b_ in zip(ref, (d_tag, d_lo, d_hi, d_ml)))
+    if parity is not None:
+        parity[f"{key}_packed2_equals_bytes_all_queries"] = same
+    return {"value": round(world * float(n_q) * args.steps / tpk, 1), "unit": "queries/s",
+            "ms_per_step": round(tpk / args.steps * 1e3, 3), "launch_ms": round(tmk["fm_ms"] / max(1, tmk["fm_launches"]), 4),
+            "byte_flavour_launch_ms": round(byte_ms, 4), "pack_ms": round(pack_ms, 3), "results_equal_byte_run": same,
+            "config": {"workload": "the same patterns as a 2-bit stream (bg_pack2_dev with bg_fm_pattern_codes, "
+                                   "bg_fm_backward_search_packed_dev): A/B against the byte flavour"}}
+
+
 def fm_legs(args, ctx, dev, stream, rank, world, do_cpu, orc, threads, parity, result):
     L = args.read_len
     pipeline_here = not args.skip_pipeline and not args.fm_big_genome  # else the seed-and-extend leg runs on the big index
@@ -632,32 +660,8 @@ def fm_legs(args, ctx, dev, stream, rank, world, do_cpu, orc, threads, parity, r
     block_bytes = (args.genome + 1 + 191) // 192 * 64
     if rank == 0:
         fm_res["roofline"].update(fm_gather_fields(fm, n_q, pat, off, (d_tag, d_lo, d_hi, d_ml), stream, fm_ms, block_bytes))
-    if not args.skip_packed:  # A/B: the same patterns as a 2-bit stream (dword load per 16 steps, no class lookups)
-        from rust_bio_amd import pack2
-        ref = (d_tag.clone(), d_lo.clone(), d_hi.clone(), d_ml.clone())
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        ppk, bad = pack2.pack_dev(pat, codes=fm.pattern_codes(), ctx=ctx, stream=stream)
-        torch.cuda.synchronize()
-        pack_ms = (time.perf_counter() - t0) * 1e3
-
-        def fm_packed_step():
-            fm.backward_search_packed_dev(n_q, ppk.data_ptr(), off.data_ptr(), d_tag.data_ptr(), d_lo.data_ptr(), d_hi.data_ptr(),
-                                          d_ml.data_ptr(), stream)
-
-        tpk = timed_steps(fm_packed_step, args.steps, args.warmup, dev)
-        tmk = kernel_timing(ctx, fm_packed_step)
-        same = bad == 0 and all(bool(torch.equal(a_, b_)) for a_, b_ in zip(ref, (d_tag, d_lo, d_hi, d_ml)))
-        fm_res["packed2"] = {"value": round(world * float(n_q) * args.steps / tpk, 1), "unit": "queries/s",
-                             "ms_per_step": round(tpk / args.steps * 1e3, 3),
-                             "launch_ms": round(tmk["fm_ms"] / max(1, tmk["fm_launches"]), 4),
-                             "byte_flavour_launch_ms": round(fm_ms, 4), "pack_ms": round(pack_ms, 3),
-                             "results_equal_byte_run": same,
-                             "config": {"workload": "the same patterns as a 2-bit stream (bg_pack2_dev with bg_fm_pattern_codes, "
-                                                    "bg_fm_backward_search_packed_dev): A/B against the byte flavour"}}
-        if parity is not None:
-            parity["fm_packed2_equals_bytes_all_queries"] = same
-        del ppk, ref
+    if not args.skip_packed:
+        fm_res["packed2"] = fm_packed_leg(args, ctx, dev, stream, world, fm, n_q, pat, off, (d_tag, d_lo, d_hi, d_ml), fm_ms, parity, "fm")
     # strong scaling on configs[2]: the SAME n_q queries in total, split over the ranks, gathered inside the step
     q_lo, q_hi = shard.partition(n_q, rank, world)
     if world > 1:  # every rank must search the same global query set: regenerate it from rank 0's seed
@@ -771,6 +775,8 @@ def fm_big_leg(args, ctx, dev, stream, rank, world, do_cpu, orc, threads, parity
                         "launch_ms": round(ms, 4), "queries_per_launch": n_q, "alg_bytes_per_query": round(alg / n_q, 1)}}
     if rank == 0:
         leg["roofline"].update(fm_gather_fields(fm, n_q, pat, off, (d_tag, d_lo, d_hi, d_ml), stream, ms, (n_g + 1 + 191) // 192 * 64))
+    if not args.skip_packed:
+        leg["packed2"] = fm_packed_leg(args, ctx, dev, stream, world, fm, n_q, pat, off, (d_tag, d_lo, d_hi, d_ml), ms, parity, "fm_big")
     if do_cpu:
         occ = orc.Occ(b, 128, N_ALPHABET)
         n_chk = max(1, int(min(n_q, 1_000_000) * args.parity_frac))

@@ -93,9 +93,11 @@ int bg_less(const uint8_t* bwt, uint64_t n, const uint8_t* alphabet, uint32_t n_
  * of (rank, rank) keys), n uint32 entries; BWT gather; RawSuffixArray::sample (suffix_array.rs:86-120) with the
  * samples and the sentinel rows returned to host arrays (what bg_fm_set_sampled_suffix_array takes: sample holds
  * ceil(n / rate) entries, extra rows come back sorted, *n_extra says how many; BG_ERR_OPS_CAP beyond extra_cap).
- * The results equal the host functions' (the suffix array of a text with one sentinel is unique).  Texts whose
- * sentinel byte occurs more than once (several sequences, suffix_array.rs:444-466) are not taken here:
- * BG_ERR_UNSUPPORTED, use bg_suffix_array.  About 29 bytes of device scratch per symbol; synchronous. */
+ * The results equal the host functions' (the suffix array of the transformed text is unique), also for texts whose
+ * sentinel byte occurs several times — several sequences, or T$R$ for an FMD index (fmindex.rs:312-340): the sentinels
+ * rank by position, the last occurrence smallest (transform_text, suffix_array.rs:444-466).  Texts are limited to
+ * 2^32 - 2 symbols (BG_ERR_TOO_LARGE; the reference indexes with usize).  About 29 bytes of device scratch per symbol;
+ * synchronous. */
 int bg_suffix_array_dev(bg_ctx* ctx, const uint8_t* d_text, uint64_t n, uint32_t* d_sa, void* stream);
 int bg_bwt_dev(bg_ctx* ctx, const uint8_t* d_text, const uint32_t* d_sa, uint64_t n, uint8_t* d_bwt, void* stream);
 int bg_sa_sample_dev(bg_ctx* ctx, const uint32_t* d_sa, const uint8_t* d_bwt, uint64_t n, uint32_t sampling_rate,

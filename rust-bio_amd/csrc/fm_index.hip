@@ -25,7 +25,11 @@
 //     bits — so that Occ::get is still exactly one 64-byte line, whatever the symbol.  n / 7.5 bytes per such
 //     symbol (a 20-letter protein text: 2.7 bytes per symbol of index); the raw BWT is kept for K6 (bwt[pos]).
 // No MFMA: this is a latency/bandwidth-bound table walk (DESIGN.md §FM roofline).
-#include <hipcub/hipcub.hpp>
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/device/device_select.hpp>
 
 #include <algorithm>
 #include <atomic>
@@ -837,12 +841,12 @@ extern "C" int bg_fm_build_dev(bg_ctx* ctx, const uint8_t* d_bwt, uint64_t n, ui
         if ((rc = dalloc((void**)&d_cnt, n_cnt * 4))) return rc;
         if ((rc = dalloc((void**)&d_scan, n_cnt * 4))) return rc;
         size_t cub_bytes = 0;
-        BG_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, cub_bytes, d_cnt, d_scan, std::max<uint64_t>(nblk, nbv), st));
+        BG_HIP(rocprim::exclusive_scan(nullptr, cub_bytes, d_cnt, d_scan, 0u, std::max<uint64_t>(nblk, nbv), rocprim::plus<uint32_t>(), st));
         if ((rc = dalloc(&d_cub, cub_bytes))) return rc;
         fmb_blocks_kernel<<<dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, st>>>(d_bwt, n, nblk, d_tab, (uint32_t*)fm->d_blocks, d_cnt);
         BG_HIP(hipGetLastError());
         for (int k = 0; k < 4; k++)
-            BG_HIP(hipcub::DeviceScan::ExclusiveSum(d_cub, cub_bytes, d_cnt + (uint64_t)k * nblk, d_scan + (uint64_t)k * nblk, nblk, st));
+            BG_HIP(rocprim::exclusive_scan(d_cub, cub_bytes, d_cnt + (uint64_t)k * nblk, d_scan + (uint64_t)k * nblk, 0u, nblk, rocprim::plus<uint32_t>(), st));
         fmb_block_heads_kernel<<<dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, st>>>(nblk, d_scan, (uint32_t*)fm->d_blocks);
         // ---- one-hot bit vectors of the dense symbols
         if ((rc = keep(&fm->d_bitvecs, n_dense * nbv * 64))) return rc;
@@ -855,7 +859,7 @@ extern "C" int bg_fm_build_dev(bg_ctx* ctx, const uint8_t* d_bwt, uint64_t n, ui
                                                                                       (uint32_t*)fm->d_bitvecs, d_cnt);
             BG_HIP(hipGetLastError());
             for (size_t d = 0; d < n_dense; d++)
-                BG_HIP(hipcub::DeviceScan::ExclusiveSum(d_cub, cub_bytes, d_cnt + d * nbv, d_scan + d * nbv, nbv, st));
+                BG_HIP(rocprim::exclusive_scan(d_cub, cub_bytes, d_cnt + d * nbv, d_scan + d * nbv, 0u, nbv, rocprim::plus<uint32_t>(), st));
             fmb_bitvec_heads_kernel<<<dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st>>>(tot, d_scan, (uint32_t*)fm->d_bitvecs);
         }
         // ---- sparse exceptions (at most kMaxExcLds positions by construction of the classes)

@@ -3,8 +3,11 @@
 // Stands where rust-bio's host code runs `suffix_array` (/root/reference/src/data_structures/suffix_array.rs:264-284)
 // and `bwt` (bwt.rs:39-49) when the text already lives in HBM: the host SA-IS (host_tables.cpp) needs ~100 s and 16 GB
 // of host memory per Gbp, which is what kept BASELINE configs[4] (a 3 Gbp reference) out of reach.  The suffix array
-// of a text whose sentinel is unique is unique, so any correct sorter reproduces the reference's array; texts with
-// several sentinels (transform_text, suffix_array.rs:444-466) are left to the host builder (BG_ERR_UNSUPPORTED).
+// of the text as the reference transforms it is unique, so any correct sorter reproduces the reference's array.  Texts
+// with several sentinels (several sequences, or T$R$ for an FMD index): transform_text (suffix_array.rs:444-466) turns
+// them into distinct symbols ordered by position, the LAST occurrence smallest — here: keys stop at the first sentinel,
+// the sentinel suffixes get their ranks (descending position) up front, and a doubling round looks at
+// rank[min(i + h, next sentinel at or after i)], never across a sentinel.
 //
 // Prefix doubling with discarding (Larsson & Sadakane 2007, as usually run on GPUs):
 //   round 0   64-bit key per suffix = its first K symbols (alphabet re-coded to b bits, K = 64 / b: 21 bases for
@@ -13,9 +16,14 @@
 //             active list is sorted, every group is rewritten in place in the order of the second rank and split;
 //             h doubles until no group is left.
 // A random genome is done after round 0 and one small round; repeats cost further (small) rounds.  Sorting,
-// scans and compaction are rocPRIM's (hipcub front end): plain library primitives, like rust-bio's own use of a
-// library suffix sorter; the kernels around them are below.  Memory: 29 bytes per symbol of scratch.
-#include <hipcub/hipcub.hpp>
+// scans and compaction are rocPRIM's (rocprim::radix_sort_pairs / inclusive_scan / select): plain library primitives,
+// like rust-bio's own use of a library suffix sorter; the kernels around them are below.  Memory: 29 bytes per symbol
+// of scratch.
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/device/device_select.hpp>
 
 #include <algorithm>
 #include <vector>
@@ -37,18 +45,47 @@ __global__ __launch_bounds__(256) void sab_presence_kernel(const uint8_t* __rest
     if (s[threadIdx.x]) atomicAdd(&cnt[threadIdx.x], min(s[threadIdx.x], 2u));  // 0, 1 or "more": saturating is enough
 }
 
-// key of suffix i: its first K symbols, b bits each, most significant first; symbols past the end count as 0
+// key of suffix i: its first K symbols, b bits each, most significant first, up to and including its first sentinel
+// (code 0): what follows a sentinel counts as 0 — a comparison never goes past one (transform_text makes every
+// sentinel a symbol of its own) — and so do symbols past the end
 __global__ __launch_bounds__(256) void sab_init_keys_kernel(const uint8_t* __restrict__ t, uint64_t n, CodeMap cm, uint32_t b, uint32_t K,
                                                             uint64_t* __restrict__ key, uint32_t* __restrict__ val) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint64_t k = 0;
+    bool open = true;
     for (uint32_t u = 0; u < K; u++) {
         const uint64_t p = i + u;
-        k = (k << b) | (p < n ? (uint64_t)cm.code[t[p]] : 0ull);
+        const uint64_t c = (open && p < n) ? (uint64_t)cm.code[t[p]] : 0ull;
+        open = open && c != 0;
+        k = (k << b) | c;
     }
     key[i] = k;
     val[i] = (uint32_t)i;
+}
+
+__global__ __launch_bounds__(256) void sab_count_byte_kernel(const uint8_t* __restrict__ t, uint64_t n, uint32_t byte,
+                                                             unsigned long long* __restrict__ cnt) {
+    uint32_t c = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) c += t[i] == byte;
+#pragma unroll
+    for (int o = 32; o; o >>= 1) c += (uint32_t)__shfl_xor((int)c, o);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(cnt, (unsigned long long)c);
+}
+
+// The c suffixes that start with a sentinel are the c smallest of the text, the last occurrence first
+// (suffix_array.rs:454-458): the sorted list holds them in rows 0 .. c - 1 in ascending position (stable sort of equal
+// keys): `sent` keeps that list (next-sentinel lookups), rows / ranks are rewritten in descending position
+__global__ __launch_bounds__(256) void sab_sentinel_rows_kernel(const uint32_t* __restrict__ suf, uint64_t c, uint32_t* __restrict__ sent,
+                                                                uint32_t* __restrict__ rank, uint32_t* __restrict__ sa,
+                                                                uint8_t* __restrict__ active) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= c) return;
+    sent[j] = suf[j];
+    const uint32_t i = suf[c - 1 - j];
+    rank[i] = (uint32_t)j;
+    sa[j] = i;
+    active[j] = 0;
 }
 
 // hp[j] = j where a new group starts (else 0): an inclusive max-scan turns it into "start of my group"
@@ -70,12 +107,28 @@ __global__ __launch_bounds__(256) void sab_round0_kernel(const uint32_t* __restr
     active[j] = !(head && next_head);
 }
 
+// second key of an active suffix: the rank of the suffix h symbols on — or of its first sentinel, if that comes first:
+// the members of a group are equal up to there, sentinel included, and the sentinels' own ranks (unique from the
+// start) decide (sent: the c sentinel positions, ascending; c == 1: the text's last byte, never before i + h)
 __global__ __launch_bounds__(256) void sab_round_keys_kernel(const uint32_t* __restrict__ act, uint64_t A, const uint32_t* __restrict__ rank,
-                                                             uint64_t n, uint64_t h, uint64_t* __restrict__ key) {
+                                                             uint64_t n, uint64_t h, const uint32_t* __restrict__ sent, uint32_t c,
+                                                             uint64_t* __restrict__ key) {
     const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= A) return;
     const uint64_t i = act[p];
-    const uint32_t r2 = i + h < n ? rank[i + h] : 0u;  // cannot happen for an active suffix (it would hold the sentinel)
+    uint64_t at = i + h;
+    if (c > 1) {  // first sentinel at or after i (there always is one: the text ends in one)
+        uint32_t lo = 0, hi = c - 1;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (sent[mid] >= i)
+                hi = mid;
+            else
+                lo = mid + 1;
+        }
+        at = min(at, (uint64_t)sent[lo]);
+    }
+    const uint32_t r2 = at < n ? rank[at] : 0u;  // at >= n cannot happen for an active suffix (it would hold the last sentinel)
     key[p] = (uint64_t)rank[i] << 32 | r2;
 }
 
@@ -160,9 +213,24 @@ extern "C" int bg_suffix_array_dev(bg_ctx* ctx, const uint8_t* d_text, uint64_t 
     if (rc) return rc;
     for (int c = 0; c < last; c++)
         if (cnt[c]) return BG_ERR_SENTINEL;  // suffix_array.rs:431-437: a byte below the sentinel
-    // several sentinels are ranked by position (transform_text): the host builder does that.  (The counters saturate
-    // at 2 per block, which still tells "exactly once" from "more than once".)
-    if (cnt[last] != 1) return BG_ERR_UNSUPPORTED;
+    // several sentinels are ranked by position (transform_text, suffix_array.rs:444-466): how many?  (The presence
+    // counters saturate at 2 per block, which still tells "exactly once" from "more than once".)
+    uint64_t n_sent = 1;
+    if (cnt[last] != 1) {
+        unsigned long long* d_c = nullptr;
+        BG_HIP(hipMalloc((void**)&d_c, 8));
+        auto count = [&]() -> int {
+            BG_HIP(hipMemsetAsync(d_c, 0, 8, st));
+            sab_count_byte_kernel<<<dim3(std::min<uint64_t>(nblk(n), 4096)), dim3(256), 0, st>>>(d_text, n, last, d_c);
+            BG_HIP(hipGetLastError());
+            BG_HIP(hipMemcpyAsync(&n_sent, d_c, 8, hipMemcpyDeviceToHost, st));
+            BG_HIP(hipStreamSynchronize(st));
+            return BG_OK;
+        };
+        rc = count();
+        hipFree(d_c);
+        if (rc) return rc;
+    }
     CodeMap cm = {};
     uint32_t sigma = 0;
     for (int c = 0; c < 256; c++)
@@ -176,7 +244,9 @@ extern "C" int bg_suffix_array_dev(bg_ctx* ctx, const uint8_t* d_text, uint64_t 
     uint8_t* active = nullptr;
     void* tmp = nullptr;
     uint64_t* d_count = nullptr;
+    uint32_t* d_sent = nullptr;
     auto run = [&]() -> int {
+        BG_HIP(hipMalloc((void**)&d_sent, n_sent * 4));
         BG_HIP(hipMalloc((void**)&keyA, n * 8));
         BG_HIP(hipMalloc((void**)&keyB, n * 8));
         BG_HIP(hipMalloc((void**)&valA, n * 4));
@@ -184,40 +254,43 @@ extern "C" int bg_suffix_array_dev(bg_ctx* ctx, const uint8_t* d_text, uint64_t 
         BG_HIP(hipMalloc((void**)&rank, n * 4));
         BG_HIP(hipMalloc((void**)&active, n));
         BG_HIP(hipMalloc((void**)&d_count, 8));
-        hipcub::DoubleBuffer<uint64_t> keys(keyA, keyB);
-        hipcub::DoubleBuffer<uint32_t> vals(valA, valB);
+        rocprim::double_buffer<uint64_t> keys(keyA, keyB);
+        rocprim::double_buffer<uint32_t> vals(valA, valB);
         size_t t_sort = 0, t_scan = 0, t_sel = 0;
-        BG_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, t_sort, keys, vals, n, 0, 64, st));
-        BG_HIP(hipcub::DeviceScan::InclusiveScan(nullptr, t_scan, (uint32_t*)nullptr, (uint32_t*)nullptr, MaxU32(), n, st));
-        BG_HIP(hipcub::DeviceSelect::Flagged(nullptr, t_sel, (uint32_t*)nullptr, (uint8_t*)nullptr, (uint32_t*)nullptr, d_count, (int64_t)n, st));
+        BG_HIP(rocprim::radix_sort_pairs(nullptr, t_sort, keys, vals, n, 0, 64, st));
+        BG_HIP(rocprim::inclusive_scan(nullptr, t_scan, (uint32_t*)nullptr, (uint32_t*)nullptr, n, MaxU32(), st));
+        BG_HIP(rocprim::select(nullptr, t_sel, (uint32_t*)nullptr, (uint8_t*)nullptr, (uint32_t*)nullptr, d_count, n, st));
         size_t tmp_bytes = std::max(std::max(t_sort, t_scan), t_sel);
         BG_HIP(hipMalloc(&tmp, std::max<size_t>(tmp_bytes, 256)));
 
         // ---- round 0
-        sab_init_keys_kernel<<<dim3(nblk(n)), dim3(256), 0, st>>>(d_text, n, cm, b, K, keys.Current(), vals.Current());
+        sab_init_keys_kernel<<<dim3(nblk(n)), dim3(256), 0, st>>>(d_text, n, cm, b, K, keys.current(), vals.current());
         BG_HIP(hipGetLastError());
-        BG_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, keys, vals, n, 0, (int)(b * K), st));
-        uint32_t* hp = (uint32_t*)keys.Alternate();  // the sort's other key buffer is free now: two uint32 arrays fit
+        BG_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, vals, n, 0, (unsigned)(b * K), st));
+        uint32_t* hp = (uint32_t*)keys.alternate();  // the sort's other key buffer is free now: two uint32 arrays fit
         uint32_t* grp = hp + n;
-        sab_heads_kernel<<<dim3(nblk(n)), dim3(256), 0, st>>>(keys.Current(), n, hp);
-        BG_HIP(hipcub::DeviceScan::InclusiveScan(tmp, tmp_bytes, hp, grp, MaxU32(), n, st));
-        sab_round0_kernel<<<dim3(nblk(n)), dim3(256), 0, st>>>(vals.Current(), grp, n, rank, d_sa, active);
+        sab_heads_kernel<<<dim3(nblk(n)), dim3(256), 0, st>>>(keys.current(), n, hp);
+        BG_HIP(rocprim::inclusive_scan(tmp, tmp_bytes, hp, grp, n, MaxU32(), st));
+        sab_round0_kernel<<<dim3(nblk(n)), dim3(256), 0, st>>>(vals.current(), grp, n, rank, d_sa, active);
+        // rows 0 .. n_sent - 1 (key 0): the sentinel suffixes, final from here on
+        sab_sentinel_rows_kernel<<<dim3(nblk(n_sent)), dim3(256), 0, st>>>(vals.current(), n_sent, d_sent, rank, d_sa, active);
         BG_HIP(hipGetLastError());
         // active suffixes, in array order
-        uint32_t* act = vals.Alternate();
-        BG_HIP(hipcub::DeviceSelect::Flagged(tmp, tmp_bytes, vals.Current(), active, act, d_count, (int64_t)n, st));
+        uint32_t* act = vals.alternate();
+        BG_HIP(rocprim::select(tmp, tmp_bytes, vals.current(), active, act, d_count, n, st));
         uint64_t A = 0;
         BG_HIP(hipMemcpyAsync(&A, d_count, 8, hipMemcpyDeviceToHost, st));
         BG_HIP(hipStreamSynchronize(st));
-        vals.selector ^= 1;  // the active list is the current value buffer from here on
+        vals.swap();  // the active list is the current value buffer from here on
 
         // ---- doubling rounds over the active suffixes only
         for (uint64_t h = K; A > 0; h *= 2) {
-            if (h > 2 * n) return BG_ERR_HIP;  // cannot happen: every suffix is unique within n symbols
-            sab_round_keys_kernel<<<dim3(nblk(A)), dim3(256), 0, st>>>(vals.Current(), A, rank, n, h, keys.Current());
+            // every suffix is unique within n symbols (a group that is tied up to its sentinels needs one round whatever h is)
+            if (h > 2 * n && h > 2 * (uint64_t)K) return BG_ERR_HIP;  // cannot happen
+            sab_round_keys_kernel<<<dim3(nblk(A)), dim3(256), 0, st>>>(vals.current(), A, rank, n, h, d_sent, (uint32_t)n_sent, keys.current());
             BG_HIP(hipGetLastError());
-            BG_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, keys, vals, A, 0, 64, st));
-            uint32_t* hpH = (uint32_t*)keys.Alternate();
+            BG_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, vals, A, 0, 64, st));
+            uint32_t* hpH = (uint32_t*)keys.alternate();
             uint32_t* hpF = hpH + A;
             // firstH / firstF need their own storage: the other value buffer and the (idle) first half of ... `active`
             // is bytes; use two fresh slices of the alternate key buffer instead when A is small, else allocate
@@ -226,12 +299,12 @@ extern "C" int bg_suffix_array_dev(bg_ctx* ctx, const uint8_t* d_text, uint64_t 
             BG_HIP(hipMalloc((void**)&firstF, A * 4));
             int rr = BG_OK;
             auto round = [&]() -> int {
-                sab_round_heads_kernel<<<dim3(nblk(A)), dim3(256), 0, st>>>(keys.Current(), A, hpH, hpF);
-                BG_HIP(hipcub::DeviceScan::InclusiveScan(tmp, tmp_bytes, hpH, firstH, MaxU32(), A, st));
-                BG_HIP(hipcub::DeviceScan::InclusiveScan(tmp, tmp_bytes, hpF, firstF, MaxU32(), A, st));
-                sab_round_apply_kernel<<<dim3(nblk(A)), dim3(256), 0, st>>>(keys.Current(), vals.Current(), A, firstH, firstF, rank, d_sa, active);
+                sab_round_heads_kernel<<<dim3(nblk(A)), dim3(256), 0, st>>>(keys.current(), A, hpH, hpF);
+                BG_HIP(rocprim::inclusive_scan(tmp, tmp_bytes, hpH, firstH, A, MaxU32(), st));
+                BG_HIP(rocprim::inclusive_scan(tmp, tmp_bytes, hpF, firstF, A, MaxU32(), st));
+                sab_round_apply_kernel<<<dim3(nblk(A)), dim3(256), 0, st>>>(keys.current(), vals.current(), A, firstH, firstF, rank, d_sa, active);
                 BG_HIP(hipGetLastError());
-                BG_HIP(hipcub::DeviceSelect::Flagged(tmp, tmp_bytes, vals.Current(), active, vals.Alternate(), d_count, (int64_t)A, st));
+                BG_HIP(rocprim::select(tmp, tmp_bytes, vals.current(), active, vals.alternate(), d_count, A, st));
                 BG_HIP(hipMemcpyAsync(&A, d_count, 8, hipMemcpyDeviceToHost, st));
                 BG_HIP(hipStreamSynchronize(st));
                 return BG_OK;
@@ -240,7 +313,7 @@ extern "C" int bg_suffix_array_dev(bg_ctx* ctx, const uint8_t* d_text, uint64_t 
             hipFree(firstH);
             hipFree(firstF);
             if (rr) return rr;
-            vals.selector ^= 1;
+            vals.swap();
         }
         return BG_OK;
     };
@@ -252,6 +325,7 @@ extern "C" int bg_suffix_array_dev(bg_ctx* ctx, const uint8_t* d_text, uint64_t 
     hipFree(rank);
     hipFree(active);
     hipFree(d_count);
+    hipFree(d_sent);
     hipFree(tmp);
     return rc;
 }

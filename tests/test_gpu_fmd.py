@@ -124,3 +124,31 @@ def test_init_interval_and_extensions():
                 iv, oiv = fmd.backward_ext(iv, a1), ofmd.backward_ext(oiv, a1)
             else:
                 iv, oiv = fmd.forward_ext(iv, a1), ofmd.forward_ext(oiv, a1)
+
+
+def test_fmd_index_built_entirely_on_the_device():
+    """T$R$ never leaves HBM: bg_suffix_array_dev (two sentinels, ranked by position as transform_text does,
+    suffix_array.rs:444-466) -> bg_bwt_dev -> bg_fm_build_dev -> SMEMs, against the oracle on the host-built tables"""
+    import torch
+    from rust_bio_amd.suffix_array import bwt_dev, suffix_array_dev
+    rng = np.random.default_rng(31)
+    fwd = synth.random_dna(30_000, seed=12).tobytes()
+    text = np.frombuffer(fwd + b"$" + revcomp(fwd) + b"$", dtype=np.uint8)
+    d_text = torch.from_numpy(text.copy()).to("cuda:0")
+    d_sa = suffix_array_dev(d_text)
+    d_b = bwt_dev(d_text, d_sa)
+    sa = suffix_array(text)
+    b = bwt(text, sa)
+    assert (d_sa.cpu().numpy().view(np.uint32).astype(np.uint64) == sa).all() and (d_b.cpu().numpy() == b).all()
+    fm = FMIndex.from_device(d_b, 16, ALPHA)
+    fmd = FMDIndex(fm)
+    ls = less(b, ALPHA)
+    ofmd = orc.FMDIndex(b, ls, orc.Occ(b, 16, ALPHA))
+    reads = []
+    for _ in range(200):
+        s = int(rng.integers(0, len(fwd) - 100))
+        rb = fwd[s:s + int(rng.integers(25, 100))]
+        reads.append(revcomp(rb) if rng.random() < 0.5 else rb)
+    got = fmd.all_smems_batch(reads, 10)
+    for q, rb in enumerate(reads):
+        assert [((iv.lower, iv.lower_rev, iv.size, iv.match_size), p, ln) for iv, p, ln in got[q]] == ofmd.all_smems(rb, 10), q

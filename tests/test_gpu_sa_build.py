@@ -1,7 +1,7 @@
 """Suffix array / BWT / sampling on the device (bg_suffix_array_dev, bg_bwt_dev, bg_sa_sample_dev: prefix doubling over
 radix sorts) against the host builders behind `suffix_array` / `bwt` (suffix_array.rs:264-284, bwt.rs:39-49), which are
 pinned to the reference's known answers in tests/test_host_tables.py: identical arrays on random, repetitive,
-single-letter, protein and N-rich texts; the refusals the header documents."""
+single-letter, protein and N-rich texts and texts with several sentinels; the refusal the header documents."""
 import numpy as np
 import pytest
 import torch
@@ -37,6 +37,18 @@ def texts():
     yield "n_run", g
     yield "protein", np.append(np.frombuffer(b"ARNDCQEGHILKMFPSTWYV", dtype=np.uint8)[rng.integers(0, 20, size=300_000)], np.uint8(ord("$")))
     yield "bytes_0_255", np.append(rng.integers(1, 256, size=200_000).astype(np.uint8), np.uint8(0))
+    # several sentinels (transform_text, suffix_array.rs:444-466: distinct symbols, the LAST occurrence smallest)
+    yield "two_sequences", np.frombuffer(b"ACGT$TTGA$", dtype=np.uint8)
+    yield "equal_sequences", np.frombuffer(b"ACGTACGT$ACGTACGT$ACGTACGT$", dtype=np.uint8)      # ties decided by the sentinels alone
+    yield "adjacent_sentinels", np.frombuffer(b"$$A$$$CA$$", dtype=np.uint8)
+    fwd = acgt[rng.integers(0, 4, size=150_000)]
+    rc_ = np.frombuffer(b"TGCA", dtype=np.uint8)[np.searchsorted(acgt, fwd[::-1])]
+    yield "fmd_text", np.concatenate([fwd, np.frombuffer(b"$", np.uint8), rc_, np.frombuffer(b"$", np.uint8)])  # fmindex.rs:312-340
+    many = acgt[rng.integers(0, 4, size=120_000)].copy()
+    many[rng.integers(0, 120_000, size=3000)] = ord("$")    # thousands of short sequences, many of them equal prefixes
+    yield "many_sentinels", np.append(many, np.uint8(ord("$")))
+    rep2 = acgt[rng.integers(0, 4, size=4000)]
+    yield "repeated_sequences", np.concatenate([np.append(rep2, np.uint8(ord("$")))] * 6)          # identical sequences, 6 sentinels
 
 
 @pytest.mark.parametrize("name,text", list(texts()), ids=[t[0] for t in texts()])
@@ -62,9 +74,5 @@ def test_sample_dev_equals_raw_suffix_array_sample():
 
 
 def test_refusals():
-    two = np.frombuffer(b"ACGT$TTGA$", dtype=np.uint8)  # several sentinels: ranked by position on the host only
-    with pytest.raises(_lib.BiogpuError) as e:
-        dev_sa(two)
-    assert e.value.status == -11
     with pytest.raises(_lib.SentinelError):
         dev_sa(np.frombuffer(b"AC#T$", dtype=np.uint8))  # '#' < '$': suffix_array.rs:431-437
