@@ -32,6 +32,7 @@
 #include <rocprim/device/device_select.hpp>
 
 #include <algorithm>
+#include <chrono>
 #include <atomic>
 #include <condition_variable>
 #include <mutex>
@@ -1251,9 +1252,16 @@ extern "C" int bg_fm_backward_search_batch(bg_fm* fm, uint64_t n_q, const uint8_
     }
     hipStream_t s_k = ctx->stream;
     std::atomic<bool> any_panic{false};
+    // BG_TRACE_HOST=1: where the host side of the stages spends its time (ms, summed over the call)
+    const bool trace = getenv("BG_TRACE_HOST") != nullptr;
+    double t_pack = 0, t_launch = 0, t_wait_set = 0, t_d_wait = 0, t_d_copy = 0;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     auto drain = [&](uint64_t c) -> int {
         bg_fm_pipe::Set& S = P.set[c % bg_fm_pipe::NSET];
+        double t0 = now();
         BG_HIP(hipEventSynchronize(S.out_done));
+        t_d_wait += now() - t0;
+        t0 = now();
         const uint64_t q0 = c * chunk, nq = std::min(n_q, q0 + chunk) - q0;
         fm_parallel_for(nq, 1 << 16, [&](uint64_t a, uint64_t b) {
             memcpy(lower + q0 + a, S.h_out + a * 8, (b - a) * 8);
@@ -1264,6 +1272,7 @@ extern "C" int bg_fm_backward_search_batch(bg_fm* fm, uint64_t n_q, const uint8_
             for (uint64_t q = a; q < b; q++) pn = pn || S.h_out[o_tag + q] == BG_FM_PANIC;
             if (pn) any_panic = true;
         });
+        t_d_copy += now() - t0;
         return BG_OK;
     };
     std::mutex mu;
@@ -1309,10 +1318,13 @@ extern "C" int bg_fm_backward_search_batch(bg_fm* fm, uint64_t n_q, const uint8_
         drainer.join();
     };
     for (uint64_t c = 0; c < nch; c++) {
+        double t0 = now();
         if (c >= bg_fm_pipe::NSET) {
             std::unique_lock<std::mutex> lk(mu);
             cv.wait(lk, [&] { return drained >= c - bg_fm_pipe::NSET + 1; });
         }
+        t_wait_set += now() - t0;
+        t0 = now();
         bg_fm_pipe::Set& S = P.set[c % bg_fm_pipe::NSET];
         const uint64_t q0 = c * chunk, nq = std::min(n_q, q0 + chunk) - q0;
         const uint64_t b0 = pat_off[q0], pb = pat_off[q0 + nq] - b0;
@@ -1321,6 +1333,8 @@ extern "C" int bg_fm_backward_search_batch(bg_fm* fm, uint64_t n_q, const uint8_
         fm_parallel_for(nq + 1, 1 << 16, [&](uint64_t a, uint64_t b) {
             for (uint64_t q = a; q < b; q++) hoff[q] = pat_off[q0 + q] - b0;
         });
+        t_pack += now() - t0;
+        t0 = now();
         bool ok = true;
         if (pb) ok = ok && hipMemcpyAsync(S.d_in, S.h_in, pb, hipMemcpyHostToDevice, P.s_in) == hipSuccess;
         ok = ok && hipMemcpyAsync(S.d_in + o_off, S.h_in + o_off, (nq + 1) * 8, hipMemcpyHostToDevice, P.s_in) == hipSuccess;
@@ -1337,13 +1351,18 @@ extern "C" int bg_fm_backward_search_batch(bg_fm* fm, uint64_t n_q, const uint8_
             stop_drainer();
             return rc;
         }
+        t_launch += now() - t0;
         {
             std::lock_guard<std::mutex> lk(mu);
             submitted = c + 1;
         }
         cv.notify_all();
     }
+    const double t0j = now();
     drainer.join();
+    if (trace)
+        fprintf(stderr, "[bg fm host] %llu stages: pack %.2f launch %.2f wait-for-set %.2f join %.2f | drainer: wait %.2f copy %.2f ms\n",
+                (unsigned long long)nch, t_pack, t_launch, t_wait_set, now() - t0j, t_d_wait, t_d_copy);
     if (drain_rc) {
         bg_tls_error = drain_err;
         return drain_rc;

@@ -4,6 +4,7 @@
 // the three wrappers, compacts a tabulated match function, and drives K1 + K2 over
 // sub-batches that share one reusable scratch (traceback words, aux rows, strip buffer).
 #include <algorithm>
+#include <chrono>
 #include <map>
 #include <type_traits>
 
@@ -475,6 +476,38 @@ extern "C" int bg_align_batch_packed_dev(bg_ctx* ctx, const bg_scoring_t* sc, in
                                 d_out, d_ops, ops_stride, stream, -1, codes);
 }
 
+// ---- operations of a stage, compacted on the device (host-buffer path) ---------------------------------------------
+// The fill / traceback leave a pair's operations right-aligned in its own slot of `stride` bytes; the caller's buffer
+// wants them back to back.  Doing that on the host cost a memcpy of ~150 bytes per pair out of a strided landing zone
+// (the drainer's whole time, and twice the bytes over PCIe).  Here: the operation counts of the stage are scanned, a
+// wavefront-quarter per pair copies its bytes into a compact buffer, and the records get their FINAL ops_off — the
+// running total of the stages before lives in a device cell — so the host only moves two contiguous blocks per stage.
+namespace {
+__global__ __launch_bounds__(256) void ops_counts_kernel(const bg_alignment_t* __restrict__ rec, uint64_t n, uint32_t* __restrict__ cnt) {
+    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n) cnt[p] = rec[p].n_ops;
+}
+// 16 lanes per pair: bytes [src, src + n_ops) -> compact + off[p]; ops_off becomes base + off[p]
+__global__ __launch_bounds__(256) void ops_compact_kernel(bg_alignment_t* __restrict__ rec, uint64_t n, const uint8_t* __restrict__ ops,
+                                                          const uint64_t* __restrict__ off, const uint64_t* __restrict__ base_cell,
+                                                          uint8_t* __restrict__ compact) {
+    const uint64_t p = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const uint32_t l16 = threadIdx.x & 15;
+    if (p >= n) return;
+    const uint32_t k = rec[p].n_ops;
+    const uint8_t* src = ops + rec[p].ops_off;
+    uint8_t* dst = compact + off[p];
+    for (uint32_t i = l16; i < k; i += 16) dst[i] = src[i];
+    // every lane of the group has read ops_off before lane 0 overwrites it (same wavefront, program order)
+    if (l16 == 0) rec[p].ops_off = *base_cell + off[p];
+}
+// after the compaction of a stage: [0] running total (the next stage's base), [1] this stage's byte count
+__global__ void ops_advance_kernel(uint64_t* cell, const uint64_t* __restrict__ off, uint64_t n, uint64_t* __restrict__ stage_total) {
+    *stage_total = off[n];
+    cell[0] += off[n];
+}
+}  // namespace
+
 // ---- pipelined host-buffer path ------------------------------------------------------------------------------
 // bg_align_batch on a large batch is PCIe + host memcpy + kernels; run as one serial sequence it spends three
 // quarters of its time outside the kernels.  The batch is cut into stages of `host_chunk_pairs` pairs that flow
@@ -485,12 +518,14 @@ extern "C" int bg_align_batch_packed_dev(bg_ctx* ctx, const bg_scoring_t* sc, in
 struct bg_host_pipe {
     static constexpr int NSET = 3;
     struct Set {
-        uint8_t *h_in = nullptr, *h_out = nullptr;  // pinned: x | y | x_off | y_off   and   records | ops
-        uint8_t *d_in = nullptr, *d_out = nullptr;
-        size_t in_cap = 0, out_cap = 0;
-        hipEvent_t in_done = nullptr, k_done = nullptr, out_done = nullptr;
+        uint8_t *h_in = nullptr, *h_out = nullptr;  // pinned: x | y | x_off | y_off   and   records | stage total | compact ops
+        uint8_t *d_in = nullptr, *d_out = nullptr;  // d_out: records | stage total | strided ops
+        uint8_t *d_cmp = nullptr, *d_scan = nullptr;  // compact ops of the stage; n_ops counts, their offsets, scan partials
+        size_t in_cap = 0, out_cap = 0, cmp_cap = 0, scan_cap = 0;
+        hipEvent_t in_done = nullptr, k_done = nullptr, out_done = nullptr, ops_done = nullptr;
     } set[NSET];
-    hipStream_t s_in = nullptr, s_out = nullptr;
+    uint64_t* d_cell = nullptr;  // running total of operation bytes over the stages of a call
+    hipStream_t s_in = nullptr, s_out = nullptr, s_ops = nullptr;  // uploads; record downloads; operation downloads (issued by the drainer)
 };
 void bg_host_pipe_free(bg_host_pipe* p) {
     if (!p) return;
@@ -499,11 +534,15 @@ void bg_host_pipe_free(bg_host_pipe* p) {
         if (s.h_out) hipHostFree(s.h_out);
         hipFree(s.d_in);
         hipFree(s.d_out);
-        for (hipEvent_t e : {s.in_done, s.k_done, s.out_done})
+        hipFree(s.d_cmp);
+        hipFree(s.d_scan);
+        for (hipEvent_t e : {s.in_done, s.k_done, s.out_done, s.ops_done})
             if (e) hipEventDestroy(e);
     }
+    hipFree(p->d_cell);
     if (p->s_in) hipStreamDestroy(p->s_in);
     if (p->s_out) hipStreamDestroy(p->s_out);
+    if (p->s_ops) hipStreamDestroy(p->s_ops);
     delete p;
 }
 namespace {
@@ -527,8 +566,10 @@ int align_batch_pipelined(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint64_
         ctx->pipe = new bg_host_pipe();
         BG_HIP(hipStreamCreateWithFlags(&ctx->pipe->s_in, hipStreamNonBlocking));
         BG_HIP(hipStreamCreateWithFlags(&ctx->pipe->s_out, hipStreamNonBlocking));
+        BG_HIP(hipStreamCreateWithFlags(&ctx->pipe->s_ops, hipStreamNonBlocking));
+        BG_HIP(hipMalloc((void**)&ctx->pipe->d_cell, 64));
         for (auto& s : ctx->pipe->set)
-            for (hipEvent_t* e : {&s.in_done, &s.k_done, &s.out_done}) BG_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+            for (hipEvent_t* e : {&s.in_done, &s.k_done, &s.out_done, &s.ops_done}) BG_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
     }
     bg_host_pipe& P = *ctx->pipe;
     const uint64_t stride = ops_buf ? (uint64_t)max_x + max_y + 4 : 0;
@@ -542,8 +583,12 @@ int align_batch_pipelined(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint64_
     }
     const uint64_t o_y = (max_xb + 255) & ~255ull, o_xo = o_y + ((max_yb + 255) & ~255ull), o_yo = o_xo + (chunk + 1) * 8;
     const size_t in_need = o_yo + (chunk + 1) * 8 + 256;
-    const uint64_t o_ops = chunk * sizeof(bg_alignment_t);
+    // out: records | this stage's operation byte count | operations (device: strided slots; host: compact)
+    const uint64_t o_tot = chunk * sizeof(bg_alignment_t), o_ops = o_tot + 256;
     const size_t out_need = o_ops + chunk * stride + 256;
+    const size_t cmp_need = chunk * stride + 256;
+    const uint64_t o_soff = ((chunk * 4 + 255) & ~255ull), o_ssum = o_soff + (((chunk + 1) * 8 + 255) & ~255ull);
+    const size_t scan_need = o_ssum + 2 * (chunk / 2048 + 2) * 8 + 256;
     for (auto& s : P.set) {
         if (s.in_cap < in_need) {
             if (s.h_in) hipHostFree(s.h_in);
@@ -563,33 +608,72 @@ int align_batch_pipelined(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint64_
             BG_HIP(hipMalloc((void**)&s.d_out, out_need));
             s.out_cap = out_need;
         }
+        if (stride && s.cmp_cap < cmp_need) {
+            hipFree(s.d_cmp);
+            s.d_cmp = nullptr;
+            s.cmp_cap = 0;
+            BG_HIP(hipMalloc((void**)&s.d_cmp, cmp_need));
+            s.cmp_cap = cmp_need;
+        }
+        if (stride && s.scan_cap < scan_need) {
+            hipFree(s.d_scan);
+            s.d_scan = nullptr;
+            s.scan_cap = 0;
+            BG_HIP(hipMalloc((void**)&s.d_scan, scan_need));
+            s.scan_cap = scan_need;
+        }
     }
     hipStream_t s_k = ctx->stream;
+    BG_HIP(hipMemsetAsync(P.d_cell, 0, 8, s_k));
     uint64_t used = 0;
     int status = BG_OK;
-    // finish stage c: wait for its download, then records and operations into the caller's buffers
+    // BG_TRACE_HOST=1: where the host side of the stages spends its time (ms, summed over the call)
+    const bool trace = getenv("BG_TRACE_HOST") != nullptr;
+    double t_pack = 0, t_launch = 0, t_wait_set = 0, t_d_wait_rec = 0, t_d_rec = 0, t_d_wait_ops = 0, t_d_ops = 0;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    // finish stage c: records (their ops_off already final) and the stage's compact operations into the caller's buffers —
+    // two contiguous blocks; the operations are fetched with their exact size once the records (and the count) are here
     auto drain = [&](uint64_t c) -> int {
         bg_host_pipe::Set& S = P.set[c % bg_host_pipe::NSET];
+        double t0 = now();
         BG_HIP(hipEventSynchronize(S.out_done));
+        t_d_wait_rec += now() - t0;
         const uint64_t p0 = c * chunk, np = std::min(n_pairs, p0 + chunk) - p0;
         const bg_alignment_t* h_rec = (const bg_alignment_t*)S.h_out;
-        const uint8_t* h_ops = S.h_out + o_ops;
-        std::vector<uint64_t> dst(np + 1);
-        dst[0] = used;
-        for (uint64_t p = 0; p < np; p++) {
-            if (h_rec[p].status) status = h_rec[p].status;
-            dst[p + 1] = dst[p] + h_rec[p].n_ops;
+        const uint64_t T = stride ? *(const uint64_t*)(S.h_out + o_tot) : 0;
+        if (T) {
+            BG_HIP(hipMemcpyAsync(S.h_out + o_ops, S.d_cmp, T, hipMemcpyDeviceToHost, P.s_ops));  // not behind the next stages' records
+            BG_HIP(hipEventRecord(S.ops_done, P.s_ops));
         }
-        if (ops_buf && dst[np] > ops_cap && status == BG_OK) status = BG_ERR_OPS_CAP;
-        parallel_for(np, 4096, [&](uint64_t a, uint64_t b) {
-            for (uint64_t p = a; p < b; p++) {
-                bg_alignment_t r = h_rec[p];
-                if (ops_buf && dst[p + 1] <= ops_cap) memcpy(ops_buf + dst[p], h_ops + r.ops_off, r.n_ops);
-                r.ops_off = dst[p];
-                out[p0 + p] = r;
-            }
+        std::atomic<int> st_rec{BG_OK};
+        t0 = now();
+        parallel_for(np, 16384, [&](uint64_t a, uint64_t b) {
+            memcpy(out + p0 + a, h_rec + a, (b - a) * sizeof(bg_alignment_t));
+            int sr = BG_OK;
+            for (uint64_t p = a; p < b; p++)
+                if (h_rec[p].status) sr = h_rec[p].status;
+            if (sr) st_rec = sr;
         });
-        used = dst[np];
+        if (st_rec) status = st_rec;
+        t_d_rec += now() - t0;
+        if (T) {
+            t0 = now();
+            BG_HIP(hipEventSynchronize(S.ops_done));
+            t_d_wait_ops += now() - t0;
+            t0 = now();
+            uint64_t fit = T;
+            if (used + T > ops_cap) {  // the caller's buffer ends inside this stage: whole pairs only, as the serial path does
+                if (status == BG_OK) status = BG_ERR_OPS_CAP;
+                fit = 0;
+                for (uint64_t p = 0; p < np; p++) {
+                    if (h_rec[p].ops_off + h_rec[p].n_ops > ops_cap) break;
+                    fit = h_rec[p].ops_off + h_rec[p].n_ops - used;
+                }
+            }
+            if (fit) parallel_memcpy(ops_buf + used, S.h_out + o_ops, fit);
+            t_d_ops += now() - t0;
+        }
+        used += T;
         return BG_OK;
     };
     // The stages are drained by a second host thread, in order, while this one packs and launches the following ones:
@@ -639,10 +723,13 @@ int align_batch_pipelined(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint64_
     };
     int rc;
     for (uint64_t c = 0; c < nch; c++) {
+        double t0 = now();
         if (c >= bg_host_pipe::NSET) {  // this stage's set is free once stage c - NSET has been drained
             std::unique_lock<std::mutex> lk(mu);
             cv.wait(lk, [&] { return drained >= c - bg_host_pipe::NSET + 1; });
         }
+        t_wait_set += now() - t0;
+        t0 = now();
         bg_host_pipe::Set& S = P.set[c % bg_host_pipe::NSET];
         const uint64_t p0 = c * chunk, np = std::min(n_pairs, p0 + chunk) - p0;
         const uint64_t xb = x_off[p0 + np] - x_off[p0], yb = y_off[p0 + np] - y_off[p0];
@@ -660,16 +747,30 @@ int align_batch_pipelined(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint64_
             }
             if (rag) ragged = true;
         });
+        t_pack += now() - t0;
+        t0 = now();
         bool in_ok = true;
         if (xb) in_ok = in_ok && hipMemcpyAsync(S.d_in, S.h_in, xb, hipMemcpyHostToDevice, P.s_in) == hipSuccess;
         if (yb) in_ok = in_ok && hipMemcpyAsync(S.d_in + o_y, S.h_in + o_y, yb, hipMemcpyHostToDevice, P.s_in) == hipSuccess;
         in_ok = in_ok && hipMemcpyAsync(S.d_in + o_xo, S.h_in + o_xo, 2 * (chunk + 1) * 8, hipMemcpyHostToDevice, P.s_in) == hipSuccess;
         in_ok = in_ok && hipEventRecord(S.in_done, P.s_in) == hipSuccess && hipStreamWaitEvent(s_k, S.in_done, 0) == hipSuccess;
         const bool uniform = !ragged;
+        bg_alignment_t* d_rec = (bg_alignment_t*)S.d_out;
         rc = !in_ok ? BG_ERR_HIP : align_batch_dev_impl(ctx, sc, mode, np, S.d_in, (const uint64_t*)(S.d_in + o_xo), S.d_in + o_y, (const uint64_t*)(S.d_in + o_yo),
-                                  max_x, max_y, (bg_alignment_t*)S.d_out, stride ? S.d_out + o_ops : nullptr, stride, s_k, uniform ? 1 : 0);
+                                  max_x, max_y, d_rec, stride ? S.d_out + o_ops : nullptr, stride, s_k, uniform ? 1 : 0);
+        if (rc == BG_OK && stride) {  // compact the stage's operations on the device, final ops_off into the records
+            uint32_t* d_cnt = (uint32_t*)S.d_scan;
+            uint64_t* d_off = (uint64_t*)(S.d_scan + o_soff);
+            ops_counts_kernel<<<dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s_k>>>(d_rec, np, d_cnt);
+            rc = bg_scan_u32(d_cnt, np, d_off, (uint64_t*)(S.d_scan + o_ssum), s_k);
+            if (rc == BG_OK) {
+                ops_compact_kernel<<<dim3((unsigned)((np * 16 + 255) / 256)), dim3(256), 0, s_k>>>(d_rec, np, S.d_out + o_ops, d_off, P.d_cell, S.d_cmp);
+                ops_advance_kernel<<<dim3(1), dim3(1), 0, s_k>>>(P.d_cell, d_off, np, (uint64_t*)(S.d_out + o_tot));
+                if (hipGetLastError() != hipSuccess) rc = BG_ERR_HIP;
+            }
+        }
         if (rc == BG_OK && (hipEventRecord(S.k_done, s_k) != hipSuccess || hipStreamWaitEvent(P.s_out, S.k_done, 0) != hipSuccess ||
-                            hipMemcpyAsync(S.h_out, S.d_out, o_ops + np * stride, hipMemcpyDeviceToHost, P.s_out) != hipSuccess ||
+                            hipMemcpyAsync(S.h_out, S.d_out, o_tot + 8, hipMemcpyDeviceToHost, P.s_out) != hipSuccess ||
                             hipEventRecord(S.out_done, P.s_out) != hipSuccess))
             rc = BG_ERR_HIP;
         if (rc) {
@@ -677,13 +778,18 @@ int align_batch_pipelined(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint64_
             stop_drainer();
             return rc;
         }
+        t_launch += now() - t0;
         {
             std::lock_guard<std::mutex> lk(mu);
             submitted = c + 1;
         }
         cv.notify_all();
     }
+    double t0j = now();
     drainer.join();
+    if (trace)
+        fprintf(stderr, "[bg host] %llu stages: pack %.2f launch %.2f wait-for-set %.2f join %.2f | drainer: wait-records %.2f copy-records %.2f wait-ops %.2f copy-ops %.2f ms\n",
+                (unsigned long long)nch, t_pack, t_launch, t_wait_set, now() - t0j, t_d_wait_rec, t_d_rec, t_d_wait_ops, t_d_ops);
     if (drain_rc) {
         bg_tls_error = drain_err;
         return drain_rc;

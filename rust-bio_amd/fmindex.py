@@ -80,16 +80,20 @@ class FMIndex:
     def device_bytes(self):
         return int(_lib.lib().bg_fm_device_bytes(self.h))
 
-    def backward_search_arrays(self, pat, pat_off):
+    def backward_search_arrays(self, pat, pat_off, out=None):
         """Batch over concatenated patterns; returns (tag u8, lower u64, upper u64, matched u32).
-        Raises AlphabetError if any query reached a byte outside the alphabet."""
+        Raises AlphabetError if any query reached a byte outside the alphabet.  `out`: the four arrays of an earlier
+        call of the same size (reused, like a caller's own Vecs — fresh arrays are paged in while they are filled)."""
         p = _lib.as_u8(pat)
         off = np.ascontiguousarray(pat_off, dtype=np.uint64)
         n = len(off) - 1
-        tag = np.zeros(n, dtype=np.uint8)
-        lo = np.zeros(n, dtype=np.uint64)
-        hi = np.zeros(n, dtype=np.uint64)
-        ml = np.zeros(n, dtype=np.uint32)
+        if out is not None and len(out[0]) == n:
+            tag, lo, hi, ml = out
+        else:
+            tag = np.zeros(n, dtype=np.uint8)
+            lo = np.zeros(n, dtype=np.uint64)
+            hi = np.zeros(n, dtype=np.uint64)
+            ml = np.zeros(n, dtype=np.uint32)
         rc = _lib.lib().bg_fm_backward_search_batch(self.h, n, p.ctypes.data, off.ctypes.data,
                                                     tag.ctypes.data, lo.ctypes.data,
                                                     hi.ctypes.data, ml.ctypes.data)

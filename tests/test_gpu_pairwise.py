@@ -158,6 +158,34 @@ def test_pipelined_host_buffer_path():
     assert out.tobytes() == out1.tobytes() and (ops == ops1).all()
 
 
+def test_pipelined_host_buffer_path_with_a_short_operations_buffer():
+    """the caller's ops buffer ends inside a stage: BG_ERR_OPS_CAP, ops_used reports the need, every record is there, and the
+    operations of the pairs that fit completely are the ones a large enough buffer receives"""
+    import ctypes as C
+    x, xo, y, yo = synth.sw_pairs(3000, 100, seed=8)
+    al = Aligner.with_scoring(engine_scoring(BASE))
+    al.ctx.set_option("host_chunk_pairs", 256)
+    try:
+        out, ops = al.align_arrays(3, x, xo, y, yo)
+        need = int(out["n_ops"].sum())
+        cap = need // 2 + 17
+        out2 = np.zeros(3000, dtype=_lib.ALN_DTYPE)
+        ops2 = np.full(cap + 64, 0xEE, dtype=np.uint8)
+        used = C.c_uint64(0)
+        sc = al.scoring.to_c()
+        xo64, yo64 = np.ascontiguousarray(xo, dtype=np.uint64), np.ascontiguousarray(yo, dtype=np.uint64)
+        rc = _lib.lib().bg_align_batch(al.ctx.h, C.byref(sc), 3, 3000, x.ctypes.data, xo64.ctypes.data, y.ctypes.data, yo64.ctypes.data,
+                                       out2.ctypes.data, ops2.ctypes.data, cap, C.byref(used))
+    finally:
+        al.ctx.set_option("host_chunk_pairs", 0)
+    assert rc == -9 and used.value == need  # BG_ERR_OPS_CAP
+    assert out2.tobytes() == out.tobytes()
+    fits = (out["ops_off"].astype(np.int64) + out["n_ops"].astype(np.int64)) <= cap
+    last = int(np.nonzero(fits)[0].max())
+    end = int(out["ops_off"][last]) + int(out["n_ops"][last])
+    assert (ops2[:end] == ops[:end]).all() and (ops2[cap:] == 0xEE).all()
+
+
 def test_blosum62_protein_batches():
     rng = np.random.default_rng(4)
     aa = b"ARNDCQEGHILKMFPSTWYVBZX"
