@@ -644,7 +644,12 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
             BG_HIP(hipStreamWaitEvent(st, B.set[(n_chunk + 1) & 1].matched, 0));
         }
         if (ctx->timing) BG_HIP(hipEventRecord(ctx->ev[0], st));
-        if (sm == SCORE_PARAMS && !ctx->band_fill_v1) {
+        // Geometry by sub-batch size: K3v2 binds a pair to 8 lanes for ~30 ms whatever the batch (throughput comes from the
+        // 16 384 pairs in flight); a small sub-batch — a whole small call, or the tail of a large one — finishes sooner
+        // with one pair per wavefront (K3: 19 ms; measured cross-over between 2 048 and 4 096 pairs,
+        // tools/exp/time_banded_small.py).  band_fill_v1: 1 always K3, -1 never (tests)
+        const bool small_batch = take <= 2048 && ctx->band_fill_v1 >= 0;
+        if (sm == SCORE_PARAMS && ctx->band_fill_v1 <= 0 && !small_batch) {
             a.started = on_device ? B.d_started : nullptr;
             a.tb_flip = kTbFlip;
             if (on_device) B.started_target += band_fill2_blocks(a.n_pairs);

@@ -62,7 +62,7 @@ struct bg_ctx {
     bool no_couples = false;  // tests: K1p without the (m, n) slot order on ragged batches
     int band_chain_global = -1;  // chain_kernel tree placement: -1 by batch size, 0 LDS, 1 global scratch
     bool band_join_global = false;  // tests: k-mer join with its table in global memory even where the LDS flavour applies
-    bool band_fill_v1 = false;  // tests: K3 (one pair per wavefront) even where K3v2 applies
+    int band_fill_v1 = 0;  // 1: K3 (one pair per wavefront) even where K3v2 applies; -1: K3v2 even for small sub-batches; 0: by size
     bool band_on_host = false;  // build bands with the host builder (band_host.cpp) instead of band_device.hip
     // the scratch above is one set per ctx: a *_dev call arriving on another stream than the previous one first
     // waits (on the device) for that call's last kernel — see bg_scratch_guard

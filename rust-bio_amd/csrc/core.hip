@@ -7,6 +7,8 @@
 #include <mutex>
 #include <thread>
 
+#include <cstdlib>
+
 #include "bg_common.h"
 
 thread_local std::string bg_tls_error;
@@ -117,6 +119,9 @@ extern "C" int bg_init(int device, bg_ctx** out) {
     }
     bg_ctx* ctx = new bg_ctx;
     ctx->device = device;
+    // BG_BAND_FILL_V1: initial value of the option of that name (the test suite pins the eight-pairs-per-wavefront fill so
+    // that its small batches keep exercising it)
+    if (const char* e = getenv("BG_BAND_FILL_V1")) ctx->band_fill_v1 = atoi(e) > 0 ? 1 : atoi(e) < 0 ? -1 : 0;
     BG_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     BG_HIP(hipEventCreate(&ctx->ev[0]));
     BG_HIP(hipEventCreate(&ctx->ev[1]));
@@ -188,7 +193,7 @@ extern "C" int bg_set_option(bg_ctx* ctx, const char* key, int64_t value) {
         return BG_OK;
     }
     if (!strcmp(key, "band_fill_v1")) {
-        ctx->band_fill_v1 = value != 0;
+        ctx->band_fill_v1 = value > 0 ? 1 : value < 0 ? -1 : 0;
         return BG_OK;
     }
     if (!strcmp(key, "band_on_host")) {

@@ -9,6 +9,10 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
         sys.path.insert(0, p)
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+# The banded pipeline picks its fill kernel by sub-batch size (K3, one pair per wavefront, up to 2048 pairs; K3v2, eight
+# pairs per wavefront, above).  The tests' batches are small: pin K3v2 so that they keep exercising the kernel large
+# batches run; tests/test_gpu_banded.py covers K3 (option 1) and the selection by size (option 0) explicitly.
+os.environ.setdefault("BG_BAND_FILL_V1", "-1")
 
 
 def pytest_configure(config):

@@ -5,6 +5,7 @@ join, compacted raster): 181 875 pairs in 2624 configurations (seed 20260924, 15
 import sys, time
 import numpy as np
 import os
+os.environ.setdefault("BG_BAND_FILL_V1", "-1")  # small fuzz batches still run K3v2 (see tests/conftest.py)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)

@@ -329,7 +329,8 @@ def test_fill_kernel_variants_agree():
                      (0, Scoring.from_scores(-5, -1, 1, -1).xclip_prefix_(0).yclip_suffix_(-1))]:
         al = BAligner.with_scoring(sc, 9, 7)
         res = []
-        for opts in ({}, {"force_wide": 1}, {"band_fill_v1": 1}):
+        # band_fill_v1: -1 K3v2 whatever the batch size, 1 K3, 0 by sub-batch size (K3 for these 80 pairs)
+        for opts in ({"band_fill_v1": -1}, {"band_fill_v1": -1, "force_wide": 1}, {"band_fill_v1": 1}, {"band_fill_v1": 0}):
             for k_, v_ in opts.items():
                 al.ctx.set_option(k_, v_)
             try:
@@ -338,7 +339,7 @@ def test_fill_kernel_variants_agree():
                 out, ops = al.last_out, al.last_ops
             res.append((out.copy(), ops.copy()))
             for k_ in opts:
-                al.ctx.set_option(k_, 0)
+                al.ctx.set_option(k_, -1 if k_ == "band_fill_v1" else 0)
         for out, ops in res[1:]:
             for f in ("score", "xstart", "xend", "ystart", "yend", "n_ops", "status", "ops_off"):
                 assert (out[f] == res[0][0][f]).all(), (mode, f)
