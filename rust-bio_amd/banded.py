@@ -6,7 +6,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib, sparse
-from .pairwise import (MODE_CUSTOM, MODE_GLOBAL, MODE_LOCAL, MODE_SEMIGLOBAL, Scoring, to_alignment)
+from .pairwise import (MODE_CUSTOM, MODE_GLOBAL, MODE_LOCAL, MODE_SEMIGLOBAL, Scoring, check_defined, to_alignment)
 
 MAX_CELLS = 5_000_000  # banded.rs:104
 
@@ -74,6 +74,7 @@ class Aligner:
         used = C.c_uint64(0)
         cells = np.zeros(n, dtype=np.uint64)
         sc = self.scoring.to_c()
+        check_defined(self.scoring, xb, xo, yb, yo)  # a closure that panics on a byte pair of this pair (pairwise.py)
         rc = _lib.lib().bg_align_banded_batch(self.ctx.h, C.byref(sc), mode, self.k, self.w, n, xb.ctypes.data,
                                               xo.ctypes.data, yb.ctypes.data, yo.ctypes.data, out.ctypes.data,
                                               ops.ctypes.data if want_ops else None, cap, C.byref(used),

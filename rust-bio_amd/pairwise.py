@@ -208,6 +208,32 @@ def to_alignment(rec, ops_buf):
                      MODE_NAMES[int(rec["mode"])])
 
 
+def check_defined(scoring, xb, xo, yb, yo):
+    """The reference calls `match_fn(x[i-1], y[j-1])` for every cell of a pair (mod.rs:729) and panics where the closure
+    does: a byte pair the tabulated closure is not defined on must not MEET inside one alignment.  Checked per pair (a
+    byte of some x against a byte of some other pair's y is fine) for the host-buffer batches of this module and of
+    banded.py; the device-resident entry points (`align_dev`, `align_packed_dev`) take pointers and stay unchecked — an
+    undefined pair scores 0 there."""
+    und = scoring._undefined
+    if und is None:
+        return
+    n = len(xo) - 1
+    hot = und & np.outer(np.bincount(xb, minlength=256) > 0, np.bincount(yb, minlength=256) > 0)
+    if not hot.any():  # no undefined pair has both of its bytes anywhere in the batch
+        return
+    pair_of_x = np.searchsorted(xo, np.arange(len(xb), dtype=np.uint64), side="right") - 1
+    pair_of_y = np.searchsorted(yo, np.arange(len(yb), dtype=np.uint64), side="right") - 1
+    for a in np.nonzero(hot.any(axis=1))[0]:
+        px = np.zeros(n, dtype=bool)
+        px[pair_of_x[xb == a]] = True
+        for b in np.nonzero(hot[a])[0]:
+            py = np.zeros(n, dtype=bool)
+            py[pair_of_y[yb == b]] = True
+            both = np.nonzero(px & py)[0]
+            if len(both):
+                raise KeyError(f"match_fn is not defined on the byte pair ({int(a)}, {int(b)}) that meets in pair {int(both[0])}")
+
+
 class Aligner:
     """Aligner<F> (mod.rs:472-1016)."""
 
@@ -261,11 +287,7 @@ class Aligner:
             ops = None
         used = C.c_uint64(0)
         sc = self.scoring.to_c()
-        if self.scoring._undefined is not None:  # the reference would panic inside match_fn on such a pair
-            hit = self.scoring._undefined & np.outer(np.bincount(xb, minlength=256) > 0, np.bincount(yb, minlength=256) > 0)
-            if hit.any():
-                a, b = np.argwhere(hit)[0]
-                raise KeyError(f"match_fn is not defined on the byte pair ({int(a)}, {int(b)}) that occurs in this batch")
+        check_defined(self.scoring, xb, xo, yb, yo)
         rc = _lib.lib().bg_align_batch(self.ctx.h, C.byref(sc), mode, n, xb.ctypes.data,
                                        xo.ctypes.data, yb.ctypes.data, yo.ctypes.data,
                                        out.ctypes.data, ops.ctypes.data if want_ops else None,

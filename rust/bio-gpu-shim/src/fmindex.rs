@@ -9,15 +9,20 @@ use bio::data_structures::bwt::{Less, BWT};
 use bio::data_structures::fmindex::{BackwardSearchResult, Interval};
 use bio::data_structures::suffix_array::RawSuffixArray;
 
-pub struct GpuFMIndex {
+/// The handle keeps the pointer of the `Context` it was built with (its stream and staging serve the host-buffer entry
+/// points below), so the borrow is part of the type: the index cannot outlive its context.
+pub struct GpuFMIndex<'ctx> {
     pub(crate) h: *mut sys::bg_fm,
+    _ctx: std::marker::PhantomData<&'ctx Context>,
 }
-// The handle is immutable after construction; searches use no shared scratch (include/biogpu.h, "Streams and threads").
-unsafe impl Send for GpuFMIndex {}
-unsafe impl Sync for GpuFMIndex {}
+// May move to another thread; NOT `Sync`: `backward_search_batch` / `occ_batch` go through the host-buffer entry
+// points, which use the context's stream and pinned staging and share its one-thread-at-a-time rule
+// (include/biogpu.h, "Streams and threads").  Threads that want to share one index wrap it in a `Mutex`, or call
+// the `*_dev` entry points of biogpu-sys on their own streams (those use no context state).
+unsafe impl Send for GpuFMIndex<'_> {}
 
-impl GpuFMIndex {
-    pub fn new(ctx: &Context, bwt: &BWT, less: &Less, occ_k: u32, alphabet: &Alphabet) -> Self {
+impl<'ctx> GpuFMIndex<'ctx> {
+    pub fn new(ctx: &'ctx Context, bwt: &BWT, less: &Less, occ_k: u32, alphabet: &Alphabet) -> Self {
         let less64: Vec<u64> = less.iter().map(|&v| v as u64).collect();
         let syms: Vec<u8> = alphabet.symbols.iter().map(|s| s as u8).collect();
         let mut h = std::ptr::null_mut();
@@ -26,7 +31,7 @@ impl GpuFMIndex {
                              syms.as_ptr(), syms.len() as u32, &mut h)
         };
         assert!(rc == 0, "{}", strerror(rc)); // BG_ERR_OUT_OF_ALPHABET == Occ::new's index panic (bwt.rs:114)
-        GpuFMIndex { h }
+        GpuFMIndex { h, _ctx: std::marker::PhantomData }
     }
 
     /// `backward_search` (fmindex.rs:144-208) for many patterns.
@@ -59,7 +64,7 @@ impl GpuFMIndex {
     }
 
     /// attach the suffix array the index was built from (`RawSuffixArray`, suffix_array.rs:25)
-    pub fn attach_sa(&self, sa: &RawSuffixArray) {
+    pub fn attach_sa(&mut self, sa: &RawSuffixArray) {
         let v: Vec<u64> = sa.iter().map(|&p| p as u64).collect();
         let rc = unsafe { sys::bg_fm_set_suffix_array(self.h, v.as_ptr(), v.len() as u64) };
         assert!(rc == 0, "{}", strerror(rc));
@@ -79,7 +84,7 @@ impl GpuFMIndex {
     }
 }
 
-impl Drop for GpuFMIndex {
+impl Drop for GpuFMIndex<'_> {
     fn drop(&mut self) {
         unsafe { sys::bg_fm_free(self.h) };
     }

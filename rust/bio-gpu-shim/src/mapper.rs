@@ -14,9 +14,9 @@ pub struct Hit {
     pub n_candidates: u32,
 }
 
-impl GpuFMIndex {
+impl GpuFMIndex<'_> {
     /// the text the index was built from, final sentinel included (windows are cut from it)
-    pub fn attach_text(&self, text: &[u8]) {
+    pub fn attach_text(&mut self, text: &[u8]) {
         let rc = unsafe { sys::bg_fm_set_text(self.h, text.as_ptr(), text.len() as u64) };
         assert!(rc == 0, "{}", strerror(rc));
     }
