@@ -1,10 +1,10 @@
 // K3v2 — banded_fill2_kernel<R, LP> + banded_epilogue_kernel.  Same recurrence and outputs as K3
 // (banded_fill.hip, design notes in banded_kernels.h; reference: banded.rs:406-723), different geometry:
 //
-//   * LP = 16 lanes own one pair — four pairs per wavefront — with R = 4 rows per lane, i.e. strips of 64
-//     rows.  A strip walks (columns its rows touch) + LP - 1 skew steps; with one pair per wavefront and
-//     128-row strips (K3) 60 % of the lane-steps fall outside a 129-wide band, here 36 %, and the per-step
-//     overhead (lane shifts, loop control) is shared by twice as many cells.
+//   * LP = 8 lanes own one pair — eight pairs per wavefront — with R = 4 rows per lane, i.e. strips of 32 rows.  A strip
+//     walks (columns its rows touch) + LP - 1 skew steps; with one pair per wavefront and 128-row strips (K3) 60 % of
+//     the lane-steps fall outside a 129-wide band, with 16 lanes x 4 rows 36 %, here 21 %, and the per-step overhead
+//     (lane shifts, loop control) is shared by eight pairs.  (Measured fill times of the other geometries: BF2_LP below.)
 //   * the last-column epilogue (banded.rs:683-723) needs scans over all rows of a pair; it runs afterwards
 //     in banded_epilogue_kernel (one wavefront per pair) from what the fill stored per row.
 //
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void banded_fill2_kernel(const BandArgs a) {
     for (uint32_t strip = 0; strip < nstrips_w; strip++) {
         const uint32_t rb = (strip * LP + ll) * R;
         const int32_t mrow = (int32_t)m - (int32_t)rb - 1;
-        int32_t Sl[R], Dl[R], Il[R], Sn[R], cf[R], cl[R], ycl[R];
+        int32_t Sl[R], Dl[R], Il[R], Sn[R], SnB[R], cf[R], cl[R], ycl[R];
         uint32_t Ly[R], px[R], celln[R], icase[R];
         uint32_t trow[R];  // offset of the row's bytes (cells cf..cl) in the pair's traceback block
         int jlo = 0x7fffffff, jhi = -1;
@@ -195,6 +195,7 @@ __global__ __launch_bounds__(256) void banded_fill2_kernel(const BandArgs a) {
             px[r] = 0;
             Sl[r] = Dl[r] = Il[r] = NEGS;
             Sn[r] = NEGS - sn_bias;
+            SnB[r] = NEGS;
             ycl[r] = NEGS;
             Ly[r] = 0;
             celln[r] = 0;
@@ -328,10 +329,16 @@ __global__ __launch_bounds__(256) void banded_fill2_kernel(const BandArgs a) {
 
         int32_t S_out = NEGS, I_out = NEGS, cm_out = NEGS;
         int32_t ca_out = 0, q_out = 0, xk_out = NEGS;
+        // NARROW: Sn[i] / Ly[i] ("first maximum of the row", banded.rs:655-660) per block of 16 steps, K1p's way: inside a
+        // block the key S | (15 - t % 16) lets ONE max keep the earliest column of the largest value (S values are multiples
+        // of 16), the block's winner is folded into the running (Sn, Ly) — strictly greater only — when the block ends
+        // (merge_rows, a wave-uniform moment): or + max per cell instead of compare + select + max
+        int32_t SnT_out = NEGS - sn_bias;  // true running Sn of this lane's last row (what the lane below reads)
         auto step = [&](const int t, Chunk& c) {
+            const int32_t tpri = 15 - (t & 15);
             int32_t S_up = wave_shr1z(S_out), I_up = wave_shr1z(I_out), cm = wave_shr1z(cm_out);
             int32_t ca = wave_shr1z(ca_out), q = wave_shr1z(q_out), xk = XP ? wave_shr1z(xk_out) : NEGS;
-            int32_t Sn_prev = wave_shr1z(Sn[R - 1]) + sn_bias;  // Sn of the row above this lane's first one, columns <= j folded in
+            int32_t Sn_prev = wave_shr1z(NARROW ? SnT_out : Sn[R - 1]) + sn_bias;  // Sn of the row above this lane's first one, columns <= j folded in
             if (ll == 0) {
                 S_up = c.S;
                 I_up = c.I;
@@ -355,7 +362,7 @@ __global__ __launch_bounds__(256) void banded_fill2_kernel(const BandArgs a) {
                     const int32_t xs_s = to_s(sc.xs), ys_s = to_s(sc.ys);
                     const int32_t match_k = (sc.match * 16) | (int32_t)C_MATCH, mismatch_k = (sc.mismatch * 16) | (int32_t)C_SUBST;
                     const int32_t xkey_j = xk;
-                    const int32_t nmj = (int32_t)(n - (uint32_t)j);
+                    (void)n;
                     const int32_t ca_in = ca;
                     int32_t cmk = cm | 15;  // fold key: clean running maximum | row priority (15 = an earlier lane)
                     // LAST: some lane of the wavefront is at column n — only then the extra I candidate
@@ -405,11 +412,8 @@ __global__ __launch_bounds__(256) void banded_fill2_kernel(const BandArgs a) {
                             } else {
                                 cmk = max(cmk, Sl[r] + (xs_s + (14 - r)));
                             }
-                            // banded.rs:655-660
-                            // (outside the band S is NEGS <= NEGS - ys <= Sn[r]: no separate band test)
-                            const bool up = Sl[r] > Sn[r];
-                            Ly[r] = up ? (uint32_t)nmj : Ly[r];
-                            Sn[r] = max(Sn[r], Sl[r]);
+                            // banded.rs:655-660, blockwise (see above; outside the band S is NEGS: never a winner)
+                            SnB[r] = max(SnB[r], Sl[r] | tpri);
                             // traceback byte, I/D flags as the keys carry them (1 = opened: kTbFlip turns them into K4's
                             // "1 = extended").  Unconditional: outside the band the byte lands on a ring slot that is
                             // rewritten before its group is handed over (left of the band) or never handed over (right of it)
@@ -424,7 +428,7 @@ __global__ __launch_bounds__(256) void banded_fill2_kernel(const BandArgs a) {
                                 icase[r] = (inb && last_col) ? ic : icase[r];
                             }
                             diag = left_S;
-                            if (LAST) Sn_prev = Sn[r] + ys_s;
+                            if (LAST) Sn_prev = max(Sn[r], SnB[r] & ~15) + ys_s;  // the true running value, this column included
                         }
                     };
                     if (__any(last_col) || __any(mrow >= 0 && mrow < R))
@@ -506,6 +510,7 @@ __global__ __launch_bounds__(256) void banded_fill2_kernel(const BandArgs a) {
                 }
                 S_out = S_up;
                 I_out = I_up;
+                if (NARROW) SnT_out = max(Sn[R - 1], SnB[R - 1] & ~15);
                 cm_out = cm;
                 ca_out = ca;
                 q_out = q;
@@ -520,6 +525,19 @@ __global__ __launch_bounds__(256) void banded_fill2_kernel(const BandArgs a) {
             c.cm = wave_shl1z(c.cm);
             c.ca = wave_shl1z(c.ca);
         };
+        // fold the block that ends at step t_end (t_end % 16 == 15) into (Sn, Ly): the winner sat at step t_end - priority
+        auto merge_rows = [&](const int t_end) {
+            const int32_t nmj_end = (int32_t)n - (jlo + t_end - ll);  // n - j at step t_end
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int32_t nb = SnB[r] & ~15;
+                const bool up = nb > Sn[r];
+                Ly[r] = up ? (uint32_t)(nmj_end + (SnB[r] & 15)) : Ly[r];
+                Sn[r] = max(Sn[r], nb);
+                SnB[r] = NEGS;
+            }
+        };
+        static_assert(2 * LP == 16 || !NARROW, "the Sn blocks are the chunk pairs");
         Chunk c_even = load_chunk(0), c_odd;
         for (int t0 = 0; t0 < nsteps_w; t0 += 2 * LP) {
             c_odd = load_chunk(t0 + LP);
@@ -528,6 +546,7 @@ __global__ __launch_bounds__(256) void banded_fill2_kernel(const BandArgs a) {
             c_even = load_chunk(t0 + 2 * LP);
 #pragma unroll 1
             for (int t = t0 + LP; t < min(t0 + 2 * LP, nsteps_w); t++) step(t, c_odd);
+            if (NARROW) merge_rows(t0 + 2 * LP - 1);  // also the last, partial block: its missing steps added nothing
             const int t_done = min(t0 + 2 * LP, nsteps_w);  // wave-uniform; FLUSH is a multiple of 2 * LP
             if ((t_done & (FLUSH - 1)) == 0) flush_tb(jlo + t_done - 1 - ll, jlo + t_done - 1 - ll - FLUSH, false);
         }

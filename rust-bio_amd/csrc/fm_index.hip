@@ -382,8 +382,16 @@ __global__ __launch_bounds__(256) void fm_search_fast_kernel(FmDev fm, uint64_t 
             return;
         }
     };
-    fetch();
-    while (__any(active)) {
+    // one fetch site: a quad whose query ended raises `need` and takes its next one at the top of the next trip (the pack
+    // code is ~200 instructions: inlined at both exits of the step it would run twice whenever a wavefront has a Partial
+    // and a Complete ending in the same step, and triple the loop's footprint in the instruction cache)
+    bool need = true;
+    for (;;) {
+        if (need) {
+            fetch();
+            need = false;
+        }
+        if (!__any(active)) break;
         if (active) {
             // one iteration of the loop at fmindex.rs:160-182; the symbol is a code already
             pos -= 1;
@@ -429,12 +437,14 @@ __global__ __launch_bounds__(256) void fm_search_fast_kernel(FmDev fm, uint64_t 
                     emit(BG_FM_PARTIAL, pl, pr + 1, matched);
                 else
                     emit(BG_FM_ABSENT, 0, 0, 0);
-                q += n_quads;
-                fetch();
+                need = true;
             } else if (pos == 0) {
                 emit(BG_FM_COMPLETE, l, r + 1, matched);
+                need = true;
+            }
+            if (need) {
                 q += n_quads;
-                fetch();
+                active = false;
             }
         }
     }
