@@ -649,9 +649,9 @@ def fm_legs(args, ctx, dev, stream, rank, world, do_cpu, orc, threads, parity, r
                                         "blocks (bg_suffix_array_dev, bg_bwt_dev, bg_sa_sample_dev, bg_fm_build_dev)"},
               "tags": {"complete": int((d_tag == 0).sum().item()), "partial": int((d_tag == 1).sum().item()),
                        "absent": int((d_tag == 2).sum().item())},
-              "roofline": {"bound": "hbm", "kernel": "fm_backward_search_kernel", "achieved": round(fm_ach, 2),
+              "roofline": {"bound": "hbm", "kernel": "fm_search_fast_kernel", "achieved": round(fm_ach, 2),
                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(fm_ach / HBM_PEAK_GBS, 5),
-                           "traffic": pmc_traffic("fm_backward_search_kernel", "fm_queries_per_launch", n_q),
+                           "traffic": pmc_traffic("fm_search_fast_kernel", "fm_queries_per_launch", n_q),
                            "launch_ms": round(fm_ms, 4), "queries_per_launch": n_q,
                            "alg_bytes_per_query": round(alg_bytes / n_q, 1),
                            "note": "the 33 MB block index of a 100 Mbp text sits in the 256 MiB Infinity Cache: see fm_big "
@@ -771,7 +771,7 @@ def fm_big_leg(args, ctx, dev, stream, rank, world, do_cpu, orc, threads, parity
                       "bwt_samples_blocks_s": round(bt["bwt_samples_blocks_s"], 2),
                       "host_peak_rss_gb": round(resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6, 1)},
            "tags": {"complete": int((d_tag == 0).sum().item()), "partial": int((d_tag == 1).sum().item())},
-           "roofline": {"bound": "hbm", "kernel": "fm_backward_search_kernel", "achieved": round(alg / (ms * 1e-3) / 1e9, 2),
+           "roofline": {"bound": "hbm", "kernel": "fm_search_fast_kernel", "achieved": round(alg / (ms * 1e-3) / 1e9, 2),
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                         "traffic": fm_big_traffic(n_q, fm.device_bytes()),
                         "launch_ms": round(ms, 4), "queries_per_launch": n_q, "alg_bytes_per_query": round(alg / n_q, 1)}}
@@ -1017,8 +1017,9 @@ def banded_leg(args, ctx, dev, rank, world, do_cpu, orc, threads, parity):
     # algorithmic bytes per pair: m + n + 8(n+1) + 2 x band_cells + 24 + n_ops
     balg = float(Pb) * (2 * Lb + 8 * (Lb + 1) + 24) + 2.0 * bcells + float(bout["n_ops"].sum())
     bfill_s = tm["fill_ms"] * 1e-3
-    Pb_launch = int(Pb / max(1, tm["fill_launches"]))
-    fill_launch_ms = tm["fill_ms"] / max(1, tm["fill_launches"])
+    # the fill runs in sub-batches of 16 384 pairs (one round of K3v2 blocks); a last, short one runs K3 (one pair per wavefront)
+    Pb_launch = min(Pb, 16384)
+    fill_launch_ms = tm["fill_ms"] / max(1.0, Pb / 16384.0)
     banded = {"value": round(world * bcells / bt / 1e9, 3), "unit": "GCUPS (band cells, host-buffer API: PCIe + band "
               "construction on the device + fill + traceback)",
               "pairs_per_s": round(world * Pb / bt, 1),

@@ -166,7 +166,11 @@ struct bg_band_scratch {
     size_t io_cap[6] = {};
     void* h_ops = nullptr;  // pinned landing zone of the operations
     size_t h_ops_cap = 0;
+    void *d_cmp = nullptr, *d_cscan = nullptr;  // host-buffer flavour: the operations compacted on the device, scan scratch
+    size_t d_cmp_cap = 0, d_cscan_cap = 0;
+    uint64_t* d_cell = nullptr;                 // ... and their running byte count over the sub-batches of a call
     hipStream_t tb_stream = nullptr;
+    hipStream_t copy_stream = nullptr;  // host-buffer flavour: sequence slices go up here
     uint32_t* d_started = nullptr;  // blocks of the K3v2 launches of the current call that have started (see banded_fill2.hip)
     uint32_t started_target = 0;    // ... and how many have been launched
 };
@@ -186,10 +190,14 @@ void bg_band_scratch_free(bg_band_scratch* b) {
         if (s.fill_gone) hipEventDestroy(s.fill_gone);
     }
     for (void* p : b->io) hipFree(p);
+    hipFree(b->d_cmp);
+    hipFree(b->d_cscan);
+    hipFree(b->d_cell);
     for (void* p : b->db) hipFree(p);
     hipHostFree(b->h_state);
     hipHostFree(b->h_ops);
     if (b->tb_stream) hipStreamDestroy(b->tb_stream);
+    if (b->copy_stream) hipStreamDestroy(b->copy_stream);
     if (b->build_stream) hipStreamDestroy(b->build_stream);
     if (b->seq_ready) hipEventDestroy(b->seq_ready);
     delete b;
@@ -358,10 +366,10 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
         d_xo = (uint64_t*)B.io[2];
         d_yo = (uint64_t*)B.io[3];
         d_out = (bg_alignment_t*)B.io[4];
-        if (xb) BG_HIP(hipMemcpyAsync((void*)d_x, x, xb, hipMemcpyHostToDevice, st));
-        if (yb) BG_HIP(hipMemcpyAsync((void*)d_y, y, yb, hipMemcpyHostToDevice, st));
         BG_HIP(hipMemcpyAsync((void*)d_xo, x_off, (n_pairs + 1) * 8, hipMemcpyHostToDevice, st));
         BG_HIP(hipMemcpyAsync((void*)d_yo, y_off, (n_pairs + 1) * 8, hipMemcpyHostToDevice, st));
+        // the sequences go up in slices of one sub-batch each on a copy stream of their own: the first sub-batch starts
+        // after 1 / n-th of the upload, the rest travels under its band construction and fill (upload_slices below)
     }
     a.x = d_x;
     a.x_off = d_xo;
@@ -370,9 +378,62 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
     a.out = d_out;
     a.ops = d_ops;
     lap("h2d sequences");
+    // host-buffer flavour with operations: they are compacted on the device, sub-batch by sub-batch (an operation list
+    // is at most m + n + 4 bytes)
+    const bool compact_on_device = !dio && ops_buf != nullptr;
+    if (compact_on_device) {
+        if ((rc = bg_reserve(&B.d_cmp, &B.d_cmp_cap, xb + yb + 4 * n_pairs + 256))) return rc;
+        if ((rc = bg_reserve(&B.d_cscan, &B.d_cscan_cap,
+                             bg_compact_ops_scratch(std::min<uint64_t>(n_pairs, ctx->chunk_pairs > 0 ? (uint64_t)ctx->chunk_pairs : 16384)))))
+            return rc;
+        if (!B.d_cell) BG_HIP(hipMalloc((void**)&B.d_cell, 64));
+        BG_HIP(hipMemsetAsync(B.d_cell, 0, 8, st));  // st_tb waits for st's events before every traceback
+    }
 
     // sub-batch size: enough wavefronts to fill the chip, small enough that a large batch pipelines
     const uint64_t chunk_pairs = ctx->chunk_pairs > 0 ? (uint64_t)ctx->chunk_pairs : 16384;
+    // host-buffer flavour: sequence slices (pairs [k * chunk_pairs, (k + 1) * chunk_pairs)) and their upload events
+    struct SliceEvents {
+        std::vector<hipEvent_t> ev;
+        ~SliceEvents() {
+            for (hipEvent_t e : ev)
+                if (e) hipEventDestroy(e);
+        }
+    } slices;
+    const uint64_t n_slices = dio ? 0 : (n_pairs + chunk_pairs - 1) / chunk_pairs;
+    uint64_t slices_up = 0, waited_fill = 0, waited_build = 0;
+    if (n_slices && !B.copy_stream) BG_HIP(hipStreamCreateWithFlags(&B.copy_stream, hipStreamNonBlocking));
+    auto upload_slices = [&](uint64_t upto) -> int {  // slices [slices_up, upto)
+        for (; slices_up < std::min(upto, n_slices); slices_up++) {
+            const uint64_t q0 = slices_up * chunk_pairs, q1 = std::min(n_pairs, q0 + chunk_pairs);
+            if (slices_up == 0) {  // behind the offsets (and whatever the caller's stream ran before)
+                hipEvent_t e0;
+                BG_HIP(hipEventCreateWithFlags(&e0, hipEventDisableTiming));
+                slices.ev.push_back(e0);
+                BG_HIP(hipEventRecord(e0, st));
+                BG_HIP(hipStreamWaitEvent(B.copy_stream, e0, 0));
+            }
+            if (x_off[q1] > x_off[q0])
+                BG_HIP(hipMemcpyAsync((uint8_t*)d_x + x_off[q0], x + x_off[q0], x_off[q1] - x_off[q0], hipMemcpyHostToDevice, B.copy_stream));
+            if (y_off[q1] > y_off[q0])
+                BG_HIP(hipMemcpyAsync((uint8_t*)d_y + y_off[q0], y + y_off[q0], y_off[q1] - y_off[q0], hipMemcpyHostToDevice, B.copy_stream));
+            hipEvent_t e;
+            BG_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            slices.ev.push_back(e);  // ev[k + 1]: slice k is on the device
+            BG_HIP(hipEventRecord(e, B.copy_stream));
+        }
+        return BG_OK;
+    };
+    // stream `s` may touch the sequences of pairs [0, upto) only behind their slices
+    auto need_seq = [&](hipStream_t s, uint64_t& waited, uint64_t upto) -> int {
+        if (!n_slices) return BG_OK;
+        const uint64_t k1 = std::min(n_slices, (upto + chunk_pairs - 1) / chunk_pairs);
+        int rcu = upload_slices(k1);
+        if (rcu) return rcu;
+        for (; waited < k1; waited++) BG_HIP(hipStreamWaitEvent(s, slices.ev[waited + 1], 0));
+        return BG_OK;
+    };
+    if ((rc = need_seq(st, waited_fill, std::min<uint64_t>(n_pairs, chunk_pairs)))) return rc;  // the first slice
     const uint64_t budget = 28ull << 30;  // traceback + aux per scratch set (two sets, of 288 GB HBM)
     const uint64_t grain = std::max<uint64_t>(1, std::min<uint64_t>(64, 65536 / (max_x + max_y + 1)));
     // Two sub-batches are in flight: while K3/K4 of one run, the band of the next one is being built —
@@ -414,6 +475,7 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
         P.matched = false;
         if (!build_on_device) return BG_OK;
         const uint64_t want = std::min<uint64_t>(chunk_pairs, n_pairs - p0);
+        if ((rc = need_seq(st_build, waited_build, p0 + want))) return rc;
         uint32_t max_m = 0, max_n = 0;
         for (uint64_t q = 0; q < want; q++) {
             max_m = std::max<uint32_t>(max_m, (uint32_t)(x_off[p0 + q + 1] - x_off[p0 + q]));
@@ -638,6 +700,7 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
         a.aux = (int32_t*)S.d_aux;
         a.pair0 = p0;
         a.n_pairs = (uint32_t)take;
+        if ((rc = need_seq(st, waited_fill, p0 + take))) return rc;
         if (on_device) BG_HIP(hipStreamWaitEvent(st, S.built, 0));
         if (on_device && p0 + take < n_pairs) {  // the next sub-batch's k-mer join goes first (see issue_match)
             if ((rc = issue_match(p0 + take, n_chunk + 1))) return rc;
@@ -684,6 +747,11 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
             ctx->last.traceback_ms += ms;
             ctx->last.traceback_launches += 1;
         }
+        // host-buffer flavour: this sub-batch's operations go, compacted, behind those of the sub-batches before it
+        // (running byte count in B.d_cell) while the next fill runs; its records get their final ops_off
+        if (compact_on_device &&
+            (rc = bg_compact_ops_dev(d_out + p0, take, d_ops, (uint8_t*)B.d_cmp, true, B.d_cell, nullptr, B.d_cscan, true, st_tb)))
+            return rc;
         BG_HIP(hipEventRecord(S.traced, st_tb));
         S.busy = true;
         lap("enqueue");
@@ -694,6 +762,7 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
     {
         uint64_t p0 = 0, n_chunk = 0;
         if ((rc = issue(0, 0))) return rc;
+        if ((rc = upload_slices(n_slices))) return rc;  // the other slices travel while the first sub-batch is built and filled
         for (;;) {
             uint64_t take = 0;
             if ((rc = finish(n_chunk, &take))) return rc;
@@ -710,35 +779,38 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
         lap("drain");
         return BG_OK;
     }
-    // results: records and (pinned) operations come back on the traceback stream
+    // results: the records (their ops_off final) and the compact operations come back on the traceback stream
     BG_HIP(hipMemcpyAsync(out, d_out, n_pairs * sizeof(bg_alignment_t), hipMemcpyDeviceToHost, st_tb));
-    if (ops_buf) {
-        if ((rc = pinned_reserve(&B.h_ops, &B.h_ops_cap, n_pairs * stride))) return rc;
-        BG_HIP(hipMemcpyAsync(B.h_ops, d_ops, n_pairs * stride, hipMemcpyDeviceToHost, st_tb));
-    }
+    uint64_t used = 0;
+    if (compact_on_device) BG_HIP(hipMemcpyAsync(&used, B.d_cell, 8, hipMemcpyDeviceToHost, st_tb));
     BG_HIP(hipStreamSynchronize(st_tb));
     BG_HIP(hipStreamSynchronize(st));
     for (auto& s : B.set) s.busy = false;
-    lap("drain + d2h");
-
-    // compact the operations: slots of `stride` bytes -> back to back (offsets serially, bytes on all threads)
-    const uint8_t* h_ops = (const uint8_t*)B.h_ops;
-    uint64_t used = 0;
-    int status = BG_OK;
-    std::vector<uint64_t> src(n_pairs);
-    for (uint64_t p = 0; p < n_pairs; p++) {
-        if (out[p].status && status == BG_OK) status = out[p].status;
-        src[p] = out[p].ops_off;
-        out[p].ops_off = used;
-        if (ops_buf && out[p].status == BG_OK && used + out[p].n_ops > ops_cap && status == BG_OK) status = BG_ERR_OPS_CAP;
-        used += out[p].n_ops;
+    if (compact_on_device && used) {
+        if ((rc = pinned_reserve(&B.h_ops, &B.h_ops_cap, used))) return rc;
+        BG_HIP(hipMemcpyAsync(B.h_ops, B.d_cmp, used, hipMemcpyDeviceToHost, st_tb));
     }
-    if (ops_buf)
-        parallel_for(n_pairs, 256, [&](unsigned, uint64_t lo, uint64_t hi) {
-            for (uint64_t p = lo; p < hi; p++)
-                if (out[p].status == BG_OK && out[p].ops_off + out[p].n_ops <= ops_cap)
-                    memcpy(ops_buf + out[p].ops_off, h_ops + src[p], out[p].n_ops);
-        });
+    int status = BG_OK;
+    bool cap_hit = false;
+    uint64_t fit = used;  // bytes of whole pairs that fit the caller's buffer
+    for (uint64_t p = 0; p < n_pairs; p++) {  // (while the operations travel)
+        if (out[p].status && status == BG_OK) status = out[p].status;
+        if (!compact_on_device) {  // no operations wanted: offsets of an (empty) compact buffer all the same
+            out[p].ops_off = used;
+            used += out[p].n_ops;
+        } else if (!cap_hit && out[p].ops_off + out[p].n_ops > ops_cap) {
+            cap_hit = true;
+            fit = out[p].ops_off;
+        }
+    }
+    if (cap_hit && status == BG_OK) status = BG_ERR_OPS_CAP;
+    if (compact_on_device && used) {
+        BG_HIP(hipStreamSynchronize(st_tb));
+        lap("drain + d2h");
+        const uint8_t* h_ops = (const uint8_t*)B.h_ops;
+        const uint64_t nb = std::min(fit, ops_cap);
+        parallel_for(nb, 1 << 20, [&](unsigned, uint64_t lo, uint64_t hi) { memcpy(ops_buf + lo, h_ops + lo, hi - lo); });
+    }
     if (ops_used) *ops_used = used;
     lap("compact ops");
     return status;

@@ -85,6 +85,17 @@ int bg_align_batch_dev_hint(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint6
                             uint32_t max_ylen, bg_alignment_t* d_out, uint8_t* d_ops, uint64_t ops_stride, void* stream,
                             int len_hint);
 
+// Operations of a batch, compacted on the device (the host-buffer paths).  The fill / traceback kernels leave a pair's
+// operations right-aligned in its own slot of the strided buffer (rec[p].ops_off says where); the caller's buffer wants
+// them back to back.  The operation counts of the n records are scanned, 16 or 64 lanes per pair copy its bytes to
+// d_compact + (global_offsets ? *d_cell : 0) + offset, the records get their FINAL ops_off = *d_cell + offset, then
+// *d_cell += the batch's byte count (a running total over the stages / sub-batches of a call, zeroed by the caller) and
+// *d_batch_total (if given) receives that count.  d_scratch: bg_compact_ops_scratch(n) bytes; long_ops: operation lists
+// of thousands of bytes (a wavefront per pair copies) rather than a few hundred (16 lanes).  Asynchronous on st.
+size_t bg_compact_ops_scratch(uint64_t n);
+int bg_compact_ops_dev(bg_alignment_t* d_rec, uint64_t n, const uint8_t* d_ops, uint8_t* d_compact, bool global_offsets, uint64_t* d_cell,
+                       uint64_t* d_batch_total, void* d_scratch, bool long_ops, hipStream_t st);
+
 // Serialises the users of a ctx's scratch across streams: constructed at the top of every *_dev entry point that
 // touches ctx->tb / aux / bnd / table, it makes `st` wait for the event the previous user recorded (if that was
 // another stream) and records its own when the entry point returns — two calls in flight on two streams with one

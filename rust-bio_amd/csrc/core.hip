@@ -232,3 +232,57 @@ extern "C" int bg_get_timing(bg_ctx* ctx, bg_timing_t* out) {
     ctx->last = {};
     return BG_OK;
 }
+
+// ---- operations compacted on the device (bg_common.h) ------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void ops_counts_kernel(const bg_alignment_t* __restrict__ rec, uint64_t n, uint32_t* __restrict__ cnt) {
+    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n) cnt[p] = rec[p].n_ops;
+}
+// LANES lanes per pair: bytes [src, src + n_ops) -> compact (+ *cell) + off[p]; ops_off becomes *cell + off[p]
+template <int LANES>
+__global__ __launch_bounds__(256) void ops_compact_kernel(bg_alignment_t* __restrict__ rec, uint64_t n, const uint8_t* __restrict__ ops,
+                                                          const uint64_t* __restrict__ off, const uint64_t* __restrict__ cell,
+                                                          uint8_t* __restrict__ compact, int global_offsets) {
+    const uint64_t p = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / LANES;
+    const uint32_t l = threadIdx.x % LANES;
+    if (p >= n) return;
+    const uint32_t k = rec[p].n_ops;
+    const uint64_t base = *cell;
+    const uint8_t* src = ops + rec[p].ops_off;
+    uint8_t* dst = compact + (global_offsets ? base : 0ull) + off[p];
+    for (uint32_t i = l; i < k; i += LANES) dst[i] = src[i];
+    // every lane of the group has read ops_off before lane 0 overwrites it (same wavefront, program order)
+    if (l == 0) rec[p].ops_off = base + off[p];
+}
+__global__ void ops_advance_kernel(uint64_t* cell, const uint64_t* __restrict__ off, uint64_t n, uint64_t* __restrict__ batch_total) {
+    if (batch_total) *batch_total = off[n];
+    cell[0] += off[n];
+}
+inline size_t a256(size_t v) { return (v + 255) & ~(size_t)255; }
+}  // namespace
+
+size_t bg_compact_ops_scratch(uint64_t n) { return a256(n * 4) + a256((n + 1) * 8) + 2 * (n / 2048 + 2) * 8 + 256; }
+
+int bg_compact_ops_dev(bg_alignment_t* d_rec, uint64_t n, const uint8_t* d_ops, uint8_t* d_compact, bool global_offsets, uint64_t* d_cell,
+                       uint64_t* d_batch_total, void* d_scratch, bool long_ops, hipStream_t st) {
+    if (n == 0) {
+        if (d_batch_total) BG_HIP(hipMemsetAsync(d_batch_total, 0, 8, st));
+        return BG_OK;
+    }
+    uint32_t* d_cnt = (uint32_t*)d_scratch;
+    uint64_t* d_off = (uint64_t*)((uint8_t*)d_scratch + a256(n * 4));
+    uint64_t* d_sums = (uint64_t*)((uint8_t*)d_off + a256((n + 1) * 8));
+    ops_counts_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(d_rec, n, d_cnt);
+    int rc = bg_scan_u32(d_cnt, n, d_off, d_sums, st);
+    if (rc) return rc;
+    // short-read batches: 16 lanes per pair; long operation lists (banded 10 kb pairs): a wavefront per pair
+    if (long_ops)
+        ops_compact_kernel<64><<<dim3((unsigned)((n * 64 + 255) / 256)), dim3(256), 0, st>>>(d_rec, n, d_ops, d_off, d_cell, d_compact, global_offsets);
+    else
+        ops_compact_kernel<16><<<dim3((unsigned)((n * 16 + 255) / 256)), dim3(256), 0, st>>>(d_rec, n, d_ops, d_off, d_cell, d_compact, global_offsets);
+    ops_advance_kernel<<<dim3(1), dim3(1), 0, st>>>(d_cell, d_off, n, d_batch_total);
+    BG_HIP(hipGetLastError());
+    return BG_OK;
+}
+

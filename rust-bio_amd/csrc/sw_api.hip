@@ -476,38 +476,6 @@ extern "C" int bg_align_batch_packed_dev(bg_ctx* ctx, const bg_scoring_t* sc, in
                                 d_out, d_ops, ops_stride, stream, -1, codes);
 }
 
-// ---- operations of a stage, compacted on the device (host-buffer path) ---------------------------------------------
-// The fill / traceback leave a pair's operations right-aligned in its own slot of `stride` bytes; the caller's buffer
-// wants them back to back.  Doing that on the host cost a memcpy of ~150 bytes per pair out of a strided landing zone
-// (the drainer's whole time, and twice the bytes over PCIe).  Here: the operation counts of the stage are scanned, a
-// wavefront-quarter per pair copies its bytes into a compact buffer, and the records get their FINAL ops_off — the
-// running total of the stages before lives in a device cell — so the host only moves two contiguous blocks per stage.
-namespace {
-__global__ __launch_bounds__(256) void ops_counts_kernel(const bg_alignment_t* __restrict__ rec, uint64_t n, uint32_t* __restrict__ cnt) {
-    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < n) cnt[p] = rec[p].n_ops;
-}
-// 16 lanes per pair: bytes [src, src + n_ops) -> compact + off[p]; ops_off becomes base + off[p]
-__global__ __launch_bounds__(256) void ops_compact_kernel(bg_alignment_t* __restrict__ rec, uint64_t n, const uint8_t* __restrict__ ops,
-                                                          const uint64_t* __restrict__ off, const uint64_t* __restrict__ base_cell,
-                                                          uint8_t* __restrict__ compact) {
-    const uint64_t p = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
-    const uint32_t l16 = threadIdx.x & 15;
-    if (p >= n) return;
-    const uint32_t k = rec[p].n_ops;
-    const uint8_t* src = ops + rec[p].ops_off;
-    uint8_t* dst = compact + off[p];
-    for (uint32_t i = l16; i < k; i += 16) dst[i] = src[i];
-    // every lane of the group has read ops_off before lane 0 overwrites it (same wavefront, program order)
-    if (l16 == 0) rec[p].ops_off = *base_cell + off[p];
-}
-// after the compaction of a stage: [0] running total (the next stage's base), [1] this stage's byte count
-__global__ void ops_advance_kernel(uint64_t* cell, const uint64_t* __restrict__ off, uint64_t n, uint64_t* __restrict__ stage_total) {
-    *stage_total = off[n];
-    cell[0] += off[n];
-}
-}  // namespace
-
 // ---- pipelined host-buffer path ------------------------------------------------------------------------------
 // bg_align_batch on a large batch is PCIe + host memcpy + kernels; run as one serial sequence it spends three
 // quarters of its time outside the kernels.  The batch is cut into stages of `host_chunk_pairs` pairs that flow
@@ -587,8 +555,7 @@ int align_batch_pipelined(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint64_
     const uint64_t o_tot = chunk * sizeof(bg_alignment_t), o_ops = o_tot + 256;
     const size_t out_need = o_ops + chunk * stride + 256;
     const size_t cmp_need = chunk * stride + 256;
-    const uint64_t o_soff = ((chunk * 4 + 255) & ~255ull), o_ssum = o_soff + (((chunk + 1) * 8 + 255) & ~255ull);
-    const size_t scan_need = o_ssum + 2 * (chunk / 2048 + 2) * 8 + 256;
+    const size_t scan_need = bg_compact_ops_scratch(chunk);
     for (auto& s : P.set) {
         if (s.in_cap < in_need) {
             if (s.h_in) hipHostFree(s.h_in);
@@ -758,17 +725,8 @@ int align_batch_pipelined(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint64_
         bg_alignment_t* d_rec = (bg_alignment_t*)S.d_out;
         rc = !in_ok ? BG_ERR_HIP : align_batch_dev_impl(ctx, sc, mode, np, S.d_in, (const uint64_t*)(S.d_in + o_xo), S.d_in + o_y, (const uint64_t*)(S.d_in + o_yo),
                                   max_x, max_y, d_rec, stride ? S.d_out + o_ops : nullptr, stride, s_k, uniform ? 1 : 0);
-        if (rc == BG_OK && stride) {  // compact the stage's operations on the device, final ops_off into the records
-            uint32_t* d_cnt = (uint32_t*)S.d_scan;
-            uint64_t* d_off = (uint64_t*)(S.d_scan + o_soff);
-            ops_counts_kernel<<<dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s_k>>>(d_rec, np, d_cnt);
-            rc = bg_scan_u32(d_cnt, np, d_off, (uint64_t*)(S.d_scan + o_ssum), s_k);
-            if (rc == BG_OK) {
-                ops_compact_kernel<<<dim3((unsigned)((np * 16 + 255) / 256)), dim3(256), 0, s_k>>>(d_rec, np, S.d_out + o_ops, d_off, P.d_cell, S.d_cmp);
-                ops_advance_kernel<<<dim3(1), dim3(1), 0, s_k>>>(P.d_cell, d_off, np, (uint64_t*)(S.d_out + o_tot));
-                if (hipGetLastError() != hipSuccess) rc = BG_ERR_HIP;
-            }
-        }
+        if (rc == BG_OK && stride)  // compact the stage's operations on the device, final ops_off into the records
+            rc = bg_compact_ops_dev(d_rec, np, S.d_out + o_ops, S.d_cmp, false, P.d_cell, (uint64_t*)(S.d_out + o_tot), S.d_scan, false, s_k);
         if (rc == BG_OK && (hipEventRecord(S.k_done, s_k) != hipSuccess || hipStreamWaitEvent(P.s_out, S.k_done, 0) != hipSuccess ||
                             hipMemcpyAsync(S.h_out, S.d_out, o_tot + 8, hipMemcpyDeviceToHost, P.s_out) != hipSuccess ||
                             hipEventRecord(S.out_done, P.s_out) != hipSuccess))

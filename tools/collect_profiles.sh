@@ -16,9 +16,9 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $R/bench.py --skip-cpu"
 # the counter passes keep one launch shape per kernel: the seed-and-extend leg reuses K2 / K5 on other batch sizes
-PMCBENCH="$BENCH --skip-pipeline --fm-big-genome 0 --steps 2 --warmup 0"
-# ... and the FM kernel on the 1 Gbp index gets passes of its own (same kernel name as the 100 Mbp leg)
-BIGBENCH="$BENCH --skip-fm --skip-k1 --skip-banded --skip-ingest --skip-pipeline --pairs 65536 --steps 2 --warmup 0"
+PMCBENCH="$BENCH --skip-pipeline --skip-packed --fm-big-genome 0 --banded-pairs 98304 --pipeline-reads-total 0 --steps 2 --warmup 0"
+# ... and the FM kernel on the 3 Gbp index gets passes of its own (same kernel name as the 100 Mbp leg)
+BIGBENCH="$BENCH --skip-fm --skip-k1 --skip-banded --skip-ingest --skip-pipeline --skip-packed --pairs 65536 --steps 2 --warmup 0"
 
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o bench -- $BENCH > "$OUT/${TAG}_bench.log" 2>&1
 cp "$OUT"/kt/bench_kernel_stats.csv "$OUT/${TAG}_bench_kernel_stats.csv" 2>/dev/null

@@ -19,7 +19,7 @@ from csrc_hash import csrc_sha  # noqa: E402
 
 out, tag = sys.argv[1], sys.argv[2]
 SHA = csrc_sha()  # the kernel sources these counters were collected with: bench.py reports them only while they match
-OURS = ("bgsw", "bgband", "bgfm", "fm_backward", "fq_", "se_", "sa_", "fmd_", "cigar_kernel", "pretty_kernel", "interval_rows")
+OURS = ("bgsw", "bgband", "bgfm", "fm_backward", "fm_search_fast", "fq_", "se_", "sa_", "fmd_", "cigar_kernel", "pretty_kernel", "interval_rows", "pack2_", "ops_compact")
 
 
 def short(k):
@@ -47,7 +47,7 @@ def launch_shape(logfile):
                     "banded_pairs_per_launch": (d.get("banded") or {}).get("pairs_per_launch"),
                     "k1_pairs_per_launch": ((next(iter(k1.values()), {})).get("roofline") or {}).get("pairs_per_launch"),
                     "ingest_bytes": int(((d.get("ingest") or {}).get("config") or {}).get("workload", "0 (0 bytes)").split("(")[-1].split()[0]),
-                    "command": "bench.py --skip-cpu --skip-pipeline --steps 2 --warmup 0"}
+                    "command": "bench.py --skip-cpu --skip-pipeline --skip-packed --fm-big-genome 0 --banded-pairs 98304 --steps 2 --warmup 0"}
     return {}
 
 
@@ -68,7 +68,7 @@ res["ingest_bytes_per_call"] = fq / 4.0
 # the FM search kernel on the index beyond the Infinity Cache (its own passes)
 big = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
-    vals = [v for k, vs in per_kernel(os.path.join(out, "big_" + c)).get(c, {}).items() if "fm_backward_search_kernel" in k for v in vs]
+    vals = [v for k, vs in per_kernel(os.path.join(out, "big_" + c)).get(c, {}).items() if "fm_search_fast_kernel" in k for v in vs]
     if vals:
         big[c] = {"launches": len(vals), "mean_bytes": sum(vals) * 1024.0 / len(vals)}
 logf = os.path.join(out, "big_FETCH_SIZE.log")
