@@ -366,7 +366,7 @@ def main():
                         "single_thread_value": round(n1 * L * L / t_one / 1e9, 4),
                         "full_parity_pass_value": round(n_chk * L * L / t_par / 1e9, 4)}
         # PCIe-inclusive rate of the host-buffer entry point (bg_align_batch): never the headline value
-        hxa, hya = x.cpu().numpy(), y.cpu().numpy()
+        hxa, hya = np.array(x.cpu().numpy()), np.array(y.cpu().numpy())  # the caller's own (numpy-allocated) buffers
         hoa = np.arange(n_pairs + 1, dtype=np.uint64) * np.uint64(L)
         hout, hopsb = aligner.align_arrays(3, hxa, hoa, hya, hoa)  # warm-up: sizes the staging sets, touches the result pages
         t_h = median_time(lambda: aligner.align_arrays(3, hxa, hoa, hya, hoa, out=hout, ops=hopsb))
