@@ -27,6 +27,16 @@
  * scratch and may be called from several threads on their own streams (with bg_enable_timing off — the timing
  * events belong to the ctx); the host-buffer flavours and bg_fmd_smems_* go through the handle's ctx and share
  * its single-thread rule.
+ *
+ * Several GPUs.  One process (and one bg_ctx, one replica of a bg_fm) per device; pairs / queries / reads are split in
+ * contiguous ranges and nothing is exchanged during a call.  What a caller gathers afterwards (one all-gather) are the
+ * FIXED-SIZE results: bg_alignment_t headers (score + coordinates), search intervals + tags, bg_seed_hit_t headers.
+ * Operation lists are variable-length and ops_off indexes the buffer of the process that made them: they stay where
+ * they are unless the caller gathers byte counts (ops_used) and bytes itself and re-bases ops_off.
+ *
+ * Limits that rust-bio does not have (it indexes with usize): an FM index, its suffix arrays and `less` hold uint32
+ * positions — texts of 2^32 - 1 symbols or more are refused with BG_ERR_TOO_LARGE (a 3.1 Gbp genome fits; the same
+ * genome followed by its reverse complement does not); a sequence of an aligner call may have up to 2^24 symbols.
  */
 #ifndef BIOGPU_H
 #define BIOGPU_H
