@@ -277,14 +277,17 @@ __global__ __launch_bounds__(256) void fm_backward_search_kernel(
 }
 
 // K5 fast path for byte patterns over a DNA-like index (four 2-bit codes, no dense symbols): when a quad takes its next
-// query, its four lanes turn the pattern into 2-bit codes — aligned dword loads, class lookups, 16 symbols per dword —
-// and park them in the quad's LDS slot (kFastSyms symbols); the LF loop then is the packed kernel's: one LDS read per
+// query, the wavefront turns the pattern into 2-bit codes — a coalesced byte load and a class lookup per 64 symbols, the
+// 16 lanes of a DPP row OR their codes into a dword — parked in the quad's LDS slot (kFastSyms symbols); the LF loop
+// then is the packed kernel's: one LDS read per
 // step for the symbol, no byte load, no class / less lookups by byte, none of the sparse / dense / panic arms.  A
 // pattern with a byte outside the four codes (N, lower case, anything that would make the reference panic) or longer
 // than the slot is tagged kTagDeferred and answered by the generic kernel launched right behind (DEFER).  Same results
 // (tests/test_gpu_fm.py, test_gpu_pack2.py); 466 -> ~560 M queries/s on the 100 Mbp index.
+// PACKED: `pat` is a 2-bit stream already (pack2.hip, the index's codes; offsets in symbols): taking a query is a funnel
+// shift of up to 16 dwords into the slot, nothing can be "bad".
 constexpr uint32_t kFastSyms = 256;
-template <bool SEEDS, bool COUNT>
+template <bool SEEDS, bool COUNT, bool PACKED = false>
 __global__ __launch_bounds__(256) void fm_search_fast_kernel(FmDev fm, uint64_t n_q, const uint8_t* __restrict__ pat,
                                                              const uint64_t* __restrict__ pat_off, uint8_t* __restrict__ tag,
                                                              uint64_t* __restrict__ lower, uint64_t* __restrict__ upper,
@@ -299,12 +302,100 @@ __global__ __launch_bounds__(256) void fm_search_fast_kernel(FmDev fm, uint64_t 
     __syncthreads();
 
     const uint32_t t = threadIdx.x & 3;
+    const uint32_t lane = threadIdx.x & 63;
     uint32_t* const slot = s_pk + (threadIdx.x >> 2) * (kFastSyms / 16);
+    uint32_t* const wave_slots = s_pk + (threadIdx.x >> 6) * 16 * (kFastSyms / 16);  // the 16 slots of this wavefront
     const uint64_t n_quads = (uint64_t)gridDim.x * (blockDim.x >> 2);
     uint64_t q = (uint64_t)blockIdx.x * (blockDim.x >> 2) + (threadIdx.x >> 2);
-    bool active = false;
+    bool active = false, need = true;
     uint32_t pos = 0, l = 0, r = 0, matched = 0, n_lines = 0;
 
+    // Taking the next query is a job of the WHOLE wavefront, one waiting quad at a time (round 3; a quad packing its own
+    // pattern ran ~300 instructions with 4 of 64 lanes active, 15 % of the kernel): the quad's query index, pattern
+    // offset and length are wave-uniform (read from the quad's leader lane), lane i looks symbol base + i up — one
+    // coalesced byte load per 64 symbols — and the 16 lanes of a DPP row OR their 2-bit codes into the dword of their 16
+    // symbols, which the row's last lane writes into the quad's LDS slot.  ~30 instructions per query.
+    auto fetch_all = [&]() {
+        uint64_t waiting = __ballot(need && t == 0);  // leaders of the quads that wait
+        while (waiting) {
+            const uint32_t leader = (uint32_t)__ffsll((unsigned long long)waiting) - 1u;
+            const bool mine = (lane >> 2) == (leader >> 2);
+            const uint64_t qs = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(q >> 32), leader) << 32) |
+                                (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)q, leader);
+            if (qs >= n_q) {  // nothing left for this quad
+                if (mine) {
+                    need = false;
+                    active = false;
+                }
+                waiting &= waiting - 1;
+                continue;
+            }
+            uint64_t off;
+            uint32_t len;
+            if (SEEDS) {
+                const uint64_t rd = qs / seeds.S;
+                const uint32_t k = (uint32_t)(qs - rd * seeds.S);
+                const uint64_t o = pat_off[rd];
+                off = o + (uint64_t)k * seeds.stride;
+                len = (uint64_t)k * seeds.stride + seeds.seed_len <= pat_off[rd + 1] - o ? seeds.seed_len : 0u;
+            } else {
+                off = pat_off[qs];
+                const uint64_t len64 = pat_off[qs + 1] - off;
+                len = len64 > kFastSyms ? kFastSyms + 1 : (uint32_t)len64;
+            }
+            bool bad = len > kFastSyms;
+            if (PACKED && len && !bad) {
+                uint32_t* const dst = wave_slots + (leader >> 2) * (kFastSyms / 16);
+                const uint32_t* pk = (const uint32_t*)pat;
+                if (lane < ((len + 15u) >> 4)) {  // dword `lane` of the slot: symbols off + 16 lane ... of the stream
+                    const uint64_t w0 = (off >> 4) + lane;
+                    const uint32_t sh = 2u * ((uint32_t)off & 15u);
+                    const uint32_t lo = pk[w0], hi = pk[w0 + 1];  // the stream is padded by one dword
+                    dst[lane] = sh ? (lo >> sh) | (hi << (32u - sh)) : lo;
+                }
+            } else if (len && !bad) {
+                uint32_t* const dst = wave_slots + (leader >> 2) * (kFastSyms / 16);
+                for (uint32_t base = 0; base < len; base += 64) {
+                    const uint32_t idx = base + lane;
+                    uint32_t c = 0;
+                    if (idx < len) {
+                        c = s_class[pat[off + idx]];
+                        bad = bad || c >= 4;
+                    }
+                    uint32_t word = (c & 3u) << (2 * (lane & 15u));
+                    word |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)word, 0x111 /*row_shr:1*/, 0xf, 0xf, true);
+                    word |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)word, 0x112 /*row_shr:2*/, 0xf, 0xf, true);
+                    word |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)word, 0x114 /*row_shr:4*/, 0xf, 0xf, true);
+                    word |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)word, 0x118 /*row_shr:8*/, 0xf, 0xf, true);
+                    if ((lane & 15u) == 15u && base + (lane & ~15u) < len) dst[(base >> 4) + (lane >> 4)] = word;
+                }
+                bad = __any(bad);
+            }
+            if (len == 0 || bad) {  // empty: Absent (fmindex.rs:185-207); a byte without a code / too long: the generic kernel's
+                if (lane == leader) {
+                    if (len == 0) {
+                        tag[qs] = (uint8_t)BG_FM_ABSENT;
+                        lower[qs] = 0;
+                        upper[qs] = 0;
+                        matched_len[qs] = 0;
+                    } else {
+                        tag[qs] = kTagDeferred;
+                    }
+                }
+                if (mine) q += n_quads;  // the same quad takes the next one in the next turn of this loop
+                continue;
+            }
+            if (mine) {
+                pos = len;
+                l = 0;
+                r = fm.n - 1;  // fmindex.rs:148
+                matched = 0;
+                active = true;
+                need = false;
+            }
+            waiting &= waiting - 1;
+        }
+    };
     auto emit = [&](uint32_t tg, uint32_t lo, uint32_t hi, uint32_t ml) {
         if (t == 0) {
             tag[q] = (uint8_t)tg;
@@ -313,84 +404,8 @@ __global__ __launch_bounds__(256) void fm_search_fast_kernel(FmDev fm, uint64_t 
             matched_len[q] = ml;
         }
     };
-    auto fetch = [&]() {
-        active = false;
-        while (q < n_q) {
-            uint64_t off;
-            uint32_t len;
-            if (SEEDS) {
-                const uint64_t rd = q / seeds.S;
-                const uint32_t k = (uint32_t)(q - rd * seeds.S);
-                const uint64_t o = pat_off[rd];
-                off = o + (uint64_t)k * seeds.stride;
-                len = (uint64_t)k * seeds.stride + seeds.seed_len <= pat_off[rd + 1] - o ? seeds.seed_len : 0u;
-            } else {
-                off = pat_off[q];
-                const uint64_t len64 = pat_off[q + 1] - off;
-                len = len64 > kFastSyms ? kFastSyms + 1 : (uint32_t)len64;
-            }
-            if (len == 0) {  // empty pattern: Absent (fmindex.rs:185-207)
-                emit(BG_FM_ABSENT, 0, 0, 0);
-                q += n_quads;
-                continue;
-            }
-            bool bad = len > kFastSyms;
-            if (!bad) {
-                // lane t packs dwords t, t + 4, ...: symbols [16 w, 16 w + 16) of the pattern, from the aligned dwords that
-                // hold them (a dword without a wanted byte is never touched)
-                for (uint32_t w = t; w * 16 < len; w += 4) {
-                    const uint64_t b0 = off + (uint64_t)w * 16;
-                    const uint32_t cnt = min(16u, len - w * 16);
-                    const uint32_t sh = (uint32_t)((uintptr_t)(pat + b0) & 3u);
-                    const uint32_t* src = (const uint32_t*)(pat + b0 - sh);
-                    const uint32_t nd = (sh + cnt + 3) >> 2;  // aligned dwords spanned: 1..5
-                    uint32_t d[5];
-#pragma unroll
-                    for (int k = 0; k < 5; k++) d[k] = (uint32_t)k < nd ? src[k] : 0u;
-                    uint32_t word = 0;
-#pragma unroll
-                    for (int g4 = 0; g4 < 4; g4++) {
-                        const uint32_t four = __builtin_amdgcn_alignbyte(d[g4 + 1], d[g4], sh);  // bytes 4 g4 .. + 3 of the 16
-#pragma unroll
-                        for (int k = 0; k < 4; k++) {
-                            const uint32_t idx = 4 * g4 + k;
-                            const uint32_t c = s_class[(four >> (8 * k)) & 0xFFu];
-                            if (idx < cnt) {
-                                bad = bad || c >= 4;
-                                word |= (c & 3u) << (2 * idx);
-                            }
-                        }
-                    }
-                    slot[w] = word;
-                }
-                // any lane of the quad saw a byte without a code?
-                uint32_t bq = bad ? 1u : 0u;
-                bq |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bq, 0xB1, 0xf, 0xf, true);
-                bq |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bq, 0x4E, 0xf, 0xf, true);
-                bad = bq != 0;
-            }
-            if (bad) {  // the generic kernel answers it
-                if (t == 0) tag[q] = kTagDeferred;
-                q += n_quads;
-                continue;
-            }
-            pos = len;
-            l = 0;
-            r = fm.n - 1;  // fmindex.rs:148
-            matched = 0;
-            active = true;
-            return;
-        }
-    };
-    // one fetch site: a quad whose query ended raises `need` and takes its next one at the top of the next trip (the pack
-    // code is ~200 instructions: inlined at both exits of the step it would run twice whenever a wavefront has a Partial
-    // and a Complete ending in the same step, and triple the loop's footprint in the instruction cache)
-    bool need = true;
     for (;;) {
-        if (need) {
-            fetch();
-            need = false;
-        }
+        if (__any(need)) fetch_all();
         if (!__any(active)) break;
         if (active) {
             // one iteration of the loop at fmindex.rs:160-182; the symbol is a code already
@@ -1118,8 +1133,15 @@ extern "C" int bg_fm_backward_search_packed_dev(bg_fm* fm, uint64_t n_q, const u
     const uint64_t blocks = std::min<uint64_t>((n_q + 63) / 64, 256 * 8);
     const SeedSrc ex = fm_codes(fm);
     if (ctx->timing) BG_HIP(hipEventRecord(ctx->ev[0], st));
-    fm_backward_search_kernel<false, false, true, false><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(
-        fm->dev, n_q, (const uint8_t*)d_packed, d_sym_off, d_tag, d_lower, d_upper, d_matched_len, nullptr, ex);
+    if (!fm->no_fast) {  // the LDS-slot kernel; patterns beyond its 256 symbols are left to the generic packed kernel
+        fm_search_fast_kernel<false, false, true><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(
+            fm->dev, n_q, (const uint8_t*)d_packed, d_sym_off, d_tag, d_lower, d_upper, d_matched_len, ex);
+        fm_backward_search_kernel<false, false, true, false, true><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(
+            fm->dev, n_q, (const uint8_t*)d_packed, d_sym_off, d_tag, d_lower, d_upper, d_matched_len, nullptr, ex);
+    } else {
+        fm_backward_search_kernel<false, false, true, false><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(
+            fm->dev, n_q, (const uint8_t*)d_packed, d_sym_off, d_tag, d_lower, d_upper, d_matched_len, nullptr, ex);
+    }
     BG_HIP(hipGetLastError());
     if (ctx->timing) {
         BG_HIP(hipEventRecord(ctx->ev[1], st));

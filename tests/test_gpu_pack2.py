@@ -51,9 +51,12 @@ def test_backward_search_on_packed_patterns_equals_the_byte_flavour_and_the_orac
     g, b, ls, fm = _index(300_000, 5)
     n_q, P = 20_011, 61
     pat, off = synth.fm_patterns(g, n_q, P, seed=8)
-    if ragged:  # patterns of every length 1..P, starting anywhere in the stream
+    if ragged:  # patterns of every length 1..P (some beyond the fast kernel's 256-symbol slot), starting anywhere in the stream
         lens = np.random.default_rng(2).integers(1, P + 1, size=n_q)
-        pat = np.concatenate([pat[int(off[q]):int(off[q]) + int(lens[q])] for q in range(n_q)])
+        lens[::97] = np.random.default_rng(3).integers(257, 400, size=len(lens[::97]))
+        starts = np.random.default_rng(4).integers(0, len(g) - 401, size=n_q)
+        pat = np.concatenate([pat[int(off[q]):int(off[q]) + int(lens[q])] if lens[q] <= P else g[int(starts[q]):int(starts[q]) + int(lens[q])]
+                              for q in range(n_q)])
         off = np.zeros(n_q + 1, dtype=np.uint64)
         off[1:] = np.cumsum(lens)
     codes = fm.pattern_codes()
