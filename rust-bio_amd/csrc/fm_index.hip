@@ -412,31 +412,28 @@ __global__ __launch_bounds__(256) void fm_search_fast_kernel(FmDev fm, uint64_t 
             pos -= 1;
             const uint32_t a = (slot[pos >> 4] >> (2 * (pos & 15u))) & 3u;
             const uint32_t less_a = s_less4[a];
+            // straight-line up to the (rare) second block load: l == 0 ranks position 0 and drops the result
+            const uint32_t lm1 = l ? l - 1 : 0u;
             const uint32_t br = r / kSymPerBlock, orr = r - br * kSymPerBlock;
+            const uint32_t bl = lm1 / kSymPerBlock, ol = lm1 - bl * kSymPerBlock;
             const uint4 vr = fm.blocks[(uint64_t)br * 4 + t];
             uint4 vl = vr;
-            uint32_t ol = 0;
-            if (l > 0) {
-                const uint32_t bl = (l - 1) / kSymPerBlock;
-                ol = (l - 1) - bl * kSymPerBlock;
-                if (bl != br) {
-                    vl = fm.blocks[(uint64_t)bl * 4 + t];
-                    if (COUNT) n_lines += 1;
-                }
+            if (bl != br) {
+                vl = fm.blocks[(uint64_t)bl * 4 + t];
+                if (COUNT) n_lines += 1;
             }
             if (COUNT) n_lines += 1;
-            uint32_t occ_r = quad_sum(block_part(vr, t, orr, a)), occ_l = 0;
-            if (l > 0) occ_l = quad_sum(block_part(vl, t, ol, a));
-            if (a == 0 && fm.n_exc) {  // sparse exceptions sit in the stream as code 0
-                if (fm.n_exc == 1) {
-                    const uint32_t e0 = s_exc[0];
-                    occ_r -= e0 <= r ? 1u : 0u;
-                    if (l > 0) occ_l -= e0 <= l - 1 ? 1u : 0u;
-                } else {
-                    occ_r -= count_le(s_exc, 0u, fm.n_exc, r);
-                    if (l > 0) occ_l -= count_le(s_exc, 0u, fm.n_exc, l - 1);
-                }
+            uint32_t occ_r = quad_sum(block_part_bf(vr, t, orr, a));
+            uint32_t occ_l = quad_sum(block_part_bf(vl, t, ol, a));
+            if (fm.n_exc == 1) {  // (uniform) the one sparse exception — the sentinel — sits in the stream as code 0
+                const uint32_t e0 = s_exc[0];
+                occ_r -= (a == 0 && e0 <= r) ? 1u : 0u;
+                occ_l -= (a == 0 && e0 <= lm1) ? 1u : 0u;
+            } else if (a == 0 && fm.n_exc) {
+                occ_r -= count_le(s_exc, 0u, fm.n_exc, r);
+                occ_l -= count_le(s_exc, 0u, fm.n_exc, lm1);
             }
+            occ_l = l ? occ_l : 0u;
             const uint32_t pl = l, pr = r;
             bool stop = occ_r == 0;  // fmindex.rs:167-170
             if (!stop) {

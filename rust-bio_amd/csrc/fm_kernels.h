@@ -71,6 +71,24 @@ __device__ __forceinline__ uint32_t block_part(const uint4 v, uint32_t t, uint32
     return (uint32_t)(__popcll(e0 << (64 - 2 * t0)) + __popcll((e1 << (32 - t1)) << (32 - t1)));
 }
 
+// block_part without branches (K5's fast kernel: the quad's lane 0 / lanes 1-3 split and the "no symbol of mine" early
+// exit cost a divergent region each — exec-mask bookkeeping the straight-line form does not have): every lane computes
+// both the counter select and the bitmap count and keeps the one its position in the quad calls for
+__device__ __forceinline__ uint32_t block_part_bf(const uint4 v, uint32_t t, uint32_t o, uint32_t c) {
+    const uint32_t lo = (c & 1) ? v.y : v.x, hi = (c & 1) ? v.w : v.z, cnt = (c & 2) ? hi : lo;
+    const int have = (int)o + 1 - ((int)t - 1) * 64;  // symbols of this lane inside [0, o] (lane 0: irrelevant)
+    const int t0 = min(max(have, 0), 32), t1 = min(max(have - 32, 0), 32);
+    const uint64_t pat = (uint64_t)c * 0x5555555555555555ull;
+    uint64_t w0 = ((uint64_t)v.y << 32) | v.x;
+    uint64_t w1 = ((uint64_t)v.w << 32) | v.z;
+    uint64_t e0 = ~(w0 ^ pat), e1 = ~(w1 ^ pat);
+    e0 = e0 & (e0 >> 1) & 0x5555555555555555ull;
+    e1 = e1 & (e1 >> 1) & 0x5555555555555555ull;
+    // the symbols beyond the first t0 / t1 leave at the top: 64 - 2 t bits, in two halves (t may be 0)
+    const uint32_t n = (uint32_t)(__popcll((e0 << (32 - t0)) << (32 - t0)) + __popcll((e1 << (32 - t1)) << (32 - t1)));
+    return t == 0 ? cnt : n;
+}
+
 // this lane's share of rank1(o) inside one bit-vector block: lane 0 holds the counter and bits 0..95, lane t >= 1
 // bits 96 + 128 (t - 1) ... + 127
 __device__ __forceinline__ uint32_t bv_part(const uint4 v, uint32_t t, uint32_t o) {
