@@ -9,7 +9,7 @@ n, L = 1_000_000, 150
 x, xo, y, yo = synth.sw_pairs(n, L, seed=2)
 al = Aligner.with_scoring(Scoring.from_scores(-5, -1, 1, -1))
 out, ops = al.align_arrays(3, x, xo, y, yo)
-for chunk in (16384, 32768, 65536, 131072, 262144, 1 << 30):
+for chunk in (98304, 122880, 131072, 147456, 172032, 196608, 245760):
     al.ctx.set_option("host_chunk_pairs", chunk)
     al.align_arrays(3, x, xo, y, yo, out=out, ops=ops)
     t0 = time.perf_counter()
