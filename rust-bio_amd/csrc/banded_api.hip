@@ -414,9 +414,9 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
                 BG_HIP(hipStreamWaitEvent(B.copy_stream, e0, 0));
             }
             if (x_off[q1] > x_off[q0])
-                BG_HIP(hipMemcpyAsync((uint8_t*)d_x + x_off[q0], x + x_off[q0], x_off[q1] - x_off[q0], hipMemcpyHostToDevice, B.copy_stream));
+                BG_HIP(bg_copy_pieces((uint8_t*)d_x + x_off[q0], x + x_off[q0], x_off[q1] - x_off[q0], hipMemcpyHostToDevice, B.copy_stream));
             if (y_off[q1] > y_off[q0])
-                BG_HIP(hipMemcpyAsync((uint8_t*)d_y + y_off[q0], y + y_off[q0], y_off[q1] - y_off[q0], hipMemcpyHostToDevice, B.copy_stream));
+                BG_HIP(bg_copy_pieces((uint8_t*)d_y + y_off[q0], y + y_off[q0], y_off[q1] - y_off[q0], hipMemcpyHostToDevice, B.copy_stream));
             hipEvent_t e;
             BG_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             slices.ev.push_back(e);  // ev[k + 1]: slice k is on the device
@@ -788,7 +788,7 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
     for (auto& s : B.set) s.busy = false;
     if (compact_on_device && used) {
         if ((rc = pinned_reserve(&B.h_ops, &B.h_ops_cap, used))) return rc;
-        BG_HIP(hipMemcpyAsync(B.h_ops, B.d_cmp, used, hipMemcpyDeviceToHost, st_tb));
+        BG_HIP(bg_copy_pieces(B.h_ops, B.d_cmp, used, hipMemcpyDeviceToHost, st_tb));
     }
     int status = BG_OK;
     bool cap_hit = false;

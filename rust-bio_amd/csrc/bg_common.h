@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -113,6 +114,21 @@ struct bg_scratch_guard {
         }
     }
 };
+// hipMemcpyAsync in pieces of at most BG_COPY_PIECE bytes (env, default 8 MB): transfers between pinned and device memory
+// beyond ~20 MB were measured to stall behind running compute kernels on this stack (the drainer of bg_align_batch
+// waited 1.7 ms for a 22 MB download against 0.2 ms for a 19.7 MB one), smaller ones ride the DMA engines
+inline hipError_t bg_copy_pieces(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t st) {
+    static const size_t piece = [] {
+        const char* e = getenv("BG_COPY_PIECE");
+        const long long v = e ? atoll(e) : 0;
+        return v > 0 ? (size_t)v : (size_t)(8u << 20);
+    }();
+    for (size_t o = 0; o < bytes; o += piece) {
+        const hipError_t rc = hipMemcpyAsync((uint8_t*)dst + o, (const uint8_t*)src + o, bytes - o < piece ? bytes - o : piece, kind, st);
+        if (rc != hipSuccess) return rc;
+    }
+    return hipSuccess;
+}
 // host threads this process may really use (affinity mask and cgroup CPU quota)
 unsigned bg_host_threads();
 // fn(0) .. fn(nt - 1) on the process-wide worker threads (created once, bg_host_threads() - 1 of them) and the caller;

@@ -1365,14 +1365,14 @@ extern "C" int bg_fm_backward_search_batch(bg_fm* fm, uint64_t n_q, const uint8_
         t_pack += now() - t0;
         t0 = now();
         bool ok = true;
-        if (pb) ok = ok && hipMemcpyAsync(S.d_in, S.h_in, pb, hipMemcpyHostToDevice, P.s_in) == hipSuccess;
+        if (pb) ok = ok && bg_copy_pieces(S.d_in, S.h_in, pb, hipMemcpyHostToDevice, P.s_in) == hipSuccess;
         ok = ok && hipMemcpyAsync(S.d_in + o_off, S.h_in + o_off, (nq + 1) * 8, hipMemcpyHostToDevice, P.s_in) == hipSuccess;
         ok = ok && hipEventRecord(S.in_done, P.s_in) == hipSuccess && hipStreamWaitEvent(s_k, S.in_done, 0) == hipSuccess;
         int rc = !ok ? BG_ERR_HIP
                      : bg_fm_backward_search_batch_dev(fm, nq, S.d_in, (const uint64_t*)(S.d_in + o_off), S.d_out + o_tag,
                                                        (uint64_t*)S.d_out, (uint64_t*)(S.d_out + o_hi), (uint32_t*)(S.d_out + o_ml), s_k);
         if (rc == BG_OK && (hipEventRecord(S.k_done, s_k) != hipSuccess || hipStreamWaitEvent(P.s_out, S.k_done, 0) != hipSuccess ||
-                            hipMemcpyAsync(S.h_out, S.d_out, o_tag + nq, hipMemcpyDeviceToHost, P.s_out) != hipSuccess ||
+                            bg_copy_pieces(S.h_out, S.d_out, o_tag + nq, hipMemcpyDeviceToHost, P.s_out) != hipSuccess ||
                             hipEventRecord(S.out_done, P.s_out) != hipSuccess))
             rc = BG_ERR_HIP;
         if (rc) {

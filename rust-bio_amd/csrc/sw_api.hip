@@ -609,7 +609,7 @@ int align_batch_pipelined(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint64_
         const bg_alignment_t* h_rec = (const bg_alignment_t*)S.h_out;
         const uint64_t T = stride ? *(const uint64_t*)(S.h_out + o_tot) : 0;
         if (T) {
-            BG_HIP(hipMemcpyAsync(S.h_out + o_ops, S.d_cmp, T, hipMemcpyDeviceToHost, P.s_ops));  // not behind the next stages' records
+            BG_HIP(bg_copy_pieces(S.h_out + o_ops, S.d_cmp, T, hipMemcpyDeviceToHost, P.s_ops));  // not behind the next stages' records
             BG_HIP(hipEventRecord(S.ops_done, P.s_ops));
         }
         std::atomic<int> st_rec{BG_OK};
@@ -717,8 +717,8 @@ int align_batch_pipelined(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint64_
         t_pack += now() - t0;
         t0 = now();
         bool in_ok = true;
-        if (xb) in_ok = in_ok && hipMemcpyAsync(S.d_in, S.h_in, xb, hipMemcpyHostToDevice, P.s_in) == hipSuccess;
-        if (yb) in_ok = in_ok && hipMemcpyAsync(S.d_in + o_y, S.h_in + o_y, yb, hipMemcpyHostToDevice, P.s_in) == hipSuccess;
+        if (xb) in_ok = in_ok && bg_copy_pieces(S.d_in, S.h_in, xb, hipMemcpyHostToDevice, P.s_in) == hipSuccess;
+        if (yb) in_ok = in_ok && bg_copy_pieces(S.d_in + o_y, S.h_in + o_y, yb, hipMemcpyHostToDevice, P.s_in) == hipSuccess;
         in_ok = in_ok && hipMemcpyAsync(S.d_in + o_xo, S.h_in + o_xo, 2 * (chunk + 1) * 8, hipMemcpyHostToDevice, P.s_in) == hipSuccess;
         in_ok = in_ok && hipEventRecord(S.in_done, P.s_in) == hipSuccess && hipStreamWaitEvent(s_k, S.in_done, 0) == hipSuccess;
         const bool uniform = !ragged;
@@ -728,7 +728,7 @@ int align_batch_pipelined(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint64_
         if (rc == BG_OK && stride)  // compact the stage's operations on the device, final ops_off into the records
             rc = bg_compact_ops_dev(d_rec, np, S.d_out + o_ops, S.d_cmp, false, P.d_cell, (uint64_t*)(S.d_out + o_tot), S.d_scan, false, s_k);
         if (rc == BG_OK && (hipEventRecord(S.k_done, s_k) != hipSuccess || hipStreamWaitEvent(P.s_out, S.k_done, 0) != hipSuccess ||
-                            hipMemcpyAsync(S.h_out, S.d_out, o_tot + 8, hipMemcpyDeviceToHost, P.s_out) != hipSuccess ||
+                            bg_copy_pieces(S.h_out, S.d_out, o_tot + 8, hipMemcpyDeviceToHost, P.s_out) != hipSuccess ||
                             hipEventRecord(S.out_done, P.s_out) != hipSuccess))
             rc = BG_ERR_HIP;
         if (rc) {
