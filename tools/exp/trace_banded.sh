@@ -1,7 +1,7 @@
 #!/bin/bash
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d /tmp/trb -o x -- python $R/tools/exp/time_banded.py $R/rust-bio_amd/libbiogpu.so 32768 > /tmp/trb.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d /tmp/trb -o x -- python $R/tools/exp/time_banded.py $R/rust-bio_amd/libbiogpu.so ${1:-49152} > /tmp/trb.log 2>&1
 tail -1 /tmp/trb.log
 python - <<'PY'
 import csv, glob
