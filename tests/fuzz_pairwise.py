@@ -1,6 +1,7 @@
 """Long differential fuzz (run by hand on a GPU box: python tests/fuzz_pairwise.py SEED SECONDS): full-matrix
 engine (K1 + K2) vs the CPU oracle over random modes, clips, match tables, alphabets and ragged lengths.
-Round 1: 568 473 pairs in 4079 configurations, 0 mismatches."""
+Round 1: 568 473 pairs in 4079 configurations, 0 mismatches; round 3 (seed 22, 40 s, final kernels): 295 558 pairs in 2137
+configurations, 0 mismatches."""
 import sys, time
 import numpy as np
 import os
