@@ -78,6 +78,7 @@ const char* bg_last_error(void); /* text of the last HIP failure on this thread 
  *   force_wide = 1     scores kept as plain int32 even where they fit the 24-bit keys of the fast kernels
  *   no_pk16 = 1        no packed-int16 fill (K1p): the int32 kernel K1 runs for every batch
  *   no_couples = 1     K1p without the (m, n) slot order on ragged batches
+ *   no_local_fast = 1  Aligner::local batches on the general K1p instead of its LF flavour (tests, A/B)
  *   band_on_host = 1   bands built by the host threads instead of the device builder
  *   band_fill_v1       1: banded fill with one pair per wavefront (K3) always; -1: eight pairs per wavefront (K3v2)
  *                      always; 0 (default): K3 for sub-batches of at most 2048 pairs (latency), K3v2 above (throughput)

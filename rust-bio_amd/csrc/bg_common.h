@@ -60,6 +60,7 @@ struct bg_ctx {
     int64_t seed_chunk_reads = 0;  // reads per pass of bg_seed_extend_batch_dev (0 = 2^20)
     bool force_wide = false;  // tests: disable the NARROW (28-bit key) kernels
     bool no_pk16 = false;     // tests: disable K1p (two pairs per lane in packed int16 halves)
+    bool no_local_fast = false;  // tests: Aligner::local on the general K1p (no LF flavour)
     bool no_couples = false;  // tests: K1p without the (m, n) slot order on ragged batches
     int band_chain_global = -1;  // chain_kernel tree placement: -1 by batch size, 0 LDS, 1 global scratch
     bool band_join_global = false;  // tests: k-mer join with its table in global memory even where the LDS flavour applies

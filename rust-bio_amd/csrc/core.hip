@@ -208,6 +208,10 @@ extern "C" int bg_set_option(bg_ctx* ctx, const char* key, int64_t value) {
         ctx->no_couples = value != 0;
         return BG_OK;
     }
+    if (!strcmp(key, "no_local_fast")) {
+        ctx->no_local_fast = value != 0;
+        return BG_OK;
+    }
     if (!strcmp(key, "no_pk16")) {
         ctx->no_pk16 = value != 0;
         return BG_OK;

@@ -20,6 +20,7 @@ sw_fill_fn get_fill_params_narrow(int lp, int r, bool local);
 sw_fill_fn get_fill_params_wide(int lp, int r, bool local);
 sw_fill_fn get_fill_matrix(int lp, int r, int sm, bool narrow, bool local);
 sw_fill_fn get_fill_pk16_local(int lp, int r, int which);
+sw_fill_fn get_fill_pk16_localfast(int lp, int r, int which);
 sw_fill_fn get_fill_pk16_semiglobal(int lp, int r, int which);
 sw_fill_fn get_fill_pk16_global(int lp, int r, int which);
 sw_fill_fn get_fill_pk16_custom(int lp, int r, int which);
@@ -305,7 +306,10 @@ static int align_batch_dev_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, u
     if (pk16) {
         const SwScoring& c = a.sc;
         const int32_t M = BG_MIN_SCORE;
-        auto getter = all_zero_clips ? get_fill_pk16_local
+        // local alignments whose gaps and mismatches cost something take the LF flavour (sw_fill_pk16.inc)
+        const bool local_fast = all_zero_clips && c.go < 0 && c.mismatch < 0 && !ctx->no_local_fast;
+        auto getter = local_fast ? get_fill_pk16_localfast
+                      : all_zero_clips ? get_fill_pk16_local
                       : (c.xp == M && c.xs == M && c.yp == 0 && c.ys == 0) ? get_fill_pk16_semiglobal
                       : (c.xp == M && c.xs == M && c.yp == M && c.ys == M) ? get_fill_pk16_global
                                                                            : get_fill_pk16_custom;
@@ -323,7 +327,7 @@ static int align_batch_dev_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, u
             fill = getter(cfg.lp, cfg.r, 0);
             fill_rest = getter(cfg.lp, cfg.r, 1);
             fill_second = getter(cfg.lp, cfg.r, 2);
-            a.g.tb_fmt = 1;
+            a.g.tb_fmt = local_fast ? 2 : 1;
         }
     }
     if (!fill) return BG_ERR_UNSUPPORTED;

@@ -61,7 +61,7 @@ struct SwScoring {
 //   Ly[m_cap+1]  Lx[n_cap+1]  colBits[m_cap+1 bytes]: (S nibble | I nibble << 4) of column n
 struct SwGeom {
     uint32_t lp, r, nsteps, nstrips, m_cap, n_cap, aux_stride;
-    uint32_t tb_fmt;  // 0: six 5-bit cells per word (K1); 1: three per 16-bit half (K1p, sw_fill_pk16.inc)
+    uint32_t tb_fmt;  // 0: six 5-bit cells per word (K1); 1: three per 16-bit half (K1p, sw_fill_pk16.inc); 2: as 1, move code 0 == C_XP (K1p LF)
     uint32_t r_inv;     // ceil(2^32 / r): (row * r_inv) >> 32 == row / r for row < 2^24 (K2 divides per traceback step)
     uint32_t lp_shift;  // log2(lp)
     __host__ __device__ uint32_t off_Ly() const { return 4; }

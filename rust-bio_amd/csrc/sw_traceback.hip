@@ -67,8 +67,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
         const uint32_t c = rr % 6;
         if (!geo.tb_fmt) return (w >> (5 * c)) & 31u;
         // tb_fmt 1 (K1p): three cells per 16-bit half, each I extends | move << 1 | D extends << 4
+        // tb_fmt 2 (K1p, LF flavour): the same, and move code 0 stands for C_XP (the floor of a local alignment)
         const uint32_t v = (w >> (5 * (c % 3) + 16 * (c / 3))) & 31u;
-        return ((v >> 1) & 7u) | ((v & 1u) << 3) | (v & 16u);
+        const uint32_t mv = (v >> 1) & 7u;
+        return ((geo.tb_fmt == 2 && mv == 0) ? (uint32_t)C_XP : mv) | ((v & 1u) << 3) | (v & 16u);
     };
     // S nibble of cell (i,j), j < n (or the fill-time value for j == n, never requested)
     auto s_fill = [&](uint32_t i, uint32_t j) -> uint32_t {
@@ -182,6 +184,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
                 break;
             case TB_XCLIP_SUFFIX: {
                 // K1p (tb_fmt 1) publishes Lx[j] <= m packed: bytes with 16 lanes per pair (m <= 192), else 16 bits
+                if (geo.tb_fmt == 2 && j != n) {  // the LF fill publishes no Lx[j < n]: no local path asks for it
+                    status = BG_ERR_TRACEBACK;
+                    layer = TB_START;
+                    continue;
+                }
                 const uint32_t lx = (j == n) ? lxn
                                     : !geo.tb_fmt ? (uint32_t)gLx[j]
                                     : geo.lp == 16 ? (uint32_t)((const uint8_t*)gLx)[j] : (uint32_t)((const uint16_t*)gLx)[j];

@@ -101,6 +101,69 @@ def test_custom_clip_fuzz():
         differential(kw, "custom", xs, ys)
 
 
+def _tie_rich_pairs(rng, n_pairs, m, n, nalpha, stragglers):
+    alpha = np.frombuffer(b"ACGT", dtype=np.uint8)[:nalpha]
+    xs, ys = [], []
+    for p in range(n_pairs):
+        mm, nn = m, n
+        if stragglers and rng.random() < 0.15:
+            mm = int(rng.integers(0, m + 1))
+        if stragglers and rng.random() < 0.15:
+            nn = int(rng.integers(0, n + 5))
+        y = alpha[rng.integers(0, nalpha, size=nn)]
+        if rng.random() < 0.6 and nn > 3 and mm > 0:  # a mutated copy: the alignment has a clear diagonal, and repeats
+            x = np.resize(y, mm + 6)[int(rng.integers(0, 4)):][:mm].copy()
+            k = int(rng.integers(0, max(1, mm // 5)))
+            x[rng.integers(0, len(x), size=k)] = alpha[rng.integers(0, nalpha, size=k)]
+            x = np.resize(x, mm)
+        else:
+            x = alpha[rng.integers(0, nalpha, size=mm)]
+        xs.append(x.astype(np.uint8).tobytes())
+        ys.append(y.astype(np.uint8).tobytes())
+    return xs, ys
+
+
+@pytest.mark.parametrize("mode", ["local", "custom"])
+def test_local_fast_flavour_of_k1p(mode):
+    """K1p's LF flavour (sw_fill_pk16.inc: no x-suffix-clip fold before column n, the floor 0 by saturation) takes every
+    all-zero-clip batch whose gap_open and mismatch are negative: tie-rich inputs (one- and two-letter alphabets, match
+    score 0, gap_extend 0), equal lengths (the fast launch) and stragglers (the rest / second launches), against the
+    oracle — and the scorings just outside its condition, which stay on the general kernel."""
+    rng = np.random.default_rng(77)
+    clips = dict(xclip_prefix=0, xclip_suffix=0, yclip_prefix=0, yclip_suffix=0)
+    n = 0
+    for trial in range(36):
+        m = int(rng.choice([150, 100, 36, 61, 120, 7, 250]))
+        nn = int(rng.choice([m, m + int(rng.integers(0, 20)), max(1, m - int(rng.integers(0, 20))), int(rng.integers(1, 200))]))
+        kw = dict(gap_open=-int(rng.integers(1, 6)), gap_extend=-int(rng.integers(0, 3)),
+                  match=int(rng.integers(0, 4)), mismatch=-int(rng.integers(1, 5)), **clips)
+        if trial % 9 == 7:
+            kw["gap_open"] = 0  # not LF
+        if trial % 9 == 8:
+            kw["mismatch"] = 0  # not LF
+        xs, ys = _tie_rich_pairs(rng, int(rng.integers(1, 90)), m, nn, int(rng.integers(1, 5)), trial % 2 == 1)
+        n += differential(kw, mode, xs, ys)
+    assert n > 1000
+
+
+def test_local_fast_flavour_equals_the_general_kernel():
+    rng = np.random.default_rng(78)
+    kw = dict(gap_open=-3, gap_extend=-1, match=1, mismatch=-2, xclip_prefix=0, xclip_suffix=0, yclip_prefix=0, yclip_suffix=0)
+    xs, ys = _tie_rich_pairs(rng, 700, 150, 150, 4, True)
+    x, xo = _lib.concat(xs)
+    y, yo = _lib.concat(ys)
+    res = []
+    for off in (0, 1):
+        al = Aligner.with_scoring(engine_scoring(kw))
+        al.ctx.set_option("no_local_fast", off)
+        out, ops = al.align_arrays(MODES["local"], x, xo, y, yo)
+        al.ctx.set_option("no_local_fast", 0)
+        res.append((out, [decode_ops(out[p], ops) for p in range(len(xs))]))
+    for f in ("score", "xstart", "xend", "ystart", "yend", "n_ops", "status"):
+        assert (res[0][0][f] == res[1][0][f]).all(), f
+    assert res[0][1] == res[1][1]
+
+
 def test_rows_per_lane_configs_and_wave_packing():
     # lengths chosen to hit every (LP, R) instantiation and partial waves
     for max_len, n_pairs in [(20, 33), (60, 17), (90, 9), (120, 13), (150, 70), (190, 5),
