@@ -372,7 +372,8 @@ def main():
         t_h = median_time(lambda: aligner.align_arrays(3, hxa, hoa, hya, hoa, out=hout, ops=hopsb))
         host_api = {"value": round(n_pairs * L * L / t_h / 1e9, 2), "unit": "GCUPS", "pairs": n_pairs,
                     "note": "bg_align_batch with pageable host buffers in and out (PCIe-inclusive), median of 3: stages of "
-                            "131072 pairs through three pinned staging sets, upload / kernels / download / compaction overlapped"}
+                            "122880 pairs through three pinned staging sets; uploads by copy commands, records and device-compacted "
+                            "operations brought back by a small kernel on a high-priority stream, all overlapped with the next stages' kernels"}
         del hout, hopsb, hxa, hya
 
     result = {"metric": "GCUPS (SW) + FM-index queries/sec", "value": round(gcups, 3), "unit": "GCUPS",

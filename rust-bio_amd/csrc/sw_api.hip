@@ -494,10 +494,10 @@ struct bg_host_pipe {
         uint8_t *d_in = nullptr, *d_out = nullptr;  // d_out: records | stage total | strided ops
         uint8_t *d_cmp = nullptr, *d_scan = nullptr;  // compact ops of the stage; n_ops counts, their offsets, scan partials
         size_t in_cap = 0, out_cap = 0, cmp_cap = 0, scan_cap = 0;
-        hipEvent_t in_done = nullptr, k_done = nullptr, out_done = nullptr, ops_done = nullptr;
+        hipEvent_t in_done = nullptr, k_done = nullptr, out_done = nullptr;
     } set[NSET];
     uint64_t* d_cell = nullptr;  // running total of operation bytes over the stages of a call
-    hipStream_t s_in = nullptr, s_out = nullptr, s_ops = nullptr;  // uploads; record downloads; operation downloads (issued by the drainer)
+    hipStream_t s_in = nullptr, s_out = nullptr;  // uploads; downloads (stage_to_host_kernel)
 };
 void bg_host_pipe_free(bg_host_pipe* p) {
     if (!p) return;
@@ -508,16 +508,36 @@ void bg_host_pipe_free(bg_host_pipe* p) {
         hipFree(s.d_out);
         hipFree(s.d_cmp);
         hipFree(s.d_scan);
-        for (hipEvent_t e : {s.in_done, s.k_done, s.out_done, s.ops_done})
+        for (hipEvent_t e : {s.in_done, s.k_done, s.out_done})
             if (e) hipEventDestroy(e);
     }
     hipFree(p->d_cell);
     if (p->s_in) hipStreamDestroy(p->s_in);
     if (p->s_out) hipStreamDestroy(p->s_out);
-    if (p->s_ops) hipStreamDestroy(p->s_ops);
     delete p;
 }
 namespace {
+// A stage's results go to the pinned host buffers by a kernel: records (size known) and the compact operations, whose
+// size only the device knows when the copy is enqueued — as copy commands the two had to be issued one after the other
+// by the host, the second once the first had arrived (1.2 ms per stage, more than the stage's kernels take).
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+template <bool NT>
+__global__ __launch_bounds__(256) void stage_to_host_kernel(const u32x4* __restrict__ rec, u32x4* __restrict__ h_rec, uint64_t rec_n16,
+                                                            const u32x4* __restrict__ ops, u32x4* __restrict__ h_ops,
+                                                            const uint64_t* __restrict__ d_total, uint64_t* __restrict__ h_total) {
+    const uint64_t tid = (uint64_t)blockIdx.x * 256 + threadIdx.x, nth = (uint64_t)gridDim.x * 256;
+    for (uint64_t i = tid; i < rec_n16; i += nth) {
+        if (NT) __builtin_nontemporal_store(rec[i], &h_rec[i]);
+        else h_rec[i] = rec[i];
+    }
+    const uint64_t T = d_total ? *d_total : 0, n16 = (T + 15) / 16;
+    for (uint64_t i = tid; i < n16; i += nth) {
+        if (NT) __builtin_nontemporal_store(ops[i], &h_ops[i]);
+        else h_ops[i] = ops[i];
+    }
+    if (tid == 0) *h_total = T;
+}
+
 template <typename F>
 void parallel_for(uint64_t n, uint64_t grain, F&& f) {  // f(begin, end) on the host threads this process may use
     const unsigned nt = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(bg_host_threads(), n / std::max<uint64_t>(grain, 1) + 1));
@@ -537,19 +557,26 @@ int align_batch_pipelined(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint64_
     if (!ctx->pipe) {
         ctx->pipe = new bg_host_pipe();
         BG_HIP(hipStreamCreateWithFlags(&ctx->pipe->s_in, hipStreamNonBlocking));
-        BG_HIP(hipStreamCreateWithFlags(&ctx->pipe->s_out, hipStreamNonBlocking));
-        BG_HIP(hipStreamCreateWithFlags(&ctx->pipe->s_ops, hipStreamNonBlocking));
+        {  // the download kernel of a finished stage goes ahead of the blocks of the next stage's fill
+            int lo = 0, hi = 0;
+            BG_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+            BG_HIP(hipStreamCreateWithPriority(&ctx->pipe->s_out, hipStreamNonBlocking, hi));
+        }
         BG_HIP(hipMalloc((void**)&ctx->pipe->d_cell, 64));
         for (auto& s : ctx->pipe->set)
-            for (hipEvent_t* e : {&s.in_done, &s.k_done, &s.out_done, &s.ops_done}) BG_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+            for (hipEvent_t* e : {&s.in_done, &s.k_done, &s.out_done}) BG_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
     }
     bg_host_pipe& P = *ctx->pipe;
     const uint64_t stride = ops_buf ? (uint64_t)max_x + max_y + 4 : 0;
-    const uint64_t nch = (n_pairs + chunk - 1) / chunk;
+    // stage c covers pairs [cut[c], cut[c + 1]).  (Shorter first stages — kernels starting 1 ms earlier — were measured: no
+    // gain, the device side of the stages is what the call waits for.)
+    std::vector<uint64_t> cut{0};
+    while (cut.back() < n_pairs) cut.push_back(std::min(n_pairs, cut.back() + chunk));
+    const uint64_t nch = cut.size() - 1;
     // capacity of a staging set: the largest stage
     uint64_t max_xb = 0, max_yb = 0;
     for (uint64_t c = 0; c < nch; c++) {
-        const uint64_t p0 = c * chunk, p1 = std::min(n_pairs, p0 + chunk);
+        const uint64_t p0 = cut[c], p1 = cut[c + 1];
         max_xb = std::max(max_xb, x_off[p1] - x_off[p0]);
         max_yb = std::max(max_yb, y_off[p1] - y_off[p0]);
     }
@@ -600,7 +627,7 @@ int align_batch_pipelined(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint64_
     int status = BG_OK;
     // BG_TRACE_HOST=1: where the host side of the stages spends its time (ms, summed over the call)
     const bool trace = getenv("BG_TRACE_HOST") != nullptr;
-    double t_pack = 0, t_launch = 0, t_wait_set = 0, t_d_wait_rec = 0, t_d_rec = 0, t_d_wait_ops = 0, t_d_ops = 0;
+    double t_pack = 0, t_launch = 0, t_wait_set = 0, t_d_wait_rec = 0, t_d_rec = 0, t_d_ops = 0;
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     // finish stage c: records (their ops_off already final) and the stage's compact operations into the caller's buffers —
     // two contiguous blocks; the operations are fetched with their exact size once the records (and the count) are here
@@ -609,13 +636,9 @@ int align_batch_pipelined(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint64_
         double t0 = now();
         BG_HIP(hipEventSynchronize(S.out_done));
         t_d_wait_rec += now() - t0;
-        const uint64_t p0 = c * chunk, np = std::min(n_pairs, p0 + chunk) - p0;
+        const uint64_t p0 = cut[c], np = cut[c + 1] - p0;
         const bg_alignment_t* h_rec = (const bg_alignment_t*)S.h_out;
         const uint64_t T = stride ? *(const uint64_t*)(S.h_out + o_tot) : 0;
-        if (T) {
-            BG_HIP(bg_copy_pieces(S.h_out + o_ops, S.d_cmp, T, hipMemcpyDeviceToHost, P.s_ops));  // not behind the next stages' records
-            BG_HIP(hipEventRecord(S.ops_done, P.s_ops));
-        }
         std::atomic<int> st_rec{BG_OK};
         t0 = now();
         parallel_for(np, 16384, [&](uint64_t a, uint64_t b) {
@@ -628,9 +651,6 @@ int align_batch_pipelined(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint64_
         if (st_rec) status = st_rec;
         t_d_rec += now() - t0;
         if (T) {
-            t0 = now();
-            BG_HIP(hipEventSynchronize(S.ops_done));
-            t_d_wait_ops += now() - t0;
             t0 = now();
             uint64_t fit = T;
             if (used + T > ops_cap) {  // the caller's buffer ends inside this stage: whole pairs only, as the serial path does
@@ -702,7 +722,7 @@ int align_batch_pipelined(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint64_
         t_wait_set += now() - t0;
         t0 = now();
         bg_host_pipe::Set& S = P.set[c % bg_host_pipe::NSET];
-        const uint64_t p0 = c * chunk, np = std::min(n_pairs, p0 + chunk) - p0;
+        const uint64_t p0 = cut[c], np = cut[c + 1] - p0;
         const uint64_t xb = x_off[p0 + np] - x_off[p0], yb = y_off[p0 + np] - y_off[p0];
         parallel_memcpy(S.h_in, x + x_off[p0], xb);
         parallel_memcpy(S.h_in + o_y, y + y_off[p0], yb);
@@ -731,10 +751,16 @@ int align_batch_pipelined(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint64_
                                   max_x, max_y, d_rec, stride ? S.d_out + o_ops : nullptr, stride, s_k, uniform ? 1 : 0);
         if (rc == BG_OK && stride)  // compact the stage's operations on the device, final ops_off into the records
             rc = bg_compact_ops_dev(d_rec, np, S.d_out + o_ops, S.d_cmp, false, P.d_cell, (uint64_t*)(S.d_out + o_tot), S.d_scan, false, s_k);
-        if (rc == BG_OK && (hipEventRecord(S.k_done, s_k) != hipSuccess || hipStreamWaitEvent(P.s_out, S.k_done, 0) != hipSuccess ||
-                            bg_copy_pieces(S.h_out, S.d_out, o_tot + 8, hipMemcpyDeviceToHost, P.s_out) != hipSuccess ||
-                            hipEventRecord(S.out_done, P.s_out) != hipSuccess))
+        if (rc == BG_OK && (hipEventRecord(S.k_done, s_k) != hipSuccess || hipStreamWaitEvent(P.s_out, S.k_done, 0) != hipSuccess))
             rc = BG_ERR_HIP;
+        if (rc == BG_OK) {
+            static const int d2h_blocks = getenv("BG_D2H_BLOCKS") ? std::max(1, atoi(getenv("BG_D2H_BLOCKS"))) : 8;
+            static const bool d2h_nt = !(getenv("BG_D2H_NT") && atoi(getenv("BG_D2H_NT")) == 0);
+            (d2h_nt ? stage_to_host_kernel<true> : stage_to_host_kernel<false>)<<<dim3(d2h_blocks), dim3(256), 0, P.s_out>>>((const u32x4*)S.d_out, (u32x4*)S.h_out, np * sizeof(bg_alignment_t) / 16,
+                                                                     (const u32x4*)S.d_cmp, (u32x4*)(S.h_out + o_ops),
+                                                                     stride ? (const uint64_t*)(S.d_out + o_tot) : nullptr, (uint64_t*)(S.h_out + o_tot));
+            if (hipGetLastError() != hipSuccess || hipEventRecord(S.out_done, P.s_out) != hipSuccess) rc = BG_ERR_HIP;
+        }
         if (rc) {
             hipDeviceSynchronize();
             stop_drainer();
@@ -750,8 +776,8 @@ int align_batch_pipelined(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint64_
     double t0j = now();
     drainer.join();
     if (trace)
-        fprintf(stderr, "[bg host] %llu stages: pack %.2f launch %.2f wait-for-set %.2f join %.2f | drainer: wait-records %.2f copy-records %.2f wait-ops %.2f copy-ops %.2f ms\n",
-                (unsigned long long)nch, t_pack, t_launch, t_wait_set, now() - t0j, t_d_wait_rec, t_d_rec, t_d_wait_ops, t_d_ops);
+        fprintf(stderr, "[bg host] %llu stages: pack %.2f launch %.2f wait-for-set %.2f join %.2f | drainer: wait-stage %.2f copy-records %.2f copy-ops %.2f ms\n",
+                (unsigned long long)nch, t_pack, t_launch, t_wait_set, now() - t0j, t_d_wait_rec, t_d_rec, t_d_ops);
     if (drain_rc) {
         bg_tls_error = drain_err;
         return drain_rc;
@@ -774,17 +800,32 @@ extern "C" int bg_align_batch(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uin
     BG_HIP(hipSetDevice(ctx->device));
     uint64_t max_x = 0, max_y = 0, max_sum = 0;
     bool uniform_len = true;
-    for (uint64_t p = 0; p < n_pairs; p++) {
-        if (x_off[p + 1] < x_off[p] || y_off[p + 1] < y_off[p]) return BG_ERR_INVALID_ARG;
-        const uint64_t lx = x_off[p + 1] - x_off[p], ly = y_off[p + 1] - y_off[p];
-        max_x = std::max(max_x, lx);
-        max_y = std::max(max_y, ly);
-        max_sum = std::max(max_sum, lx + ly);
-        uniform_len = uniform_len && lx == x_off[1] - x_off[0] && ly == y_off[1] - y_off[0];
+    {
+        std::mutex mu;
+        bool bad = false;
+        parallel_for(n_pairs, 1 << 16, [&](uint64_t a, uint64_t b) {
+            uint64_t mx = 0, my = 0, ms = 0;
+            bool uni = true, neg = false;
+            for (uint64_t p = a; p < b; p++) {
+                neg = neg || x_off[p + 1] < x_off[p] || y_off[p + 1] < y_off[p];
+                const uint64_t lx = x_off[p + 1] - x_off[p], ly = y_off[p + 1] - y_off[p];
+                mx = std::max(mx, lx);
+                my = std::max(my, ly);
+                ms = std::max(ms, lx + ly);
+                uni = uni && lx == x_off[1] - x_off[0] && ly == y_off[1] - y_off[0];
+            }
+            std::lock_guard<std::mutex> lk(mu);
+            max_x = std::max(max_x, mx);
+            max_y = std::max(max_y, my);
+            max_sum = std::max(max_sum, ms);
+            uniform_len = uniform_len && uni;
+            bad = bad || neg;
+        });
+        if (bad) return BG_ERR_INVALID_ARG;
     }
     if (max_x > (1u << 24) || max_y > (1u << 24)) return BG_ERR_TOO_LARGE;
     {  // large batches flow through the staged pipeline
-        const uint64_t chunk = ctx->host_chunk_pairs > 0 ? (uint64_t)ctx->host_chunk_pairs : 131072;
+        const uint64_t chunk = ctx->host_chunk_pairs > 0 ? (uint64_t)ctx->host_chunk_pairs : 122880;  // five rounds of K1p blocks over the 256 CUs
         if (n_pairs >= 2 * chunk && !sc->matrix)
             return align_batch_pipelined(ctx, sc, mode, n_pairs, x, x_off, y, y_off, (uint32_t)max_x, (uint32_t)max_y, chunk, out, ops_buf, ops_cap,
                                          ops_used);
