@@ -63,14 +63,20 @@ class Aligner:
                                                    cells.ctypes.data), "bg_band_create_batch")
         return boff, start, end, cells
 
-    def align_arrays(self, mode, x, x_off, y, y_off, want_ops=True):
+    def align_arrays(self, mode, x, x_off, y, y_off, want_ops=True, out=None, ops=None):
+        """Host-buffer batch through bg_align_banded_batch.  Returns (records, ops_buf); `out` / `ops` may be the arrays of an
+        earlier call of the same shape (reused, like a caller's own Vecs — fresh ones cost a page fault per 4 KB written)."""
         xb, yb = _lib.as_u8(x), _lib.as_u8(y)
         xo = np.ascontiguousarray(x_off, dtype=np.uint64)
         yo = np.ascontiguousarray(y_off, dtype=np.uint64)
         n = len(xo) - 1
-        out = np.zeros(n, dtype=_lib.ALN_DTYPE)
+        if out is None or len(out) != n:
+            out = np.zeros(n, dtype=_lib.ALN_DTYPE)
         cap = int(xo[-1] + yo[-1]) + 4 * n + 8 if want_ops else 0
-        ops = np.zeros(max(cap, 1), dtype=np.uint8) if want_ops else None
+        if want_ops and (ops is None or len(ops) != max(cap, 1)):
+            ops = np.zeros(max(cap, 1), dtype=np.uint8)
+        if not want_ops:
+            ops = None
         used = C.c_uint64(0)
         cells = np.zeros(n, dtype=np.uint64)
         sc = self.scoring.to_c()

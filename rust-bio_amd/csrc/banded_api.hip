@@ -169,6 +169,9 @@ struct bg_band_scratch {
     void *d_cmp = nullptr, *d_cscan = nullptr;  // host-buffer flavour: the operations compacted on the device, scan scratch
     size_t d_cmp_cap = 0, d_cscan_cap = 0;
     uint64_t* d_cell = nullptr;                 // ... and their running byte count over the sub-batches of a call
+    uint64_t* d_dlslot = nullptr;               // per sub-batch {bytes, end offset} of its compacted operations (ring of kDlSlots)
+    hipStream_t dl_stream = nullptr;            // ... which a few blocks on this high-priority stream bring to h_ops meanwhile
+    static constexpr uint64_t kDlSlots = 1024;
     hipStream_t tb_stream = nullptr;
     hipStream_t copy_stream = nullptr;  // host-buffer flavour: sequence slices go up here
     uint32_t* d_started = nullptr;  // blocks of the K3v2 launches of the current call that have started (see banded_fill2.hip)
@@ -193,6 +196,8 @@ void bg_band_scratch_free(bg_band_scratch* b) {
     hipFree(b->d_cmp);
     hipFree(b->d_cscan);
     hipFree(b->d_cell);
+    hipFree(b->d_dlslot);
+    if (b->dl_stream) hipStreamDestroy(b->dl_stream);
     for (void* p : b->db) hipFree(p);
     hipHostFree(b->h_state);
     hipHostFree(b->h_ops);
@@ -388,6 +393,15 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
             return rc;
         if (!B.d_cell) BG_HIP(hipMalloc((void**)&B.d_cell, 64));
         BG_HIP(hipMemsetAsync(B.d_cell, 0, 8, st));  // st_tb waits for st's events before every traceback
+        // the operations of a sub-batch leave for the pinned buffer as soon as they are compacted, while the next ones are
+        // computed (one download of everything after the last sub-batch was 20 ms of a 490 ms call, with the device idle)
+        if ((rc = pinned_reserve(&B.h_ops, &B.h_ops_cap, xb + yb + 4 * n_pairs + 256))) return rc;
+        if (!B.d_dlslot) BG_HIP(hipMalloc((void**)&B.d_dlslot, bg_band_scratch::kDlSlots * 16));
+        if (!B.dl_stream) {
+            int lo = 0, hi = 0;
+            BG_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+            BG_HIP(hipStreamCreateWithPriority(&B.dl_stream, hipStreamNonBlocking, hi));
+        }
     }
 
     // sub-batch size: enough wavefronts to fill the chip, small enough that a large batch pipelines
@@ -749,10 +763,18 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
         }
         // host-buffer flavour: this sub-batch's operations go, compacted, behind those of the sub-batches before it
         // (running byte count in B.d_cell) while the next fill runs; its records get their final ops_off
-        if (compact_on_device &&
-            (rc = bg_compact_ops_dev(d_out + p0, take, d_ops, (uint8_t*)B.d_cmp, true, B.d_cell, nullptr, B.d_cscan, true, st_tb)))
-            return rc;
+        uint64_t* dl = nullptr;
+        if (compact_on_device) {
+            if (n_chunk && n_chunk % bg_band_scratch::kDlSlots == 0) BG_HIP(hipStreamSynchronize(B.dl_stream));  // the ring comes round
+            dl = B.d_dlslot + 2 * (n_chunk % bg_band_scratch::kDlSlots);
+            if ((rc = bg_compact_ops_dev(d_out + p0, take, d_ops, (uint8_t*)B.d_cmp, true, B.d_cell, dl, B.d_cscan, true, st_tb))) return rc;
+            BG_HIP(hipMemcpyAsync(dl + 1, B.d_cell, 8, hipMemcpyDeviceToDevice, st_tb));
+        }
         BG_HIP(hipEventRecord(S.traced, st_tb));
+        if (dl) {
+            BG_HIP(hipStreamWaitEvent(B.dl_stream, S.traced, 0));
+            if ((rc = bg_range_to_host((const uint8_t*)B.d_cmp, (uint8_t*)B.h_ops, dl, B.dl_stream))) return rc;
+        }
         S.busy = true;
         lap("enqueue");
         *take_out = take;
@@ -762,12 +784,17 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
     {
         uint64_t p0 = 0, n_chunk = 0;
         if ((rc = issue(0, 0))) return rc;
-        if ((rc = upload_slices(n_slices))) return rc;  // the other slices travel while the first sub-batch is built and filled
+        // The caller's buffers are pageable: an upload keeps this thread inside the copy call for its whole duration
+        // (~30 ms per slice), and the device idle if the next launches wait behind it.  So slice c + 2 goes up right
+        // after the fill of sub-batch c has been launched (44 ms of kernels to hide behind), one slice per round — not
+        // all of them after the first issue (measured: the first round took 90 ms instead of 58).
+        if ((rc = upload_slices(2))) return rc;
         for (;;) {
             uint64_t take = 0;
             if ((rc = finish(n_chunk, &take))) return rc;
             p0 += take;
             if (p0 >= n_pairs) break;
+            if ((rc = upload_slices(n_chunk + 3))) return rc;
             n_chunk++;
             if ((rc = issue(p0, n_chunk))) return rc;
         }
@@ -786,10 +813,7 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
     BG_HIP(hipStreamSynchronize(st_tb));
     BG_HIP(hipStreamSynchronize(st));
     for (auto& s : B.set) s.busy = false;
-    if (compact_on_device && used) {
-        if ((rc = pinned_reserve(&B.h_ops, &B.h_ops_cap, used))) return rc;
-        BG_HIP(bg_copy_pieces(B.h_ops, B.d_cmp, used, hipMemcpyDeviceToHost, st_tb));
-    }
+    // (the operations are in B.h_ops once the download stream has drained: synchronised below)
     int status = BG_OK;
     bool cap_hit = false;
     uint64_t fit = used;  // bytes of whole pairs that fit the caller's buffer
@@ -805,7 +829,7 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
     }
     if (cap_hit && status == BG_OK) status = BG_ERR_OPS_CAP;
     if (compact_on_device && used) {
-        BG_HIP(hipStreamSynchronize(st_tb));
+        BG_HIP(hipStreamSynchronize(B.dl_stream));
         lap("drain + d2h");
         const uint8_t* h_ops = (const uint8_t*)B.h_ops;
         const uint64_t nb = std::min(fit, ops_cap);

@@ -95,6 +95,7 @@ int bg_align_batch_dev_hint(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint6
 // *d_batch_total (if given) receives that count.  d_scratch: bg_compact_ops_scratch(n) bytes; long_ops: operation lists
 // of thousands of bytes (a wavefront per pair copies) rather than a few hundred (16 lanes).  Asynchronous on st.
 size_t bg_compact_ops_scratch(uint64_t n);
+int bg_range_to_host(const uint8_t* d_src, uint8_t* h_dst, const uint64_t* d_slot /* {bytes, end offset} */, hipStream_t st);
 int bg_compact_ops_dev(bg_alignment_t* d_rec, uint64_t n, const uint8_t* d_ops, uint8_t* d_compact, bool global_offsets, uint64_t* d_cell,
                        uint64_t* d_batch_total, void* d_scratch, bool long_ops, hipStream_t st);
 

@@ -266,6 +266,26 @@ __global__ void ops_advance_kernel(uint64_t* cell, const uint64_t* __restrict__ 
 inline size_t a256(size_t v) { return (v + 255) & ~(size_t)255; }
 }  // namespace
 
+// bytes [slot[1] - slot[0], slot[1]) of d_src to the same offsets of a pinned host buffer, by a few blocks on the caller's
+// (high-priority) stream: a download whose extent only the device knows when it is enqueued (sw_api.hip's stage results
+// are fetched the same way).  Whole 16-byte units around the range travel: the bytes around it belong to the neighbouring
+// ranges, whose own downloads — earlier or later on the same stream — bring their final values.
+typedef uint32_t bg_u32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void range_to_host_kernel(const uint8_t* __restrict__ d_src, uint8_t* __restrict__ h_dst,
+                                                            const uint64_t* __restrict__ slot) {
+    const uint64_t end = slot[1], start = end - slot[0];
+    const uint64_t a = start >> 4, b = (end + 15) >> 4;
+    const bg_u32x4* src = (const bg_u32x4*)d_src;
+    bg_u32x4* dst = (bg_u32x4*)h_dst;
+    for (uint64_t i = a + (uint64_t)blockIdx.x * 256 + threadIdx.x; i < b; i += (uint64_t)gridDim.x * 256)
+        __builtin_nontemporal_store(src[i], &dst[i]);
+}
+int bg_range_to_host(const uint8_t* d_src, uint8_t* h_dst, const uint64_t* d_slot, hipStream_t st) {
+    range_to_host_kernel<<<dim3(8), dim3(256), 0, st>>>(d_src, h_dst, d_slot);
+    BG_HIP(hipGetLastError());
+    return BG_OK;
+}
+
 size_t bg_compact_ops_scratch(uint64_t n) { return a256(n * 4) + a256((n + 1) * 8) + 2 * (n / 2048 + 2) * 8 + 256; }
 
 int bg_compact_ops_dev(bg_alignment_t* d_rec, uint64_t n, const uint8_t* d_ops, uint8_t* d_compact, bool global_offsets, uint64_t* d_cell,

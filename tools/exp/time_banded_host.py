@@ -15,10 +15,10 @@ hx, hy = bx.cpu().numpy(), by.cpu().numpy()
 hoff = np.arange(Pb + 1, dtype=np.uint64) * np.uint64(Lb)
 del bx, by
 bal = BandedAligner.with_scoring(Scoring.from_scores(-5, -1, 1, -1), kb, wb, ctx=ctx)
-bal.align_arrays(2, hx, hoff, hy, hoff)
+o, q = bal.align_arrays(2, hx, hoff, hy, hoff)
 for rep in range(2):
     print("---- call", rep, file=sys.stderr, flush=True)
     t0 = time.perf_counter()
-    bal.align_arrays(2, hx, hoff, hy, hoff)
+    bal.align_arrays(2, hx, hoff, hy, hoff, out=o, ops=q)
     dt = time.perf_counter() - t0
     print("%.1f ms  %.0f pairs/s" % (dt * 1e3, Pb / dt), flush=True)
