@@ -325,7 +325,7 @@ static int align_batch_dev_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, u
         } else {
             cfg.r = r_pick;
             fill = getter(cfg.lp, cfg.r, 0);
-            fill_rest = getter(cfg.lp, cfg.r, 1);
+            fill_rest = local_fast ? nullptr : getter(cfg.lp, cfg.r, 1);  // LF: the first launch takes every wavefront
             fill_second = getter(cfg.lp, cfg.r, 2);
             a.g.tb_fmt = local_fast ? 2 : 1;
         }
@@ -422,11 +422,10 @@ static int align_batch_dev_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, u
         fill<<<dim3((nwaves + 3) / 4), dim3(256), 0, st>>>(a);
         BG_HIP(hipGetLastError());
         if (ctx->timing) BG_HIP(hipEventRecord(ctx->ev[1], st));
-        if (fill_rest) {  // what the fast launch skipped: wavefronts with other read lengths, then the second pairs of unequal couples
-            fill_rest<<<dim3((nwaves + 3) / 4), dim3(256), 0, st>>>(a);
-            fill_second<<<dim3((nwaves + 3) / 4), dim3(256), 0, st>>>(a);
-            BG_HIP(hipGetLastError());
-        }
+        // what the fast launch skipped: wavefronts with other read lengths, then the second pairs of unequal couples
+        if (fill_rest) fill_rest<<<dim3((nwaves + 3) / 4), dim3(256), 0, st>>>(a);
+        if (fill_second) fill_second<<<dim3((nwaves + 3) / 4), dim3(256), 0, st>>>(a);
+        BG_HIP(hipGetLastError());
         if (ctx->timing) {
             BG_HIP(hipEventSynchronize(ctx->ev[1]));
             float ms = 0;
