@@ -424,7 +424,7 @@ static int align_batch_dev_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, u
         if (ctx->timing) BG_HIP(hipEventRecord(ctx->ev[1], st));
         // what the fast launch skipped: wavefronts with other read lengths, then the second pairs of unequal couples
         if (fill_rest) fill_rest<<<dim3((nwaves + 3) / 4), dim3(256), 0, st>>>(a);
-        if (fill_second) fill_second<<<dim3((nwaves + 3) / 4), dim3(256), 0, st>>>(a);
+        if (fill_second && len_hint != 1) fill_second<<<dim3((nwaves + 3) / 4), dim3(256), 0, st>>>(a);  // (1: the caller knows the lengths agree)
         BG_HIP(hipGetLastError());
         if (ctx->timing) {
             BG_HIP(hipEventSynchronize(ctx->ev[1]));
