@@ -1,7 +1,9 @@
 """Long differential fuzz (run by hand on a GPU box: python tests/fuzz_pairwise.py SEED SECONDS): full-matrix
 engine (K1 + K2) vs the CPU oracle over random modes, clips, match tables, alphabets and ragged lengths.
 Round 1: 568 473 pairs in 4079 configurations, 0 mismatches; round 3 (seed 22, 40 s, final kernels): 295 558 pairs in 2137
-configurations, 0 mismatches."""
+configurations, 0 mismatches.
+Round 3, final kernels (K1p LF, host path with the download kernel): seeds 32, 52, 72: 305 071 + 214 681 + 651 675 pairs,
+0 mismatches."""
 import sys, time
 import numpy as np
 import os
