@@ -5,7 +5,7 @@ Round 2, final K1p (unpredicated steady-state steps) and K2 (common move sequenc
 907 813 + 862 813 pairs, 0 mismatches.  Round 3 (packed-stream loads in the same kernel body): seeds 5 and 21,
 1 234 724 pairs, 0 mismatches.
 Round 3, final K1p (the LF flavour of the local kernel: no fold during the fill, the floor by saturation; multiply-add
-cell packing in every flavour): seeds 31, 41, 51, 61, 73: 1 023 922 + 1 181 880 + 603 645 + 1 292 857 pairs (+ the runs
+cell packing in every flavour): seeds 31, 51, 61, 73: 1 023 922 + 1 181 880 + 603 645 + 1 292 857 pairs (+ the runs
 before the last refactoring), 0 mismatches."""
 import os
 import sys
