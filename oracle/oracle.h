@@ -57,6 +57,10 @@ int orc_align(const orc_scoring_t* sc, int mode, const uint8_t* x, uint64_t m, c
 /* Batch of independent pairs over `threads` host threads, one Aligner per thread (the
  * reference's &mut self API forces exactly that). ops for pair p are written at
  * ops + p*ops_stride. Used for differential tests and as the timed CPU baseline. */
+/* test hook (pairwise.cpp): custom() without the x-suffix-clip fold of the columns before n — what the engine's LF kernel
+ * leaves out; a traceback that asks for such an Lx[j] fails (-2) and is counted */
+void orc_test_lf_hook(int on);
+uint64_t orc_test_lf_lx_reads(void);
 int orc_align_batch(const orc_scoring_t* sc, int mode, uint64_t n_pairs, const uint8_t* x,
                     const uint64_t* x_off, const uint8_t* y, const uint64_t* y_off,
                     orc_alignment_t* out, uint64_t* ops, uint64_t ops_stride, int threads);

@@ -61,6 +61,10 @@ def lib():
         L.orc_align_batch.argtypes = [C.POINTER(Scoring), C.c_int, C.c_uint64, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_uint64, C.c_int]
+        L.orc_test_lf_hook.restype = None
+        L.orc_test_lf_hook.argtypes = [C.c_int]
+        L.orc_test_lf_lx_reads.restype = C.c_uint64
+        L.orc_test_lf_lx_reads.argtypes = []
         L.orc_suffix_array.restype = C.c_int
         L.orc_suffix_array.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
         L.orc_bwt.restype = None
@@ -219,6 +223,16 @@ def align_batch(scoring, mode, x, x_off, y, y_off, threads=1, want_ops=True):
     if rc:
         raise RuntimeError(f"oracle align_batch failed rc={rc}")
     return out, ops, stride
+
+
+def lf_hook(on):
+    """test hook of pairwise.cpp: Aligner::custom without the x-suffix-clip fold of the columns before n (what the engine's
+    LF kernel leaves out); a traceback that asks for such an Lx[j] makes the call fail and is counted"""
+    lib().orc_test_lf_hook(1 if on else 0)
+
+
+def lf_lx_reads():
+    return int(lib().orc_test_lf_lx_reads())
 
 
 def banded_align(scoring, mode, k, w, x, y):

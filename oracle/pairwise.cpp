@@ -5,9 +5,17 @@
 // Integer arithmetic is i32 and wraps like a Rust release build (compiled with -fwrapv).
 #include "pairwise_impl.h"
 
+#include <atomic>
 #include <thread>
 
 namespace orc {
+
+// Test hook (tests/test_oracle_lf_property.py; off unless a test switches it on): the one thing the LF flavour of the
+// engine's local kernel (rust-bio_amd/csrc/sw_fill_pk16.inc) leaves out of this algorithm — the x-suffix-clip fold of the
+// columns before n — so that "no local alignment needs it" can be checked against the restatement itself, on the CPU:
+// with the hook on, custom() keeps no fold for 0 < j < n and a traceback that asks for such an Lx[j] throws.
+std::atomic<int> g_lf_hook{0};
+std::atomic<uint64_t> g_lf_lx_reads{0};
 
 // pairwise/mod.rs:591-922  Aligner::custom
 Alignment Aligner::custom(const uint8_t* x, size_t m, const uint8_t* y, size_t n) {
@@ -190,7 +198,8 @@ Alignment Aligner::custom(const uint8_t* x, size_t m, const uint8_t* y, size_t n
             D[curr][i] = best_d_score;
 
             // Track the score if we do suffix clip (x) from here
-            if (S[curr][i] + sc.xclip_suffix > S[curr][m]) {
+            if (!(g_lf_hook.load(std::memory_order_relaxed) && j != n) &&  // (test hook, see the top of this file)
+                S[curr][i] + sc.xclip_suffix > S[curr][m]) {
                 S[curr][m] = S[curr][i] + sc.xclip_suffix;
                 Lx[j] = m - i;
             }
@@ -282,6 +291,10 @@ Alignment Aligner::custom(const uint8_t* x, size_t m, const uint8_t* y, size_t n
                 next_layer = traceback.get(0, j).get_s_bits();
                 break;
             case TB_XCLIP_SUFFIX:
+                if (g_lf_hook.load(std::memory_order_relaxed) && j != n && j != 0) {  // (test hook)
+                    g_lf_lx_reads++;
+                    throw OracleError("LF hook: the traceback asked for Lx[j] of a column before n");
+                }
                 operations.push_back({ORC_OP_XCLIP, Lx[j]});
                 i -= Lx[j];
                 xend = i;
@@ -392,6 +405,9 @@ Scoring scoring_from_c(const orc_scoring_t* sc) {
 }
 
 }  // namespace orc
+
+extern "C" void orc_test_lf_hook(int on) { orc::g_lf_hook = on; }
+extern "C" uint64_t orc_test_lf_lx_reads(void) { return orc::g_lf_lx_reads.load(); }
 
 extern "C" int orc_align(const orc_scoring_t* sc, int mode, const uint8_t* x, uint64_t m,
                          const uint8_t* y, uint64_t n, orc_alignment_t* out, uint64_t* ops,
