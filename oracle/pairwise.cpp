@@ -14,11 +14,18 @@ namespace orc {
 // engine's local kernel (rust-bio_amd/csrc/sw_fill_pk16.inc) leaves out of this algorithm — the x-suffix-clip fold of the
 // columns before n — so that "no local alignment needs it" can be checked against the restatement itself, on the CPU:
 // with the hook on, custom() keeps no fold for 0 < j < n and a traceback that asks for such an Lx[j] throws.
+// The hook is a TEMPLATE parameter of the restatement: custom() reads the flag once and runs custom_impl<false> — whose
+// inner loop is byte for byte the reference's, and what bench.py times as cpu_baseline — unless a test switched it on.
 std::atomic<int> g_lf_hook{0};
 std::atomic<uint64_t> g_lf_lx_reads{0};
 
-// pairwise/mod.rs:591-922  Aligner::custom
 Alignment Aligner::custom(const uint8_t* x, size_t m, const uint8_t* y, size_t n) {
+    return g_lf_hook.load(std::memory_order_relaxed) ? custom_impl<true>(x, m, y, n) : custom_impl<false>(x, m, y, n);
+}
+
+// pairwise/mod.rs:591-922  Aligner::custom
+template <bool LF_HOOK>
+Alignment Aligner::custom_impl(const uint8_t* x, size_t m, const uint8_t* y, size_t n) {
     const Scoring& sc = scoring;
     traceback.init(m, n);  // mod.rs:593
 
@@ -198,7 +205,7 @@ Alignment Aligner::custom(const uint8_t* x, size_t m, const uint8_t* y, size_t n
             D[curr][i] = best_d_score;
 
             // Track the score if we do suffix clip (x) from here
-            if (!(g_lf_hook.load(std::memory_order_relaxed) && j != n) &&  // (test hook, see the top of this file)
+            if (!(LF_HOOK && j != n) &&  // (test hook, compiled out of custom_impl<false>: see the top of this file)
                 S[curr][i] + sc.xclip_suffix > S[curr][m]) {
                 S[curr][m] = S[curr][i] + sc.xclip_suffix;
                 Lx[j] = m - i;
@@ -291,7 +298,7 @@ Alignment Aligner::custom(const uint8_t* x, size_t m, const uint8_t* y, size_t n
                 next_layer = traceback.get(0, j).get_s_bits();
                 break;
             case TB_XCLIP_SUFFIX:
-                if (g_lf_hook.load(std::memory_order_relaxed) && j != n && j != 0) {  // (test hook)
+                if (LF_HOOK && j != n && j != 0) {  // (test hook)
                     g_lf_lx_reads++;
                     throw OracleError("LF hook: the traceback asked for Lx[j] of a column before n");
                 }

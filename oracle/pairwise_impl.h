@@ -114,6 +114,8 @@ struct Aligner {
     Scoring scoring;
     explicit Aligner(const Scoring& s) : scoring(s) {}
     Alignment custom(const uint8_t* x, size_t m, const uint8_t* y, size_t n);
+    template <bool LF_HOOK>
+    Alignment custom_impl(const uint8_t* x, size_t m, const uint8_t* y, size_t n);  // LF_HOOK: tests only (pairwise.cpp)
     Alignment global(const uint8_t* x, size_t m, const uint8_t* y, size_t n);
     Alignment semiglobal(const uint8_t* x, size_t m, const uint8_t* y, size_t n);
     Alignment local(const uint8_t* x, size_t m, const uint8_t* y, size_t n);
