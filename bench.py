@@ -63,7 +63,8 @@ def parse_args():
     ap.add_argument("--skip-banded", action="store_true")
     ap.add_argument("--banded-pairs", type=int, default=100_000,
                     help="banded leg: 10 kb pairs per GPU, and in total for banded.strong (configs[3]: 100k, split over the GPUs)")
-    ap.add_argument("--banded-parity-pairs", type=int, default=1024, help="banded leg: pairs compared with the oracle (>= 1 %)")
+    ap.add_argument("--banded-parity-pairs", type=int, default=5120,
+                    help="banded leg: pairs compared with the oracle (5 % of configs[3]; ~13 s of the 16-thread oracle)")
     ap.add_argument("--banded-chunk", type=int, default=0, help="banded leg: pairs per sub-batch (0 = the library's default)")
     ap.add_argument("--skip-pipeline", action="store_true")
     ap.add_argument("--pipeline-reads", type=int, default=1_250_000,
@@ -1056,7 +1057,9 @@ def banded_leg(args, ctx, dev, rank, world, do_cpu, orc, threads, parity):
             kq, oq = int(bout["n_ops"][p]), int(bout["ops_off"][p])
             okb = okb and bool((bops[oq:oq + kq] == kind[p, :kq]).all())
         parity.update({"banded_pairs_checked": nsb, "banded_pairs_total": Pb, "banded_bit_exact": okb})
-        nt = min(nsb, 4 * threads)
+        # >= 512 pairs: with 4 pairs per thread the 200 MB traceback matrix + memset of a 10 kb pair's first run on every
+        # thread dominated (0.16 GCUPS on 64 pairs against 0.49 over the parity pass — the same code)
+        nt = min(nsb, max(512, 4 * threads))
         t_all = median_time(lambda: orc.banded_align_batch(osc, "semiglobal", kb, wb, hx[:nt * Lb], hoff[:nt + 1],
                                                            hy[:nt * Lb], hoff[:nt + 1], threads=min(nt, threads), want_ops=False))
         banded["cpu_baseline"] = {"value": round(float(ocells[:nt].sum()) / t_all / 1e9, 4), "unit": "GCUPS (band cells)",
