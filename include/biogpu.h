@@ -303,8 +303,11 @@ int bg_align_batch_dev(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint64_t n
                        bg_alignment_t* d_out, uint8_t* d_ops, uint64_t ops_stride, void* stream);
 /* The same on 2-bit streams (bg_pack2_dev above): d_x / d_y hold 16 symbols per dword, the offsets count symbols,
  * `codes` are the bytes the four codes stand for.  Short reads under MatchParams scoring (the packed-int16 kernel) read
- * the codes as they are; every other case unpacks the streams into ctx scratch first (one stream synchronisation) and
- * runs the byte kernels — same results either way. */
+ * the codes as they are and the call stays asynchronous like bg_align_batch_dev.  Every other case (long reads, wide
+ * scores, a matrix) is a FALLBACK that is not: it reads the two stream lengths d_x_off[n_pairs] / d_y_off[n_pairs] back
+ * (two blocking copies + one synchronisation of `stream`), may grow the ctx's unpack scratch (hipMalloc), unpacks both
+ * streams there and runs the byte kernels — same results either way.  That scratch belongs to the ctx: calls on one ctx
+ * are serialised by the ctx's scratch guard (an event), so use one ctx per stream for concurrent batches. */
 int bg_align_batch_packed_dev(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint64_t n_pairs, const uint32_t* d_x,
                               const uint64_t* d_x_off, const uint32_t* d_y, const uint64_t* d_y_off,
                               const uint8_t* codes, uint32_t max_xlen, uint32_t max_ylen, bg_alignment_t* d_out,

@@ -241,7 +241,9 @@ extern "C" int bg_get_timing(bg_ctx* ctx, bg_timing_t* out) {
 namespace {
 __global__ __launch_bounds__(256) void ops_counts_kernel(const bg_alignment_t* __restrict__ rec, uint64_t n, uint32_t* __restrict__ cnt) {
     const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < n) cnt[p] = rec[p].n_ops;
+    // a failed pair (BG_ERR_OPS_CAP: n_ops beyond its slot, ops_off before it) contributes no bytes, as the host
+    // compaction this replaces did
+    if (p < n) cnt[p] = rec[p].status == BG_OK ? rec[p].n_ops : 0u;
 }
 // LANES lanes per pair: bytes [src, src + n_ops) -> compact (+ *cell) + off[p]; ops_off becomes *cell + off[p]
 template <int LANES>
@@ -251,7 +253,7 @@ __global__ __launch_bounds__(256) void ops_compact_kernel(bg_alignment_t* __rest
     const uint64_t p = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / LANES;
     const uint32_t l = threadIdx.x % LANES;
     if (p >= n) return;
-    const uint32_t k = rec[p].n_ops;
+    const uint32_t k = rec[p].status == BG_OK ? rec[p].n_ops : 0u;
     const uint64_t base = *cell;
     const uint8_t* src = ops + rec[p].ops_off;
     uint8_t* dst = compact + (global_offsets ? base : 0ull) + off[p];

@@ -68,6 +68,9 @@ struct SeedSrc {
 // COUNT: the block loads of the launch are counted (bench.py: requested lines against the gather ceiling of
 // tools/microbench/ub_gather64.hip); the results are the same.
 constexpr uint8_t kTagDeferred = 0xFF;  // fm_search_fast_kernel leaves such a query to the generic kernel
+static_assert(kTagDeferred > BG_FM_PANIC, "the deferral mark must not collide with a BG_FM_* tag");
+// (the DEFER launch reads every tag once — n_q bytes, ~10 us per 10 M queries — and the fast kernel writes every tag it
+//  owns, deferred or answered, so a caller's stale tag buffer cannot fake a deferral)
 // DEFER: only the queries whose tag is kTagDeferred are searched (second launch behind fm_search_fast_kernel)
 template <bool JUMP, bool SEEDS, bool PACKED = false, bool COUNT = false, bool DEFER = false>
 __global__ __launch_bounds__(256) void fm_backward_search_kernel(

@@ -307,7 +307,9 @@ static int align_batch_dev_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, u
         const SwScoring& c = a.sc;
         const int32_t M = BG_MIN_SCORE;
         // local alignments whose gaps and mismatches cost something take the LF flavour (sw_fill_pk16.inc)
-        const bool local_fast = all_zero_clips && c.go < 0 && c.mismatch < 0 && !ctx->no_local_fast;
+        // (match >= 0: the LF cell's unsigned mad needs matchkey - mismatchkey >= 0; MatchParams::new asserts it, mod.rs:199-200,
+        //  but nothing in the C API does)
+        const bool local_fast = all_zero_clips && c.go < 0 && c.mismatch < 0 && c.match >= 0 && !ctx->no_local_fast;
         auto getter = local_fast ? get_fill_pk16_localfast
                       : all_zero_clips ? get_fill_pk16_local
                       : (c.xp == M && c.xs == M && c.yp == 0 && c.ys == 0) ? get_fill_pk16_semiglobal

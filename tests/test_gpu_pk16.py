@@ -215,3 +215,27 @@ def test_ragged_batches_visit_pairs_in_length_order():
     rec = d_out.cpu().numpy().view(_lib.ALN_DTYPE)
     for f in ("score", "xstart", "xend", "ystart", "yend", "n_ops"):
         assert (rec[f] == out[f]).all(), f
+
+
+def test_raw_scorings_with_negative_match_stay_off_the_lf_flavour():
+    """ADVICE r3: the LF cell's unsigned multiply-add needs match >= mismatch; MatchParams::new asserts match >= 0
+    (mod.rs:199-200) and so do the wrappers, but a raw bg_scoring_t can say anything: such scorings must take the general
+    K1p (same answers as the oracle, which does the reference's arithmetic on whatever it is given)."""
+    rng = np.random.default_rng(77)
+    xs, ys = related_pairs(rng, 300, lambda p: 40, lambda p: 44)
+    for match, mismatch in ((-2, -1), (-1, -3), (-3, -3)):
+        sc = Scoring.from_scores(-2, -1, 0, -1)
+        object.__setattr__(sc.match_fn, "match_score", match)  # past the constructor's assert (frozen dataclass)
+        object.__setattr__(sc.match_fn, "mismatch_score", mismatch)
+        sc.match_scores = (match, mismatch)
+        al = Aligner.with_scoring(sc)
+        x, xo = _lib.concat(xs)
+        y, yo = _lib.concat(ys)
+        out, ops = al.align_arrays(MODES["local"], x, xo, y, yo)
+        kw = dict(gap_open=-2, gap_extend=-1, match=match, mismatch=mismatch)
+        oout, oops, stride = orc.align_batch(orc.make_scoring(**kw, **dict(CLIPS, xclip_prefix=0, xclip_suffix=0, yclip_prefix=0,
+                                                                           yclip_suffix=0)), "local", x, xo, y, yo, threads=8)
+        for f in ("score", "xstart", "xend", "ystart", "yend", "n_ops"):
+            assert (out[f].astype(np.int64) == oout[f].astype(np.int64)).all(), (f, match, mismatch)
+        for p in range(len(xs)):
+            assert decode_ops(out[p], ops) == orc.decode_ops(oops[p * stride:p * stride + int(oout["n_ops"][p])])
