@@ -90,6 +90,7 @@ struct BandArgs {
     int32_t mode, filter_clips;
     uint32_t tb_flip;   // XORed onto every traceback byte K4 reads (kTbFlip after K3v2, 0 after K3)
     uint32_t* started;  // K3v2: every block counts itself in when it starts (nullptr: nobody is waiting for that)
+    int32_t interior_off;  // K3v2: 1 = no strip takes the reduced step (tests: the general step everywhere)
 };
 
 typedef void (*band_fill_fn)(const BandArgs);

@@ -65,6 +65,7 @@ struct bg_ctx {
     int band_chain_global = -1;  // chain_kernel tree placement: -1 by batch size, 0 LDS, 1 global scratch
     bool band_join_global = false;  // tests: k-mer join with its table in global memory even where the LDS flavour applies
     int band_fill_v1 = 0;  // 1: K3 (one pair per wavefront) even where K3v2 applies; -1: K3v2 even for small sub-batches; 0: by size
+    bool band_interior_off = false;  // tests: K3v2 takes its general step in every strip (no reduced step in interior strips)
     bool band_on_host = false;  // build bands with the host builder (band_host.cpp) instead of band_device.hip
     // the scratch above is one set per ctx: a *_dev call arriving on another stream than the previous one first
     // waits (on the device) for that call's last kernel — see bg_scratch_guard

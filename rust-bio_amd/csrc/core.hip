@@ -196,6 +196,10 @@ extern "C" int bg_set_option(bg_ctx* ctx, const char* key, int64_t value) {
         ctx->band_fill_v1 = value > 0 ? 1 : value < 0 ? -1 : 0;
         return BG_OK;
     }
+    if (!strcmp(key, "band_interior_off")) {
+        ctx->band_interior_off = value != 0;
+        return BG_OK;
+    }
     if (!strcmp(key, "band_on_host")) {
         ctx->band_on_host = value != 0;
         return BG_OK;

@@ -330,7 +330,10 @@ def test_fill_kernel_variants_agree():
         al = BAligner.with_scoring(sc, 9, 7)
         res = []
         # band_fill_v1: -1 K3v2 whatever the batch size, 1 K3, 0 by sub-batch size (K3 for these 80 pairs)
-        for opts in ({"band_fill_v1": -1}, {"band_fill_v1": -1, "force_wide": 1}, {"band_fill_v1": 1}, {"band_fill_v1": 0}):
+        # band_interior_off: K3v2's general step in every strip (by default semiglobal-like scorings take a reduced step
+        # in the strips that neither reach column n nor hold row m)
+        for opts in ({"band_fill_v1": -1}, {"band_fill_v1": -1, "force_wide": 1}, {"band_fill_v1": 1}, {"band_fill_v1": 0},
+                     {"band_fill_v1": -1, "band_interior_off": 1}):
             for k_, v_ in opts.items():
                 al.ctx.set_option(k_, v_)
             try:
