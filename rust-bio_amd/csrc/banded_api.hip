@@ -729,7 +729,9 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
         if (sm == SCORE_PARAMS && ctx->band_fill_v1 <= 0 && !small_batch) {
             a.started = on_device ? B.d_started : nullptr;
             a.tb_flip = kTbFlip;
-            a.interior_off = ctx->band_interior_off ? 1 : 0;
+            // interior runs (band_split): scaled keys, x kept whole, a real y-prefix clip — semiglobal-like scorings
+            a.split = (narrow && !ctx->band_interior_off && cs.xclip_prefix <= BG_MIN_SCORE / 2 && cs.xclip_suffix <= BG_MIN_SCORE / 2 &&
+                       cs.yclip_prefix > BG_MIN_SCORE / 2) ? 1 : 0;
             if (on_device) B.started_target += band_fill2_blocks(a.n_pairs);
             launch_band_fill2(a, narrow, st, S.fill_gone);  // K3v2: eight pairs per wavefront + separate epilogue
             S.fill_gone_valid = true;

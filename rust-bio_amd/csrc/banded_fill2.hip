@@ -303,19 +303,37 @@ uint32_t band_fill2_blocks(uint32_t n_pairs) {
     return (jobs + 3) / 4;
 }
 
-bool launch_band_fill2(const BandArgs& a, bool narrow, hipStream_t st, hipEvent_t after_fill) {
-
+bool launch_band_fill2(const BandArgs& a0, bool narrow, hipStream_t st, hipEvent_t after_fill) {
     constexpr int LP = BF2_LP, PW = 64 / LP;
+    BandArgs a = a0;
     const uint32_t jobs = (a.n_pairs + PW - 1) / PW;
+    const dim3 grid((jobs + 3) / 4);
     if (narrow) {
-        if (a.sc.xp > NEG / 2)
-            launch_fill2_narrow_xp(a, dim3((jobs + 3) / 4), st);
-        else
-            launch_fill2_narrow(a, dim3((jobs + 3) / 4), st);
+        // scorings that admit interior runs (band_split, banded_kernels.h): K3v2 on the strips before them, K3i on the runs,
+        // K3v2 on the strips behind them — three launches, the first and the last a few strips per pair
+        const bool split = a.split && a.sc.xp <= NEG / 2;
+        uint32_t* const started = a.started;
+        if (!split) {
+            a.phase = 0;
+            a.split = 0;
+            if (a.sc.xp > NEG / 2) launch_fill2_narrow_xp(a, grid, st);
+            else launch_fill2_narrow(a, grid, st);
+        } else {
+            a.started = nullptr;  // whoever waits for "the fill is resident" means the long launch
+            a.phase = 1;
+            launch_fill2_narrow(a, grid, st);
+            a.started = started;
+            launch_fill2i(a, grid, st);
+            a.started = nullptr;
+            a.phase = 2;
+            launch_fill2_narrow(a, grid, st);
+        }
         if (after_fill) (void)hipEventRecord(after_fill, st);
         banded_epilogue_kernel<2, true><<<dim3((a.n_pairs + 3) / 4), dim3(256), 0, st>>>(a);
     } else {
-        launch_fill2_wide(a, dim3((jobs + 3) / 4), st);
+        a.phase = 0;
+        a.split = 0;
+        launch_fill2_wide(a, grid, st);
         if (after_fill) (void)hipEventRecord(after_fill, st);
         banded_epilogue_kernel<2, false><<<dim3((a.n_pairs + 3) / 4), dim3(256), 0, st>>>(a);
     }

@@ -90,14 +90,35 @@ struct BandArgs {
     int32_t mode, filter_clips;
     uint32_t tb_flip;   // XORed onto every traceback byte K4 reads (kTbFlip after K3v2, 0 after K3)
     uint32_t* started;  // K3v2: every block counts itself in when it starts (nullptr: nobody is waiting for that)
-    int32_t interior_off;  // K3v2: 1 = no strip takes the reduced step (tests: the general step everywhere)
+    int32_t phase;  // K3v2: 0 all strips of every pair; 1 / 2: the strips before / behind the interior run (band_split)
+    int32_t split;  // the scoring admits interior runs (host decision, banded_api.hip): band_split may say yes
 };
+
+// Interior run of a pair: the strips [s_a, s_b) of RS rows each that banded_fill2i_kernel takes with its reduced cell.
+// Scoring-level condition (BandArgs::split, set by the host): scaled keys apply, xclip_prefix = xclip_suffix = MIN_SCORE and
+// yclip_prefix is a real score (semiglobal-like) — then the x-suffix-clip fold S[curr][m] (banded.rs:648-653) only ever
+// holds MIN_SCORE + something, every band cell holds a real score (the y-prefix-clip candidate, banded.rs:633-642), and
+// the fold wins neither a cell nor Sn[m] once row m has had a band cell of its own — which is the pair-level condition
+// below.  Strip-level: no row with column 0 in its band (closed forms, banded.rs:440-499) in or right above the strip,
+// no row inside the band of column n (the j == n candidate and records, banded.rs:590-596, 683-723), not row m.
+__device__ __forceinline__ bool band_split(const SwScoring& sc, const BandPair& bp, uint32_t m, const int2* rowc, uint32_t RS,
+                                           uint32_t& s_a, uint32_t& s_b) {
+    (void)sc;
+    if (m < 2 || bp.start_n < 1) return false;
+    const int2 rcm = rowc[m];
+    if (!(rcm.y >= rcm.x && rcm.y >= 1)) return false;  // row m has a band cell in a column >= 1
+    const uint32_t rows0 = bp.end_0 > bp.start_0 ? bp.end_0 : 0;  // rows below rows0 - 1 do not touch column 0
+    s_a = max(1u, (rows0 + RS - 1) / RS);  // the row above strip s_a (s_a * RS) is >= end_0
+    s_b = min((bp.start_n - 1) / RS, (m - 1) / RS);  // the strip of the first row inside column n's band / of row m
+    return s_a < s_b;
+}
 
 typedef void (*band_fill_fn)(const BandArgs);
 band_fill_fn get_band_fill(int sm);
 // K3v2 (banded_fill2.hip): LP lanes per pair, R rows per lane, MatchParams scoring; the last-column
 // epilogue runs in its own kernel.  Returns false if the geometry is not instantiated.
-bool launch_band_fill2(const BandArgs& a, bool narrow, hipStream_t st, hipEvent_t after_fill = nullptr);  // after_fill: recorded between the fill and its epilogue
+bool launch_band_fill2(const BandArgs& a, bool narrow, hipStream_t st, hipEvent_t after_fill = nullptr);
+void launch_fill2i(const BandArgs& a, dim3 grid, hipStream_t st);  // banded_fill2i.hip: the interior runs  // after_fill: recorded between the fill and its epilogue
 uint32_t band_fill2_blocks(uint32_t n_pairs);  // thread blocks launch_band_fill2 starts for n_pairs
 // holds `st` until *counter >= target (or ~20 ms have passed): "the fill kernel's blocks are all resident"
 void launch_band_wait_started(const uint32_t* counter, uint32_t target, hipStream_t st);

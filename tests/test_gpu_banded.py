@@ -374,3 +374,39 @@ def test_device_resident_entry_equals_host_entry():
         k_ = int(rec["n_ops"][p])
         assert int(rec["ops_off"][p]) == (p + 1) * stride - k_
         assert (ops[p, stride - k_:] == ops_h[int(out_h["ops_off"][p]):int(out_h["ops_off"][p]) + k_]).all()
+
+
+@pytest.mark.parametrize("case", [
+    dict(mode="semiglobal", kw=dict(gap_open=-5, gap_extend=-1, match=1, mismatch=-1), k=16, w=32),
+    dict(mode="semiglobal", kw=dict(gap_open=-3, gap_extend=-2, match=2, mismatch=-4), k=12, w=9),
+    dict(mode="semiglobal", kw=dict(gap_open=0, gap_extend=-1, match=1, mismatch=0), k=10, w=40),
+    dict(mode="custom", kw=dict(gap_open=-4, gap_extend=-1, match=3, mismatch=-2, yclip_prefix=-3, yclip_suffix=-2), k=14, w=20),
+    dict(mode="custom", kw=dict(gap_open=-6, gap_extend=0, match=1, mismatch=-3, yclip_prefix=0, yclip_suffix=MIN_SCORE), k=11, w=17),
+], ids=lambda c: "%s-k%d-w%d" % (c["mode"], c["k"], c["w"]))
+def test_interior_runs_long_reads_vs_oracle(case):
+    """Scorings that keep x whole and clip y's prefix at a real price split every pair into K3v2 strips, an interior run
+    (banded_fill2i.hip) and K3v2 strips again: 2-4 kb reads (60-120 strips of 32 rows), indels that move the band, a few
+    unrelated and short pairs in the same wavefronts — whole alignments against the oracle."""
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(str(sorted(case['kw'].items())).encode()))
+    xs, ys = [], []
+    for p in range(20):
+        n = int(rng.integers(1800, 4200))
+        y = synth.random_dna(n, 7000 + p)
+        if p % 7 == 6:
+            x = synth.random_dna(int(rng.integers(300, 900)), 9000 + p)  # unrelated: the band is whatever the chain finds
+        else:
+            xm, lens = synth.mutate_fixed(y.reshape(1, -1), 8000 + p, 0.05, 0.03, 0.03)
+            x = xm[0][:int(lens[0])]
+            if p % 5 == 0:  # a long deletion and a long insertion: the band turns
+                c = int(rng.integers(200, len(x) - 400))
+                x = np.concatenate([x[:c], x[c + int(rng.integers(20, 90)):]])
+                c = int(rng.integers(200, len(x) - 200))
+                x = np.concatenate([x[:c], synth.random_dna(int(rng.integers(20, 90)), 9500 + p), x[c:]])
+            if p % 4 == 1:
+                x = x[int(rng.integers(1, 300)):len(x) - int(rng.integers(1, 300))]  # x inside y
+        xs.append(np.asarray(x, dtype=np.uint8).tobytes())
+        ys.append(np.asarray(y, dtype=np.uint8).tobytes())
+    kw = dict(BASE)
+    kw.update(case["kw"])
+    differential(kw, True, case["mode"], case["k"], case["w"], xs, ys)
