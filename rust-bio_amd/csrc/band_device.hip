@@ -331,6 +331,9 @@ __device__ __forceinline__ bool frag_less(const Frag& p, const Frag& q) { return
 template <bool LDS_TREE, int PART = 0>
 __global__ __launch_bounds__(64) void chain_kernel(const BandDevArgs a) {
     extern __shared__ __align__(16) uint8_t s_raw[];
+    // This kernel mostly waits for memory; next to a fill (two wavefronts per SIMD that always have a vector instruction
+    // ready, and are older) it otherwise issues only when both of them stall
+    __builtin_amdgcn_s_setprio(3);
     const uint32_t pair = blockIdx.x;
     const uint32_t lane = threadIdx.x;
     BandDevPair* st = a.state + pair;
@@ -725,6 +728,7 @@ __global__ __launch_bounds__(256) void band_kernel(const BandDevArgs a) {
     __shared__ uint16_t s_anchor[kMaxChainMatches + 2];
     __shared__ uint32_t s_wtot[4], s_nanchor, s_lo, s_hi;
     constexpr uint32_t G = 4;  // lanes per anchor: they share the columns of its gap, its k-mer and its run
+    __builtin_amdgcn_s_setprio(3);  // (runs next to a fill: see chain_kernel)
     const uint32_t pair = blockIdx.x;
     const BandDevPair* st = a.state + pair;
     if (st->flags != BP_OK) return;
@@ -850,6 +854,7 @@ __device__ __forceinline__ uint64_t block_sum(uint64_t v, uint64_t* s_tmp) {
 // one whose end exceeds i, its last column the last one whose start does not — every column hands its index to
 // the rows it is the first / the last column of.  Anything else goes back to the host builder.
 __global__ __launch_bounds__(256) void band_rows_kernel(const BandDevArgs a) {
+    __builtin_amdgcn_s_setprio(3);  // (runs next to a fill: see chain_kernel)
     const uint32_t pair = blockIdx.x;
     BandDevPair* st = a.state + pair;
     if (st->flags == BP_HOST_FALLBACK) return;

@@ -448,7 +448,7 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
         return BG_OK;
     };
     if ((rc = need_seq(st, waited_fill, std::min<uint64_t>(n_pairs, chunk_pairs)))) return rc;  // the first slice
-    const uint64_t budget = 28ull << 30;  // traceback + aux per scratch set (two sets, of 288 GB HBM)
+    const uint64_t budget = 40ull << 30;  // traceback + aux per scratch set (two sets, of 288 GB HBM)
     const uint64_t grain = std::max<uint64_t>(1, std::min<uint64_t>(64, 65536 / (max_x + max_y + 1)));
     // Two sub-batches are in flight: while K3/K4 of one run, the band of the next one is being built —
     // by band_device.hip on its own stream, or by the host threads.
@@ -483,12 +483,21 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
     // run for sub-batch c + 1 on the idle device just before fill c is launched — finish(c) calls this once it knows
     // where c + 1 starts and lets the fill wait for it — and the event loop of c + 1 then has the whole fill to itself.  It touches nothing of the scratch set (K4 of c - 1
     // may still be reading that), only the builder's own arrays, which raster c has finished with.
+    // Sub-batch sizes: a batch that is not a whole number of sub-batches takes its REMAINDER FIRST.  A fill is one round
+    // of resident wavefronts that lasts as long as its slowest pair whatever the sub-batch size, so a short sub-batch at
+    // the end costs a full fill with the device idle around it (100 000 pairs = 6 x 16 384 + 1 696: 30 ms of 345); up
+    // front it runs under the band construction of the first full sub-batch, which nothing else would overlap.
+    const uint64_t first_want = (n_pairs > chunk_pairs && n_pairs % chunk_pairs && !ctx->band_tail_last) ? n_pairs % chunk_pairs : 0;
+    auto want_at = [&](uint64_t p0) -> uint64_t {
+        if (p0 == 0 && first_want) return first_want;
+        return std::min<uint64_t>(chunk_pairs, n_pairs - p0);
+    };
     auto issue_match = [&](uint64_t p0, uint64_t n_chunk) -> int {
         Plan& P = plan[n_chunk & 1];
         int rc = BG_OK;
         P.matched = false;
         if (!build_on_device) return BG_OK;
-        const uint64_t want = std::min<uint64_t>(chunk_pairs, n_pairs - p0);
+        const uint64_t want = want_at(p0);
         if ((rc = need_seq(st_build, waited_build, p0 + want))) return rc;
         uint32_t max_m = 0, max_n = 0;
         for (uint64_t q = 0; q < want; q++) {
@@ -545,7 +554,7 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
         d.g_score = (uint32_t*)B.db[15];
         d.g_back = (int16_t*)B.db[16];
         if ((rc = launch_band_match(d, st_build))) return rc;
-        if ((rc = launch_band_chain(d, st_build, 1))) return rc;
+        if (ctx->band_prep_early && (rc = launch_band_chain(d, st_build, 1))) return rc;
         BG_HIP(hipEventRecord(B.set[n_chunk & 1].matched, st_build));
         P.d = d;
         P.p0 = p0;
@@ -567,7 +576,7 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
             BG_HIP(hipEventSynchronize(S.traced));
             S.busy = false;
         }
-        const uint64_t want = std::min<uint64_t>(chunk_pairs, n_pairs - p0);
+        const uint64_t want = want_at(p0);
         P.want = want;
         hp.assign(want, HostPair());
         row0.resize(want + 1);
@@ -597,8 +606,11 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
             // first delays the whole kernel: fill 57 -> 116 ms).  The raster kernels start when that fill is done and
             // overlap K4 of sub-batch c.
             if (B.started_target) launch_band_wait_started(B.d_started, B.started_target, st_build);
+            // (the chaining's preparation — 16 KB of LDS per wavefront — used to run with the join in the window between two
+            //  fills; next to K3i, which leaves half of a SIMD's registers and 30 KB of LDS per CU, it runs under the fill)
+            if (!ctx->band_prep_early && (rc = launch_band_chain(d, st_build, 1))) return rc;
             if ((rc = launch_band_chain(d, st_build, 2))) return rc;
-            if (n_chunk >= 1 && B.set[(n_chunk - 1) & 1].busy) {  // (the raster does not have to wait for the fill's epilogue)
+            if (ctx->band_raster_late && n_chunk >= 1 && B.set[(n_chunk - 1) & 1].busy) {  // (the raster does not have to wait for the fill's epilogue)
                 bg_band_scratch::Set& prev = B.set[(n_chunk - 1) & 1];
                 BG_HIP(hipStreamWaitEvent(st_build, prev.fill_gone_valid ? prev.fill_gone : prev.filled, 0));
             }
@@ -725,7 +737,8 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
         // 16 384 pairs in flight); a small sub-batch — a whole small call, or the tail of a large one — finishes sooner
         // with one pair per wavefront (K3: 19 ms; measured cross-over between 2 048 and 4 096 pairs,
         // tools/exp/time_banded_small.py).  band_fill_v1: 1 always K3, -1 never (tests)
-        const bool small_batch = take <= 2048 && ctx->band_fill_v1 >= 0;
+        // (the remainder sub-batch of a large call runs first, under the next one's band construction: K3v2 / K3i there)
+        const bool small_batch = take <= 2048 && ctx->band_fill_v1 >= 0 && n_pairs <= 2048;
         if (sm == SCORE_PARAMS && ctx->band_fill_v1 <= 0 && !small_batch) {
             a.started = on_device ? B.d_started : nullptr;
             a.tb_flip = kTbFlip;

@@ -14,6 +14,7 @@ namespace {
 // per-row values the fill left in aux.  The arithmetic is K3's (banded_fill.hip), fed from memory.
 template <int R, bool NARROW>
 __global__ __launch_bounds__(256) void banded_epilogue_kernel(const BandArgs a) {
+    __builtin_amdgcn_s_setprio(3);  // (short, latency bound, next to other kernels)
     constexpr int RS = 64 * R;
     const int lane = threadIdx.x & 63;
     const uint32_t pair = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);

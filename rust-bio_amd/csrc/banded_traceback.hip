@@ -10,6 +10,7 @@
 namespace bgband_dev {
 
 __global__ __launch_bounds__(256) void banded_traceback_kernel(const BandArgs a) {
+    __builtin_amdgcn_s_setprio(3);  // a chain of dependent loads that runs next to the following sub-batch's fill
     const uint32_t pair = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63;
     if (pair >= a.n_pairs) return;  // wave-uniform

@@ -200,6 +200,18 @@ extern "C" int bg_set_option(bg_ctx* ctx, const char* key, int64_t value) {
         ctx->band_interior_off = value != 0;
         return BG_OK;
     }
+    if (!strcmp(key, "band_tail_last")) {
+        ctx->band_tail_last = value != 0;
+        return BG_OK;
+    }
+    if (!strcmp(key, "band_prep_early")) {
+        ctx->band_prep_early = value != 0;
+        return BG_OK;
+    }
+    if (!strcmp(key, "band_raster_late")) {
+        ctx->band_raster_late = value != 0;
+        return BG_OK;
+    }
     if (!strcmp(key, "band_on_host")) {
         ctx->band_on_host = value != 0;
         return BG_OK;

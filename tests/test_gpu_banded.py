@@ -410,3 +410,40 @@ def test_interior_runs_long_reads_vs_oracle(case):
     kw = dict(BASE)
     kw.update(case["kw"])
     differential(kw, True, case["mode"], case["k"], case["w"], xs, ys)
+
+
+@pytest.mark.parametrize("opts", [{}, {"band_tail_last": 1}, {"band_prep_early": 1, "band_raster_late": 1}],
+                         ids=["default", "tail-last", "round3-order"])
+def test_several_sub_batches_and_the_remainder_first(opts):
+    """A batch that spans several sub-batches (chunk_pairs = 16, 70 pairs: the remainder of 6 runs first, then four full
+    ones) through both entry points: same alignments as the oracle whatever the order of the pipeline's stages, and the
+    host-buffer flavour's compacted operations are where the records say."""
+    xs, ys = synth.ragged_pairs(70, 700, seed=4711, min_len=150)
+    al = Aligner.with_scoring(engine_scoring(dict(BASE, yclip_prefix=0, yclip_suffix=0), True), 9, 11)
+    al.ctx.set_option("chunk_pairs", 16)
+    for k_, v_ in opts.items():
+        al.ctx.set_option(k_, v_)
+    x, xo = _lib.concat(xs)
+    y, yo = _lib.concat(ys)
+    out, ops = al.align_arrays(MODES["custom"], x, xo, y, yo)
+    osc = orc.make_scoring(**dict(BASE, yclip_prefix=0, yclip_suffix=0), match_scores_some=1)
+    assert (out["status"] == 0).all()
+    spans = []
+    for p in range(len(xs)):
+        want = orc.banded_align(osc, "custom", 9, 11, xs[p], ys[p])
+        assert int(out["score"][p]) == want["score"] and decode_ops(out[p], ops) == want["ops"], p
+        spans.append((int(out["ops_off"][p]), int(out["n_ops"][p])))
+    spans.sort()
+    assert spans[0][0] == 0 and all(a[0] + a[1] == b[0] for a, b in zip(spans, spans[1:]))  # back to back, no overlap
+    # the device-resident entry over the same sub-batches
+    import torch
+    dev = torch.device("cuda:0")
+    dx, dy = torch.from_numpy(x.copy()).to(dev), torch.from_numpy(y.copy()).to(dev)
+    dxo, dyo = torch.from_numpy(xo.astype(np.int64)).to(dev), torch.from_numpy(yo.astype(np.int64)).to(dev)
+    stride = int(max(len(a) + len(b) for a, b in zip(xs, ys))) + 8
+    d_out = torch.zeros(len(xs) * 64, dtype=torch.uint8, device=dev)
+    d_ops = torch.zeros(len(xs) * stride, dtype=torch.uint8, device=dev)
+    al.align_dev(MODES["custom"], len(xs), dx.data_ptr(), dxo.data_ptr(), dy.data_ptr(), dyo.data_ptr(), d_out.data_ptr(),
+                 d_ops.data_ptr(), stride)
+    rec = d_out.view(torch.int32).view(len(xs), 16).cpu().numpy()
+    assert (rec[:, 0] == out["score"]).all()
