@@ -83,7 +83,7 @@ const char* bg_last_error(void); /* text of the last HIP failure on this thread 
  *   band_fill_v1       1: banded fill with one pair per wavefront (K3) always; -1: eight pairs per wavefront (K3v2)
  *                      always; 0 (default): K3 for sub-batches of at most 2048 pairs (latency), K3v2 above (throughput)
  *   band_interior_off = 1  banded fill (K3v2) with its general step in every strip (tests, A/B: no reduced interior step)
- *   band_tail_last / band_prep_early / band_raster_late = 1  A/B switches of the banded pipeline's order (round-3 behaviour)
+ *   band_tail_last / band_window / band_raster_late = 1  A/B switches of the banded pipeline's order (round-3 behaviour)
  *   band_chain_global  chaining tree placement: 0 LDS, 1 global scratch, -1 by batch size (default)
  *   band_join_global = 1  k-mer join with its table in global memory even where the LDS flavour applies
  * Unknown keys return BG_ERR_INVALID_ARG. */

@@ -158,15 +158,15 @@ __global__ __launch_bounds__(256) void kmer_match_kernel(const BandDevArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------- B1 (LDS)
-// The whole join of a pair in LDS: both sequences, a table of 16 384 first positions, the per-position chain links and
-// a 16-bit tag per y k-mer — 20 + 64 + 20 + 20 KB for 10 kb reads, one block of 512 threads per CU.  kmer_match_kernel
+// The whole join of a pair in LDS: both sequences, a table of 8 192 first positions, the per-position chain links and
+// a 16-bit tag per y k-mer — 20 + 32 + 20 + 20 KB for 10 kb reads, one block of 512 threads per CU.  kmer_match_kernel
 // keeps table, links and hashes in global memory (a 128 KB table per pair: 28 GB of HBM traffic per 16 384 pairs for
 // 164 MB of sequences, every probe a chain of dependent L2 / HBM round trips); it had to fit next to a running fill
 // (20 KB of LDS), which the join no longer does (banded_api.hip).  Every thread owns a contiguous run of positions and
 // rolls a polynomial hash along it (one byte in, one byte out per position); what is hashed how is ours to choose —
 // candidates are compared byte for byte — and the matches come out exactly as kmer_match_kernel leaves them: in x
 // order, the y positions of one x position ascending.
-constexpr uint32_t kLdsJoinTable = 16384;
+constexpr uint32_t kLdsJoinTable = 8192;  // (16 384 in round 3: 124 KB per 10 kb pair; with 8 192 slots the join is 91 KB and fits next to two K3i blocks)
 constexpr uint32_t kLdsJoinThreads = 512;
 constexpr uint32_t kRollBase = 0x9E3779B1u;
 __host__ __device__ inline size_t lds_join_bytes(uint32_t m, uint32_t n) {
@@ -203,7 +203,8 @@ __global__ __launch_bounds__(512) void kmer_match_lds_kernel(const BandDevArgs a
         for (uint32_t t = 0; t < k; t++) h = h * kRollBase + q[t];
         return h;
     };
-    auto slot_of = [](uint32_t h) { return (h * 0x85EBCA6Bu) >> 18; };  // 14 bits
+    auto slot_of = [](uint32_t h) { return (h * 0x85EBCA6Bu) >> 19; };  // 13 bits
+    static_assert(kLdsJoinTable == 1u << 13, "slot_of");
     auto tag_of = [](uint32_t h) { return (uint16_t)(h ^ (h >> 16)); };
     __syncthreads();
     {  // y positions into the table: a contiguous run per thread, the hash rolled along it

@@ -554,7 +554,7 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
         d.g_score = (uint32_t*)B.db[15];
         d.g_back = (int16_t*)B.db[16];
         if ((rc = launch_band_match(d, st_build))) return rc;
-        if (ctx->band_prep_early && (rc = launch_band_chain(d, st_build, 1))) return rc;
+        if ((rc = launch_band_chain(d, st_build, 1))) return rc;
         BG_HIP(hipEventRecord(B.set[n_chunk & 1].matched, st_build));
         P.d = d;
         P.p0 = p0;
@@ -606,9 +606,6 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
             // first delays the whole kernel: fill 57 -> 116 ms).  The raster kernels start when that fill is done and
             // overlap K4 of sub-batch c.
             if (B.started_target) launch_band_wait_started(B.d_started, B.started_target, st_build);
-            // (the chaining's preparation — 16 KB of LDS per wavefront — used to run with the join in the window between two
-            //  fills; next to K3i, which leaves half of a SIMD's registers and 30 KB of LDS per CU, it runs under the fill)
-            if (!ctx->band_prep_early && (rc = launch_band_chain(d, st_build, 1))) return rc;
             if ((rc = launch_band_chain(d, st_build, 2))) return rc;
             if (ctx->band_raster_late && n_chunk >= 1 && B.set[(n_chunk - 1) & 1].busy) {  // (the raster does not have to wait for the fill's epilogue)
                 bg_band_scratch::Set& prev = B.set[(n_chunk - 1) & 1];
@@ -730,7 +727,10 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
         if (on_device) BG_HIP(hipStreamWaitEvent(st, S.built, 0));
         if (on_device && p0 + take < n_pairs) {  // the next sub-batch's k-mer join goes first (see issue_match)
             if ((rc = issue_match(p0 + take, n_chunk + 1))) return rc;
-            BG_HIP(hipStreamWaitEvent(st, B.set[(n_chunk + 1) & 1].matched, 0));
+            // Round 3: the fill waited for the join (124 KB of LDS per block: it could only run in a window between two
+            // fills).  With K3i on 32-byte rings (two blocks = 66 KB per CU) the join (91 KB) and the chaining's
+            // preparation (16 KB per wavefront) fit NEXT to a fill: no window, fills back to back.
+            if (ctx->band_window) BG_HIP(hipStreamWaitEvent(st, B.set[(n_chunk + 1) & 1].matched, 0));
         }
         if (ctx->timing) BG_HIP(hipEventRecord(ctx->ev[0], st));
         // Geometry by sub-batch size: K3v2 binds a pair to 8 lanes for ~30 ms whatever the batch (throughput comes from the
@@ -743,10 +743,13 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
             a.started = on_device ? B.d_started : nullptr;
             a.tb_flip = kTbFlip;
             // interior runs (band_split): scaled keys, x kept whole, a real y-prefix clip — semiglobal-like scorings
+            a.ring32 = ctx->band_window ? 0 : 1;
             a.split = (narrow && !ctx->band_interior_off && cs.xclip_prefix <= BG_MIN_SCORE / 2 && cs.xclip_suffix <= BG_MIN_SCORE / 2 &&
                        cs.yclip_prefix > BG_MIN_SCORE / 2) ? 1 : 0;
             if (on_device) B.started_target += band_fill2_blocks(a.n_pairs);
-            launch_band_fill2(a, narrow, st, S.fill_gone);  // K3v2: eight pairs per wavefront + separate epilogue
+            // K3v2 / K3i: eight pairs per wavefront; the epilogue goes to the traceback stream, ahead of K4 — the fill
+            // stream goes straight on with the next sub-batch (event timing keeps everything on one stream)
+            launch_band_fill2(a, narrow, st, S.fill_gone, ctx->timing || ctx->band_window ? nullptr : st_tb);
             S.fill_gone_valid = true;
         }
         else {

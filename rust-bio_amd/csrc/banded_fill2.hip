@@ -304,7 +304,8 @@ uint32_t band_fill2_blocks(uint32_t n_pairs) {
     return (jobs + 3) / 4;
 }
 
-bool launch_band_fill2(const BandArgs& a0, bool narrow, hipStream_t st, hipEvent_t after_fill) {
+bool launch_band_fill2(const BandArgs& a0, bool narrow, hipStream_t st, hipEvent_t after_fill, hipStream_t epi) {
+    // epi: the epilogue runs there, behind after_fill (so that `st` can go on with the fill of the next sub-batch); null: on st
     constexpr int LP = BF2_LP, PW = 64 / LP;
     BandArgs a = a0;
     const uint32_t jobs = (a.n_pairs + PW - 1) / PW;
@@ -330,13 +331,15 @@ bool launch_band_fill2(const BandArgs& a0, bool narrow, hipStream_t st, hipEvent
             launch_fill2_narrow(a, grid, st);
         }
         if (after_fill) (void)hipEventRecord(after_fill, st);
-        banded_epilogue_kernel<2, true><<<dim3((a.n_pairs + 3) / 4), dim3(256), 0, st>>>(a);
+        if (epi && after_fill) (void)hipStreamWaitEvent(epi, after_fill, 0);
+        banded_epilogue_kernel<2, true><<<dim3((a.n_pairs + 3) / 4), dim3(256), 0, epi && after_fill ? epi : st>>>(a);
     } else {
         a.phase = 0;
         a.split = 0;
         launch_fill2_wide(a, grid, st);
         if (after_fill) (void)hipEventRecord(after_fill, st);
-        banded_epilogue_kernel<2, false><<<dim3((a.n_pairs + 3) / 4), dim3(256), 0, st>>>(a);
+        if (epi && after_fill) (void)hipStreamWaitEvent(epi, after_fill, 0);
+        banded_epilogue_kernel<2, false><<<dim3((a.n_pairs + 3) / 4), dim3(256), 0, epi && after_fill ? epi : st>>>(a);
     }
     return true;
 }

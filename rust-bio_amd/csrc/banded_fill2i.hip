@@ -32,9 +32,8 @@ __device__ __forceinline__ uint32_t bfi(uint32_t a, uint32_t b) {  // (MASK & a)
     return r;
 }
 
-template <int R, int LP>
+template <int R, int LP, int RING>  // RING: bytes of LDS per row (64: banded_fill2.inc's; 32: half the LDS, twice the hand-overs)
 __global__ __launch_bounds__(256) void banded_fill2i_kernel(const BandArgs a) {
-    constexpr int RING = 64;          // bytes of LDS per row (banded_fill2.inc)
     constexpr int FLUSH = RING / 2;   // steps between two hand-overs of complete 16-byte groups
     static_assert(FLUSH % (2 * LP) == 0 && 2 * LP == 16, "hand-overs fall on chunk-pair boundaries; the Sn blocks are the chunk pairs");
     constexpr int LANE_LDS = R * RING + 4;  // lanes one bank apart
@@ -266,7 +265,10 @@ __global__ __launch_bounds__(256) void banded_fill2i_kernel(const BandArgs a) {
 }  // namespace
 
 void launch_fill2i(const BandArgs& a, dim3 grid, hipStream_t st) {
-    banded_fill2i_kernel<BF2_R, BF2_LP><<<grid, dim3(256), 0, st>>>(a);
+    if (a.ring32)
+        banded_fill2i_kernel<BF2_R, BF2_LP, 32><<<grid, dim3(256), 0, st>>>(a);
+    else
+        banded_fill2i_kernel<BF2_R, BF2_LP, 64><<<grid, dim3(256), 0, st>>>(a);
 }
 
 }  // namespace bgband_dev

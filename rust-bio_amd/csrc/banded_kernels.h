@@ -91,6 +91,7 @@ struct BandArgs {
     uint32_t tb_flip;   // XORed onto every traceback byte K4 reads (kTbFlip after K3v2, 0 after K3)
     uint32_t* started;  // K3v2: every block counts itself in when it starts (nullptr: nobody is waiting for that)
     int32_t phase;  // K3v2: 0 all strips of every pair; 1 / 2: the strips before / behind the interior run (band_split)
+    int32_t ring32; // K3i with 32-byte rings (33 KB of LDS per block instead of 65)
     int32_t split;  // the scoring admits interior runs (host decision, banded_api.hip): band_split may say yes
 };
 
@@ -117,7 +118,7 @@ typedef void (*band_fill_fn)(const BandArgs);
 band_fill_fn get_band_fill(int sm);
 // K3v2 (banded_fill2.hip): LP lanes per pair, R rows per lane, MatchParams scoring; the last-column
 // epilogue runs in its own kernel.  Returns false if the geometry is not instantiated.
-bool launch_band_fill2(const BandArgs& a, bool narrow, hipStream_t st, hipEvent_t after_fill = nullptr);
+bool launch_band_fill2(const BandArgs& a, bool narrow, hipStream_t st, hipEvent_t after_fill = nullptr, hipStream_t epi = nullptr);
 void launch_fill2i(const BandArgs& a, dim3 grid, hipStream_t st);  // banded_fill2i.hip: the interior runs  // after_fill: recorded between the fill and its epilogue
 uint32_t band_fill2_blocks(uint32_t n_pairs);  // thread blocks launch_band_fill2 starts for n_pairs
 // holds `st` until *counter >= target (or ~20 ms have passed): "the fill kernel's blocks are all resident"

@@ -67,7 +67,7 @@ struct bg_ctx {
     int band_fill_v1 = 0;  // 1: K3 (one pair per wavefront) even where K3v2 applies; -1: K3v2 even for small sub-batches; 0: by size
     bool band_interior_off = false;  // tests: K3v2 takes its general step in every strip (no reduced step in interior strips)
     bool band_tail_last = false;   // A/B: the remainder sub-batch of a large banded call runs last (round 3) instead of first
-    bool band_prep_early = false;  // A/B: the chaining's preparation runs with the join between two fills (round 3)
+    bool band_window = false;      // A/B: K3i on 64-byte rings, and the fill waits for the next sub-batch's join + preparation (round 3's window between two fills)
     bool band_raster_late = false; // A/B: the raster of sub-batch c + 1 waits for fill c to leave the device (round 3)
     bool band_on_host = false;  // build bands with the host builder (band_host.cpp) instead of band_device.hip
     // the scratch above is one set per ctx: a *_dev call arriving on another stream than the previous one first

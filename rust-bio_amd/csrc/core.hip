@@ -204,8 +204,8 @@ extern "C" int bg_set_option(bg_ctx* ctx, const char* key, int64_t value) {
         ctx->band_tail_last = value != 0;
         return BG_OK;
     }
-    if (!strcmp(key, "band_prep_early")) {
-        ctx->band_prep_early = value != 0;
+    if (!strcmp(key, "band_window")) {
+        ctx->band_window = value != 0;
         return BG_OK;
     }
     if (!strcmp(key, "band_raster_late")) {

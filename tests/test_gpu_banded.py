@@ -412,7 +412,7 @@ def test_interior_runs_long_reads_vs_oracle(case):
     differential(kw, True, case["mode"], case["k"], case["w"], xs, ys)
 
 
-@pytest.mark.parametrize("opts", [{}, {"band_tail_last": 1}, {"band_prep_early": 1, "band_raster_late": 1}],
+@pytest.mark.parametrize("opts", [{}, {"band_tail_last": 1}, {"band_window": 1, "band_raster_late": 1}],
                          ids=["default", "tail-last", "round3-order"])
 def test_several_sub_batches_and_the_remainder_first(opts):
     """A batch that spans several sub-batches (chunk_pairs = 16, 70 pairs: the remainder of 6 runs first, then four full
@@ -440,7 +440,7 @@ def test_several_sub_batches_and_the_remainder_first(opts):
     dev = torch.device("cuda:0")
     dx, dy = torch.from_numpy(x.copy()).to(dev), torch.from_numpy(y.copy()).to(dev)
     dxo, dyo = torch.from_numpy(xo.astype(np.int64)).to(dev), torch.from_numpy(yo.astype(np.int64)).to(dev)
-    stride = int(max(len(a) + len(b) for a, b in zip(xs, ys))) + 8
+    stride = max(len(a) for a in xs) + max(len(b) for b in ys) + 8
     d_out = torch.zeros(len(xs) * 64, dtype=torch.uint8, device=dev)
     d_ops = torch.zeros(len(xs) * stride, dtype=torch.uint8, device=dev)
     al.align_dev(MODES["custom"], len(xs), dx.data_ptr(), dxo.data_ptr(), dy.data_ptr(), dyo.data_ptr(), d_out.data_ptr(),
