@@ -153,6 +153,7 @@ struct bg_band_scratch {
         size_t dc_pairs = 0, dc_rowc = 0, dc_roff = 0, dc_tb = 0, dc_aux = 0;
         hipEvent_t copied = nullptr, filled = nullptr, traced = nullptr, built = nullptr, matched = nullptr;
         hipEvent_t fill_gone = nullptr;  // the fill kernel itself is off the device (its epilogue may still run)
+        hipEvent_t cleared = nullptr;    // the aux block has been zeroed (on aux_stream)
         bool busy = false, fill_gone_valid = false;
     } set[2];
     // device band builder (band_device.hip): scratch slices per pair + its per-pair state
@@ -173,6 +174,7 @@ struct bg_band_scratch {
     hipStream_t dl_stream = nullptr;            // ... which a few blocks on this high-priority stream bring to h_ops meanwhile
     static constexpr uint64_t kDlSlots = 1024;
     hipStream_t tb_stream = nullptr;
+    hipStream_t aux_stream = nullptr;   // clears the aux block of the next sub-batch under the running fill
     hipStream_t copy_stream = nullptr;  // host-buffer flavour: sequence slices go up here
     uint32_t* d_started = nullptr;  // blocks of the K3v2 launches of the current call that have started (see banded_fill2.hip)
     uint32_t started_target = 0;    // ... and how many have been launched
@@ -191,6 +193,7 @@ void bg_band_scratch_free(bg_band_scratch* b) {
         if (s.built) hipEventDestroy(s.built);
         if (s.matched) hipEventDestroy(s.matched);
         if (s.fill_gone) hipEventDestroy(s.fill_gone);
+        if (s.cleared) hipEventDestroy(s.cleared);
     }
     for (void* p : b->io) hipFree(p);
     hipFree(b->d_cmp);
@@ -202,6 +205,7 @@ void bg_band_scratch_free(bg_band_scratch* b) {
     hipHostFree(b->h_state);
     hipHostFree(b->h_ops);
     if (b->tb_stream) hipStreamDestroy(b->tb_stream);
+    if (b->aux_stream) hipStreamDestroy(b->aux_stream);
     if (b->copy_stream) hipStreamDestroy(b->copy_stream);
     if (b->build_stream) hipStreamDestroy(b->build_stream);
     if (b->seq_ready) hipEventDestroy(b->seq_ready);
@@ -715,7 +719,13 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
             BG_HIP(hipMemcpyAsync(S.d_roff, h_roff, rows * 4, hipMemcpyHostToDevice, st));
         }
         BG_HIP(hipEventRecord(S.copied, st));
-        BG_HIP(hipMemsetAsync(S.d_aux, 0, auxw * 4, st));
+        // the aux block is cleared on a stream of its own: 7 GB per sub-batch, 1.8 ms that used to sit between two fills
+        // (the set's previous user, K4 of two sub-batches ago, is done: issue() waited for it)
+        if (!B.aux_stream) BG_HIP(hipStreamCreateWithFlags(&B.aux_stream, hipStreamNonBlocking));
+        if (!S.cleared) BG_HIP(hipEventCreateWithFlags(&S.cleared, hipEventDisableTiming));
+        BG_HIP(hipMemsetAsync(S.d_aux, 0, auxw * 4, B.aux_stream));
+        BG_HIP(hipEventRecord(S.cleared, B.aux_stream));
+        BG_HIP(hipStreamWaitEvent(st, S.cleared, 0));
         a.pairs = (const BandPair*)S.d_pairs;
         a.rowc = (const int2*)S.d_rowc;
         a.row_off = (const uint32_t*)S.d_roff;
@@ -754,6 +764,7 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
         }
         else {
             a.tb_flip = 0;
+            a.split = 0;  // (K4 reads it too)
             fill<<<dim3((unsigned)((take + 3) / 4)), dim3(256), 0, st>>>(a);
             S.fill_gone_valid = false;
         }

@@ -33,7 +33,7 @@ __device__ __forceinline__ uint32_t bfi(uint32_t a, uint32_t b) {  // (MASK & a)
 }
 
 template <int R, int LP, int RING>  // RING: bytes of LDS per row (64: banded_fill2.inc's; 32: half the LDS, twice the hand-overs)
-__global__ __launch_bounds__(256) void banded_fill2i_kernel(const BandArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void banded_fill2i_kernel(const BandArgs a) {
     constexpr int FLUSH = RING / 2;   // steps between two hand-overs of complete 16-byte groups
     static_assert(FLUSH % (2 * LP) == 0 && 2 * LP == 16, "hand-overs fall on chunk-pair boundaries; the Sn blocks are the chunk pairs");
     constexpr int LANE_LDS = R * RING + 4;  // lanes one bank apart
@@ -48,6 +48,7 @@ __global__ __launch_bounds__(256) void banded_fill2i_kernel(const BandArgs a) {
     const int32_t sn_bias = to_s(a.sc.ys);  // Sn[] is kept without its constant term (banded_fill2.inc)
     constexpr int PW = 64 / LP;
     constexpr int RS = LP * R;
+    static_assert(RS == (int)kSplitStripRows, "K4 tells the rows of an interior run by this");
     const int lane = threadIdx.x & 63;
     const int g = lane / LP, ll = lane % LP;
     if (a.started && threadIdx.x == 0) atomicAdd(a.started, 1u);  // see launch_band_wait_started
@@ -89,8 +90,15 @@ __global__ __launch_bounds__(256) void banded_fill2i_kernel(const BandArgs a) {
     s_lo_w = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_lo_w);
     s_hi_w = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_hi_w);
 
-    const int32_t ge_s = sc.ge * 16, go_t = sc.go * 16 + 8;  // open candidates carry bit 3
-    const int32_t match_k = (sc.match * 16) | (int32_t)C_MATCH, mismatch_k = (sc.mismatch * 16) | (int32_t)C_SUBST;
+    // Keys of this kernel: score << 4 | candidate priority << 1 | "the gap was opened here".  I and D values CARRY their
+    // priority (C_INS, C_DEL) in bits 1-3 wherever they go, so they enter the cell's maximum as they are (K3v2 clears the
+    // low bits of both and ors the priority in: two instructions per cell each); the open flag sits below the priority,
+    // where it cannot reorder candidates of different kinds, and makes "open" win a tie against "extend" as the
+    // reference's strict '>' does (banded.rs:583-589, 601-607).  The traceback byte of an interior row is therefore
+    // bit 0 = I opened, bits 1-3 = the S move, bit 4 = D opened (tb_cell_norm, banded_kernels.h, for K4).
+    constexpr int32_t kI = (int32_t)(C_INS << 1), kD = (int32_t)(C_DEL << 1);
+    const int32_t ge_s = sc.ge * 16, go_ti = sc.go * 16 + (kI | 1), go_td = sc.go * 16 + (kD | 1);
+    const int32_t match_k = (sc.match * 16) | (int32_t)(C_MATCH << 1), mismatch_k = (sc.mismatch * 16) | (int32_t)(C_SUBST << 1);
 
     for (uint32_t strip = s_lo_w; strip < s_hi_w; strip++) {
         const bool act = live && strip >= s_lo && strip < s_hi;
@@ -103,7 +111,8 @@ __global__ __launch_bounds__(256) void banded_fill2i_kernel(const BandArgs a) {
         for (int r = 0; r < R; r++) {
             const uint32_t i = rb + r + 1;
             px[r] = 0;
-            Sl[r] = Dl[r] = NEGS;
+            Sl[r] = NEGS;
+            Dl[r] = NEGS | kD;
             Sn[r] = NEGS - sn_bias;
             SnB[r] = NEGS;
             ycl[r] = NEGS;
@@ -118,7 +127,7 @@ __global__ __launch_bounds__(256) void banded_fill2i_kernel(const BandArgs a) {
                 if (rc.y >= rc.x) {
                     trow[r] = roff[i];
                     px[r] = x[i - 1];
-                    ycl[r] = (int32_t)((uint32_t)to_s(sc.yp + sc.go + sc.ge * ((int32_t)i - 1)) | C_YP);
+                    ycl[r] = (int32_t)((uint32_t)to_s(sc.yp + sc.go + sc.ge * ((int32_t)i - 1)) | (C_YP << 1));
                     jlo = min(jlo, rc.x);
                     jhi = max(jhi, rc.y);
                 }
@@ -166,19 +175,19 @@ __global__ __launch_bounds__(256) void banded_fill2i_kernel(const BandArgs a) {
         // what the pair's first lane needs at column j (the y symbol and the cell above the strip, as the strip above left
         // it in bnd), prepared LP columns at a time: lane ll of the pair prepares column jlo + t0 + ll
         auto load_chunk = [&](int t0) -> Chunk {
-            Chunk c = {0, NEGS, NEGS};
+            Chunk c = {0, NEGS, NEGS | kI};
             const int jj = jlo + t0 + ll;
             if (jj >= 1 && jj <= jhi) {
                 c.q = y[jj - 1];
                 if (rc_above.y >= rc_above.x && jj >= rc_above.x && jj <= rc_above.y) {
                     const int2 b2 = *(const int2*)&bnd[jj];
                     c.S = b2.x;
-                    c.I = b2.y;
+                    c.I = b2.y | kI;  // (bnd holds K3v2's clean values)
                 }
             }
             return c;
         };
-        int32_t S_out = NEGS, I_out = NEGS, q_out = 0;
+        int32_t S_out = NEGS, I_out = NEGS | kI, q_out = 0;
         auto step = [&](const int t, Chunk& c) {
             const int32_t tpri = 15 - (t & 15);
             int32_t S_up = wave_shr1z(S_out), I_up = wave_shr1z(I_out), q = wave_shr1z(q_out);
@@ -197,27 +206,26 @@ __global__ __launch_bounds__(256) void banded_fill2i_kernel(const BandArgs a) {
                     const bool inb = (uint32_t)jc < wn[r];
                     const int32_t left_S = Sl[r];
                     const int32_t m_key = diag + (px[r] == (uint32_t)q ? match_k : mismatch_k);
-                    const int32_t Iv_t = max(I_up + ge_s, S_up + go_t);    // banded.rs:580-588
-                    const int32_t Dv_t = max(Dl[r] + ge_s, left_S + go_t);  // banded.rs:598-607
-                    const int32_t Iv = Iv_t & ~15, Dv = Dv_t & ~15;
-                    // banded.rs:609-642 (i != m: S[curr][i] = MIN_SCORE first): first maximum == max over (score | priority)
-                    int32_t kb = max(m_key, (int32_t)((uint32_t)Iv | C_INS));
-                    kb = max(kb, (int32_t)((uint32_t)Dv | C_DEL));
+                    const int32_t Iv_t = max(I_up + ge_s, S_up + go_ti);    // banded.rs:580-588
+                    const int32_t Dv_t = max(Dl[r] + ge_s, left_S + go_td);  // banded.rs:598-607
+                    // banded.rs:609-642 (i != m: S[curr][i] = MIN_SCORE first): first maximum == max over the keys
+                    int32_t kb = max(m_key, Iv_t);
+                    kb = max(kb, Dv_t);
                     kb = max(kb, ycl[r]);
                     const int32_t best = kb & ~15;
                     Sl[r] = inb ? best : NEGS;  // outside the band: MIN_SCORE towards every neighbour
-                    Dl[r] = inb ? Dv : NEGS;
+                    Dl[r] = inb ? (Dv_t & ~1) : (NEGS | kD);
                     S_up = Sl[r];
-                    I_up = inb ? Iv : NEGS;
+                    I_up = inb ? (Iv_t & ~1) : (NEGS | kI);
                     SnB[r] = max(SnB[r], Sl[r] | tpri);  // banded.rs:655-660, per block of 16 steps
-                    const uint32_t cell = bfi<16>((uint32_t)Dv_t << 1, bfi<8>((uint32_t)Iv_t, (uint32_t)kb));
+                    const uint32_t cell = bfi<16>((uint32_t)Dv_t << 4, bfi<1>((uint32_t)Iv_t, (uint32_t)kb));
                     s_row[r * RING + ((uint32_t)jc & (uint32_t)(RING - 1))] = (uint8_t)cell;
                     diag = left_S;
                 }
                 S_out = S_up;
                 I_out = I_up;
                 q_out = q;
-                if (ll == LP - 1) bnd[j] = make_int4(S_up, I_up, NEGS, 0);  // (fold fields: what a strip without a fold hands on)
+                if (ll == LP - 1) bnd[j] = make_int4(S_up, I_up & ~15, NEGS, 0);  // (K3v2's clean I; fold fields: what a strip without a fold hands on)
             }
             c.q = wave_shl1z(c.q);
             c.S = wave_shl1z(c.S);

@@ -114,6 +114,11 @@ __device__ __forceinline__ bool band_split(const SwScoring& sc, const BandPair& 
     return s_a < s_b;
 }
 
+constexpr uint32_t kSplitStripRows = 32;  // rows per strip of the kernels that split pairs (BF2_LP * BF2_R)
+// Traceback byte of a row inside an interior run (banded_fill2i.hip: bit 0 = I opened, bits 1-3 = S move, bit 4 = D opened)
+// in the layout of every other row (bits 0-2 = S move, bit 3 = I opened, bit 4 = D opened)
+__device__ __forceinline__ uint32_t tb_cell_norm(uint32_t b) { return ((b >> 1) & 7u) | ((b & 1u) << 3) | (b & 16u); }
+
 typedef void (*band_fill_fn)(const BandArgs);
 band_fill_fn get_band_fill(int sm);
 // K3v2 (banded_fill2.hip): LP lanes per pair, R rows per lane, MatchParams scoring; the last-column

@@ -111,8 +111,21 @@ __global__ __launch_bounds__(256) void banded_traceback_kernel(const BandArgs a)
         const int2 rc = rowc[i];
         return rc.y >= rc.x && (int)j >= rc.x && (int)j <= rc.y;
     };
+    // rows of the pair's interior run (band_split; filled by banded_fill2i.hip) keep their bytes in that kernel's layout
+    uint32_t in_lo = 1, in_hi = 0;  // rows in_lo .. in_hi
+    {
+        uint32_t s_a = 0, s_b = 0;
+        if (a.split && m != 0 && band_split(sc, bp, m, rowc, kSplitStripRows, s_a, s_b)) {
+            in_lo = s_a * kSplitStripRows + 1;
+            in_hi = s_b * kSplitStripRows;
+        }
+    }
+    auto raw_cell = [&](uint32_t i, uint32_t off) -> uint32_t {
+        const uint32_t b = tb[off];
+        return (i >= in_lo && i <= in_hi) ? tb_cell_norm(b) : b;
+    };
     // K3v2 leaves the I/D flags as its keys carry them (1 = opened): a.tb_flip turns them into 1 = extended
-    auto cellb = [&](uint32_t i, uint32_t j) -> uint32_t { return (uint32_t)tb[roff[i] + tb_cell_off(j - (uint32_t)rowc[i].x)] ^ a.tb_flip; };
+    auto cellb = [&](uint32_t i, uint32_t j) -> uint32_t { return raw_cell(i, roff[i] + tb_cell_off(j - (uint32_t)rowc[i].x)) ^ a.tb_flip; };
     // S nibble a cell carried while the matrix was being filled (what "open" I/D moves copied)
     auto s_fill = [&](uint32_t i, uint32_t j) -> uint32_t {
         if (i == 0) {
@@ -193,7 +206,7 @@ __global__ __launch_bounds__(256) void banded_traceback_kernel(const BandArgs a)
                 const uint32_t ii = i - lane, jj = j - lane;
                 const int2 rc = rowc[ii];
                 if (rc.y >= rc.x && (int)jj >= rc.x && (int)jj <= rc.y) {
-                    st = s_nibble_of_code((uint32_t)tb[roff[ii] + tb_cell_off(jj - (uint32_t)rc.x)] & 7u);
+                    st = s_nibble_of_code(raw_cell(ii, roff[ii] + tb_cell_off(jj - (uint32_t)rc.x)) & 7u);
                     ok = st == TB_MATCH || st == TB_SUBST;
                 }
             }
