@@ -60,6 +60,7 @@ def parse_args():
     ap.add_argument("--skip-k1", action="store_true")
     ap.add_argument("--skip-packed", action="store_true", help="no 2-bit packed A/B legs (packed2)")
     ap.add_argument("--k1-pairs", type=int, default=1_000_000, help="int32-kernel legs: pairs per GPU (configs[1]'s 1M)")
+    ap.add_argument("--skip-semiglobal", action="store_true", help="no Aligner::semiglobal leg on the headline pairs")
     ap.add_argument("--skip-banded", action="store_true")
     ap.add_argument("--banded-pairs", type=int, default=100_000,
                     help="banded leg: 10 kb pairs per GPU, and in total for banded.strong (configs[3]: 100k, split over the GPUs)")
@@ -454,6 +455,36 @@ def main():
         if parity is not None:
             parity["sw_int32_equals_int16_all_pairs"] = same
         del d_out32, d_ops32
+    # north_star names Aligner::semiglobal next to ::local (mod.rs:954-984): the same pairs through the semiglobal flavour of
+    # K1p (the general packed kernel: no LF shortcut), its own roofline, every pair against the oracle
+    if not args.skip_semiglobal:
+        d_outs, d_opss = torch.empty_like(d_out), torch.empty_like(d_ops)
+
+        def sg_step():
+            aligner.align_dev(2, n_pairs, x.data_ptr(), xo.data_ptr(), y.data_ptr(), yo.data_ptr(),
+                              L, L, d_outs.data_ptr(), d_opss.data_ptr(), stride, stream)
+
+        tsg = timed_steps(sg_step, args.steps, args.warmup, dev)
+        tmsg = kernel_timing(ctx, sg_step)
+        fsg = tmsg["fill_ms"] / max(1, tmsg["fill_launches"])
+        n_ops_sg = float(d_outs.view(torch.int32).view(n_pairs, 16)[:, 7].to(torch.int64).sum().item()) / n_pairs
+        sg = {"value": round(world * float(n_pairs) * L * L * args.steps / tsg / 1e9, 3), "unit": "GCUPS",
+              "dtype": "int16" if L <= 192 else "int32", "ms_per_step": round(tsg / args.steps * 1e3, 3),
+              "config": {"workload": f"{n_pairs} x {L} bp read pairs per GPU (the headline pairs), Aligner::semiglobal "
+                                     "affine-gap (-5,-1,+1,-1), score+coords+traceback ops"},
+              "roofline": sw_roofline("sw_fill_pk16_kernel" if L <= 192 else "sw_fill_kernel", fsg,
+                                      tmsg["traceback_ms"] / max(1, tmsg["traceback_launches"]),
+                                      n_pairs / (tmsg["fill_launches"] / 2), L, n_ops_sg,
+                                      "K1p, semiglobal flavour (x-suffix-clip fold and clip candidates kept): VALU-bound",
+                                      shape_key="sg_pairs_per_launch")}
+        if do_cpu:
+            n_chk = max(1, int(n_pairs * args.parity_frac))
+            oksg, t_parsg = sw_parity(orc, osc, "semiglobal", x, y, L, d_outs, d_opss, stride, n_chk, threads)
+            parity.update({"semiglobal_pairs_checked": n_chk, "semiglobal_bit_exact": oksg})
+            sg["cpu_baseline"] = {"value": round(n_chk * L * L / t_parsg / 1e9, 4), "unit": "GCUPS", "cores": threads, "kind": "port",
+                                  "sample": f"{n_chk} of the {n_pairs} pairs (the parity pass), oracle Aligner::semiglobal"}
+        result["semiglobal"] = sg
+        del d_outs, d_opss
     del x, y, d_ops, d_out
     torch.cuda.empty_cache()
 

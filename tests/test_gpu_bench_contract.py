@@ -41,6 +41,8 @@ def test_bench_line_has_the_contract_fields_and_green_parity():
     assert d["fm"]["strong"]["queries_total"] == 20000 and d["banded"]["strong"]["pairs_total"] == 70
     assert d["seed_extend"]["strong"]["reads_total"] == 4001 and d["seed_extend"]["strong"]["gathered_records"] == 4001
     assert d["value_int32"] > 0 and d["int32"]["records_and_ops_equal_int16_run"] is True
+    sg = d["semiglobal"]  # north_star: Aligner::local / semiglobal
+    assert sg["value"] > 0 and sg["roofline"]["frac"] > 0 and sg["cpu_baseline"]["value"] > 0 and d["parity"]["semiglobal_bit_exact"] is True
     assert d["packed2"]["records_and_ops_equal_byte_run"] is True and d["fm"]["packed2"]["results_equal_byte_run"] is True
     assert d["fm"]["roofline"]["requested_lines_per_launch"] > 0
     flags = {k: v for k, v in d["parity"].items() if isinstance(v, bool)}

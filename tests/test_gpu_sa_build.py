@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 import torch
 
+import oracle_py as orc
 from rust_bio_amd import _lib, synth
 from rust_bio_amd.bwt import bwt
 from rust_bio_amd.suffix_array import SampledSuffixArray, bwt_dev, sample_dev, suffix_array, suffix_array_dev
@@ -58,6 +59,11 @@ def test_device_suffix_array_and_bwt_equal_the_host_builders(name, text):
     assert (got == want).all(), name
     d_b = bwt_dev(d_text, d_sa)
     assert (d_b.cpu().numpy() == bwt(text, want)).all()
+    # ... and the oracle's restatement of suffix_array.rs:264-284 / bwt.rs:39-49 directly (the host builder is product
+    # code of its own: the device builder's parity does not rest on it)
+    osa = orc.suffix_array(text)
+    assert (got == np.asarray(osa, dtype=np.uint64)).all(), name
+    assert bytes(d_b.cpu().numpy()) == bytes(orc.bwt(text, osa)), name
 
 
 def test_sample_dev_equals_raw_suffix_array_sample():
