@@ -618,6 +618,12 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
             if ((rc = launch_band_raster(d, st_build))) return rc;
             BG_HIP(hipMemcpyAsync(B.h_state, d.state, want * sizeof(BandDevPair), hipMemcpyDeviceToHost, st_build));
             BG_HIP(hipEventRecord(S.built, st_build));
+            // The builder's own arrays are free again: the join and the chain preparation of the NEXT sub-batch go right
+            // behind, without waiting for the host to learn this one's sizes (finish() used to issue them: 2 ms of round trip
+            // on the builder's path, and they landed in the gap between two fills).  Speculative in one respect: the next
+            // sub-batch starts at p0 + want only if the scratch budget takes all of this one — otherwise finish() re-issues.
+            if (p0 + want < n_pairs && !ctx->band_window)
+                if ((rc = issue_match(p0 + want, n_chunk + 1))) return rc;
         } else {
         std::atomic<bool> bad_input{false};
             parallel_for(want, grain, [&](unsigned, uint64_t lo, uint64_t hi) {
@@ -736,7 +742,9 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
         if ((rc = need_seq(st, waited_fill, p0 + take))) return rc;
         if (on_device) BG_HIP(hipStreamWaitEvent(st, S.built, 0));
         if (on_device && p0 + take < n_pairs) {  // the next sub-batch's k-mer join goes first (see issue_match)
-            if ((rc = issue_match(p0 + take, n_chunk + 1))) return rc;
+            const Plan& N = plan[(n_chunk + 1) & 1];
+            if (!(N.matched && N.p0 == p0 + take))
+                if ((rc = issue_match(p0 + take, n_chunk + 1))) return rc;
             // Round 3: the fill waited for the join (124 KB of LDS per block: it could only run in a window between two
             // fills).  With K3i on 32-byte rings (two blocks = 66 KB per CU) the join (91 KB) and the chaining's
             // preparation (16 KB per wavefront) fit NEXT to a fill: no window, fills back to back.

@@ -122,7 +122,16 @@ extern "C" int bg_init(int device, bg_ctx** out) {
     // BG_BAND_FILL_V1: initial value of the option of that name (the test suite pins the eight-pairs-per-wavefront fill so
     // that its small batches keep exercising it)
     if (const char* e = getenv("BG_BAND_FILL_V1")) ctx->band_fill_v1 = atoi(e) > 0 ? 1 : atoi(e) < 0 ? -1 : 0;
-    BG_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    // The ctx's own stream carries the long kernels of the pipelines (the banded fills above all); helper streams (band
+    // construction, traceback, copies) are created at the default priority.  BG_STREAM_PRIO=0: default priority here too (A/B)
+    {
+        int lo = 0, hi = 0;
+        const char* e = getenv("BG_STREAM_PRIO");
+        if ((!e || atoi(e) != 0) && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo)
+            BG_HIP(hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, hi));
+        else
+            BG_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    }
     BG_HIP(hipEventCreate(&ctx->ev[0]));
     BG_HIP(hipEventCreate(&ctx->ev[1]));
     BG_HIP(hipEventCreateWithFlags(&ctx->scratch_done, hipEventDisableTiming));

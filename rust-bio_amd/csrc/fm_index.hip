@@ -1099,6 +1099,8 @@ int bg_fm_search_seeds_dev(bg_fm* fm, uint64_t n_reads, const uint8_t* d_reads, 
     const uint64_t blocks = std::min<uint64_t>((n_q + 63) / 64, 256 * 8);
     SeedSrc src = fm_codes(fm);
     src.S = S, src.stride = stride, src.seed_len = seed_len;
+    bg_ctx* ctx = fm->ctx;
+    if (ctx && ctx->timing) BG_HIP(hipEventRecord(ctx->ev[0], st));
     if (fm_fast_ok(fm) && seed_len <= kFastSyms) {
         fm_search_fast_kernel<true, false><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(fm->dev, n_q, d_reads, d_read_off, d_tag, d_lower,
                                                                                         d_upper, d_matched_len, src);
@@ -1109,6 +1111,14 @@ int bg_fm_search_seeds_dev(bg_fm* fm, uint64_t n_reads, const uint8_t* d_reads, 
             fm->dev, n_q, d_reads, d_read_off, d_tag, d_lower, d_upper, d_matched_len, nullptr, src);
     }
     BG_HIP(hipGetLastError());
+    if (ctx && ctx->timing) {  // (the seed search inside bg_seed_extend_batch_dev: kernel_ms.seed_search of bench.py)
+        BG_HIP(hipEventRecord(ctx->ev[1], st));
+        BG_HIP(hipEventSynchronize(ctx->ev[1]));
+        float ms = 0;
+        BG_HIP(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+        ctx->last.fm_ms += ms;
+        ctx->last.fm_launches += 1;
+    }
     return BG_OK;
 }
 
