@@ -13,6 +13,8 @@
 // moves per step instead of seven, three chunk fields instead of six, a cell of 29 instructions, and — the kernel being
 // this one loop — 2 x ~110 VGPRs per SIMD instead of 2 x 218: the builder kernels of the next sub-batch (the chaining's event
 // loop above all) find room next to it.
+#include <type_traits>
+
 #include "banded_kernels.h"
 
 namespace bgband_dev {
@@ -188,7 +190,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             return c;
         };
         int32_t S_out = NEGS, I_out = NEGS | kI, q_out = 0;
-        auto step = [&](const int t, Chunk& c) {
+        // all_in: every row of every lane that has a column at this step is inside its band (the 16-step blocks between T1
+        // and T2 below) — no band test, nothing forced to MIN_SCORE: four instructions per cell less
+        auto step = [&](const int t, Chunk& c, auto all_in_tag) {
+            constexpr bool ALL_IN = decltype(all_in_tag)::value;
             const int32_t tpri = 15 - (t & 15);
             int32_t S_up = wave_shr1z(S_out), I_up = wave_shr1z(I_out), q = wave_shr1z(q_out);
             if (ll == 0) {
@@ -203,7 +208,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
                 for (int r = 0; r < R; r++) {
                     const int32_t jc = j - cf[r];
-                    const bool inb = (uint32_t)jc < wn[r];
+                    const bool inb = ALL_IN || (uint32_t)jc < wn[r];
                     const int32_t left_S = Sl[r];
                     const int32_t m_key = diag + (px[r] == (uint32_t)q ? match_k : mismatch_k);
                     const int32_t Iv_t = max(I_up + ge_s, S_up + go_ti);    // banded.rs:580-588
@@ -242,14 +247,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 SnB[r] = NEGS;
             }
         };
+        // steps T1 .. T2: every lane of every pair that takes part in this strip has all its R rows inside their bands
+        int T1 = -0x40000000, T2 = 0x40000000;  // (a pair that sits this strip out has no say)
+        if (jhi >= jlo) {
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                T1 = wn[r] ? max(T1, cf[r] - jlo + ll) : 0x40000000;
+                T2 = min(T2, cl[r] - jlo + ll);
+            }
+        }
+#pragma unroll
+        for (int o = 32; o; o >>= 1) {
+            T1 = max(T1, __shfl_xor(T1, o));
+            T2 = min(T2, __shfl_xor(T2, o));
+        }
+        T1 = __builtin_amdgcn_readfirstlane(T1);
+        T2 = __builtin_amdgcn_readfirstlane(T2);
         Chunk c_even = load_chunk(0), c_odd;
         for (int t0 = 0; t0 < nsteps_w; t0 += 2 * LP) {
             c_odd = load_chunk(t0 + LP);
+            if (t0 >= T1 && t0 + 2 * LP - 1 <= T2) {  // (then t0 + 2 * LP <= nsteps_w as well)
+#pragma unroll 2
+                for (int t = t0; t < t0 + LP; t++) step(t, c_even, std::true_type{});
+                c_even = load_chunk(t0 + 2 * LP);
+#pragma unroll 2
+                for (int t = t0 + LP; t < t0 + 2 * LP; t++) step(t, c_odd, std::true_type{});
+            } else {
 #pragma unroll 1
-            for (int t = t0; t < min(t0 + LP, nsteps_w); t++) step(t, c_even);
-            c_even = load_chunk(t0 + 2 * LP);
+                for (int t = t0; t < min(t0 + LP, nsteps_w); t++) step(t, c_even, std::false_type{});
+                c_even = load_chunk(t0 + 2 * LP);
 #pragma unroll 1
-            for (int t = t0 + LP; t < min(t0 + 2 * LP, nsteps_w); t++) step(t, c_odd);
+                for (int t = t0 + LP; t < min(t0 + 2 * LP, nsteps_w); t++) step(t, c_odd, std::false_type{});
+            }
             merge_rows(t0 + 2 * LP - 1);
             const int t_done = min(t0 + 2 * LP, nsteps_w);
             if ((t_done & (FLUSH - 1)) == 0) flush_tb(jlo + t_done - 1 - ll, jlo + t_done - 1 - ll - FLUSH, false);
