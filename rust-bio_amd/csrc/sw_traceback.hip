@@ -48,53 +48,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
     // back in it: the 64 bytes a lane wrote for 16 / NW consecutive steps (one tile row, tb_word_off) are
     // fetched once into this thread's LDS slot and the following cells are served from there — one global
     // round trip per ~8 cells of the path instead of one per cell.
+    // (Round 4 built the prefetch DESIGN.md had sketched: every miss also fetched the slot a diagonal walk needs next
+    //  — previous tile row of the lane, or the lane above — into 16 registers, and a miss that found its slot there
+    //  copied it from registers.  Measured on 1 M x 150 bp: 1.69 ms against 1.39 — the 16 registers cost the fifth
+    //  wavefront per SIMD (102 -> 128 VGPRs; with five and spills: 3.85 ms), and the second load per miss doubles the
+    //  requests of a kernel that already sits near the gather rate.  Removed.)
     __shared__ __align__(16) uint32_t s_seg[256 * kSegStride];
     uint32_t* seg = s_seg + threadIdx.x * kSegStride;
     uint64_t seg_tag = ~0ull;
-    // The slot a path needs next is predictable: down a diagonal (nine moves in ten on reads like the bench's) it is the
-    // previous tile row of the same lane after (g % tsteps) + 1 steps, or the slot of the lane above after rr + 1 steps,
-    // whichever comes first.  With 64 paths per wavefront out of step, some lane misses at nearly every step and the
-    // whole wavefront waits a memory round trip with it: so every miss also fetches the PREDICTED next slot into
-    // registers (64 bytes), and a miss that finds its slot there costs four LDS writes instead of the round trip.
-    uint4 pre[4];
-    uint64_t pre_tag = ~0ull;
-#pragma unroll
-    for (int q = 0; q < 4; q++) pre[q] = make_uint4(0, 0, 0, 0);
-    constexpr uint32_t tsteps = 16 / NW;
-    auto slot_base = [&](uint32_t i, uint32_t j, uint64_t& g, uint32_t& rr) -> uint64_t {
-        const uint32_t i1 = i - 1, lrow = __umulhi(i1, geo.r_inv);  // i1 / R, exact (sw_kernels.h)
-        rr = i1 - lrow * R;
-        const uint32_t st = lrow >> geo.lp_shift, llc = lrow & (LP - 1);
-        g = (uint64_t)st * geo.nsteps + (j - 1 + llc);
-        return (g / tsteps) * 1024ull + (grp * LP + llc) * 16u;
-    };
     // packed 5 bits of inner cell (1 <= i <= m, 1 <= j <= n)
     auto cell = [&](uint32_t i, uint32_t j) -> uint32_t {
-        uint64_t g;
-        uint32_t rr;
-        const uint64_t base = slot_base(i, j, g, rr);
+        const uint32_t i1 = i - 1, lrow = __umulhi(i1, geo.r_inv), rr = i1 - lrow * R;  // i1 / R, exact (sw_kernels.h)
+        const uint32_t st = lrow >> geo.lp_shift, llc = lrow & (LP - 1);
+        const uint64_t g = (uint64_t)st * geo.nsteps + (j - 1 + llc);
+        constexpr uint32_t tsteps = 16 / NW;
+        const uint64_t base = (g / tsteps) * 1024ull + (grp * LP + llc) * 16u;
         if (base != seg_tag) {
-            if (base == pre_tag) {
 #pragma unroll
-                for (int q = 0; q < 4; q++) *(uint4*)&seg[4 * q] = pre[q];
-            } else {
-#pragma unroll
-                for (int q = 0; q < 4; q++) *(uint4*)&seg[4 * q] = *(const uint4*)&tbj[base + 4 * q];
-            }
+            for (int q = 0; q < 4; q++) *(uint4*)&seg[4 * q] = *(const uint4*)&tbj[base + 4 * q];
             seg_tag = base;
-            // the slot a diagonal walk from here leaves this one for
-            const uint32_t d = min((uint32_t)(g % tsteps), rr) + 1;
-            pre_tag = ~0ull;
-            if (i > d && j > d) {
-                uint64_t g2;
-                uint32_t rr2;
-                const uint64_t nb = slot_base(i - d, j - d, g2, rr2);
-                if (nb != base) {
-#pragma unroll
-                    for (int q = 0; q < 4; q++) pre[q] = *(const uint4*)&tbj[nb + 4 * q];
-                    pre_tag = nb;
-                }
-            }
         }
         const uint32_t w = seg[(uint32_t)(g % tsteps) * NW + rr / 6];
         const uint32_t c = rr % 6;

@@ -71,6 +71,32 @@ WORKER = textwrap.dedent("""
     assert full.shape == (n_pairs, 5)
     if rank == 0:
         assert (full == align(0, n_pairs)).all(), "sharded alignment records differ from the unsharded run"
+    # ---- ragged pairs, shards balanced by the sum of DP cells (SURVEY.md section 8(e)): mixed read lengths, the boundary
+    # of partition_balanced, ragged gather (different record counts per rank), against the unsharded run
+    rng = np.random.default_rng(9)
+    lens_x = rng.choice([40, 75, 150, 300, 600], size=1501)
+    lens_y = (lens_x * rng.uniform(0.8, 1.3, size=1501)).astype(np.int64) + 1
+    rxo = np.concatenate([[0], np.cumsum(lens_x)]).astype(np.int64)
+    ryo = np.concatenate([[0], np.cumsum(lens_y)]).astype(np.int64)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    rx, ry = acgt[rng.integers(0, 4, size=int(rxo[-1]))], acgt[rng.integers(0, 4, size=int(ryo[-1]))]
+    bounds = shard.partition_balanced(lens_x * lens_y, world)
+    cells = [int((lens_x[bounds[r]:bounds[r + 1]] * lens_y[bounds[r]:bounds[r + 1]]).sum()) for r in range(world)]
+    assert bounds[0] == 0 and bounds[-1] == 1501 and bounds[1] != 1501 // 2            # not the equal-count split
+    assert abs(cells[0] - cells[1]) <= int((lens_x * lens_y).max())                     # balanced to within one pair
+    def align_ragged(lo, hi):
+        k = hi - lo
+        dx = torch.from_numpy(rx[rxo[lo]:rxo[hi]].copy()).to(dev); dy = torch.from_numpy(ry[ryo[lo]:ryo[hi]].copy()).to(dev)
+        ox = torch.from_numpy(rxo[lo:hi + 1] - rxo[lo]).to(dev); oy = torch.from_numpy(ryo[lo:hi + 1] - ryo[lo]).to(dev)
+        mx, my = int(lens_x.max()), int(lens_y.max())
+        out = torch.empty(k * 64, dtype=torch.uint8, device=dev); ops = torch.empty(k * (mx + my + 4), dtype=torch.uint8, device=dev)
+        al.align_dev(3, k, dx.data_ptr(), ox.data_ptr(), dy.data_ptr(), oy.data_ptr(), mx, my, out.data_ptr(), ops.data_ptr(), mx + my + 4, st)
+        torch.cuda.synchronize()
+        return out.view(torch.int32).view(k, 16)[:, :5].contiguous().cpu()
+    full = shard.gather_records(align_ragged(bounds[rank], bounds[rank + 1]))
+    assert full.shape == (1501, 5)
+    if rank == 0:
+        assert (full == align_ragged(0, 1501)).all(), "cost-balanced ragged shards differ from the unsharded run"
     t = shard.max_over_ranks(1.0 + rank, torch.device("cpu"))
     assert t == 2.0
     shard.barrier()
