@@ -290,18 +290,24 @@ __global__ __launch_bounds__(256) void fm_backward_search_kernel(
 // PACKED: `pat` is a 2-bit stream already (pack2.hip, the index's codes; offsets in symbols): taking a query is a funnel
 // shift of up to 16 dwords into the slot, nothing can be "bad".
 constexpr uint32_t kFastSyms = 256;
-template <bool SEEDS, bool COUNT, bool PACKED = false>
+// STEP2: the LF loop takes two pattern symbols per block access from the index's 2-step rank blocks (fm_kernels.h:
+// Fm2Dev; f2.blocks2 != null), single steps — the last symbol of an odd-length pattern, and the two steps of a double
+// step that found nothing — from the same blocks: half the requests of a query against a request-rate limit.
+template <bool SEEDS, bool COUNT, bool PACKED = false, bool STEP2 = false>
 __global__ __launch_bounds__(256) void fm_search_fast_kernel(FmDev fm, uint64_t n_q, const uint8_t* __restrict__ pat,
                                                              const uint64_t* __restrict__ pat_off, uint8_t* __restrict__ tag,
                                                              uint64_t* __restrict__ lower, uint64_t* __restrict__ upper,
-                                                             uint32_t* __restrict__ matched_len, const SeedSrc seeds) {
+                                                             uint32_t* __restrict__ matched_len, const SeedSrc seeds, const Fm2Dev f2) {
     __shared__ uint16_t s_class[256];
     __shared__ uint32_t s_less4[4];
     __shared__ uint32_t s_exc[kMaxExcLds];
-    __shared__ uint32_t s_pk[64 * (kFastSyms / 16)];
+    __shared__ uint32_t s_pk[64 * (kFastSyms / 16) + 1];  // (+1: the 2-step funnel reads one dword past a slot's last)
     for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) s_class[i] = fm.sym_class[i];
     if (threadIdx.x < 4) s_less4[threadIdx.x] = fm.less[(seeds.code_bytes >> (8 * threadIdx.x)) & 0xFFu];
     for (uint32_t i = threadIdx.x; i < fm.n_exc; i += blockDim.x) s_exc[i] = fm.exc_pos[i];
+    if (threadIdx.x == 0) s_pk[64 * (kFastSyms / 16)] = 0;
+    __shared__ uint32_t s_c2[16];
+    if (STEP2 && threadIdx.x < 16) s_c2[threadIdx.x] = f2.c2[threadIdx.x];
     __syncthreads();
 
     const uint32_t t = threadIdx.x & 3;
@@ -310,7 +316,7 @@ __global__ __launch_bounds__(256) void fm_search_fast_kernel(FmDev fm, uint64_t 
     uint32_t* const wave_slots = s_pk + (threadIdx.x >> 6) * 16 * (kFastSyms / 16);  // the 16 slots of this wavefront
     const uint64_t n_quads = (uint64_t)gridDim.x * (blockDim.x >> 2);
     uint64_t q = (uint64_t)blockIdx.x * (blockDim.x >> 2) + (threadIdx.x >> 2);
-    bool active = false, need = true;
+    bool active = false, need = true, force1 = false;
     uint32_t pos = 0, l = 0, r = 0, matched = 0, n_lines = 0;
 
     // Taking the next query is a job of the WHOLE wavefront, one waiting quad at a time (round 3; a quad packing its own
@@ -395,6 +401,7 @@ __global__ __launch_bounds__(256) void fm_search_fast_kernel(FmDev fm, uint64_t 
                 matched = 0;
                 active = true;
                 need = false;
+                force1 = false;
             }
             waiting &= waiting - 1;
         }
@@ -410,7 +417,84 @@ __global__ __launch_bounds__(256) void fm_search_fast_kernel(FmDev fm, uint64_t 
     for (;;) {
         if (__any(need)) fetch_all();
         if (!__any(active)) break;
-        if (active) {
+        if (STEP2 && active) {
+            // two iterations of the loop at fmindex.rs:160-182 per block access (fm_kernels.h), or one (`single`)
+            const bool single = force1 || pos == 1;
+            uint32_t c, base;
+            if (single) {
+                const uint32_t p1 = pos - 1;
+                c = ((slot[p1 >> 4] >> (2 * (p1 & 15u))) & 3u) << 2;
+                base = s_less4[c >> 2];
+            } else {
+                const uint32_t p2 = pos - 2, ix = p2 >> 4;  // symbols pos-2 (second, low bits) and pos-1 (first): one nibble
+                c = __builtin_amdgcn_alignbit(slot[ix + 1], slot[ix], 2 * (p2 & 15u)) & 15u;
+                base = s_c2[c];
+            }
+            const uint32_t lm1 = l ? l - 1 : 0u;
+            const uint32_t br = r / kSym2PerBlock, orr = r % kSym2PerBlock, bl = lm1 / kSym2PerBlock, ol = lm1 % kSym2PerBlock;
+            const uint4 rc = f2.blocks2[(uint64_t)br * 8 + t], rs = f2.blocks2[(uint64_t)br * 8 + 4 + t];
+            uint4 lc = rc, ls = rs;
+            if (bl != br) {
+                lc = f2.blocks2[(uint64_t)bl * 8 + t];
+                ls = f2.blocks2[(uint64_t)bl * 8 + 4 + t];
+                if (COUNT) n_lines += 1;
+            }
+            if (COUNT) n_lines += 1;
+            uint32_t occ_r = quad_sum(block2_part(rc, rs, t, orr, c, single));
+            uint32_t occ_l = quad_sum(block2_part(lc, ls, t, ol, c, single));
+#pragma unroll
+            for (uint32_t e = 0; e < kMaxExc2; e++) {  // positions that hold a 0 for a symbol without a code (the sentinel: two entries)
+                if (e < f2.n_exc) {                    // (uniform; unrolled: the entries are kernel arguments, read by the scalar unit)
+                    const uint32_t pe = f2.exc_pos[e], ne = f2.exc_nib[e];
+                    const bool hit = single ? ((ne & 16u) != 0 && c == 0) : ((ne & 15u) == c);
+                    occ_r -= (hit && pe <= r) ? 1u : 0u;
+                    occ_l -= (hit && pe <= lm1) ? 1u : 0u;
+                }
+            }
+            occ_l = l ? occ_l : 0u;
+            if (!single) {
+                if (occ_r == occ_l) {
+                    force1 = true;  // no row of [l, r] has this pair in front: the reference's two steps say how it ends
+                } else {
+                    l = base + occ_l;
+                    r = base + occ_r - 1;
+                    pos -= 2;
+                    matched += 2;
+                    if (pos == 0) {
+                        emit(BG_FM_COMPLETE, l, r + 1, matched);
+                        need = true;
+                    }
+                }
+            } else {
+                pos -= 1;
+                const uint32_t pl = l, pr = r;
+                bool stop = occ_r == 0;  // fmindex.rs:167-170
+                if (!stop) {
+                    l = base + occ_l;  // fmindex.rs:171
+                    r = base + occ_r - 1;
+                    if (l > r)  // fmindex.rs:177-180
+                        stop = true;
+                    else
+                        matched += 1;
+                }
+                if (stop) {
+                    if (matched)
+                        emit(BG_FM_PARTIAL, pl, pr + 1, matched);
+                    else
+                        emit(BG_FM_ABSENT, 0, 0, 0);
+                    need = true;
+                } else if (pos == 0) {
+                    emit(BG_FM_COMPLETE, l, r + 1, matched);
+                    need = true;
+                }
+            }
+            if (need) {
+                q += n_quads;
+                active = false;
+                force1 = false;
+            }
+        }
+        if (!STEP2 && active) {
             // one iteration of the loop at fmindex.rs:160-182; the symbol is a code already
             pos -= 1;
             const uint32_t a = (slot[pos >> 4] >> (2 * (pos & 15u))) & 3u;
@@ -692,6 +776,18 @@ extern "C" int bg_fm_build(bg_ctx* ctx, const uint8_t* bwt, uint64_t n, const ui
     fm->dev.n_exc = gen ? 0u : (uint32_t)exc_pos.size();
     fm->dev.nbv_blocks = (uint32_t)nbv;
     fm->dev.n_dense = (uint32_t)n_dense;
+    {
+        // 2-step rank blocks (fm_step2.hip) lean on less[] being the BWT's own cumulative counts (LF maps the occurrences
+        // of a symbol to the rows from less[symbol] on); a caller's less that says otherwise keeps single steps, where
+        // the reference's arithmetic on whatever it was given is reproduced as it is
+        bool consistent = true;
+        uint64_t run = 0;
+        for (uint32_t c = 0; c < m && consistent; c++) {
+            if (hist[c] && less[c] != run) consistent = false;
+            run += hist[c];
+        }
+        if (consistent) fm_build_step2(fm, ctx->stream);
+    }
     *out = fm;
     return BG_OK;
 }
@@ -953,6 +1049,7 @@ extern "C" int bg_fm_build_dev(bg_ctx* ctx, const uint8_t* d_bwt, uint64_t n, ui
         bg_fm_free(fm);
         return rc;
     }
+    fm_build_step2(fm, st);  // 2-step rank blocks (fm_step2.hip): less[] is this builder's own
     *out = fm;
     return BG_OK;
 }
@@ -960,6 +1057,7 @@ extern "C" int bg_fm_build_dev(bg_ctx* ctx, const uint8_t* d_bwt, uint64_t n, ui
 extern "C" int bg_fm_free(bg_fm* fm) {
     if (!fm) return BG_OK;
     hipFree(fm->d_blocks);
+    hipFree(fm->d_blocks2);
     hipFree(fm->d_exc_pos);
     hipFree(fm->d_exc_sym_pos);
     hipFree(fm->d_class);
@@ -981,6 +1079,8 @@ extern "C" uint64_t bg_fm_device_bytes(const bg_fm* fm) { return fm ? fm->bytes 
 
 // the four 2-bit codes all stand for symbols and no symbol is ranked by a bit vector: the packed / fast kernels apply
 static bool fm_fast_ok(const bg_fm* fm) { return !fm->dev.n_dense && fm->n_codes == 4 && !fm->no_fast; }
+// ... and the index has 2-step rank blocks (fm_step2.hip): the fast kernels take two symbols per block access
+static bool fm_step2_ok(const bg_fm* fm) { return fm->dev2.blocks2 != nullptr && !fm->no_step2; }
 static SeedSrc fm_codes(const bg_fm* fm) {
     SeedSrc ex{};
     ex.code_bytes = (uint32_t)fm->code_byte[0] | (uint32_t)fm->code_byte[1] << 8 | (uint32_t)fm->code_byte[2] << 16 |
@@ -990,6 +1090,10 @@ static SeedSrc fm_codes(const bg_fm* fm) {
 
 extern "C" int bg_fm_set_option(bg_fm* fm, const char* key, int64_t value) {
     if (!fm || !key) return BG_ERR_INVALID_ARG;
+    if (!strcmp(key, "no_step2")) {  // searches take single steps only, whether the index has 2-step blocks or not (tests, A/B)
+        fm->no_step2 = value != 0;
+        return BG_OK;
+    }
     if (!strcmp(key, "jump_min_queries")) {  // batch size from which K5 builds / uses its jump table; < 0: never (default)
         std::lock_guard<std::mutex> lk(fm->jump_mu);
         fm->no_jump = value < 0;
@@ -1070,8 +1174,12 @@ extern "C" int bg_fm_backward_search_batch_dev(bg_fm* fm, uint64_t n_q, const ui
     } else if (fm_fast_ok(fm)) {
         // DNA-like index: patterns become 2-bit codes in LDS when a quad takes them; what that path cannot hold (a byte
         // outside the four codes, more than kFastSyms symbols) is left to the generic kernel behind it
-        fm_search_fast_kernel<false, false><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(
-            fm->dev, n_q, d_pat, d_pat_off, d_tag, d_lower, d_upper, d_matched_len, fm_codes(fm));
+        if (fm_step2_ok(fm))
+            fm_search_fast_kernel<false, false, false, true><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(
+                fm->dev, n_q, d_pat, d_pat_off, d_tag, d_lower, d_upper, d_matched_len, fm_codes(fm), fm->dev2);
+        else
+            fm_search_fast_kernel<false, false><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(
+                fm->dev, n_q, d_pat, d_pat_off, d_tag, d_lower, d_upper, d_matched_len, fm_codes(fm), fm->dev2);
         fm_backward_search_kernel<false, false, false, false, true><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(
             fm->dev, n_q, d_pat, d_pat_off, d_tag, d_lower, d_upper, d_matched_len, nullptr, SeedSrc{});
     } else {
@@ -1102,8 +1210,12 @@ int bg_fm_search_seeds_dev(bg_fm* fm, uint64_t n_reads, const uint8_t* d_reads, 
     bg_ctx* ctx = fm->ctx;
     if (ctx && ctx->timing) BG_HIP(hipEventRecord(ctx->ev[0], st));
     if (fm_fast_ok(fm) && seed_len <= kFastSyms) {
-        fm_search_fast_kernel<true, false><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(fm->dev, n_q, d_reads, d_read_off, d_tag, d_lower,
-                                                                                        d_upper, d_matched_len, src);
+        if (fm_step2_ok(fm))
+            fm_search_fast_kernel<true, false, false, true><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(fm->dev, n_q, d_reads, d_read_off, d_tag,
+                                                                                                         d_lower, d_upper, d_matched_len, src, fm->dev2);
+        else
+            fm_search_fast_kernel<true, false><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(fm->dev, n_q, d_reads, d_read_off, d_tag, d_lower,
+                                                                                            d_upper, d_matched_len, src, fm->dev2);
         fm_backward_search_kernel<false, true, false, false, true><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(
             fm->dev, n_q, d_reads, d_read_off, d_tag, d_lower, d_upper, d_matched_len, nullptr, src);
     } else {
@@ -1144,8 +1256,12 @@ extern "C" int bg_fm_backward_search_packed_dev(bg_fm* fm, uint64_t n_q, const u
     const SeedSrc ex = fm_codes(fm);
     if (ctx->timing) BG_HIP(hipEventRecord(ctx->ev[0], st));
     if (!fm->no_fast) {  // the LDS-slot kernel; patterns beyond its 256 symbols are left to the generic packed kernel
-        fm_search_fast_kernel<false, false, true><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(
-            fm->dev, n_q, (const uint8_t*)d_packed, d_sym_off, d_tag, d_lower, d_upper, d_matched_len, ex);
+        if (fm_step2_ok(fm))
+            fm_search_fast_kernel<false, false, true, true><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(
+                fm->dev, n_q, (const uint8_t*)d_packed, d_sym_off, d_tag, d_lower, d_upper, d_matched_len, ex, fm->dev2);
+        else
+            fm_search_fast_kernel<false, false, true><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(
+                fm->dev, n_q, (const uint8_t*)d_packed, d_sym_off, d_tag, d_lower, d_upper, d_matched_len, ex, fm->dev2);
         fm_backward_search_kernel<false, false, true, false, true><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(
             fm->dev, n_q, (const uint8_t*)d_packed, d_sym_off, d_tag, d_lower, d_upper, d_matched_len, nullptr, ex);
     } else {
@@ -1182,8 +1298,12 @@ extern "C" int bg_fm_backward_search_count_lines_dev(bg_fm* fm, uint64_t n_q, co
         SeedSrc ex = fm_codes(fm);
         ex.lines = d_cnt;
         if (fm_fast_ok(fm)) {
-            fm_search_fast_kernel<false, true><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(fm->dev, n_q, d_pat, d_pat_off, d_tag,
-                                                                                           d_lower, d_upper, d_matched_len, ex);
+            if (fm_step2_ok(fm))
+                fm_search_fast_kernel<false, true, false, true><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(fm->dev, n_q, d_pat, d_pat_off, d_tag,
+                                                                                                            d_lower, d_upper, d_matched_len, ex, fm->dev2);
+            else
+                fm_search_fast_kernel<false, true><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(fm->dev, n_q, d_pat, d_pat_off, d_tag,
+                                                                                               d_lower, d_upper, d_matched_len, ex, fm->dev2);
             fm_backward_search_kernel<false, false, false, true, true><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(
                 fm->dev, n_q, d_pat, d_pat_off, d_tag, d_lower, d_upper, d_matched_len, nullptr, ex);
         } else {

@@ -89,6 +89,50 @@ __device__ __forceinline__ uint32_t block_part_bf(const uint4 v, uint32_t t, uin
     return t == 0 ? cnt : n;
 }
 
+// ---- 2-step rank blocks (round 4) ---------------------------------------------------------------------------------------
+// The memory system delivers random 128-byte lines at the rate of random 64-byte lines (tools/microbench/ub_gather128,
+// profiles/r04_ub_gather128.json: 64 against 64 G lines/s inside the Infinity Cache, 53 against 53 at 1 GB, 51 against 51
+// at 3 GB), and K5 sits at 0.9 of that rate — so the way to more queries per second is fewer requests per query: a block
+// that answers TWO pattern symbols at once.  Position i of the BWT carries the pair (L[i], L[LF(i)]) — the two symbols in
+// front of suffix i — as a 4-bit code (first symbol << 2 | second); one 128-byte block per 128 positions: sixteen
+// counters (pairs of each code before the block) + 128 nibbles.  Two LF steps with symbols a then b collapse to
+//   l' = C2[a][b] + Occ2(ab, l - 1),  r' = C2[a][b] + Occ2(ab, r) - 1,   C2[a][b] = less[b] + #{j < less[a] : L[j] = b}
+// (the rows below less[a] + Occ(a, .) that hold b are exactly the images of the rows that hold the pair).  The double
+// step is valid iff Occ2(ab, r) > Occ2(ab, l - 1); otherwise — and for the last symbol of an odd-length pattern — the
+// same block answers a single step (first component == a: four counters summed, the high two bits of every nibble), so
+// Partial(pl, pr, matched_len) comes out exactly as fmindex.rs:160-182 produces it.  Positions whose first or second
+// symbol has no 2-bit code (the sentinel) hold 0 in that component and are listed on the side (at most kMaxExc2).
+constexpr uint32_t kSym2PerBlock = 128;
+constexpr uint32_t kMaxExc2 = 8;
+struct Fm2Dev {
+    const uint4* blocks2;        // null: no 2-step blocks (index not DNA-like, too many exceptions, or switched off)
+    uint32_t c2[16];             // C2[a << 2 | b]
+    uint32_t exc_pos[kMaxExc2];  // sorted
+    uint8_t exc_nib[kMaxExc2];   // the nibble stored there | 16 if the FIRST component is the one without a code
+    uint32_t n_exc;
+};
+// this lane's share of Occ2 inside one block: lane t holds counters 4t .. 4t+3 (vc) and nibbles 32t .. 32t+31 (vs).
+// c: the pair code; single: only the first component (c >> 2) counts
+__device__ __forceinline__ uint32_t block2_part(const uint4 vc, const uint4 vs, uint32_t t, uint32_t o, uint32_t c, bool single) {
+    const uint32_t lo = (c & 1) ? vc.y : vc.x, hi = (c & 1) ? vc.w : vc.z, one = (c & 2) ? hi : lo;
+    const uint32_t cnt = single ? vc.x + vc.y + vc.z + vc.w : one;
+    const int have = (int)o + 1 - (int)t * 32;  // nibbles of this lane inside [0, o]
+    const int h0 = min(max(have, 0), 16), h1 = min(max(have - 16, 0), 16);
+    const uint64_t msk = single ? 0xCCCCCCCCCCCCCCCCull : 0xFFFFFFFFFFFFFFFFull;
+    const uint64_t pat = (uint64_t)c * 0x1111111111111111ull;
+    uint64_t x0 = ((((uint64_t)vs.y << 32) | vs.x) ^ pat) & msk;
+    uint64_t x1 = ((((uint64_t)vs.w << 32) | vs.z) ^ pat) & msk;
+    // a nibble that is zero: or its four bits into bit 0
+    x0 |= x0 >> 1;
+    x1 |= x1 >> 1;
+    x0 |= x0 >> 2;
+    x1 |= x1 >> 2;
+    const uint64_t z0 = ~x0 & 0x1111111111111111ull, z1 = ~x1 & 0x1111111111111111ull;
+    // the nibbles beyond the first h leave at the top: 64 - 4 h bits, in two halves (h may be 0)
+    const uint32_t n = (uint32_t)(__popcll((z0 << (32 - 2 * h0)) << (32 - 2 * h0)) + __popcll((z1 << (32 - 2 * h1)) << (32 - 2 * h1)));
+    return n + (t == (c >> 2) ? cnt : 0u);
+}
+
 // this lane's share of rank1(o) inside one bit-vector block: lane 0 holds the counter and bits 0..95, lane t >= 1
 // bits 96 + 128 (t - 1) ... + 127
 __device__ __forceinline__ uint32_t bv_part(const uint4 v, uint32_t t, uint32_t o) {
@@ -123,6 +167,9 @@ __device__ __forceinline__ uint4 bv_load(const FmDev& fm, uint32_t d, uint32_t r
 struct bg_fm {
     bg_ctx* ctx = nullptr;
     bgfm::FmDev dev = {};
+    bgfm::Fm2Dev dev2 = {};      // 2-step rank blocks (fm_kernels.h), built behind the index by fm_build_step2
+    void* d_blocks2 = nullptr;
+    bool no_step2 = false;       // option "no_step2": searches take single steps only (tests, A/B)
     void* d_blocks = nullptr;
     void* d_exc_pos = nullptr;
     void* d_exc_sym_pos = nullptr;
@@ -158,6 +205,8 @@ struct bg_fm {
     bool fmd_ok = false;  // the BWT is a word over dna::n_alphabet() + '$' (FMDIndex::from, fmindex.rs:323-327)
 };
 
+// fm_step2.hip: builds fm->dev2 behind a finished index (best effort; synchronises the stream)
+void fm_build_step2(bg_fm* fm, hipStream_t st);
 // internal entry points shared between the FM translation units
 int bg_fm_search_seeds_dev(bg_fm* fm, uint64_t n_reads, const uint8_t* d_reads, const uint64_t* d_read_off, uint32_t S,
                            uint32_t stride, uint32_t seed_len, uint8_t* d_tag, uint64_t* d_lower, uint64_t* d_upper,

@@ -251,3 +251,73 @@ def test_fast_kernel_with_deferred_patterns_equals_the_generic_kernel_and_the_or
     ok = otag != 3  # a panicking query has no interval
     assert (tag == otag).all() and (lo.astype(np.uint64)[ok] == olo[ok]).all() and (hi.astype(np.uint64)[ok] == ohi[ok]).all()
     assert (ml.astype(np.uint64)[ok] == oml[ok]).all()
+
+
+@pytest.mark.parametrize("text_kind", ["genome", "short_periodic", "two_sentinels", "dev_built"])
+def test_two_step_rank_blocks_equal_single_steps_and_the_oracle(text_kind):
+    """DNA-like indexes carry 2-step rank blocks (fm_step2.hip): the fast kernel takes two pattern symbols per block
+    access and falls back to single steps from the same blocks for the odd last symbol and for the two steps of a pair
+    that no row has in front.  Patterns of every length parity that end Complete, Partial after an even / an odd number
+    of matched symbols, Absent at the first symbol or the second: identical to the single-step kernel (option no_step2)
+    and to the oracle; also through the packed entry point and with the index built on the device."""
+    import torch
+    rng = np.random.default_rng({"genome": 1, "short_periodic": 2, "two_sentinels": 3, "dev_built": 4}[text_kind])
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    if text_kind == "short_periodic":
+        g = np.append(np.tile(np.frombuffer(b"ACGTTGCAAC", dtype=np.uint8), 37), np.uint8(ord("$")))
+    elif text_kind == "two_sentinels":
+        fwd = acgt[rng.integers(0, 4, size=30_000)]
+        rc_ = np.frombuffer(b"TGCA", dtype=np.uint8)[np.searchsorted(acgt, fwd[::-1])]
+        g = np.concatenate([fwd, np.frombuffer(b"$", np.uint8), rc_, np.frombuffer(b"$", np.uint8)])
+    else:
+        g = synth.genome(300_000, 29)
+    alpha = b"ACGTNacgtn"
+    sa = suffix_array(g)
+    b = bwt(g, sa)
+    ls = less(b, alpha)
+    if text_kind == "dev_built":
+        d_b = torch.from_numpy(np.ascontiguousarray(b)).to("cuda:0")
+        fm = FMIndex.from_device(d_b, 64, alpha)
+    else:
+        fm = FMIndex(b, ls, Occ(b, 64, alpha))
+    pats = []
+    body = g[:-1] if text_kind != "two_sentinels" else g[:30_000]
+    for q in range(8000):
+        ln = int(rng.integers(1, 70))
+        s0 = int(rng.integers(0, max(1, len(body) - ln - 1)))
+        p = body[s0:s0 + ln].copy()
+        kind = q % 8
+        if kind in (1, 2) and ln >= 2:   # a substitution somewhere: Partial after an even or an odd number of symbols
+            k = int(rng.integers(0, ln))
+            p[k] = acgt[(int(np.searchsorted(acgt, p[k])) + 1 + int(rng.integers(0, 3))) % 4]
+        elif kind == 3:                  # random: mostly Partial after ~9-10 symbols
+            p = acgt[rng.integers(0, 4, size=ln)]
+        elif kind == 4 and ln >= 2:      # the very first (last) symbol pair is wrong in its second symbol
+            p[-2] = acgt[(int(np.searchsorted(acgt, p[-2])) + 2) % 4]
+        elif kind == 5:
+            p = p[:int(rng.integers(1, 3))]  # one or two symbols
+        pats.append(bytes(p))
+    pat, off = _lib.concat(pats)
+    d_pat = torch.from_numpy(pat.copy()).to("cuda:0")
+    d_off = torch.from_numpy(off.astype(np.int64)).to("cuda:0")
+    n_q = len(pats)
+
+    def run(no_step2):
+        fm.set_option("no_step2", no_step2)
+        tag = torch.full((n_q,), 77, dtype=torch.uint8, device="cuda:0")
+        lo, hi = torch.zeros(n_q, dtype=torch.int64, device="cuda:0"), torch.zeros(n_q, dtype=torch.int64, device="cuda:0")
+        ml = torch.zeros(n_q, dtype=torch.int32, device="cuda:0")
+        fm.backward_search_dev(n_q, d_pat.data_ptr(), d_off.data_ptr(), tag.data_ptr(), lo.data_ptr(), hi.data_ptr(), ml.data_ptr())
+        torch.cuda.synchronize()
+        fm.set_option("no_step2", 0)
+        return tag.cpu().numpy(), lo.cpu().numpy(), hi.cpu().numpy(), ml.cpu().numpy()
+
+    two, one = run(0), run(1)
+    for a, c in zip(two, one):
+        assert (a == c).all()
+    otag, olo, ohi, oml = orc.backward_search_batch(b, ls, orc.Occ(b, 64, alpha), pat, off, threads=8)
+    tag, lo, hi, ml = two
+    assert (tag == otag).all() and (lo == olo.astype(np.int64)).all() and (hi == ohi.astype(np.int64)).all()
+    assert (ml.astype(np.uint64) == oml).all()
+    assert (tag == 0).any() and (tag == 1).any()
+    assert ((ml[tag == 1] % 2) == 0).any() and ((ml[tag == 1] % 2) == 1).any()  # Partial after even and odd lengths
