@@ -180,15 +180,16 @@ def valu_frac(kernel, launch_ms, shape_key, shape_val):
 _GATHER = {}
 
 
-def gather_ceiling(footprint_bytes):
-    """The chip's measured rate for K5's access shape — quads reading two dependent random 64-byte lines per step at full
-    occupancy — over a table of `footprint_bytes`: tools/microbench/ub_gather64 (built by __graft_entry__.build()), run here,
+def gather_ceiling(footprint_bytes, line_bytes=64):
+    """The chip's measured rate for K5's access shape — quads reading two dependent random lines per step at full
+    occupancy — over a table of `footprint_bytes`: tools/microbench/ub_gather64 (64-byte lines: single LF steps) or
+    ub_gather128 (128-byte lines, four lanes per query: the 2-step rank blocks), built by __graft_entry__.build(), run here,
     on this GPU, next to the leg it is compared with.  Returns G lines/s or None when the binary is missing."""
     import subprocess
-    exe = os.path.join(ROOT, "tools", "microbench", "ub_gather64")
+    exe = os.path.join(ROOT, "tools", "microbench", "ub_gather128" if line_bytes == 128 else "ub_gather64")
     mb = round(footprint_bytes / 1e6, 1)
-    if mb in _GATHER:
-        return _GATHER[mb]
+    if (mb, line_bytes) in _GATHER:
+        return _GATHER[(mb, line_bytes)]
     val = None
     if os.path.exists(exe):
         try:
@@ -197,27 +198,34 @@ def gather_ceiling(footprint_bytes):
             for ln in out.stdout.decode().splitlines():
                 if ln.startswith("{"):
                     d = json.loads(ln)
-                    if d["dep"] == 1 and d["lines_per_step"] == 2:
+                    if line_bytes == 128 and d.get("variant") == "w128x4":
+                        val = d["glines_per_s"]
+                    if line_bytes == 64 and d.get("dep") == 1 and d.get("lines_per_step") == 2:
                         val = d["glines_per_s"]
         except (OSError, subprocess.SubprocessError, ValueError):
             val = None
-    _GATHER[mb] = val
+    _GATHER[(mb, line_bytes)] = val
     return val
 
 
 def fm_gather_fields(fm, n_q, pat, off, bufs, stream, launch_ms, block_bytes):
-    """requested 64-byte block loads of one launch (the counting instantiation of K5, outside the timed region) against
-    the gather ceiling at the index's footprint"""
+    """requested block loads of one launch (the counting instantiation of K5, outside the timed region) against the gather
+    ceiling at the footprint of the blocks the search really reads: the 2-step rank blocks (128-byte lines, n bytes) when
+    the index has them, the 1-step blocks (64-byte lines, n / 3 bytes) otherwise"""
     d_tag, d_lo, d_hi, d_ml = bufs
     lines = fm.backward_search_count_lines_dev(n_q, pat.data_ptr(), off.data_ptr(), d_tag.data_ptr(), d_lo.data_ptr(), d_hi.data_ptr(),
                                                d_ml.data_ptr(), stream)
-    ceil_g = gather_ceiling(block_bytes)
+    s2 = fm.step2_bytes()
+    line_bytes = 128 if s2 else 64
+    foot = s2 if s2 else block_bytes
+    ceil_g = gather_ceiling(foot, line_bytes)
     rate = lines / (launch_ms * 1e-3) / 1e9
-    return {"requested_lines_per_launch": lines, "glines_per_s": round(rate, 2),
+    return {"requested_lines_per_launch": lines, "line_bytes": line_bytes, "lf_steps_per_block_access": 2 if s2 else 1,
+            "glines_per_s": round(rate, 2), "requested_gb_per_s": round(rate * line_bytes, 1),
             "gather_ceiling_glines_per_s": ceil_g,
             "frac_of_gather_ceiling": round(rate / ceil_g, 4) if ceil_g else None,
-            "gather_ceiling_source": "tools/microbench/ub_gather64 (two dependent random 64-B lines per quad-step, 8 waves/SIMD) "
-                                     f"on a {round(block_bytes / 1e6)} MB table, run beside this leg"}
+            "gather_ceiling_source": f"tools/microbench/{'ub_gather128 (w128x4' if s2 else 'ub_gather64 ('}two dependent random "
+                                     f"{line_bytes}-B lines per quad-step, 8 waves/SIMD) on a {round(foot / 1e6)} MB table, run beside this leg"}
 
 
 def timed_steps(fn, steps, warmup, device):

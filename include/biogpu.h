@@ -137,6 +137,10 @@ int bg_fm_build_dev(bg_ctx* ctx, const uint8_t* d_bwt, uint64_t n, uint32_t occ_
                     uint32_t n_sym, uint64_t* less_out, bg_fm** out, void* stream);
 int bg_fm_free(bg_fm* fm);
 uint64_t bg_fm_device_bytes(const bg_fm* fm);
+/* Bytes of the index's 2-step rank blocks (128-byte lines: 16 pair counters + 128 four-bit pair codes per 128 BWT
+ * positions; built behind DNA-like indexes whose `less` is the BWT's own, fm_step2.hip) that the searches take two
+ * pattern symbols per block access from; 0: single steps (no such blocks, or bg_fm_set_option "no_step2" = 1). */
+uint64_t bg_fm_step2_bytes(const bg_fm* fm);
 
 /* Result tags of FMIndexable::backward_search (fmindex.rs:92-96). */
 enum { BG_FM_COMPLETE = 0, BG_FM_PARTIAL = 1, BG_FM_ABSENT = 2,
@@ -482,6 +486,41 @@ int bg_cigar_batch_dev(bg_ctx* ctx, uint64_t n, const bg_alignment_t* d_aln, con
 int bg_pretty_batch(bg_ctx* ctx, uint64_t n, const bg_alignment_t* aln, const uint8_t* ops, uint64_t ops_bytes,
                     const uint8_t* x, const uint64_t* x_off, const uint8_t* y, const uint64_t* y_off, uint32_t ncol,
                     char* out, uint64_t out_cap, uint64_t* out_off);
+
+/* ------------------------------------------------------------------ several GPUs (comm.hip)
+ * north_star: "query batches shard embarrassingly across the 8 GPUs of one node with a single RCCL all-gather over xGMI
+ * only to collect per-query scores/intervals".  One process and one bg_ctx per GPU.  rust-bio has no counterpart (a
+ * single-process library); the shim's align_batch_sharded / backward_search_sharded (rust/bio-gpu-shim) are built on these.
+ *   bg_shard_range     rank's contiguous slice [rank * N / W, (rank + 1) * N / W) of N units
+ *   bg_shard_balanced  world + 1 boundaries of contiguous slices of (nearly) equal total cost (sum of DP cells of mixed-
+ *                      length pairs, of pattern lengths): boundary r = first unit where the running cost passes r/W of it
+ *   bg_comm_unique_id  (one rank) the 128-byte id every rank hands to bg_comm_init — distribute it however the job
+ *                      talks (a file, an environment variable, MPI)
+ *   bg_comm_init       RCCL communicator of this rank's ctx (ncclCommInitRank; librccl.so is opened at run time:
+ *                      BG_ERR_UNSUPPORTED if it is not there)
+ *   bg_comm_init_host  host-staged communicator for the ranks of ONE node, named `name` (POSIX shared memory): moves the
+ *                      records through host memory.  For what RCCL cannot do — several ranks on one GPU (tests) — and,
+ *                      with ctx == NULL, for plain host pointers (no GPU at all)
+ *   bg_gather_records  every rank contributes n_local records of rec_bytes bytes (device pointers; host pointers for
+ *                      a ctx-less host communicator) and receives all of them in rank order in `all` (capacity: the sum
+ *                      of the counts); counts_out (optional, host, world entries) says how many each rank brought.  RCCL:
+ *                      one ncclAllGather on `stream` when the shards are equal, grouped broadcasts when they are ragged;
+ *                      the call returns when the collective is queued (the counts cost one stream synchronisation). */
+#define BG_COMM_ID_BYTES 128
+typedef struct bg_comm bg_comm;
+int bg_shard_range(uint64_t n_units, int rank, int world, uint64_t* lo, uint64_t* hi);
+int bg_shard_balanced(const uint64_t* costs, uint64_t n, int world, uint64_t* bounds);
+int bg_comm_unique_id(uint8_t* id /* BG_COMM_ID_BYTES */);
+int bg_comm_init(bg_ctx* ctx, int rank, int world, const uint8_t* id /* BG_COMM_ID_BYTES */, bg_comm** out);
+int bg_comm_init_host(bg_ctx* ctx, int rank, int world, const char* name, bg_comm** out);
+int bg_gather_records(bg_comm* comm, const void* local, uint64_t n_local, uint32_t rec_bytes, void* all, uint64_t* counts_out,
+                      void* stream);
+/* ... for records in HOST memory (the results of the host-buffer entry points): staged through device scratch for an
+ * RCCL communicator, through the shared segment for a host-staged one; all_cap = records `all` can hold (BG_ERR_OPS_CAP
+ * if the ranks bring more).  Synchronous. */
+int bg_gather_records_host(bg_comm* comm, const void* local, uint64_t n_local, uint32_t rec_bytes, void* all, uint64_t all_cap,
+                           uint64_t* counts_out);
+int bg_comm_free(bg_comm* comm);
 
 /* Timing of the last *_dev / batch call's kernels on this ctx, measured with HIP events on
  * the stream the kernels ran on (used by bench.py for the roofline line). */

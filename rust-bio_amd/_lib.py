@@ -93,7 +93,9 @@ SYMBOLS = ["bg_device_count", "bg_init", "bg_free", "bg_strerror", "bg_last_erro
            "bg_fastq_parse_dev", "bg_cigar_batch", "bg_cigar_batch_dev", "bg_get_timing", "bg_enable_timing",
            "bg_pretty_batch", "bg_suffix_array_dev", "bg_bwt_dev", "bg_sa_sample_dev", "bg_fm_build_dev", "bg_fm_set_text", "bg_fm_set_text_dev", "bg_seed_extend_batch", "bg_seed_extend_batch_dev",
            "bg_pack2_dev", "bg_unpack2_dev", "bg_fm_pattern_codes", "bg_fm_backward_search_packed_dev",
-           "bg_fm_backward_search_count_lines_dev", "bg_align_batch_packed_dev"]
+           "bg_fm_backward_search_count_lines_dev", "bg_align_batch_packed_dev", "bg_fm_step2_bytes",
+           "bg_shard_range", "bg_shard_balanced", "bg_comm_unique_id", "bg_comm_init", "bg_comm_init_host",
+           "bg_gather_records", "bg_gather_records_host", "bg_comm_free"]
 
 
 def build(force=False):
@@ -132,6 +134,16 @@ def lib():
         L.bg_fm_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
         L.bg_fm_device_bytes.restype = u64
         L.bg_fm_device_bytes.argtypes = [vp]
+        L.bg_fm_step2_bytes.restype = u64
+        L.bg_fm_step2_bytes.argtypes = [vp]
+        L.bg_shard_range.argtypes = [u64, i32, i32, C.POINTER(u64), C.POINTER(u64)]
+        L.bg_shard_balanced.argtypes = [vp, u64, i32, vp]
+        L.bg_comm_unique_id.argtypes = [vp]
+        L.bg_comm_init.argtypes = [vp, i32, i32, vp, C.POINTER(vp)]
+        L.bg_comm_init_host.argtypes = [vp, i32, i32, C.c_char_p, C.POINTER(vp)]
+        L.bg_gather_records.argtypes = [vp, vp, u64, u32, vp, vp, vp]
+        L.bg_gather_records_host.argtypes = [vp, vp, u64, u32, vp, u64, vp]
+        L.bg_comm_free.argtypes = [vp]
         L.bg_fm_backward_search_batch.argtypes = [vp, u64, vp, vp, vp, vp, vp, vp]
         L.bg_fm_backward_search_batch_dev.argtypes = [vp, u64, vp, vp, vp, vp, vp, vp, vp]
         L.bg_fmd_interval_batch.argtypes = [vp, u64, vp, vp, vp, vp]

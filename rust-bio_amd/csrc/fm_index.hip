@@ -306,8 +306,12 @@ __global__ __launch_bounds__(256) void fm_search_fast_kernel(FmDev fm, uint64_t 
     if (threadIdx.x < 4) s_less4[threadIdx.x] = fm.less[(seeds.code_bytes >> (8 * threadIdx.x)) & 0xFFu];
     for (uint32_t i = threadIdx.x; i < fm.n_exc; i += blockDim.x) s_exc[i] = fm.exc_pos[i];
     if (threadIdx.x == 0) s_pk[64 * (kFastSyms / 16)] = 0;
-    __shared__ uint32_t s_c2[16];
+    __shared__ uint32_t s_c2[16], s_e2pos[kMaxExc2], s_e2nib[kMaxExc2];
     if (STEP2 && threadIdx.x < 16) s_c2[threadIdx.x] = f2.c2[threadIdx.x];
+    if (STEP2 && threadIdx.x < kMaxExc2) {
+        s_e2pos[threadIdx.x] = f2.exc_pos[threadIdx.x];
+        s_e2nib[threadIdx.x] = f2.exc_nib[threadIdx.x];
+    }
     __syncthreads();
 
     const uint32_t t = threadIdx.x & 3;
@@ -418,18 +422,18 @@ __global__ __launch_bounds__(256) void fm_search_fast_kernel(FmDev fm, uint64_t 
         if (__any(need)) fetch_all();
         if (!__any(active)) break;
         if (STEP2 && active) {
-            // two iterations of the loop at fmindex.rs:160-182 per block access (fm_kernels.h), or one (`single`)
+            // two iterations of the loop at fmindex.rs:160-182 per block access (fm_kernels.h), or one (`single`: the last
+            // symbol of an odd length, and the two symbols of a pair that no row of the interval has in front).  One code
+            // path for both: k symbols, a 4-bit code whose low half is masked off for a single step, and ONE end
+            // condition — Occ(r) == Occ(l - 1) is "the pair does not occur" for a double step and, for a single one, both
+            // of the reference's (occ_r == 0 implies it; l > r is it), which report the same (pl, pr, matched_len)
             const bool single = force1 || pos == 1;
-            uint32_t c, base;
-            if (single) {
-                const uint32_t p1 = pos - 1;
-                c = ((slot[p1 >> 4] >> (2 * (p1 & 15u))) & 3u) << 2;
-                base = s_less4[c >> 2];
-            } else {
-                const uint32_t p2 = pos - 2, ix = p2 >> 4;  // symbols pos-2 (second, low bits) and pos-1 (first): one nibble
-                c = __builtin_amdgcn_alignbit(slot[ix + 1], slot[ix], 2 * (p2 & 15u)) & 15u;
-                base = s_c2[c];
-            }
+            const uint32_t k = single ? 1u : 2u;
+            const uint32_t p2 = pos - k, ix = p2 >> 4;
+            // symbols pos-2 (second: low bits) and pos-1 (first) as one nibble; a single step reads its symbol into the high half
+            uint32_t c = __builtin_amdgcn_alignbit(slot[ix + 1], slot[ix], 2 * (p2 & 15u));
+            c = single ? (c & 3u) << 2 : (c & 15u);
+            const uint32_t base = single ? s_less4[c >> 2] : s_c2[c];
             const uint32_t lm1 = l ? l - 1 : 0u;
             const uint32_t br = r / kSym2PerBlock, orr = r % kSym2PerBlock, bl = lm1 / kSym2PerBlock, ol = lm1 % kSym2PerBlock;
             const uint4 rc = f2.blocks2[(uint64_t)br * 8 + t], rs = f2.blocks2[(uint64_t)br * 8 + 4 + t];
@@ -442,48 +446,39 @@ __global__ __launch_bounds__(256) void fm_search_fast_kernel(FmDev fm, uint64_t 
             if (COUNT) n_lines += 1;
             uint32_t occ_r = quad_sum(block2_part(rc, rs, t, orr, c, single));
             uint32_t occ_l = quad_sum(block2_part(lc, ls, t, ol, c, single));
-#pragma unroll
-            for (uint32_t e = 0; e < kMaxExc2; e++) {  // positions that hold a 0 for a symbol without a code (the sentinel: two entries)
-                if (e < f2.n_exc) {                    // (uniform; unrolled: the entries are kernel arguments, read by the scalar unit)
-                    const uint32_t pe = f2.exc_pos[e], ne = f2.exc_nib[e];
-                    const bool hit = single ? ((ne & 16u) != 0 && c == 0) : ((ne & 15u) == c);
-                    occ_r -= (hit && pe <= r) ? 1u : 0u;
-                    occ_l -= (hit && pe <= lm1) ? 1u : 0u;
+            // positions that hold a 0 for a symbol without a code: the first two inline (one sentinel: exactly two; unused
+            // entries sit at position 2^32 - 1, which no rank reaches), more of them (several sentinels) in a loop
+            {
+                const uint32_t key = single ? 16u : c;  // what an entry must say to have been counted: "first component" / this nibble
+                const uint32_t e0 = f2.exc_pos[0], n0 = single ? (f2.exc_nib[0] & 16u) | (c ? 32u : 0u) : (f2.exc_nib[0] & 15u);
+                const uint32_t e1 = f2.exc_pos[1], n1 = single ? (f2.exc_nib[1] & 16u) | (c ? 32u : 0u) : (f2.exc_nib[1] & 15u);
+                occ_r -= (n0 == key && e0 <= r) ? 1u : 0u;
+                occ_l -= (n0 == key && e0 <= lm1) ? 1u : 0u;
+                occ_r -= (n1 == key && e1 <= r) ? 1u : 0u;
+                occ_l -= (n1 == key && e1 <= lm1) ? 1u : 0u;
+                for (uint32_t e = 2; e < f2.n_exc; e++) {  // (uniform)
+                    const uint32_t pe = s_e2pos[e], ne = s_e2nib[e];
+                    const uint32_t nk = single ? (ne & 16u) | (c ? 32u : 0u) : (ne & 15u);
+                    occ_r -= (nk == key && pe <= r) ? 1u : 0u;
+                    occ_l -= (nk == key && pe <= lm1) ? 1u : 0u;
                 }
             }
             occ_l = l ? occ_l : 0u;
-            if (!single) {
-                if (occ_r == occ_l) {
-                    force1 = true;  // no row of [l, r] has this pair in front: the reference's two steps say how it ends
-                } else {
-                    l = base + occ_l;
-                    r = base + occ_r - 1;
-                    pos -= 2;
-                    matched += 2;
-                    if (pos == 0) {
-                        emit(BG_FM_COMPLETE, l, r + 1, matched);
-                        need = true;
-                    }
-                }
+            const bool empty = occ_r == occ_l;
+            if (empty && !single) {
+                force1 = true;  // nothing changes: the two single steps that follow say how the query ends
+            } else if (empty) {
+                if (matched)
+                    emit(BG_FM_PARTIAL, l, r + 1, matched);
+                else
+                    emit(BG_FM_ABSENT, 0, 0, 0);
+                need = true;
             } else {
-                pos -= 1;
-                const uint32_t pl = l, pr = r;
-                bool stop = occ_r == 0;  // fmindex.rs:167-170
-                if (!stop) {
-                    l = base + occ_l;  // fmindex.rs:171
-                    r = base + occ_r - 1;
-                    if (l > r)  // fmindex.rs:177-180
-                        stop = true;
-                    else
-                        matched += 1;
-                }
-                if (stop) {
-                    if (matched)
-                        emit(BG_FM_PARTIAL, pl, pr + 1, matched);
-                    else
-                        emit(BG_FM_ABSENT, 0, 0, 0);
-                    need = true;
-                } else if (pos == 0) {
+                l = base + occ_l;  // fmindex.rs:171 (twice for a double step)
+                r = base + occ_r - 1;
+                pos = p2;
+                matched += k;
+                if (pos == 0) {
                     emit(BG_FM_COMPLETE, l, r + 1, matched);
                     need = true;
                 }
@@ -1076,6 +1071,9 @@ extern "C" int bg_fm_free(bg_fm* fm) {
 }
 
 extern "C" uint64_t bg_fm_device_bytes(const bg_fm* fm) { return fm ? fm->bytes : 0; }
+extern "C" uint64_t bg_fm_step2_bytes(const bg_fm* fm) {
+    return fm && fm->dev2.blocks2 && !fm->no_step2 ? ((uint64_t)fm->dev.n + kSym2PerBlock - 1) / kSym2PerBlock * 128 : 0;
+}
 
 // the four 2-bit codes all stand for symbols and no symbol is ranked by a bit vector: the packed / fast kernels apply
 static bool fm_fast_ok(const bg_fm* fm) { return !fm->dev.n_dense && fm->n_codes == 4 && !fm->no_fast; }

@@ -173,6 +173,10 @@ void fm_build_step2(bg_fm* fm, hipStream_t st) {
     fm->bytes += nblk * 128;
     fm->dev2.blocks2 = (const uint4*)d_b2;
     for (int k = 0; k < 16; k++) fm->dev2.c2[k] = c2[k];
+    for (uint32_t e = 0; e < kMaxExc2; e++) {  // unused entries: a position no rank reaches (the kernel reads two of them unconditionally)
+        fm->dev2.exc_pos[e] = 0xFFFFFFFFu;
+        fm->dev2.exc_nib[e] = 0xFF;
+    }
     for (uint32_t e = 0; e < ne; e++) {
         fm->dev2.exc_pos[e] = exc[e].x;
         fm->dev2.exc_nib[e] = (uint8_t)exc[e].y;

@@ -80,6 +80,10 @@ class FMIndex:
     def device_bytes(self):
         return int(_lib.lib().bg_fm_device_bytes(self.h))
 
+    def step2_bytes(self):
+        """bytes of the 2-step rank blocks the searches use (0: single steps)"""
+        return int(_lib.lib().bg_fm_step2_bytes(self.h))
+
     def backward_search_arrays(self, pat, pat_off, out=None):
         """Batch over concatenated patterns; returns (tag u8, lower u64, upper u64, matched u32).
         Raises AlphabetError if any query reached a byte outside the alphabet.  `out`: the four arrays of an earlier

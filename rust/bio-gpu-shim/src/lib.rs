@@ -39,6 +39,64 @@ impl Drop for Context {
     }
 }
 
+/// Several GPUs (include/biogpu.h "several GPUs", csrc/comm.hip): one process and one [`Context`] per device, the batch
+/// cut with [`shard_range`], and the one collective of a sharded batch — the all-gather of fixed-size result records —
+/// over RCCL ([`Comm::rccl`]; the id comes from [`Comm::unique_id`] on one rank and travels however the job talks) or
+/// through shared memory for ranks RCCL cannot serve ([`Comm::host`]).
+pub struct Comm {
+    raw: *mut sys::bg_comm,
+    pub rank: i32,
+    pub world: i32,
+}
+
+/// rank's contiguous slice `[rank * n / world, (rank + 1) * n / world)`
+pub fn shard_range(n_units: u64, rank: i32, world: i32) -> (u64, u64) {
+    let (mut lo, mut hi) = (0u64, 0u64);
+    let rc = unsafe { sys::bg_shard_range(n_units, rank, world, &mut lo, &mut hi) };
+    assert!(rc == 0, "bg_shard_range: {}", strerror(rc));
+    (lo, hi)
+}
+
+impl Comm {
+    pub fn unique_id() -> [u8; 128] {
+        let mut id = [0u8; 128];
+        let rc = unsafe { sys::bg_comm_unique_id(id.as_mut_ptr()) };
+        assert!(rc == 0, "bg_comm_unique_id: {}", strerror(rc));
+        id
+    }
+    pub fn rccl(ctx: &Context, rank: i32, world: i32, id: &[u8; 128]) -> Self {
+        let mut raw = std::ptr::null_mut();
+        let rc = unsafe { sys::bg_comm_init(ctx.raw, rank, world, id.as_ptr(), &mut raw) };
+        assert!(rc == 0, "bg_comm_init: {}", strerror(rc));
+        Comm { raw, rank, world }
+    }
+    pub fn host(ctx: Option<&Context>, rank: i32, world: i32, name: &str) -> Self {
+        let mut raw = std::ptr::null_mut();
+        let cname = std::ffi::CString::new(name).unwrap();
+        let rc = unsafe {
+            sys::bg_comm_init_host(ctx.map_or(std::ptr::null_mut(), |c| c.raw), rank, world, cname.as_ptr(), &mut raw)
+        };
+        assert!(rc == 0, "bg_comm_init_host: {}", strerror(rc));
+        Comm { raw, rank, world }
+    }
+    /// every rank's `local` records (`rec_bytes` each, host memory) on every rank, in rank order
+    pub fn gather_records_host(&self, local: &[u8], rec_bytes: u32, total_records: u64) -> Vec<u8> {
+        let mut all = vec![0u8; (total_records as usize) * rec_bytes as usize];
+        let rc = unsafe {
+            sys::bg_gather_records_host(self.raw, local.as_ptr() as *const _, (local.len() / rec_bytes as usize) as u64, rec_bytes,
+                                        all.as_mut_ptr() as *mut _, total_records, std::ptr::null_mut())
+        };
+        assert!(rc == 0, "bg_gather_records_host: {}", strerror(rc));
+        all
+    }
+}
+
+impl Drop for Comm {
+    fn drop(&mut self) {
+        unsafe { sys::bg_comm_free(self.raw) };
+    }
+}
+
 pub(crate) fn strerror(rc: i32) -> String {
     unsafe { CStr::from_ptr(sys::bg_strerror(rc)) }.to_string_lossy().into_owned()
 }

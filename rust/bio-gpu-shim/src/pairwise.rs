@@ -82,6 +82,33 @@ impl<F: MatchFunc> Aligner<F> {
         out.iter().map(|r| to_alignment(r, &ops)).collect()
     }
 
+    /// New: the batch sharded over the ranks of `comm` (north_star: "query batches shard embarrassingly across the 8
+    /// GPUs ... a single RCCL all-gather ... only to collect per-query scores"): this rank aligns its slice (returned as
+    /// full `Alignment`s, operations included) and every rank receives `{score, xstart, xend, ystart, yend}` of ALL pairs.
+    pub fn align_batch_sharded(&mut self, comm: &crate::Comm, mode: AlignmentMode, xs: &[&[u8]], ys: &[&[u8]])
+                               -> (Vec<Alignment>, Vec<[i32; 5]>) {
+        let (lo, hi) = crate::shard_range(xs.len() as u64, comm.rank, comm.world);
+        let mine = self.align_batch(mode, &xs[lo as usize..hi as usize], &ys[lo as usize..hi as usize]);
+        let mut local = Vec::with_capacity(mine.len() * 20);
+        for a in &mine {
+            let c = |v: usize| i32::try_from(v).expect("coordinate");
+            for v in [a.score, c(a.xstart), c(a.xend), c(a.ystart), c(a.yend)] {
+                local.extend_from_slice(&v.to_ne_bytes());
+            }
+        }
+        let all = comm.gather_records_host(&local, 20, xs.len() as u64);
+        let recs = all.chunks_exact(20)
+            .map(|c| {
+                let mut r = [0i32; 5];
+                for (k, w) in c.chunks_exact(4).enumerate() {
+                    r[k] = i32::from_ne_bytes([w[0], w[1], w[2], w[3]]);
+                }
+                r
+            })
+            .collect();
+        (mine, recs)
+    }
+
     /// mod.rs:591
     pub fn custom(&mut self, x: TextSlice<'_>, y: TextSlice<'_>) -> Alignment {
         self.align_batch(AlignmentMode::Custom, &[x], &[y]).pop().unwrap()
