@@ -444,8 +444,9 @@ __global__ __launch_bounds__(256) void fm_search_fast_kernel(FmDev fm, uint64_t 
                 if (COUNT) n_lines += 1;
             }
             if (COUNT) n_lines += 1;
-            uint32_t occ_r = quad_sum(block2_part(rc, rs, t, orr, c, single));
-            uint32_t occ_l = quad_sum(block2_part(lc, ls, t, ol, c, single));
+            const Pair2Key key2 = pair2_key(c, single);
+            uint32_t occ_r = quad_sum(block2_part(rc, rs, t, orr, c, single, key2));
+            uint32_t occ_l = quad_sum(block2_part(lc, ls, t, ol, c, single, key2));
             // positions that hold a 0 for a symbol without a code: the first two inline (one sentinel: exactly two; unused
             // entries sit at position 2^32 - 1, which no rank reaches), more of them (several sentinels) in a loop
             {

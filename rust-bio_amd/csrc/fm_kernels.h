@@ -95,7 +95,7 @@ __device__ __forceinline__ uint32_t block_part_bf(const uint4 v, uint32_t t, uin
 // at 3 GB), and K5 sits at 0.9 of that rate — so the way to more queries per second is fewer requests per query: a block
 // that answers TWO pattern symbols at once.  Position i of the BWT carries the pair (L[i], L[LF(i)]) — the two symbols in
 // front of suffix i — as a 4-bit code (first symbol << 2 | second); one 128-byte block per 128 positions: sixteen
-// counters (pairs of each code before the block) + 128 nibbles.  Two LF steps with symbols a then b collapse to
+// counters (pairs of each code before the block) + the 128 codes bit-sliced (per 32 positions: four dwords, one per bit).  Two LF steps with symbols a then b collapse to
 //   l' = C2[a][b] + Occ2(ab, l - 1),  r' = C2[a][b] + Occ2(ab, r) - 1,   C2[a][b] = less[b] + #{j < less[a] : L[j] = b}
 // (the rows below less[a] + Occ(a, .) that hold b are exactly the images of the rows that hold the pair).  The double
 // step is valid iff Occ2(ab, r) > Occ2(ab, l - 1); otherwise — and for the last symbol of an odd-length pattern — the
@@ -111,25 +111,31 @@ struct Fm2Dev {
     uint8_t exc_nib[kMaxExc2];   // the nibble stored there | 16 if the FIRST component is the one without a code
     uint32_t n_exc;
 };
-// this lane's share of Occ2 inside one block: lane t holds counters 4t .. 4t+3 (vc) and nibbles 32t .. 32t+31 (vs).
-// c: the pair code; single: only the first component (c >> 2) counts
-__device__ __forceinline__ uint32_t block2_part(const uint4 vc, const uint4 vs, uint32_t t, uint32_t o, uint32_t c, bool single) {
+// this lane's share of Occ2 inside one block: lane t holds counters 4t .. 4t+3 (vc) and, bit-sliced, the pair codes of
+// positions 32t .. 32t+31 (vs.x/y/z/w = bit 0/1/2/3 of each code: "code == c" is three ANDs of four XORs, not a nibble
+// comparison — the search is bound by vector instructions once its requests are halved).
+// c: the pair code; inv: per bit of c, 0 where it is set and ~0 where it is clear (Pair2Key, once per step);
+// single: only the first component (c >> 2, bits 2-3) counts — dc = ~0 makes bits 0-1 match anything
+struct Pair2Key {
+    uint32_t inv0, inv1, inv2, inv3, dc;
+};
+__device__ __forceinline__ Pair2Key pair2_key(uint32_t c, bool single) {
+    Pair2Key k;
+    k.inv0 = (c & 1u) - 1u;
+    k.inv1 = ((c >> 1) & 1u) - 1u;
+    k.inv2 = ((c >> 2) & 1u) - 1u;
+    k.inv3 = ((c >> 3) & 1u) - 1u;
+    k.dc = single ? ~0u : 0u;
+    return k;
+}
+__device__ __forceinline__ uint32_t block2_part(const uint4 vc, const uint4 vs, uint32_t t, uint32_t o, uint32_t c, bool single,
+                                                const Pair2Key& k) {
     const uint32_t lo = (c & 1) ? vc.y : vc.x, hi = (c & 1) ? vc.w : vc.z, one = (c & 2) ? hi : lo;
     const uint32_t cnt = single ? vc.x + vc.y + vc.z + vc.w : one;
-    const int have = (int)o + 1 - (int)t * 32;  // nibbles of this lane inside [0, o]
-    const int h0 = min(max(have, 0), 16), h1 = min(max(have - 16, 0), 16);
-    const uint64_t msk = single ? 0xCCCCCCCCCCCCCCCCull : 0xFFFFFFFFFFFFFFFFull;
-    const uint64_t pat = (uint64_t)c * 0x1111111111111111ull;
-    uint64_t x0 = ((((uint64_t)vs.y << 32) | vs.x) ^ pat) & msk;
-    uint64_t x1 = ((((uint64_t)vs.w << 32) | vs.z) ^ pat) & msk;
-    // a nibble that is zero: or its four bits into bit 0
-    x0 |= x0 >> 1;
-    x1 |= x1 >> 1;
-    x0 |= x0 >> 2;
-    x1 |= x1 >> 2;
-    const uint64_t z0 = ~x0 & 0x1111111111111111ull, z1 = ~x1 & 0x1111111111111111ull;
-    // the nibbles beyond the first h leave at the top: 64 - 4 h bits, in two halves (h may be 0)
-    const uint32_t n = (uint32_t)(__popcll((z0 << (32 - 2 * h0)) << (32 - 2 * h0)) + __popcll((z1 << (32 - 2 * h1)) << (32 - 2 * h1)));
+    const uint32_t m = ((vs.x ^ k.inv0) | k.dc) & ((vs.y ^ k.inv1) | k.dc) & (vs.z ^ k.inv2) & (vs.w ^ k.inv3);
+    const int h = min(max((int)o + 1 - (int)t * 32, 0), 32);  // positions of this lane inside [0, o]
+    // matches among the first h positions = all matches - those from position h on (a 64-bit shift: h may be 32)
+    const uint32_t n = (uint32_t)__popc(m) - (uint32_t)__popc((uint32_t)((uint64_t)m >> h));
     return n + (t == (c >> 2) ? cnt : 0u);
 }
 

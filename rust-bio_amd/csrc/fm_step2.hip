@@ -7,7 +7,7 @@
 //           in the 1-step block of i; c2 = code of L[j] (the rows LF maps a symbol's occurrences to are consecutive, so the
 //           four streams of j walk the BWT sequentially: cache-friendly) -> nibble c << 2 | c2 into a byte array; a
 //           position whose L[i] or L[j] has no code goes to the exception list with 0 in that component;
-//   pass 2 (one thread per 128-position block): 128 nibbles -> 64 bytes + how many of each of the 16 codes;
+//   pass 2 (one thread per 128-position block): 128 nibbles -> 64 bytes, bit-sliced per 32 positions, + how many of each of the 16 codes;
 //   sixteen exclusive scans (rocPRIM) -> the counters; C2[a][b] = less[b] + Occ(b, less[a] - 1) by sixteen threads.
 #include <rocprim/device/device_scan.hpp>
 
@@ -85,18 +85,20 @@ __global__ __launch_bounds__(256) void fm2_pack_kernel(const uint8_t* __restrict
     uint32_t c[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) c[k] = 0;
-    for (uint32_t w = 0; w < 16; w++) {
-        uint32_t word = 0;
-        for (uint32_t t = 0; t < 8; t++) {
-            const uint64_t i = lo + 8 * w + t;
+    for (uint32_t g = 0; g < 4; g++) {  // 32 positions: one dword per bit of the code (fm_kernels.h: block2_part)
+        uint32_t plane[4] = {0, 0, 0, 0};
+        for (uint32_t t = 0; t < 32; t++) {
+            const uint64_t i = lo + 32 * g + t;
             if (i < n) {
                 const uint32_t v = nib[i] & 15u;
-                word |= v << (4 * t);
+#pragma unroll
+                for (int b = 0; b < 4; b++) plane[b] |= ((v >> b) & 1u) << t;
 #pragma unroll
                 for (int k = 0; k < 16; k++) c[k] += (v == (uint32_t)k) ? 1u : 0u;
             }
         }
-        blocks2[blk * 32 + 16 + w] = word;
+#pragma unroll
+        for (int b = 0; b < 4; b++) blocks2[blk * 32 + 16 + 4 * g + b] = plane[b];
     }
 #pragma unroll
     for (int k = 0; k < 16; k++) cnt[(uint64_t)k * nblk + blk] = c[k];

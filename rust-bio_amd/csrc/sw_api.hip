@@ -18,6 +18,7 @@
 namespace bgsw {
 sw_fill_fn get_fill_params_narrow(int lp, int r, bool local);
 sw_fill_fn get_fill_params_wide(int lp, int r, bool local);
+sw_fill_fn get_fill_params_lf(int lp, int r);
 sw_fill_fn get_fill_matrix(int lp, int r, int sm, bool narrow, bool local);
 sw_fill_fn get_fill_pk16_local(int lp, int r, int which);
 sw_fill_fn get_fill_pk16_localfast(int lp, int r, int which);
@@ -297,6 +298,16 @@ static int align_batch_dev_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, u
         // on); a table beyond 64 classes or wide scores take the 12-row geometry that is instantiated for everything
         cfg.r = 12;
         fill = get_fill_matrix(cfg.lp, cfg.r, sm, narrow, all_zero_clips);
+    }
+    // K1's LF flavour (sw_fill.inc): Aligner::local under MatchParams whose gaps and mismatches cost something, scaled
+    // keys, reads of one strip — the reference-width (int32) kernel without the clip machinery such alignments never use
+    a.g.tb_fmt = 0;
+    if (fill && sm == SCORE_PARAMS && narrow && all_zero_clips && a.sc.go < 0 && a.sc.mismatch < 0 && a.sc.match >= 0 &&
+        !ctx->no_local_fast && max_xlen <= (uint32_t)(cfg.lp * cfg.r)) {
+        if (sw_fill_fn lf = get_fill_params_lf(cfg.lp, cfg.r)) {
+            fill = lf;
+            a.g.tb_fmt = 3;
+        }
     }
     // K1p: short reads whose scores fit 12 bits (sw_fill_pk16.inc) — two pairs per lane, one instantiation
     // unit per clip pattern.  Bound: no real DP value, nor the epilogue's go * i terms, may leave +-2040.

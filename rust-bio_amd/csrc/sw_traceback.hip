@@ -71,6 +71,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
         const uint32_t w = seg[(uint32_t)(g % tsteps) * NW + rr / 6];
         const uint32_t c = rr % 6;
         if (!geo.tb_fmt) return (w >> (5 * c)) & 31u;
+        if (geo.tb_fmt == 3) {  // K1's LF flavour: tb_fmt 0's packing, each cell I opened | move << 1 | D opened << 4
+            const uint32_t u = (w >> (5 * c)) & 31u;
+            return ((u >> 1) & 7u) | ((~u & 1u) << 3) | (~u & 16u);
+        }
         // tb_fmt 1 (K1p): three cells per 16-bit half, each I extends | move << 1 | D extends << 4
         // tb_fmt 2 (K1p, LF flavour): the same, and move code 0 stands for C_XP (the floor of a local alignment)
         const uint32_t v = (w >> (5 * (c % 3) + 16 * (c / 3))) & 31u;
@@ -189,7 +193,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
                 break;
             case TB_XCLIP_SUFFIX: {
                 // K1p (tb_fmt 1) publishes Lx[j] <= m packed: bytes with 16 lanes per pair (m <= 192), else 16 bits
-                if (geo.tb_fmt == 2 && j != n) {  // the LF fill publishes no Lx[j < n]: no local path asks for it
+                if ((geo.tb_fmt == 2 || geo.tb_fmt == 3) && j != n) {  // the LF fills publish no Lx[j < n]: no local path asks for it
                     status = BG_ERR_TRACEBACK;
                     layer = TB_START;
                     continue;
