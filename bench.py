@@ -165,6 +165,15 @@ def fm_big_traffic(n_q, index_bytes):
     return int(sum(d[c]["mean_bytes"] for c in ("FETCH_SIZE", "WRITE_SIZE") if c in d))
 
 
+def seed_extend_traffic(reads, genome):
+    """FETCH + WRITE bytes of ALL kernels of one bg_seed_extend_batch_dev call (K5 on the seed windows, K6, the se_* stages,
+    K1p semiglobal, K2) from the newest committed PMC passes of this leg (tools/collect_profiles.sh: the `big` passes)"""
+    d = (_newest_profile("r*_pmc_traffic.json") or {}).get("seed_extend")
+    if not d or d.get("reads_per_call") != reads or d.get("genome") != genome:
+        return None
+    return int(d["bytes_per_call"])
+
+
 def valu_frac(kernel, launch_ms, shape_key, shape_val):
     """VALU issue utilisation of `kernel`: SQ_INSTS_VALU (wave instructions per launch, from the newest committed
     tools/sq_counters.sh pass of this command) x 64 lanes / launch time / 78.6 T full-rate lane-ops/s."""
@@ -892,7 +901,8 @@ def seed_extend_leg(args, ctx, dev, stream, rank, world, do_cpu, orc, threads, p
                          "align_traceback": round(tm["traceback_ms"], 3)},
            "roofline": {"bound": "hbm", "kernel": "whole pipeline (K5 seeds, K6 locate, gather, K1p semiglobal, K2, best hit)",
                         "achieved": round(alg / (ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
+                        "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": seed_extend_traffic(Rp, n_genome),
+                        "calls_in_run": args.warmup + args.steps + 1,  # (weak leg; tools/pmc_summary.py divides the PMC totals by it)
                         "alg_bytes_per_read": round(alg / Rp, 1),
                         "note": "dominated by the candidates' semiglobal fill (VALU-bound like the headline kernel)"}}
     # strong scaling on configs[4]: the SAME reads in total (10 M), split over the ranks, one all-gather of 24-byte

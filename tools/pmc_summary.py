@@ -80,6 +80,29 @@ if big and os.path.exists(logf):
             big["index_bytes"] = fb["config"]["index_bytes"]
             big["alg_bytes_per_launch"] = fb["roofline"]["alg_bytes_per_query"] * fb["roofline"]["queries_per_launch"]
     res["fm_big"] = big
+# the seed-and-extend leg of the same passes: every kernel of bg_seed_extend_batch_dev, bytes per call
+SE_KERNELS = ("se_", "sa_sampled_get", "sa_raw", "interval_rows", "fm_search_fast_kernel<true", "fm_backward_search_kernel<false, true",
+              "semiglobal", "sw_fill_pk16", "sw_traceback_kernel")
+se = {"kernels": {}}
+tot_bytes = 0.0
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    for k, vs in per_kernel(os.path.join(out, "big_" + c)).get(c, {}).items():
+        if any(t in k for t in SE_KERNELS):
+            se["kernels"].setdefault(k, {})[c] = {"launches": len(vs), "mean_bytes": sum(vs) * 1024.0 / len(vs), "total_bytes": sum(vs) * 1024.0}
+            tot_bytes += sum(vs) * 1024.0
+if se["kernels"] and os.path.exists(logf):
+    for ln in open(logf):
+        if ln.startswith("{") and '"seed_extend"' in ln:
+            sl = json.loads(ln)["seed_extend"]
+            calls = sl["roofline"].get("calls_in_run") or 1
+            se["reads_per_call"] = int(sl["config"]["workload"].split()[0])
+            se["genome"] = sl["config"]["genome"]
+            se["calls_in_run"] = calls
+            se["bytes_per_call"] = tot_bytes / calls
+            se["note"] = ("FETCH + WRITE of every kernel of the pipeline over the run / calls; includes the 65 536-pair headline leg's "
+                          "K1p / K2 launches of the same command (< 2 % of the pipeline's candidates)")
+    if "bytes_per_call" in se:
+        res["seed_extend"] = se
 json.dump(res, open(os.path.join(out, tag + "_pmc_traffic.json"), "w"), indent=1)
 
 # ---- issue counters
