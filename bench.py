@@ -1108,7 +1108,9 @@ def banded_leg(args, ctx, dev, rank, world, do_cpu, orc, threads, parity):
         parity.update({"banded_pairs_checked": nsb, "banded_pairs_total": Pb, "banded_bit_exact": okb})
         # >= 512 pairs: with 4 pairs per thread the 200 MB traceback matrix + memset of a 10 kb pair's first run on every
         # thread dominated (0.16 GCUPS on 64 pairs against 0.49 over the parity pass — the same code)
-        nt = min(nsb, max(512, 4 * threads))
+        # (2048 pairs: ~4 s per run on 16 threads; 512 still read 0.43 against the parity pass's 0.60 — every thread's first pair
+        #  pays the page faults of its 200 MB matrix)
+        nt = min(nsb, max(2048, 4 * threads))
         t_all = median_time(lambda: orc.banded_align_batch(osc, "semiglobal", kb, wb, hx[:nt * Lb], hoff[:nt + 1],
                                                            hy[:nt * Lb], hoff[:nt + 1], threads=min(nt, threads), want_ops=False))
         banded["cpu_baseline"] = {"value": round(float(ocells[:nt].sum()) / t_all / 1e9, 4), "unit": "GCUPS (band cells)",
