@@ -87,7 +87,7 @@ se = {"kernels": {}}
 tot_bytes = 0.0
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for k, vs in per_kernel(os.path.join(out, "big_" + c)).get(c, {}).items():
-        if any(t in k for t in SE_KERNELS):
+        if not k.startswith(("at::", "void at::", "elementwise_kernel", "rocprim", "void rocprim")) and any(t in k for t in SE_KERNELS):
             se["kernels"].setdefault(k, {})[c] = {"launches": len(vs), "mean_bytes": sum(vs) * 1024.0 / len(vs), "total_bytes": sum(vs) * 1024.0}
             tot_bytes += sum(vs) * 1024.0
 if se["kernels"] and os.path.exists(logf):
