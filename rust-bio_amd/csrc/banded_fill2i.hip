@@ -5,6 +5,7 @@
 // rings and handed over in whole 16-byte groups; strips talk through bnd / gSn / gLy) — so K3v2 runs the strips before the
 // run (phase 1), this kernel the run, K3v2 the strips behind it (phase 2), and nothing in between has to be converted.
 // What an interior strip does not have (reference: banded.rs:556-680):
+// The traceback rings are indexed by step here (K3v2: by column): conflict-free byte writes, hand-overs realign.
 //   * x clips: no x-prefix-clip candidate (564-572, 625-631), and the x-suffix-clip fold S[curr][m] / Lx[j] (648-653) is
 //     MIN_SCORE + something that never wins (band_split's conditions) — not computed, not published;
 //   * column n: no Sn[i-1] + go candidate (590-596), no last-column records;
@@ -160,8 +161,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 for (int k = 0; k < FLUSH / 16 + 2; k++) {
                     const int gk = g0 + k;
                     if (gk < g1) {
-                        const uint32_t* src = (const uint32_t*)(s_row + r * RING + ((gk * 16) & (RING - 1)));
-                        *(uint4*)(tb + trow[r] + (uint32_t)gk * kTbGroupStride) = make_uint4(src[0], src[1], src[2], src[3]);
+                        // the ring is indexed by STEP (below): cell c of the row was computed at step c + off, so the
+                        // group's 16 bytes start at ring byte (16 gk + off) % RING — any alignment, possibly wrapping:
+                        // five aligned dwords, funnel-shifted into four
+                        const uint32_t sbyte = ((uint32_t)gk * 16u + (uint32_t)(cf[r] - jlo + ll)) & (uint32_t)(RING - 1);
+                        const uint8_t* ring = s_row + r * RING;
+                        const uint32_t d0 = sbyte & ~3u, sh = sbyte & 3u;
+                        uint32_t w[5];
+#pragma unroll
+                        for (int q = 0; q < 5; q++) w[q] = *(const uint32_t*)(ring + ((d0 + 4u * q) & (uint32_t)(RING - 1)));
+                        *(uint4*)(tb + trow[r] + (uint32_t)gk * kTbGroupStride) =
+                            make_uint4(__builtin_amdgcn_alignbyte(w[1], w[0], sh), __builtin_amdgcn_alignbyte(w[2], w[1], sh),
+                                       __builtin_amdgcn_alignbyte(w[3], w[2], sh), __builtin_amdgcn_alignbyte(w[4], w[3], sh));
                     }
                 }
             }
@@ -224,7 +235,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     I_up = inb ? (Iv_t & ~1) : (NEGS | kI);
                     SnB[r] = max(SnB[r], Sl[r] | tpri);  // banded.rs:655-660, per block of 16 steps
                     const uint32_t cell = bfi<16>((uint32_t)Dv_t << 4, bfi<1>((uint32_t)Iv_t, (uint32_t)kb));
-                    s_row[r * RING + ((uint32_t)jc & (uint32_t)(RING - 1))] = (uint8_t)cell;
+                    // ring slot = the STEP (not the column): the 64 byte writes of a step hit 64 different banks (lanes are
+                    // one bank apart), and no cell needs an address of its own
+                    s_row[r * RING + ((uint32_t)t & (uint32_t)(RING - 1))] = (uint8_t)cell;
                     diag = left_S;
                 }
                 S_out = S_up;
