@@ -447,22 +447,21 @@ __global__ __launch_bounds__(256) void fm_search_fast_kernel(FmDev fm, uint64_t 
             const Pair2Key key2 = pair2_key(c, single);
             uint32_t occ_r = quad_sum(block2_part(rc, rs, t, orr, c, single, key2));
             uint32_t occ_l = quad_sum(block2_part(lc, ls, t, ol, c, single, key2));
-            // Positions that hold a 0 for a symbol without a code (the sentinel: two of them) are counted for no code by
-            // the counters, so only a rank INSIDE such a position's own block has counted its stored code: a wave-uniform
-            // test of the two blocks against the listed ones, and the correction in the (rare) branch behind it
+            // positions that hold a 0 for a symbol without a code: the first two inline (one sentinel: exactly two; unused
+            // entries sit at position 2^32 - 1, which no rank reaches), more of them (several sentinels) in a loop
             {
-                bool near = false;
-#pragma unroll
-                for (uint32_t e = 0; e < kMaxExc2; e++)
-                    if (e < f2.n_exc) near = near || br == (f2.exc_pos[e] / kSym2PerBlock) || bl == (f2.exc_pos[e] / kSym2PerBlock);
-                if (__any(near)) {
-                    const uint32_t key = single ? 16u : c;  // what an entry must say to have been counted: "first component" / this code
-                    for (uint32_t e = 0; e < f2.n_exc; e++) {
-                        const uint32_t pe = s_e2pos[e], ne = s_e2nib[e], be = pe / kSym2PerBlock;
-                        const uint32_t nk = single ? (ne & 16u) | (c ? 32u : 0u) : (ne & 15u);
-                        occ_r -= (nk == key && be == br && pe <= r) ? 1u : 0u;
-                        occ_l -= (nk == key && be == bl && pe <= lm1) ? 1u : 0u;
-                    }
+                const uint32_t key = single ? 16u : c;  // what an entry must say to have been counted: "first component" / this nibble
+                const uint32_t e0 = f2.exc_pos[0], n0 = single ? (f2.exc_nib[0] & 16u) | (c ? 32u : 0u) : (f2.exc_nib[0] & 15u);
+                const uint32_t e1 = f2.exc_pos[1], n1 = single ? (f2.exc_nib[1] & 16u) | (c ? 32u : 0u) : (f2.exc_nib[1] & 15u);
+                occ_r -= (n0 == key && e0 <= r) ? 1u : 0u;
+                occ_l -= (n0 == key && e0 <= lm1) ? 1u : 0u;
+                occ_r -= (n1 == key && e1 <= r) ? 1u : 0u;
+                occ_l -= (n1 == key && e1 <= lm1) ? 1u : 0u;
+                for (uint32_t e = 2; e < f2.n_exc; e++) {  // (uniform)
+                    const uint32_t pe = s_e2pos[e], ne = s_e2nib[e];
+                    const uint32_t nk = single ? (ne & 16u) | (c ? 32u : 0u) : (ne & 15u);
+                    occ_r -= (nk == key && pe <= r) ? 1u : 0u;
+                    occ_l -= (nk == key && pe <= lm1) ? 1u : 0u;
                 }
             }
             occ_l = l ? occ_l : 0u;

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void fm2_nibble_kernel(const FmDev fm, const L
     const uint32_t i = (uint32_t)i64;
     const uint32_t c = fm_code_at(fm, i);
     if (c == 0 && fm_is_exc(fm, i)) {  // L[i] has no code (the sentinel): first component 0, LF(i) is nobody's business
-        nib[i] = 16;  // bit 4: an exception position — stored with code 0, counted for no code (fm2_pack_kernel)
+        nib[i] = 0;
         const uint32_t k = atomicAdd(n_exc, 1u);
         if (k < cap) exc[k] = make_uint2(i, 16u);
         return;
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void fm2_nibble_kernel(const FmDev fm, const L
     const bool e2 = j >= fm.n || (c2 == 0 && fm_is_exc(fm, j));
     if (e2) c2 = 0;
     const uint32_t v = (c << 2) | c2;
-    nib[i] = (uint8_t)(v | (e2 ? 16u : 0u));
+    nib[i] = (uint8_t)v;
     if (e2) {
         const uint32_t k = atomicAdd(n_exc, 1u);
         if (k < cap) exc[k] = make_uint2(i, v);
@@ -90,13 +90,11 @@ __global__ __launch_bounds__(256) void fm2_pack_kernel(const uint8_t* __restrict
         for (uint32_t t = 0; t < 32; t++) {
             const uint64_t i = lo + 32 * g + t;
             if (i < n) {
-                const uint32_t raw = nib[i], v = raw & 15u;
+                const uint32_t v = nib[i] & 15u;
 #pragma unroll
                 for (int b = 0; b < 4; b++) plane[b] |= ((v >> b) & 1u) << t;
-                // an exception position is counted for NO code: the counters of the blocks behind it are exact, and only a
-                // rank inside its own block has to take the stored code back out (fm_search_fast_kernel<STEP2>)
 #pragma unroll
-                for (int k = 0; k < 16; k++) c[k] += (raw == (uint32_t)k) ? 1u : 0u;
+                for (int k = 0; k < 16; k++) c[k] += (v == (uint32_t)k) ? 1u : 0u;
             }
         }
 #pragma unroll
