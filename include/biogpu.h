@@ -83,6 +83,9 @@ const char* bg_last_error(void); /* text of the last HIP failure on this thread 
  *   band_fill_v1       1: banded fill with one pair per wavefront (K3) always; -1: eight pairs per wavefront (K3v2)
  *                      always; 0 (default): K3 for sub-batches of at most 2048 pairs (latency), K3v2 above (throughput)
  *   band_interior_off = 1  banded fill (K3v2) with its general step in every strip (tests, A/B: no reduced interior step)
+ *   band_packed_off = 1    interior runs on the int32 kernel (K3i) only: no packed-int16 kernel (K3p) in front of it
+ *   band_packed_thresh     K3p's detect-and-recompute threshold in key units (score * 16); 0 = derived from the scoring,
+ *                          65535 = every pair is flagged and recomputed by the int32 kernels (tests)
  *   band_tail_last / band_window / band_raster_late = 1  A/B switches of the banded pipeline's order (round-3 behaviour)
  *   band_chain_global  chaining tree placement: 0 LDS, 1 global scratch, -1 by batch size (default)
  *   band_join_global = 1  k-mer join with its table in global memory even where the LDS flavour applies
@@ -529,6 +532,9 @@ typedef struct {
     uint32_t fill_launches, traceback_launches, fm_launches;
 } bg_timing_t;
 int bg_get_timing(bg_ctx* ctx, bg_timing_t* out);
+/* Pairs of the last banded call on this ctx that the packed-int16 fill flagged (a band cell below the floor of its strip's
+ * 16-bit range) and the int32 kernels recomputed.  Waits for the call's kernels. */
+int bg_band_redo_pairs(bg_ctx* ctx, uint64_t* out);
 int bg_enable_timing(bg_ctx* ctx, int on);
 
 #ifdef __cplusplus

@@ -90,7 +90,7 @@ SYMBOLS = ["bg_device_count", "bg_init", "bg_free", "bg_strerror", "bg_last_erro
            "bg_align_batch", "bg_align_batch_dev", "bg_align_banded_batch", "bg_align_banded_batch_dev", "bg_band_create_batch",
            "bg_align_banded_bands_batch", "bg_band_from_matches_batch", "bg_sparse_find_kmer_matches", "bg_sparse_sdpkpp",
            "bg_sparse_lcskpp", "bg_sparse_sdpkpp_union_lcskpp_path", "bg_sparse_expand_kmer_matches", "bg_fastq_parse",
-           "bg_fastq_parse_dev", "bg_cigar_batch", "bg_cigar_batch_dev", "bg_get_timing", "bg_enable_timing",
+           "bg_fastq_parse_dev", "bg_cigar_batch", "bg_cigar_batch_dev", "bg_get_timing", "bg_enable_timing", "bg_band_redo_pairs",
            "bg_pretty_batch", "bg_suffix_array_dev", "bg_bwt_dev", "bg_sa_sample_dev", "bg_fm_build_dev", "bg_fm_set_text", "bg_fm_set_text_dev", "bg_seed_extend_batch", "bg_seed_extend_batch_dev",
            "bg_pack2_dev", "bg_unpack2_dev", "bg_fm_pattern_codes", "bg_fm_backward_search_packed_dev",
            "bg_fm_backward_search_count_lines_dev", "bg_align_batch_packed_dev", "bg_fm_step2_bytes",
@@ -194,6 +194,7 @@ def lib():
         L.bg_align_batch_packed_dev.argtypes = [vp, C.POINTER(ScoringC), i32, u64, vp, vp, vp, vp, vp, u32, u32, vp, vp, u64, vp]
         L.bg_get_timing.argtypes = [vp, C.POINTER(TimingC)]
         L.bg_enable_timing.argtypes = [vp, i32]
+        L.bg_band_redo_pairs.argtypes = [vp, C.POINTER(u64)]
         for s in SYMBOLS:
             if getattr(L, s).restype is C.c_int or s.startswith("bg_") and getattr(L, s).restype is None:
                 pass
@@ -219,6 +220,12 @@ class Context:
         t = TimingC()
         check(lib().bg_get_timing(self.h, C.byref(t)))
         return {k: getattr(t, k) for k, _ in TimingC._fields_}
+
+    def band_redo_pairs(self):
+        """pairs of the last banded call that the packed fill flagged and the int32 kernels recomputed"""
+        v = C.c_uint64(0)
+        check(lib().bg_band_redo_pairs(self.h, C.byref(v)))
+        return int(v.value)
 
     def close(self):
         if self.h:

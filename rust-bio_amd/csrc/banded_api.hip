@@ -180,6 +180,17 @@ struct bg_band_scratch {
     uint32_t started_target = 0;    // ... and how many have been launched
 };
 
+extern "C" int bg_band_redo_pairs(bg_ctx* ctx, uint64_t* out) {
+    if (!ctx || !out) return BG_ERR_INVALID_ARG;
+    *out = 0;
+    if (!ctx->band || !ctx->band->d_started) return BG_OK;
+    BG_HIP(hipDeviceSynchronize());
+    uint32_t v = 0;
+    BG_HIP(hipMemcpy(&v, ctx->band->d_started + 1, 4, hipMemcpyDeviceToHost));
+    *out = v;
+    return BG_OK;
+}
+
 void bg_band_scratch_free(bg_band_scratch* b) {
     if (!b) return;
     for (auto& s : b->set) {
@@ -474,7 +485,7 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
     }
     hipStream_t st_build = B.build_stream;
     if (!B.d_started) BG_HIP(hipMalloc((void**)&B.d_started, 64));
-    BG_HIP(hipMemsetAsync(B.d_started, 0, 4, st));
+    BG_HIP(hipMemsetAsync(B.d_started, 0, 8, st));  // [0] blocks started, [1] pairs K3p flagged
     B.started_target = 0;
     BG_HIP(hipEventRecord(B.seq_ready, st));
     BG_HIP(hipStreamWaitEvent(st_build, B.seq_ready, 0));
@@ -764,6 +775,18 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
             a.ring32 = ctx->band_window ? 0 : 1;
             a.split = (narrow && !ctx->band_interior_off && cs.xclip_prefix <= BG_MIN_SCORE / 2 && cs.xclip_suffix <= BG_MIN_SCORE / 2 &&
                        cs.yclip_prefix > BG_MIN_SCORE / 2) ? 1 : 0;
+            // ... and, where the scoring and the lengths fit its 16-bit strip-relative keys, K3p takes the runs first
+            // (banded_fill2p.hip: target / threshold as computed there; at least 2^14 key units == 1024 score units of room)
+            {
+                const int64_t mk = ((int64_t)a.sc.match << 4) + 12, mis = ((int64_t)-a.sc.mismatch << 4) - 10;
+                const int64_t target = (0xfff0 - (mk + mis) - ((int64_t)a.sc.match << 9) - 32) & ~15ll;
+                const int64_t thresh = ((int64_t)a.sc.match << 9) + 16 + ((int64_t)-a.sc.go << 4) + 32;
+                a.packed = (a.split && !ctx->band_packed_off && a.sc.match >= 0 && a.sc.match <= 64 && a.sc.mismatch <= -1 &&
+                            a.sc.mismatch >= -1024 && a.sc.go <= -1 && a.sc.go >= -1024 && a.sc.ge <= 0 && a.sc.ge >= -1024 &&
+                            max_y < 65536 && target - thresh >= (1 << 14)) ? 1 : 0;
+                a.pk_thresh = (int32_t)ctx->band_packed_thresh;
+                a.redo_count = B.d_started + 1;
+            }
             if (on_device) B.started_target += band_fill2_blocks(a.n_pairs);
             // K3v2 / K3i: eight pairs per wavefront; the epilogue goes to the traceback stream, ahead of K4 — the fill
             // stream goes straight on with the next sub-batch (event timing keeps everything on one stream)

@@ -325,7 +325,21 @@ bool launch_band_fill2(const BandArgs& a0, bool narrow, hipStream_t st, hipEvent
             a.phase = 1;
             launch_fill2_narrow(a, grid, st);
             a.started = started;
-            launch_fill2i(a, grid, st);
+            if (a.packed) {
+                // K3p first (two pairs per lane group, 16-bit keys relative to a per-strip base); the pairs it flags — a
+                // band cell below the floor of its strip — go through the int32 kernels again: phase 1 once more (bnd is
+                // reused by every strip, so the run's first boundary row has to be rebuilt), then K3i.  Both launches find
+                // no flag and leave within microseconds in the usual case.
+                launch_fill2p(a, st);
+                a.started = nullptr;
+                a.redo = 1;
+                a.phase = 1;
+                launch_fill2_narrow(a, grid, st);
+                launch_fill2i(a, grid, st);
+                a.redo = 0;
+            } else {
+                launch_fill2i(a, grid, st);
+            }
             a.started = nullptr;
             a.phase = 2;
             launch_fill2_narrow(a, grid, st);

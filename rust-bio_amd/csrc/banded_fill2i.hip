@@ -70,6 +70,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         m = (uint32_t)(a.x_off[a.pair0 + pair + 1] - xo);
         n = (uint32_t)(a.y_off[a.pair0 + pair + 1] - yo);
         live = bp.flags == BP_OK && m != 0;
+        if (a.redo && live) live = (a.aux + bp.aux_off)[5] != 0;  // only what K3p flagged (banded_fill2p.hip)
     }
     const uint8_t* x = a.x + xo;
     const uint8_t* y = a.y + yo;

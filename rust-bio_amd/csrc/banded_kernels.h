@@ -48,7 +48,7 @@ struct BandPair {
     uint32_t _pad;
 };
 
-// aux record (int32 words): [0] score  [1] S nibble of (m,n)  [2] Lx[n]  [3] Ly[m]  [4..7] spare
+// aux record (int32 words): [0] score  [1] S nibble of (m,n)  [2] Lx[n]  [3] Ly[m]  [5] K3p: "redo this pair"  [4,6,7] spare
 //   Ly[m+1]  Lx[n+1]  V[n+1] (S[curr][m] after each column)  Sn[m+1]  bits[m+1 bytes]  bnd int4[n+1]
 struct BandAux {
     uint32_t m, n;
@@ -93,6 +93,10 @@ struct BandArgs {
     int32_t phase;  // K3v2: 0 all strips of every pair; 1 / 2: the strips before / behind the interior run (band_split)
     int32_t ring32; // K3i with 32-byte rings (33 KB of LDS per block instead of 65)
     int32_t split;  // the scoring admits interior runs (host decision, banded_api.hip): band_split may say yes
+    int32_t packed;     // the interior runs go to K3p (banded_fill2p.hip) first; K3i redoes what it flags
+    int32_t redo;       // K3v2 phase 1 / K3i: only the pairs K3p flagged (aux[5] != 0)
+    int32_t pk_thresh;  // K3p: the threshold a band cell's key has to exceed (0: derived from the scoring; tests raise it)
+    uint32_t* redo_count;  // K3p counts the pairs it flags here (nullptr: nobody asks)
 };
 
 // Interior run of a pair: the strips [s_a, s_b) of RS rows each that banded_fill2i_kernel takes with its reduced cell.
@@ -124,7 +128,8 @@ band_fill_fn get_band_fill(int sm);
 // K3v2 (banded_fill2.hip): LP lanes per pair, R rows per lane, MatchParams scoring; the last-column
 // epilogue runs in its own kernel.  Returns false if the geometry is not instantiated.
 bool launch_band_fill2(const BandArgs& a, bool narrow, hipStream_t st, hipEvent_t after_fill = nullptr, hipStream_t epi = nullptr);
-void launch_fill2i(const BandArgs& a, dim3 grid, hipStream_t st);  // banded_fill2i.hip: the interior runs  // after_fill: recorded between the fill and its epilogue
+void launch_fill2i(const BandArgs& a, dim3 grid, hipStream_t st);  // banded_fill2i.hip: the interior runs
+void launch_fill2p(const BandArgs& a, hipStream_t st);             // banded_fill2p.hip: the same, two pairs per lane group
 uint32_t band_fill2_blocks(uint32_t n_pairs);  // thread blocks launch_band_fill2 starts for n_pairs
 // holds `st` until *counter >= target (or ~20 ms have passed): "the fill kernel's blocks are all resident"
 void launch_band_wait_started(const uint32_t* counter, uint32_t target, hipStream_t st);

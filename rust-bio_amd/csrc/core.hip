@@ -209,6 +209,15 @@ extern "C" int bg_set_option(bg_ctx* ctx, const char* key, int64_t value) {
         ctx->band_interior_off = value != 0;
         return BG_OK;
     }
+    if (!strcmp(key, "band_packed_off")) {
+        ctx->band_packed_off = value != 0;
+        return BG_OK;
+    }
+    if (!strcmp(key, "band_packed_thresh")) {
+        if (value < 0 || value > 0xffff) return BG_ERR_INVALID_ARG;
+        ctx->band_packed_thresh = value;
+        return BG_OK;
+    }
     if (!strcmp(key, "band_tail_last")) {
         ctx->band_tail_last = value != 0;
         return BG_OK;

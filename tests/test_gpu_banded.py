@@ -35,8 +35,11 @@ def as_dict(a):
             "xlen": a.xlen, "ylen": a.ylen, "ops": a.operations}
 
 
-def differential(kw, some, mode, k, w, xs, ys):
+def differential(kw, some, mode, k, w, xs, ys, opts=None):
     al = Aligner.with_scoring(engine_scoring(kw, some), k, w)
+    for k_, v_ in (opts or {}).items():
+        al.ctx.set_option(k_, v_)
+    differential.last_ctx = al.ctx
     x, xo = _lib.concat(xs)
     y, yo = _lib.concat(ys)
     try:
@@ -46,6 +49,8 @@ def differential(kw, some, mode, k, w, xs, ys):
         assert e.status in (-10, -11), e  # some pair: traceback does not terminate / panics in the reference
         out, ops = al.last_out, al.last_ops
         engine_failed = True
+    for k_ in (opts or {}):
+        al.ctx.set_option(k_, 0)  # (the default ctx is shared between Aligners)
     okw = dict(kw)
     okw["match_scores_some"] = 1 if some else 0
     osc = orc.make_scoring(**okw)
@@ -333,7 +338,7 @@ def test_fill_kernel_variants_agree():
         # band_interior_off: K3v2's general step in every strip (by default semiglobal-like scorings take a reduced step
         # in the strips that neither reach column n nor hold row m)
         for opts in ({"band_fill_v1": -1}, {"band_fill_v1": -1, "force_wide": 1}, {"band_fill_v1": 1}, {"band_fill_v1": 0},
-                     {"band_fill_v1": -1, "band_interior_off": 1}):
+                     {"band_fill_v1": -1, "band_interior_off": 1}, {"band_fill_v1": -1, "band_packed_off": 1}):
             for k_, v_ in opts.items():
                 al.ctx.set_option(k_, v_)
             try:
@@ -410,6 +415,20 @@ def test_interior_runs_long_reads_vs_oracle(case):
     kw = dict(BASE)
     kw.update(case["kw"])
     differential(kw, True, case["mode"], case["k"], case["w"], xs, ys)
+    packed = case["kw"]["gap_open"] <= -1  # (banded_api.hip: what K3p's unsigned keys need)
+    redo_default = differential.last_ctx.band_redo_pairs()
+    assert redo_default <= 2, redo_default  # related reads: no band cell anywhere near the floor of its strip
+    # the interior runs again: on the int32 kernel alone, with every pair flagged and recomputed, and with a threshold in the
+    # middle of the range (some pairs of a lane group flagged, others not)
+    for opts, redo in (({"band_packed_off": 1}, "none"), ({"band_packed_thresh": 65535}, "all"), ({"band_packed_thresh": 63000}, "some")):
+        differential(kw, True, case["mode"], case["k"], case["w"], xs, ys, opts)
+        n = differential.last_ctx.band_redo_pairs()
+        if not packed or redo == "none":
+            assert n == 0, (opts, n)
+        elif redo == "all":
+            assert n >= 10, (opts, n)  # every pair that has an interior run
+        else:
+            assert n >= 1, (opts, n)
 
 
 @pytest.mark.parametrize("opts", [{}, {"band_tail_last": 1}, {"band_window": 1, "band_raster_late": 1}],

@@ -35,9 +35,11 @@ def measure(tag):
         tag, wall * 1e3, Pb / wall, c / wall / 1e9, t["fill_ms"], t["traceback_ms"], c / (t["fill_ms"] + t["traceback_ms"]) / 1e6), flush=True)
     return d_bout.clone(), d_bops.clone()
 base = measure("default")
+print("   redo pairs:", ctx.band_redo_pairs(), flush=True)
 for o in opts:
     ctx.set_option(o, 1)
     got = measure(o + "=1")
+    print("   redo pairs:", ctx.band_redo_pairs(), flush=True)
     ctx.set_option(o, 0)
     rec_a, rec_b = base[0].view(torch.int32).view(Pb, 16), got[0].view(torch.int32).view(Pb, 16)
     print("   records equal:", bool((rec_a == rec_b).all().item()), " ops equal:", bool((base[1] == got[1]).all().item()), flush=True)
