@@ -427,7 +427,7 @@ def test_interior_runs_long_reads_vs_oracle(case):
             assert n == 0, (opts, n)
         elif redo == "all":
             assert n >= 10, (opts, n)  # every pair that has an interior run
-        else:
+        elif case["kw"]["gap_extend"] < 0:  # (without an extension penalty no band cell sinks that far below its row's best)
             assert n >= 1, (opts, n)
 
 
