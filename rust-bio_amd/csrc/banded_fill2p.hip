@@ -60,12 +60,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     constexpr int RING = 32;   // bytes of LDS per row and pair, indexed by step (banded_fill2i.hip)
     constexpr int FLUSH = 16;  // steps between two hand-overs of complete 16-byte groups == the blocks of the Sn / Ly merge
     static_assert(LP == 16, "a block of 16 steps is one chunk: lane ll prepares / hands over step t0 + ll");
-    constexpr int LANE_LDS = 2 * R * RING + 4;  // lanes one bank apart (an odd number of dwords)
-    static_assert((LANE_LDS / 4) % 2 == 1, "bank mapping");
-    __shared__ __align__(16) uint8_t s_tb_all[256 * LANE_LDS];
-    uint8_t* const s_row = s_tb_all + threadIdx.x * LANE_LDS;
-    // the strip's last row on its way to bnd: (S, I) of both pairs per step, one block of 16 steps per lane group
-    __shared__ uint2 s_hand_all[256 / LP][16];
+    // The rings of a wavefront are interleaved dword by dword: dword d of ring (pair h, row r) of lane L sits at
+    // ((h * R + r) * 8 + d) * 256 + L * 4 of the wavefront's 8 KB — whatever dword the lanes touch, lane L is in bank L (no
+    // padding: two blocks are 68 KB, and the 91 KB k-mer join of the next sub-batch fits next to them, banded_api.hip)
+    constexpr int WAVE_LDS = 64 * 2 * R * RING;
+    __shared__ __align__(16) uint8_t s_tb_all[4 * WAVE_LDS];
+    uint8_t* const s_row = s_tb_all + (threadIdx.x >> 6) * WAVE_LDS + (threadIdx.x & 63) * 4;
+    auto ring_at = [&](int hr, uint32_t byte) -> uint8_t* { return s_row + ((uint32_t)hr * 8u + (byte >> 2)) * 256u + (byte & 3u); };
+    // the strip's last row on its way to bnd: (S, I) of both pairs per step, eight steps per lane group (33 KB per block in
+    // all, what K3i takes: the LDS of a CU is handed out in pieces, and one more of them per block keeps the join out)
+    __shared__ uint2 s_hand_all[256 / LP][8];
     constexpr int32_t NEGS = kNarrowFloor * 16;
     auto to_s = [](int32_t v) -> int32_t {  // the reference's integers -> the scaled domain (K3v2's map)
         if (v <= NEG / 2) return NEGS + (int32_t)((uint32_t)(max(v, NEG - (1 << 20)) - NEG) << 4);
@@ -254,11 +258,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         const int gk = g0 + k;
                         if (gk < g1) {
                             const uint32_t sbyte = ((uint32_t)gk * 16u + (uint32_t)(o + ll)) & (uint32_t)(RING - 1);
-                            const uint8_t* ring = s_row + (h * R + r) * RING;
                             const uint32_t d0 = sbyte & ~3u, sh = sbyte & 3u;
                             uint32_t w[5];
 #pragma unroll
-                            for (int q = 0; q < 5; q++) w[q] = *(const uint32_t*)(ring + ((d0 + 4u * q) & (uint32_t)(RING - 1)));
+                            for (int q = 0; q < 5; q++) w[q] = *(const uint32_t*)ring_at(h * R + r, (d0 + 4u * q) & (uint32_t)(RING - 1));
                             *(uint4*)(P[h].tb + trow[h][r] + (uint32_t)gk * kTbGroupStride) =
                                 make_uint4(__builtin_amdgcn_alignbyte(w[1], w[0], sh), __builtin_amdgcn_alignbyte(w[2], w[1], sh),
                                            __builtin_amdgcn_alignbyte(w[3], w[2], sh), __builtin_amdgcn_alignbyte(w[4], w[3], sh));
@@ -357,14 +360,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     SnB[r] = pk_max(SnB[r], Sl[r] | tpri);  // banded.rs:655-660, per block of 16 steps
                     const pk cell = sel(BIT4, Dv_t << 4, sel(ONE, Iv_t, kb));
                     const uint32_t slot = (uint32_t)t & (uint32_t)(RING - 1);
-                    s_row[r * RING + slot] = (uint8_t)cell;
-                    s_row[(R + r) * RING + slot] = (uint8_t)(cell >> 16);
+                    *ring_at(r, slot) = (uint8_t)cell;
+                    *ring_at(R + r, slot) = (uint8_t)(cell >> 16);
                     diag = left_S;
                 }
                 S_out = S_up;
                 I_out = I_up;
                 q_out = q;
-                if (ll == LP - 1) s_hand[t & 15] = make_uint2(S_up, I_up);
+                if (ll == LP - 1) s_hand[t & 7] = make_uint2(S_up, I_up);
             }
             c.q = wave_shl1z(c.q);
             c.S = wave_shl1z(c.S);
@@ -402,13 +405,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
         T1 = __builtin_amdgcn_readfirstlane(T1);
         T2 = __builtin_amdgcn_readfirstlane(T2);
-        // the last row of the strip, block by block: lane ll takes the step t0 + ll of the group's last lane to bnd (16 lanes, 16
-        // consecutive columns) — one store per lane and block instead of one per step of the last lane, and nothing a later
-        // wait for the chunk loads has to sit out
+        // the last row of the strip, eight steps at a time: lane ll < 8 takes the step t0 + ll of the group's last lane to bnd
+        // (eight consecutive columns) — one store per lane instead of one per step of the last lane, and nothing a later wait
+        // for the chunk loads has to sit out
         auto hand_over = [&](int t0, int t_end) {
-            const uint2 v = s_hand[ll];
+            const uint2 v = s_hand[ll & 7];
             const int t = t0 + ll, tl = t - (LP - 1);
-            if (t < t_end && tl >= 0) {
+            if (ll < 8 && t < t_end && tl >= 0) {
 #pragma unroll
                 for (int h = 0; h < 2; h++)
                     if (tl <= span[h])
@@ -423,14 +426,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const int t_end = min(t0 + 16, nsteps_w);
             if (all_in) {
 #pragma unroll
-                for (int k = 0; k < 16; k++) step(t0 + k, c0, std::true_type{});
+                for (int k = 0; k < 8; k++) step(t0 + k, c0, std::true_type{});
+                hand_over(t0, t0 + 8);
+#pragma unroll
+                for (int k = 8; k < 16; k++) step(t0 + k, c0, std::true_type{});
             } else {
 #pragma unroll 1
-                for (int t = t0; t < t_end; t++) step(t, c0, std::false_type{});
+                for (int t = t0; t < min(t0 + 8, t_end); t++) step(t, c0, std::false_type{});
+                hand_over(t0, t_end);
+#pragma unroll 1
+                for (int t = t0 + 8; t < t_end; t++) step(t, c0, std::false_type{});
             }
-            c0 = finish_chunk(raw);  // (the only loads in flight: the stores below are issued behind this wait)
+            c0 = finish_chunk(raw);  // (waits for these loads and the first half's stores; the stores below are issued behind it)
             merge_rows(t0 + 15);
-            hand_over(t0, t_end);
+            hand_over(t0 + 8, t_end);
             if ((t_end & (FLUSH - 1)) == 0) flush_tb(t_end - 1 - ll, t_end - 1 - ll - FLUSH, false);
         }
         {
