@@ -157,6 +157,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const uint32_t rb = (strip * LP + ll) * R;  // rows rb + 1 .. rb + R, all of them in [2, m - 1] with columns >= 1
         bool act[2];
         int32_t jlo[2], span[2], shift[2];
+        uint32_t sn_init[2];
         uint32_t trow[2][R];
         pk Sl[R], Dl[R], Sn[R], SnB[R], ycl[R], Ly[R], px[R], off[R], wn[R];
 #pragma unroll
@@ -218,7 +219,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (lo <= hi) lo = max(1, lo - 1);  // one extra column on the left: the diagonal arrives through the pipeline
             jlo[h] = lo;
             span[h] = hi >= lo ? hi - lo : -1;
+            // Sn[i] starts at MIN_SCORE (K3i: NEGS - sn_bias); clamped into the range it still decides every "S + ys > Sn[i]" as
+            // the exact value would (below the floor: every band cell is above; above the cap: none is)
             const uint32_t sn0 = (uint32_t)min(max(NEGS - sn_bias - shift[h], 0), 0xffff);
+            sn_init[h] = sn0;
 #pragma unroll
             for (int r = 0; r < R; r++) {
                 const uint32_t w = (uint32_t)max(cl[r] - cf[r] + 1, 0);
@@ -318,6 +322,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         };
         pk S_out = 0, I_out = 0, q_out = 0;
         pk lo_acc = 0xffffffffu;  // minimum over the band cells of this lane
+        pk last_acc = 0;          // maximum over this lane's last row (the group's last lane: the next strip's base)
         auto step = [&](const int t, Chunk& c, auto all_in_tag) {
             constexpr bool ALL_IN = decltype(all_in_tag)::value;
             const pk tpri = dup16(15u - ((uint32_t)t & 15u));
@@ -367,6 +372,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 S_out = S_up;
                 I_out = I_up;
                 q_out = q;
+                last_acc = pk_max(last_acc, S_up);
                 if (ll == LP - 1) s_hand[t & 7] = make_uint2(S_up, I_up);
             }
             c.q = wave_shl1z(c.q);
@@ -455,14 +461,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int r = 0; r < R; r++) {
                 const uint32_t i = rb + r + 1;
                 if (act[h] && half_of(wn[r], h) != 0) {
-                    gSn[i] = from_s((int32_t)half_of(Sn[r], h) + shift[h] + sn_bias);
+                    // (a row that never raised its Sn keeps the exact initial value, not the clamped one)
+                    const uint32_t sn = half_of(Sn[r], h);
+                    gSn[i] = from_s(sn == sn_init[h] ? NEGS : (int32_t)sn + shift[h] + sn_bias);
                     gLy[i] = (int32_t)half_of(Ly[r], h);
                 }
             }
             if (act[h] && half_of(lo_acc, h) <= thresh) P[h].bad = true;
-            // the next strip's base: the maximum of this strip's last row (the last lane's row R - 1)
-            const int32_t last_max = (int32_t)half_of(Sn[R - 1], h) + shift[h];
-            P[h].base = __shfl(last_max, g * LP + LP - 1);
+            // the next strip's base: the maximum of this strip's last row (the last lane's row R - 1); a last row without a
+            // band cell leaves nothing to hang the next strip's range on: the int32 kernels take the pair
+            const int32_t last_rel = __shfl((int32_t)half_of(last_acc, h), g * LP + LP - 1);
+            if (act[h] && last_rel == 0) P[h].bad = true;
+            P[h].base = last_rel + shift[h];
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next strip reads bnd / gSn of this one
     }
