@@ -52,6 +52,12 @@ __device__ __forceinline__ pk sel(pk mask, pk a, pk b) {  // (a & mask) | (b & ~
     return r;
 }
 __device__ __forceinline__ pk selv(pk mask, pk a, pk b) { return (a & mask) | (b & ~mask); }
+// lane L of a row of 16 takes v of lane L - 1; the row's first lane keeps `first` (DPP row_shr:1 without bound_ctrl: a lane
+// without a source keeps the old destination) — the lane group is exactly a DPP row, so the value from above the strip
+// enters the pipeline without a select
+__device__ __forceinline__ pk row_shr1_first(pk first, pk v) {
+    return (pk)__builtin_amdgcn_update_dpp((int)first, (int)v, 0x111, 0xf, 0xf, false);
+}
 // 0xffff in every half that is non-zero
 __device__ __forceinline__ pk nz_mask(pk v, pk one) { return pk_sub(pk_subs(one, v), one); }
 
@@ -326,12 +332,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         auto step = [&](const int t, Chunk& c, auto all_in_tag) {
             constexpr bool ALL_IN = decltype(all_in_tag)::value;
             const pk tpri = dup16(15u - ((uint32_t)t & 15u));
-            pk S_up = wave_shr1z(S_out), I_up = wave_shr1z(I_out), q = wave_shr1z(q_out);
-            if (ll == 0) {
-                S_up = c.S;
-                I_up = c.I;
-                q = c.q;
-            }
+            // (the chunk moves on first: its old registers then die in the three moves below, which write them in place)
+            const pk cS = c.S, cI = c.I, cq = c.q;
+            c.q = wave_shl1z(cq);
+            c.S = wave_shl1z(cS);
+            c.I = wave_shl1z(cI);
+            pk S_up = row_shr1_first(cS, S_out), I_up = row_shr1_first(cI, I_out), q = row_shr1_first(cq, q_out);
             const int tl = t - ll;  // column jlo[h] + tl of either pair
             if (ALL_IN || (tl >= 0 && tl <= span_max)) {  // (all-in blocks: every lane has a column)
                 const pk tlp = dup16((uint32_t)tl);
@@ -375,9 +381,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 last_acc = pk_max(last_acc, S_up);
                 if (ll == LP - 1) s_hand[t & 7] = make_uint2(S_up, I_up);
             }
-            c.q = wave_shl1z(c.q);
-            c.S = wave_shl1z(c.S);
-            c.I = wave_shl1z(c.I);
         };
         auto merge_rows = [&](const int t_end) {  // the block that ends at step t_end into (Sn, Ly)
             // Ly = n - j of the block's first maximum: n - (jlo + t_end - ll) + (steps before t_end)
@@ -427,19 +430,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         };
         Chunk c0 = finish_chunk(issue_chunk(0));
         for (int t0 = 0; t0 < nsteps_w; t0 += 16) {
-            const bool all_in = t0 >= T1 && t0 + 15 <= T2;  // (then t0 + 16 <= nsteps_w as well)
+            // (all-in by half block: then the half's last step is below nsteps_w as well)
+            const bool all_in_a = t0 >= T1 && t0 + 7 <= T2, all_in_b = t0 + 8 >= T1 && t0 + 15 <= T2;
             const Raw raw = issue_chunk(t0 + 16);
             const int t_end = min(t0 + 16, nsteps_w);
-            if (all_in) {
+            if (all_in_a) {
 #pragma unroll
                 for (int k = 0; k < 8; k++) step(t0 + k, c0, std::true_type{});
-                hand_over(t0, t0 + 8);
-#pragma unroll
-                for (int k = 8; k < 16; k++) step(t0 + k, c0, std::true_type{});
             } else {
 #pragma unroll 1
                 for (int t = t0; t < min(t0 + 8, t_end); t++) step(t, c0, std::false_type{});
-                hand_over(t0, t_end);
+            }
+            hand_over(t0, t_end);
+            if (all_in_b) {
+#pragma unroll
+                for (int k = 8; k < 16; k++) step(t0 + k, c0, std::true_type{});
+            } else {
 #pragma unroll 1
                 for (int t = t0 + 8; t < t_end; t++) step(t, c0, std::false_type{});
             }
