@@ -79,6 +79,8 @@ const char* bg_last_error(void); /* text of the last HIP failure on this thread 
  *   no_pk16 = 1        no packed-int16 fill (K1p): the int32 kernel K1 runs for every batch
  *   no_couples = 1     K1p without the (m, n) slot order on ragged batches
  *   no_local_fast = 1  Aligner::local batches on the general K1p instead of its LF flavour (tests, A/B)
+ *   fm_host_bytes = 1  bg_fm_backward_search_batch stages the pattern bytes as they are (default: packed to 2-bit codes by
+ *                      the host threads where the index takes packed patterns; tests, A/B)
  *   band_on_host = 1   bands built by the host threads instead of the device builder
  *   band_fill_v1       1: banded fill with one pair per wavefront (K3) always; -1: eight pairs per wavefront (K3v2)
  *                      always; 0 (default): K3 for sub-batches of at most 2048 pairs (latency), K3v2 above (throughput)
@@ -182,6 +184,11 @@ int bg_pack2_dev(bg_ctx* ctx, const uint8_t* d_bytes, uint64_t n, const uint8_t*
                  uint64_t* d_n_invalid, void* stream);
 int bg_unpack2_dev(bg_ctx* ctx, const uint32_t* d_packed, uint64_t n, const uint8_t* codes, uint8_t* d_bytes,
                    void* stream);
+/* The same packing on the host (no GPU involved; AVX2 where the CPU has it): `packed` must hold (n + 15) / 16 dwords.
+ * Returns 1 if every byte was one of the four codes, 0 if not (such bytes are stored as whatever their low bits say:
+ * take the byte entry points), a negative BG_ERR_* for bad arguments.  bg_fm_backward_search_batch packs its stages
+ * with it on the worker threads. */
+int bg_pack2_host(const uint8_t* bytes, uint64_t n, const uint8_t* codes, uint32_t* packed);
 /* The byte values of the index's four 2-bit codes — the `codes` to pack its patterns with.  BG_ERR_UNSUPPORTED when
  * the text has fewer than four frequent letters or symbols ranked by bit vectors: such an
  * index takes byte patterns only. */

@@ -90,7 +90,7 @@ SYMBOLS = ["bg_device_count", "bg_init", "bg_free", "bg_strerror", "bg_last_erro
            "bg_align_batch", "bg_align_batch_dev", "bg_align_banded_batch", "bg_align_banded_batch_dev", "bg_band_create_batch",
            "bg_align_banded_bands_batch", "bg_band_from_matches_batch", "bg_sparse_find_kmer_matches", "bg_sparse_sdpkpp",
            "bg_sparse_lcskpp", "bg_sparse_sdpkpp_union_lcskpp_path", "bg_sparse_expand_kmer_matches", "bg_fastq_parse",
-           "bg_fastq_parse_dev", "bg_cigar_batch", "bg_cigar_batch_dev", "bg_get_timing", "bg_enable_timing", "bg_band_redo_pairs",
+           "bg_fastq_parse_dev", "bg_cigar_batch", "bg_cigar_batch_dev", "bg_get_timing", "bg_enable_timing", "bg_band_redo_pairs", "bg_pack2_host",
            "bg_pretty_batch", "bg_suffix_array_dev", "bg_bwt_dev", "bg_sa_sample_dev", "bg_fm_build_dev", "bg_fm_set_text", "bg_fm_set_text_dev", "bg_seed_extend_batch", "bg_seed_extend_batch_dev",
            "bg_pack2_dev", "bg_unpack2_dev", "bg_fm_pattern_codes", "bg_fm_backward_search_packed_dev",
            "bg_fm_backward_search_count_lines_dev", "bg_align_batch_packed_dev", "bg_fm_step2_bytes",
@@ -195,6 +195,7 @@ def lib():
         L.bg_get_timing.argtypes = [vp, C.POINTER(TimingC)]
         L.bg_enable_timing.argtypes = [vp, i32]
         L.bg_band_redo_pairs.argtypes = [vp, C.POINTER(u64)]
+        L.bg_pack2_host.argtypes = [vp, u64, vp, vp]
         for s in SYMBOLS:
             if getattr(L, s).restype is C.c_int or s.startswith("bg_") and getattr(L, s).restype is None:
                 pass

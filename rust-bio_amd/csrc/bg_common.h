@@ -55,6 +55,7 @@ struct bg_ctx {
     bg_host_pipe* pipe = nullptr;     // persistent staging of bg_align_batch's pipelined path
     bg_seed_scratch* seed = nullptr;  // persistent scratch of the seed-and-extend pipeline
     bg_fm_pipe* fm_pipe = nullptr;    // persistent pinned / device staging of bg_fm_backward_search_batch
+    bool fm_host_bytes = false;       // tests, A/B: bg_fm_backward_search_batch stages the pattern bytes (no 2-bit packing on the host)
     int64_t host_chunk_pairs = 0;     // pairs per pipeline stage of bg_align_batch (0 = default)
     int64_t chunk_pairs = 0;  // 0 = default
     int64_t seed_chunk_reads = 0;  // reads per pass of bg_seed_extend_batch_dev (0 = 2^20)
@@ -139,6 +140,10 @@ inline hipError_t bg_copy_pieces(void* dst, const void* src, size_t bytes, hipMe
 }
 // host threads this process may really use (affinity mask and cgroup CPU quota)
 unsigned bg_host_threads();
+namespace bgpack {
+// host_pack2.cpp: bytes -> 2-bit stream (16 symbols per dword); false if a byte is none of the four codes
+bool pack2_host(const uint8_t* src, uint64_t n, const uint8_t codes[4], uint32_t* dst);
+}
 // fn(0) .. fn(nt - 1) on the process-wide worker threads (created once, bg_host_threads() - 1 of them) and the caller;
 // returns when all have run.  Calls from several threads share the workers.  (Spawning 16 threads per parallel loop cost
 // 0.4 ms a loop: a fifth of what bg_align_batch spends per stage.)

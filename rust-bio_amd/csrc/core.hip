@@ -234,6 +234,10 @@ extern "C" int bg_set_option(bg_ctx* ctx, const char* key, int64_t value) {
         ctx->band_on_host = value != 0;
         return BG_OK;
     }
+    if (!strcmp(key, "fm_host_bytes")) {
+        ctx->fm_host_bytes = value != 0;
+        return BG_OK;
+    }
     if (!strcmp(key, "host_chunk_pairs")) {
         ctx->host_chunk_pairs = value;
         return BG_OK;

@@ -1387,7 +1387,7 @@ extern "C" int bg_fm_backward_search_batch(bg_fm* fm, uint64_t n_q, const uint8_
         max_pb = std::max(max_pb, pat_off[q1] - pat_off[q0]);
     }
     // staging layout: in = pattern bytes | offsets ; out = lower | upper | matched_len | tag
-    const uint64_t o_off = (max_pb + 255) & ~255ull;
+    const uint64_t o_off = (max_pb + 8 + 255) & ~255ull;  // (+8: the packed flavour's dword past the last symbol)
     const size_t in_need = o_off + (chunk + 1) * 8 + 256;
     const uint64_t o_hi = chunk * 8, o_ml = 2 * chunk * 8, o_tag = o_ml + chunk * 4;
     const size_t out_need = o_tag + chunk + 256;
@@ -1413,6 +1413,12 @@ extern "C" int bg_fm_backward_search_batch(bg_fm* fm, uint64_t n_q, const uint8_
     }
     hipStream_t s_k = ctx->stream;
     std::atomic<bool> any_panic{false};
+    // The patterns travel as 2-bit codes where the index takes them (bg_fm_pattern_codes) — packed by the worker threads
+    // into the pinned stage instead of copied there: a quarter of the bytes to write and to send over the link, and the
+    // packed kernel on the other side.  A stage with a byte outside the four codes is staged as bytes after all.
+    uint8_t pcodes[4] = {0, 0, 0, 0};
+    const bool can_pack = !ctx->fm_host_bytes && bg_fm_pattern_codes(fm, pcodes) == BG_OK;
+    uint64_t n_packed_stages = 0;
     // BG_TRACE_HOST=1: where the host side of the stages spends its time (ms, summed over the call)
     const bool trace = getenv("BG_TRACE_HOST") != nullptr;
     double t_pack = 0, t_launch = 0, t_wait_set = 0, t_d_wait = 0, t_d_copy = 0;
@@ -1489,7 +1495,19 @@ extern "C" int bg_fm_backward_search_batch(bg_fm* fm, uint64_t n_q, const uint8_
         bg_fm_pipe::Set& S = P.set[c % bg_fm_pipe::NSET];
         const uint64_t q0 = c * chunk, nq = std::min(n_q, q0 + chunk) - q0;
         const uint64_t b0 = pat_off[q0], pb = pat_off[q0 + nq] - b0;
-        fm_parallel_for(pb, 1 << 20, [&](uint64_t a, uint64_t b) { memcpy(S.h_in + a, pat + b0 + a, b - a); });
+        bool packed = can_pack && pb != 0;
+        if (packed) {
+            std::atomic<bool> all_codes{true};
+            // (ranges start at multiples of 64 symbols: whole dwords per thread)
+            fm_parallel_for((pb + 63) / 64, 1 << 14, [&](uint64_t a, uint64_t b) {
+                const uint64_t s0 = a * 64, s1 = std::min(pb, b * 64);
+                if (!bgpack::pack2_host(pat + b0 + s0, s1 - s0, pcodes, (uint32_t*)S.h_in + s0 / 16)) all_codes = false;
+            });
+            packed = all_codes;
+        }
+        if (!packed) fm_parallel_for(pb, 1 << 20, [&](uint64_t a, uint64_t b) { memcpy(S.h_in + a, pat + b0 + a, b - a); });
+        n_packed_stages += packed ? 1 : 0;
+        const uint64_t in_bytes = packed ? ((pb + 15) / 16 + 1) * 4 : pb;
         uint64_t* hoff = (uint64_t*)(S.h_in + o_off);
         fm_parallel_for(nq + 1, 1 << 16, [&](uint64_t a, uint64_t b) {
             for (uint64_t q = a; q < b; q++) hoff[q] = pat_off[q0 + q] - b0;
@@ -1497,10 +1515,13 @@ extern "C" int bg_fm_backward_search_batch(bg_fm* fm, uint64_t n_q, const uint8_
         t_pack += now() - t0;
         t0 = now();
         bool ok = true;
-        if (pb) ok = ok && bg_copy_pieces(S.d_in, S.h_in, pb, hipMemcpyHostToDevice, P.s_in) == hipSuccess;
+        if (pb) ok = ok && bg_copy_pieces(S.d_in, S.h_in, in_bytes, hipMemcpyHostToDevice, P.s_in) == hipSuccess;
         ok = ok && hipMemcpyAsync(S.d_in + o_off, S.h_in + o_off, (nq + 1) * 8, hipMemcpyHostToDevice, P.s_in) == hipSuccess;
         ok = ok && hipEventRecord(S.in_done, P.s_in) == hipSuccess && hipStreamWaitEvent(s_k, S.in_done, 0) == hipSuccess;
         int rc = !ok ? BG_ERR_HIP
+                 : packed
+                     ? bg_fm_backward_search_packed_dev(fm, nq, (const uint32_t*)S.d_in, (const uint64_t*)(S.d_in + o_off), S.d_out + o_tag,
+                                                        (uint64_t*)S.d_out, (uint64_t*)(S.d_out + o_hi), (uint32_t*)(S.d_out + o_ml), s_k)
                      : bg_fm_backward_search_batch_dev(fm, nq, S.d_in, (const uint64_t*)(S.d_in + o_off), S.d_out + o_tag,
                                                        (uint64_t*)S.d_out, (uint64_t*)(S.d_out + o_hi), (uint32_t*)(S.d_out + o_ml), s_k);
         if (rc == BG_OK && (hipEventRecord(S.k_done, s_k) != hipSuccess || hipStreamWaitEvent(P.s_out, S.k_done, 0) != hipSuccess ||
@@ -1522,8 +1543,8 @@ extern "C" int bg_fm_backward_search_batch(bg_fm* fm, uint64_t n_q, const uint8_
     const double t0j = now();
     drainer.join();
     if (trace)
-        fprintf(stderr, "[bg fm host] %llu stages: pack %.2f launch %.2f wait-for-set %.2f join %.2f | drainer: wait %.2f copy %.2f ms\n",
-                (unsigned long long)nch, t_pack, t_launch, t_wait_set, now() - t0j, t_d_wait, t_d_copy);
+        fprintf(stderr, "[bg fm host] %llu stages (%llu as 2-bit codes): pack %.2f launch %.2f wait-for-set %.2f join %.2f | drainer: wait %.2f copy %.2f ms\n",
+                (unsigned long long)nch, (unsigned long long)n_packed_stages, t_pack, t_launch, t_wait_set, now() - t0j, t_d_wait, t_d_copy);
     if (drain_rc) {
         bg_tls_error = drain_err;
         return drain_rc;

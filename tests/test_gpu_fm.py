@@ -321,3 +321,44 @@ def test_two_step_rank_blocks_equal_single_steps_and_the_oracle(text_kind):
     assert (ml.astype(np.uint64) == oml).all()
     assert (tag == 0).any() and (tag == 1).any()
     assert ((ml[tag == 1] % 2) == 0).any() and ((ml[tag == 1] % 2) == 1).any()  # Partial after even and odd lengths
+
+
+def test_host_entry_packs_patterns_on_the_host_and_falls_back_per_stage():
+    """bg_fm_backward_search_batch stages its patterns as 2-bit codes (bg_pack2_host on the worker threads) and runs the packed
+    kernel; a stage that holds a byte outside the four codes goes up as bytes.  2.2 M short patterns = three stages, the second
+    one with foreign bytes: same arrays as with fm_host_bytes = 1 (everything as bytes), and as the oracle on a sample."""
+    g = synth.genome(300_000, 11)
+    sa, b, ls, fm = build(g, b"ACGTNacgtn", 64)
+    rng = np.random.default_rng(5)
+    nq = 2_200_000
+    lens = rng.integers(0, 40, size=nq).astype(np.uint64)
+    off = np.zeros(nq + 1, dtype=np.uint64)
+    off[1:] = np.cumsum(lens)
+    starts = rng.integers(0, len(g) - 64, size=nq)
+    pat = np.empty(int(off[-1]), dtype=np.uint8)
+    idx = np.repeat(starts, lens.astype(np.int64)) + (np.arange(int(off[-1])) - np.repeat(off[:-1].astype(np.int64), lens.astype(np.int64)))
+    pat[:] = g[idx]
+    mut = rng.integers(0, len(pat), size=len(pat) // 50)
+    pat[mut] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=len(mut))]
+    # foreign bytes in the second stage only (queries 2^20 .. 2^21)
+    q_bad = rng.integers(1 << 20, 1 << 21, size=2000)
+    q_bad = q_bad[lens[q_bad] > 0]
+    pat[(off[q_bad] + rng.integers(0, 1 << 30, size=len(q_bad)) % lens[q_bad]).astype(np.int64)] = ord("N")
+
+    tag_b = np.zeros(nq, dtype=np.uint8); lo_b = np.zeros(nq, dtype=np.uint64); hi_b = np.zeros(nq, dtype=np.uint64); ml_b = np.zeros(nq, dtype=np.uint32)
+    tag_p = np.zeros(nq, dtype=np.uint8); lo_p = np.zeros(nq, dtype=np.uint64); hi_p = np.zeros(nq, dtype=np.uint64); ml_p = np.zeros(nq, dtype=np.uint32)
+    L = _lib.lib()
+    rcs = []
+    for opt, (t_, l_, h_, m_) in ((1, (tag_b, lo_b, hi_b, ml_b)), (0, (tag_p, lo_p, hi_p, ml_p))):
+        fm.ctx.set_option("fm_host_bytes", opt)
+        rcs.append(L.bg_fm_backward_search_batch(fm.h, nq, pat.ctypes.data, off.ctypes.data, t_.ctypes.data, l_.ctypes.data,
+                                                 h_.ctypes.data, m_.ctypes.data))
+    fm.ctx.set_option("fm_host_bytes", 0)
+    assert rcs[0] == rcs[1]  # (the status of a search that reached a foreign byte, if any did)
+    assert (tag_b == tag_p).all() and (lo_b == lo_p).all() and (hi_b == hi_p).all() and (ml_b == ml_p).all()
+    # a sample of the clean first stage against the oracle
+    occ = orc.Occ(b, 64, b"ACGTNacgtn")
+    sel = np.arange(0, 20000)
+    sub_off = off[:20001] - off[0]
+    otag, olo, ohi, oml = orc.backward_search_batch(b, ls, occ, pat[:int(off[20000])], sub_off, threads=8)
+    assert (tag_p[sel] == otag).all() and (lo_p[sel] == olo).all() and (hi_p[sel] == ohi).all() and (ml_p[sel].astype(np.uint64) == oml).all()
