@@ -1065,6 +1065,7 @@ def banded_leg(args, ctx, dev, rank, world, do_cpu, orc, threads, parity):
     bal.align_arrays(2, hx, hoff, hy, hoff)
     tm = ctx.timing()
     ctx.enable_timing(False)
+    redo_pairs = ctx.band_redo_pairs()  # pairs the packed-int16 fill (K3p) flagged and the int32 kernels recomputed
     bcells = float(bal.last_cells.sum())
     # algorithmic bytes per pair: m + n + 8(n+1) + 2 x band_cells + 24 + n_ops
     balg = float(Pb) * (2 * Lb + 8 * (Lb + 1) + 24) + 2.0 * bcells + float(bout["n_ops"].sum())
@@ -1083,6 +1084,8 @@ def banded_leg(args, ctx, dev, rank, world, do_cpu, orc, threads, parity):
               "strong": strong,
               "kernel_ms": {"fill": round(tm["fill_ms"], 2), "traceback": round(tm["traceback_ms"], 2)},
               "dp_only_gcups": round(bcells / ((tm["fill_ms"] + tm["traceback_ms"]) * 1e-3) / 1e9, 2),
+              "packed_fill": {"kernel": "banded_fill2p_kernel<2, 16> (K3p: interior strips, two pairs per lane group, 16-bit keys "
+                                        "relative to a per-strip base)", "pairs_recomputed_by_int32_kernels": redo_pairs},
               "host_threads": host_cores(),
               "roofline": {"bound": "hbm", "kernel": "banded_fill", "achieved": round(balg / bfill_s / 1e9, 2),
                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(balg / bfill_s / 1e9 / HBM_PEAK_GBS, 5),
