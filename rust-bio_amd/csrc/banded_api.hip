@@ -337,6 +337,7 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
     if (sc->matrix) {
         const int A = bg_compact_matrix(sc->matrix, code_map, table);
         sm = A <= kMaxLdsAlphabet ? SCORE_LDS : SCORE_GLOBAL;
+        ctx->table_hash = 0;  // (sw_api.hip keeps its compacted matrix here between calls)
         if ((rc = bg_reserve(&ctx->table, &ctx->table_bytes, 256 + table.size() * 4))) return rc;
         BG_HIP(hipMemcpy((uint8_t*)ctx->table + 256, table.data(), table.size() * 4, hipMemcpyHostToDevice));
         BG_HIP(hipMemcpy(ctx->table, code_map.data(), 256, hipMemcpyHostToDevice));

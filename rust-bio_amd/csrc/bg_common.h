@@ -51,6 +51,8 @@ struct bg_ctx {
     size_t unpk_cap[2] = {};
     void* table = nullptr;  // compacted scoring table + code map
     size_t table_bytes = 0;
+    uint64_t table_hash = 0;  // hash of the score matrix whose compacted form `table` holds (0: none / the banded path's)
+    int table_alpha = 0;      // ... and its number of classes
     bg_band_scratch* band = nullptr;  // persistent scratch of the banded pipeline
     bg_host_pipe* pipe = nullptr;     // persistent staging of bg_align_batch's pipelined path
     bg_seed_scratch* seed = nullptr;  // persistent scratch of the seed-and-extend pipeline

@@ -261,16 +261,37 @@ static int align_batch_dev_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, u
 
     int sm = SCORE_PARAMS;
     if (sc->matrix) {
-        std::vector<uint8_t> code_map;
-        std::vector<int32_t> table;
-        const int A = compact_matrix(sc->matrix, code_map, table);
+        // The compacted table stays on the device between calls: a caller aligns batch after batch under one matrix
+        // (`Aligner::with_scoring` once, `local()` per pair), and compacting 65 536 entries, two copies and a
+        // synchronisation per call were 3 ms next to a 31 ms step.  Recognised by a hash of the 256 KB.
+        uint64_t h = 0xcbf29ce484222325ull;
+        {
+            const uint64_t* w = (const uint64_t*)sc->matrix;
+            uint64_t h2 = 0x9e3779b97f4a7c15ull;
+            for (size_t t = 0; t < 32768; t += 2) {
+                h = (h ^ w[t]) * 0x100000001b3ull;
+                h2 = (h2 + w[t + 1]) * 0xff51afd7ed558ccdull;
+                h2 ^= h2 >> 32;
+            }
+            h ^= h2;
+            if (h == 0) h = 1;
+        }
+        if (ctx->table_hash != h) {
+            std::vector<uint8_t> code_map;
+            std::vector<int32_t> table;
+            const int A = compact_matrix(sc->matrix, code_map, table);
+            const size_t bytes = 256 + table.size() * 4;
+            ctx->table_hash = 0;
+            if ((rc = bg_reserve(&ctx->table, &ctx->table_bytes, bytes))) return rc;
+            BG_HIP(hipMemcpyAsync((uint8_t*)ctx->table + 256, table.data(), table.size() * 4,
+                                  hipMemcpyHostToDevice, st));
+            BG_HIP(hipMemcpyAsync(ctx->table, code_map.data(), 256, hipMemcpyHostToDevice, st));
+            BG_HIP(hipStreamSynchronize(st));  // the host vectors go out of scope
+            ctx->table_hash = h;
+            ctx->table_alpha = A;
+        }
+        const int A = ctx->table_alpha;
         sm = A <= kMaxLdsAlphabet ? SCORE_LDS : SCORE_GLOBAL;
-        const size_t bytes = 256 + table.size() * 4;
-        if ((rc = bg_reserve(&ctx->table, &ctx->table_bytes, bytes))) return rc;
-        BG_HIP(hipMemcpyAsync((uint8_t*)ctx->table + 256, table.data(), table.size() * 4,
-                              hipMemcpyHostToDevice, st));
-        BG_HIP(hipMemcpyAsync(ctx->table, code_map.data(), 256, hipMemcpyHostToDevice, st));
-        BG_HIP(hipStreamSynchronize(st));  // the host vectors go out of scope
         a.code_map = (const uint8_t*)ctx->table;
         a.table = (const int32_t*)((uint8_t*)ctx->table + 256);
         a.alpha = A;
