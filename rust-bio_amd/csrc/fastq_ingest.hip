@@ -314,8 +314,27 @@ __global__ __launch_bounds__(256) void fq_measure_kernel(const uint8_t* __restri
     {  // fastq.rs:275-277: line[1..].trim_end().splitn(2, ' ')
         const uint64_t a = ls[r.hdr] + 1;
         const uint32_t n = info[r.hdr].trim - 1;  // the '@' is not whitespace: trim >= 1
+        // the first space of the header: aligned 8-byte loads with a SWAR byte test (a byte at a time this was a chain of
+        // 10-20 dependent loads per record and two thirds of the kernel's 0.19 ms)
         uint32_t sp = 0;
-        while (sp < n && t[a + sp] != ' ') sp++;
+        {
+            const uint8_t* p = t + a;
+            while (sp < n && ((uintptr_t)(p + sp) & 7)) {
+                if (p[sp] == ' ') goto found;
+                sp++;
+            }
+            while (sp + 8 <= n) {
+                const uint64_t w = *(const uint64_t*)(p + sp) ^ 0x2020202020202020ull;
+                const uint64_t z = (w - 0x0101010101010101ull) & ~w & 0x8080808080808080ull;
+                if (z) {
+                    sp += (uint32_t)(__ffsll((long long)z) - 1) >> 3;
+                    goto found;
+                }
+                sp += 8;
+            }
+            while (sp < n && p[sp] != ' ') sp++;
+        found:;
+        }
         o.id_off = a;
         o.id_len = sp;
         if (sp < n) {
@@ -372,77 +391,96 @@ __global__ __launch_bounds__(256) void fq_scan_apply_kernel(const uint32_t* __re
 }
 
 // ---- F6: gather + Record::check (fastq.rs:388-410) ----------------------------------------------------
-// one wavefront copies n bytes (arbitrary alignments): dword stores on the destination's alignment, the source
+// G lanes copy n bytes (arbitrary alignments): dword stores on the destination's alignment, the source
 // read as aligned dword pairs and funnel-shifted; collects "has a byte >= 0x80" and, for sequences, "has a byte
-// that is not alphabetic or one of - . *" (fastq.rs:392-401)
-template <bool SEQ>
+// that is not alphabetic or one of - . *" (fastq.rs:392-401).  (head and tail are at most 15 bytes, one per lane: G >= 16)
+template <bool SEQ, int G>
 __device__ __forceinline__ void copy_line(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, uint32_t n, int lane, const uint8_t* t_end,
                                           bool& hi, bool& bad) {
     auto classify = [&](uint32_t c) {
         hi |= c >= 0x80;
         if (SEQ) bad |= !((c >= 'A' && c <= 'Z') || (c >= 'a' && c <= 'z') || c == '-' || c == '.' || c == '*');
     };
-    const uint32_t head = min(n, (uint32_t)((4 - ((uintptr_t)dst & 3)) & 3));
+    // 16-byte stores on the destination's alignment; a lane's 16 source bytes are five aligned dwords funnel-shifted
+    // into four (dword pieces made 8 loads and 4 stores of the same 16 bytes: the kernel went from 0.41 to 0.29 ms per 1 M records)
+    const uint32_t head = min(n, (uint32_t)((16 - ((uintptr_t)dst & 15)) & 15));
+    static_assert(G >= 16, "head and tail are up to 15 bytes, one per lane");
     if ((uint32_t)lane < head) {
         const uint8_t c = src[lane];
         dst[lane] = c;
         classify(c);
     }
-    const uint32_t nd = (n - head) >> 2;
-    for (uint32_t j = lane; j < nd; j += 64) {
-        const uint8_t* p = src + head + 4 * j;
-        const uint32_t sh = 8u * (uint32_t)((uintptr_t)p & 3);
-        const uint8_t* pa = p - ((uintptr_t)p & 3);
-        uint32_t w;
-        if (sh == 0) {
-            w = *(const uint32_t*)pa;
-        } else if (pa + 8 <= t_end) {
-            w = (*(const uint32_t*)pa >> sh) | (*(const uint32_t*)(pa + 4) << (32 - sh));
+    const uint32_t nq = (n - head) >> 4;
+    for (uint32_t j = lane; j < nq; j += G) {
+        const uint8_t* p = src + head + 16 * j;
+        const uint32_t sh = (uint32_t)((uintptr_t)p & 3);
+        const uint8_t* pa = p - sh;
+        uint32_t w[4];
+        if (pa + 20 <= t_end) {
+            uint32_t r[5];
+#pragma unroll
+            for (int q = 0; q < 5; q++) r[q] = *(const uint32_t*)(pa + 4 * q);
+#pragma unroll
+            for (int q = 0; q < 4; q++) w[q] = __builtin_amdgcn_alignbyte(r[q + 1], r[q], sh);
         } else {
-            w = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                w[q] = (uint32_t)p[4 * q] | ((uint32_t)p[4 * q + 1] << 8) | ((uint32_t)p[4 * q + 2] << 16) | ((uint32_t)p[4 * q + 3] << 24);
         }
-        *(uint32_t*)(dst + head + 4 * j) = w;
-        if (SEQ) {
-            classify(w & 0xff);
-            classify((w >> 8) & 0xff);
-            classify((w >> 16) & 0xff);
-            classify(w >> 24);
-        } else {
-            hi |= (w & 0x80808080u) != 0;
+        *(uint4*)(dst + head + 16 * j) = make_uint4(w[0], w[1], w[2], w[3]);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if (SEQ) {
+                classify(w[q] & 0xff);
+                classify((w[q] >> 8) & 0xff);
+                classify((w[q] >> 16) & 0xff);
+                classify(w[q] >> 24);
+            } else {
+                hi |= (w[q] & 0x80808080u) != 0;
+            }
         }
     }
-    const uint32_t done = head + 4 * nd;
+    const uint32_t done = head + 16 * nq;
     if ((uint32_t)lane < n - done) {
         const uint8_t c = src[done + lane];
         dst[done + lane] = c;
         classify(c);
     }
 }
+// G lanes per record: a record of short reads is two lines of ~40 dwords behind a chain of dependent loads (record ->
+// lines -> line starts -> text) — with a whole wavefront per record most lanes idle and the kernel is as long as the
+// number of wavefronts times that chain; 16 lanes per record: a quarter of the wavefronts (0.67 -> 0.40 ms per 1 M
+// records of 150 bp).  Long lines (the average line beyond 256 bytes) keep the wavefront per record.
+template <int G>
 __global__ __launch_bounds__(256) void fq_gather_kernel(const uint8_t* __restrict__ t, uint64_t len, const uint64_t* __restrict__ ls,
                                                         const LineInfo* __restrict__ info, uint64_t n_lines, const RecLines* __restrict__ rl,
                                                         uint64_t n_rec, bg_fastq_record_t* __restrict__ recs, const uint64_t* __restrict__ seq_off,
                                                         const uint64_t* __restrict__ qual_off, uint8_t* __restrict__ seq, uint8_t* __restrict__ qual) {
-    const int lane = threadIdx.x & 63;
-    const uint64_t k = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (k >= n_rec) return;
+    const int lane = threadIdx.x % G;
+    const uint64_t k = (uint64_t)blockIdx.x * (blockDim.x / G) + threadIdx.x / G;
+    if (k >= n_rec) return;  // (uniform over the G lanes of a record)
     const RecLines r = rl[k];
     uint64_t so = seq_off[k], qo = qual_off[k];
     bool seq_hi = false, seq_bad = false, qual_hi = false, unused = false;
     for (uint32_t i = 0; i < r.n_seq; i++) {
         const uint64_t l = r.hdr + 1 + i;
         const uint32_t n = info[l].trim;
-        copy_line<true>(seq + so, t + ls[l], n, lane, t + len, seq_hi, seq_bad);
+        copy_line<true, G>(seq + so, t + ls[l], n, lane, t + len, seq_hi, seq_bad);
         so += n;
         if (r.qual0 + i < n_lines) {
             const uint64_t lq = r.qual0 + i;
             const uint32_t nq = info[lq].trim;
-            copy_line<false>(qual + qo, t + ls[lq], nq, lane, t + len, qual_hi, unused);
+            copy_line<false, G>(qual + qo, t + ls[lq], nq, lane, t + len, qual_hi, unused);
             qo += nq;
         }
     }
-    seq_hi = __any(seq_hi);
-    seq_bad = __any(seq_bad);
-    qual_hi = __any(qual_hi);
+    {  // "any" over the G lanes of the record
+        const int sh = (threadIdx.x & 63) / G * G;
+        const uint64_t gm = (G == 64 ? ~0ull : ((1ull << G) - 1)) << sh;
+        seq_hi = (__ballot(seq_hi) & gm) != 0;
+        seq_bad = (__ballot(seq_bad) & gm) != 0;
+        qual_hi = (__ballot(qual_hi) & gm) != 0;
+    }
     if (lane == 0) {
         bg_fastq_record_t o = recs[k];
         o.seq_off = seq_off[k];
@@ -643,14 +681,17 @@ extern "C" int bg_fastq_parse_dev(bg_ctx* ctx, const uint8_t* d_text, uint64_t l
     int rc;
     // F1: newline counts per chunk, their scan (+ total), line starts
     const uint64_t nchunks = (len + kChunk - 1) / kChunk;
-    const size_t head = nchunks * 4 + (nchunks + 2) * 8 + nchunks + 128;
+    const size_t n_part = 2 * (nchunks / 2048 + 2);  // partial sums of the two-level scan
+    const size_t head = nchunks * 4 + 16 + (nchunks + 2 + n_part) * 8 + nchunks + 128;
     if ((rc = bg_reserve(&ctx->aux, &ctx->aux_bytes, head))) return rc;
     uint32_t* d_cnt = (uint32_t*)ctx->aux;
     uint64_t* d_base = (uint64_t*)((uint8_t*)ctx->aux + ((nchunks * 4 + 15) & ~(size_t)15));
-    uint64_t* d_total = d_base + nchunks;
-    uint8_t* d_hi = (uint8_t*)(d_total + 2);
+    uint64_t* d_total = d_base + nchunks;  // (the scan's closing offset)
+    uint64_t* d_part = d_total + 2;
+    uint8_t* d_hi = (uint8_t*)(d_part + n_part);
     fq_count_newlines_kernel<<<dim3((uint32_t)nchunks), dim3(256), 0, st>>>(d_text, len, d_cnt, d_hi);
-    fq_scan_small_kernel<uint32_t><<<dim3(1), dim3(1024), 0, st>>>(d_cnt, d_base, nchunks, d_total);
+    // (a single block scanning the ~79 000 chunk counts of a 323 MB text took 148 us; block sums + their scan + apply: 20)
+    if ((rc = scan_lengths(d_cnt, nchunks, d_base, d_part, st))) return rc;
     BG_HIP(hipGetLastError());
     uint64_t n_nl = 0;
     uint8_t last_byte = 0;
@@ -716,8 +757,12 @@ extern "C" int bg_fastq_parse_dev(bg_ctx* ctx, const uint8_t* d_text, uint64_t l
     fq_measure_kernel<<<dim3((uint32_t)((n_rec + 255) / 256)), dim3(256), 0, st>>>(d_text, d_ls, d_info, n_lines, d_rl, n_rec, d_recs, d_sl, d_ql);
     if ((rc = scan_lengths(d_sl, n_rec, d_seq_off, d_sum, st))) return rc;
     if ((rc = scan_lengths(d_ql, n_rec, d_qual_off, d_sum, st))) return rc;
-    fq_gather_kernel<<<dim3((uint32_t)((n_rec + 3) / 4)), dim3(256), 0, st>>>(d_text, len, d_ls, d_info, n_lines, d_rl, n_rec, d_recs, d_seq_off, d_qual_off,
-                                                                                d_seq, d_qual);
+    if (len / n_lines <= 256)
+        fq_gather_kernel<16><<<dim3((uint32_t)((n_rec + 15) / 16)), dim3(256), 0, st>>>(d_text, len, d_ls, d_info, n_lines, d_rl, n_rec, d_recs, d_seq_off,
+                                                                                          d_qual_off, d_seq, d_qual);
+    else
+        fq_gather_kernel<64><<<dim3((uint32_t)((n_rec + 3) / 4)), dim3(256), 0, st>>>(d_text, len, d_ls, d_info, n_lines, d_rl, n_rec, d_recs, d_seq_off,
+                                                                                        d_qual_off, d_seq, d_qual);
     BG_HIP(hipGetLastError());
     BG_HIP(hipStreamSynchronize(st));
     return BG_OK;

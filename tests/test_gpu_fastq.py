@@ -148,3 +148,27 @@ def test_cigar_kats_and_batches_against_the_oracle():
                 o = ops[int(out["ops_off"][p]):int(out["ops_off"][p]) + int(out["n_ops"][p])].astype(np.uint64)
                 want = orc.cigar({"xstart": int(out["xstart"][p]), "xend": int(out["xend"][p]), "xlen": int(out["xlen"][p]), "mode": mode}, o, hard)
                 assert got[p] == want, (mode, p, got[p], want)
+
+
+def test_long_reads_and_header_spaces_at_every_offset():
+    """Lines beyond 256 bytes on average take the wavefront-per-record gather, short ones 16 lanes per record; both copy in
+    16-byte pieces whose source and destination alignments take every value; the header's first space is found eight bytes
+    at a time from the first 8-byte boundary on."""
+    rng = np.random.default_rng(9)
+    alpha = np.frombuffer(b"ACGTNacgtn-.*", dtype=np.uint8)
+    for lo, hi in ((257, 900), (1, 40), (120, 330)):
+        out = []
+        for k in range(300):
+            ln = int(rng.integers(lo, hi))
+            seq = alpha[rng.integers(0, len(alpha), size=ln)].tobytes()
+            qual = rng.integers(33, 75, size=ln).astype(np.uint8).tobytes()
+            idl = int(rng.integers(1, 30))
+            hdr = b"@" + bytes(rng.integers(97, 123, size=idl).astype(np.uint8))
+            if k % 3:
+                hdr += b" " + bytes(rng.integers(97, 123, size=int(rng.integers(0, 25))).astype(np.uint8))
+            if k % 7 == 0:
+                hdr += b"  second space"
+            out.append(hdr + b"\n" + seq + b"\n+\n" + qual + b"\n")
+        t = b"".join(out)
+        for cut in (0, 1, 2, 3, 5):  # shift every alignment by dropping leading records' bytes... a prefix record of odd length
+            same_as_oracle((b"@p\n" + b"A" * cut + b"\n+\n" + b"I" * cut + b"\n" if cut else b"") + t)
