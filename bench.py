@@ -465,7 +465,7 @@ def main():
                            "config": {"workload": "the headline workload (same pairs, same scoring) through K1, the int32 kernel: "
                                                   "ctx option no_pk16 = 1"},
                            "records_and_ops_equal_int16_run": same,
-                           "roofline": sw_roofline("sw_fill_kernel<10, 16, 0, true, true>", f32,
+                           "roofline": sw_roofline("sw_fill_kernel<10, 16, 0, true, true, true>", f32,  # (R, LP, SM, LOCAL, NARROW, LF)
                                                    tm32["traceback_ms"] / max(1, tm32["traceback_launches"]),
                                                    n_pairs / (tm32["fill_launches"] / 2), L, n_ops_mean,
                                                    "K1 (int32): VALU-bound", shape_key="k1_pairs_per_launch")}
@@ -489,7 +489,7 @@ def main():
               "dtype": "int16" if L <= 192 else "int32", "ms_per_step": round(tsg / args.steps * 1e3, 3),
               "config": {"workload": f"{n_pairs} x {L} bp read pairs per GPU (the headline pairs), Aligner::semiglobal "
                                      "affine-gap (-5,-1,+1,-1), score+coords+traceback ops"},
-              "roofline": sw_roofline("sw_fill_pk16_kernel" if L <= 192 else "sw_fill_kernel", fsg,
+              "roofline": sw_roofline("sw_fill_pk16_kernel<10, 16, 2, 2, 0, 0, false>" if L <= 192 else "sw_fill_kernel", fsg,
                                       tmsg["traceback_ms"] / max(1, tmsg["traceback_launches"]),
                                       n_pairs / (tmsg["fill_launches"] / 2), L, n_ops_sg,
                                       "K1p, semiglobal flavour (x-suffix-clip fold and clip candidates kept): VALU-bound",
@@ -550,7 +550,8 @@ def k1_legs(args, ctx, dev, stream, rank, world, do_cpu, orc, threads, parity):
               Scoring.from_scores(-500, -100, 100, -100), dict(match=100, mismatch=-100),
               f"{n} x {L} bp DNA pairs per GPU, Aligner::local, from_scores(-500,-100,100,-100): scores beyond K1p's 12 bits")]
     # template arguments <R, LP, SM, LOCAL, NARROW> of the instantiation each case runs (profile lookups go by name)
-    knames = {"blosum62_protein": "sw_fill_kernel<10, 16, 1, true, true>", "wide_scores_dna": "sw_fill_kernel<10, 16, 0, true, true>"}  # R = 10 rows x 16 lanes, SM, LOCAL, NARROW
+    knames = {"blosum62_protein": "sw_fill_kernel<10, 16, 1, true, true, false>",
+              "wide_scores_dna": "sw_fill_kernel<10, 16, 0, true, true, true>"}  # R = 10 rows x 16 lanes, SM, LOCAL, NARROW, LF
     for name, (x, xo, y, yo), scoring, okw, desc in cases:
         kname = knames[name]
         d_out = torch.empty(n * 64, dtype=torch.uint8, device=dev)

@@ -46,6 +46,7 @@ def launch_shape(logfile):
                     "fm_queries_per_launch": ((d.get("fm") or {}).get("roofline") or {}).get("queries_per_launch"),
                     "banded_pairs_per_launch": (d.get("banded") or {}).get("pairs_per_launch"),
                     "k1_pairs_per_launch": ((next(iter(k1.values()), {})).get("roofline") or {}).get("pairs_per_launch"),
+                    "sg_pairs_per_launch": ((d.get("semiglobal") or {}).get("roofline") or {}).get("pairs_per_launch"),
                     "ingest_bytes": int(((d.get("ingest") or {}).get("config") or {}).get("workload", "0 (0 bytes)").split("(")[-1].split()[0]),
                     "command": "bench.py --skip-cpu --skip-pipeline --skip-packed --fm-big-genome 0 --banded-pairs 98304 --steps 2 --warmup 0"}
     return {}
