@@ -33,6 +33,28 @@ impl Context {
     }
 }
 
+impl Context {
+    /// Pairs of the last banded call on this context that the packed 16-bit fill handed to the int32 kernels
+    /// (`bg_band_redo_pairs`): a statistic — the alignments are the same either way.
+    pub fn band_redo_pairs(&self) -> u64 {
+        let mut n = 0u64;
+        let rc = unsafe { sys::bg_band_redo_pairs(self.raw, &mut n) };
+        assert!(rc == 0, "bg_band_redo_pairs: {}", strerror(rc));
+        n
+    }
+}
+
+/// `bytes` as the engine's 2-bit stream (16 symbols per little-endian dword, `codes[c]` = the byte of code c): the host-side
+/// twin of `bg_pack2_dev`.  `None` if a byte is none of the four codes (such input takes the byte entry points).
+pub fn pack2(bytes: &[u8], codes: &[u8; 4]) -> Option<Vec<u32>> {
+    let mut out = vec![0u32; (bytes.len() + 15) / 16];
+    match unsafe { sys::bg_pack2_host(bytes.as_ptr(), bytes.len() as u64, codes.as_ptr(), out.as_mut_ptr()) } {
+        1 => Some(out),
+        0 => None,
+        rc => panic!("bg_pack2_host: {}", rc),
+    }
+}
+
 impl Drop for Context {
     fn drop(&mut self) {
         unsafe { sys::bg_free(self.raw) };
