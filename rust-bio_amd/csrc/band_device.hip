@@ -174,7 +174,8 @@ __host__ __device__ inline size_t lds_join_bytes(uint32_t m, uint32_t n) {
 }
 __global__ __launch_bounds__(512) void kmer_match_lds_kernel(const BandDevArgs a) {
     extern __shared__ __align__(16) uint8_t s_seq[];
-    __builtin_amdgcn_s_setprio(3);  // (runs next to a fill, one block per CU: see chain_kernel)
+    // (no raised wave priority here: on its own stream the join has a whole fill to finish under, and at priority 3 it
+    //  took the issue slots the fill needed)
     const uint32_t pair = blockIdx.x;
     const uint32_t tid = threadIdx.x, nth = blockDim.x;
     const uint64_t xo = a.x_off[a.pair0 + pair], yo = a.y_off[a.pair0 + pair];

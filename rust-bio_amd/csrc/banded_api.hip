@@ -152,14 +152,16 @@ struct bg_band_scratch {
         void *d_pairs = nullptr, *d_rowc = nullptr, *d_roff = nullptr, *d_tb = nullptr, *d_aux = nullptr;
         size_t dc_pairs = 0, dc_rowc = 0, dc_roff = 0, dc_tb = 0, dc_aux = 0;
         hipEvent_t copied = nullptr, filled = nullptr, traced = nullptr, built = nullptr, matched = nullptr;
+        bool built_valid = false;  // `built` has been recorded in this call
         hipEvent_t fill_gone = nullptr;  // the fill kernel itself is off the device (its epilogue may still run)
         hipEvent_t cleared = nullptr;    // the aux block has been zeroed (on aux_stream)
         bool busy = false, fill_gone_valid = false;
     } set[2];
     // device band builder (band_device.hip): scratch slices per pair + its per-pair state
-    void* db[17] = {};
-    size_t db_cap[17] = {};
+    void* db[2][17] = {};  // the builder's own arrays, one set per sub-batch parity (the join of c + 2 runs next to the chaining of c + 1)
+    size_t db_cap[2][17] = {};
     hipStream_t build_stream = nullptr;
+    hipStream_t join_stream = nullptr;  // k-mer join + chain preparation of the sub-batch after next
     hipEvent_t seq_ready = nullptr;
     void* h_state = nullptr;  // pinned copy of the builder's BandDevPair array
     size_t h_state_cap = 0;
@@ -212,7 +214,9 @@ void bg_band_scratch_free(bg_band_scratch* b) {
     hipFree(b->d_cell);
     hipFree(b->d_dlslot);
     if (b->dl_stream) hipStreamDestroy(b->dl_stream);
-    for (void* p : b->db) hipFree(p);
+    for (auto& set : b->db)
+        for (void* p : set) hipFree(p);
+    if (b->join_stream) hipStreamDestroy(b->join_stream);
     hipHostFree(b->h_state);
     hipHostFree(b->h_ops);
     if (b->tb_stream) hipStreamDestroy(b->tb_stream);
@@ -432,6 +436,7 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
     } slices;
     const uint64_t n_slices = dio ? 0 : (n_pairs + chunk_pairs - 1) / chunk_pairs;
     uint64_t slices_up = 0, waited_fill = 0, waited_build = 0;
+    (void)waited_build;
     if (n_slices && !B.copy_stream) BG_HIP(hipStreamCreateWithFlags(&B.copy_stream, hipStreamNonBlocking));
     auto upload_slices = [&](uint64_t upto) -> int {  // slices [slices_up, upto)
         for (; slices_up < std::min(upto, n_slices); slices_up++) {
@@ -485,11 +490,20 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
         }
     }
     hipStream_t st_build = B.build_stream;
+    // The join (and the chain preparation behind it) of a sub-batch on a stream of its own: the builder's kernels are one
+    // chain per sub-batch — join, preparation, chaining, raster, row ranges — and under the fill that chain, not the fill,
+    // was the cycle (44 ms per 16 384 pairs, 14 of them the join).  With the builder's arrays twice the join of c + 2 runs
+    // next to the chaining of c + 1 (`band_join_serial` = 1: one stream, as before).
+    if (!B.join_stream) BG_HIP(hipStreamCreateWithFlags(&B.join_stream, hipStreamNonBlocking));
+    hipStream_t st_join = ctx->band_join_serial ? st_build : B.join_stream;
+    for (auto& s : B.set) s.built_valid = false;
+    uint64_t waited_join = 0;
     if (!B.d_started) BG_HIP(hipMalloc((void**)&B.d_started, 64));
     BG_HIP(hipMemsetAsync(B.d_started, 0, 8, st));  // [0] blocks started, [1] pairs K3p flagged
     B.started_target = 0;
     BG_HIP(hipEventRecord(B.seq_ready, st));
     BG_HIP(hipStreamWaitEvent(st_build, B.seq_ready, 0));
+    if (st_join != st_build) BG_HIP(hipStreamWaitEvent(st_join, B.seq_ready, 0));
 
     const bool build_on_device = dev_kw != nullptr && !ctx->band_on_host;
     // First half of the device builder for the sub-batch that starts at p0: the k-mer join (B1) and the event
@@ -514,7 +528,11 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
         P.matched = false;
         if (!build_on_device) return BG_OK;
         const uint64_t want = want_at(p0);
-        if ((rc = need_seq(st_build, waited_build, p0 + want))) return rc;
+        if ((rc = need_seq(st_join, waited_join, p0 + want))) return rc;
+        // this parity's arrays were last read by the raster of two sub-batches ago
+        if (st_join != st_build && n_chunk >= 2 && B.set[n_chunk & 1].built_valid) BG_HIP(hipStreamWaitEvent(st_join, B.set[n_chunk & 1].built, 0));
+        void** db = B.db[n_chunk & 1];
+        size_t* db_cap = B.db_cap[n_chunk & 1];
         uint32_t max_m = 0, max_n = 0;
         for (uint64_t q = 0; q < want; q++) {
             max_m = std::max<uint32_t>(max_m, (uint32_t)(x_off[p0 + q + 1] - x_off[p0 + q]));
@@ -552,26 +570,26 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
                                  (size_t)want * (d.max_n + 1) * 4, (size_t)want * sizeof(BandDevPair), (size_t)(want + 1) * 8,
                                  (size_t)want * (d.cap_matches + 1) * 16, (size_t)want * d.cap_matches * 4, (size_t)want * d.cap_matches * 2};
         for (int i = 0; i < 17; i++)
-            if ((rc = bg_reserve(&B.db[i], &B.db_cap[i], std::max<size_t>(need[i], 64)))) return rc;
-        d.head = (uint32_t*)B.db[0];
-        d.next = (uint32_t*)B.db[1];
-        d.hy = (uint64_t*)B.db[2];
-        d.mx = (uint32_t*)B.db[4];
-        d.my = (uint32_t*)B.db[5];
-        d.path = (uint32_t*)B.db[6];
-        d.qpos = (uint32_t*)B.db[7];
-        d.upos = (uint32_t*)B.db[8];
-        d.cont = (int32_t*)B.db[9];
-        d.col_start = (uint32_t*)B.db[10];
-        d.col_end = (uint32_t*)B.db[11];
-        d.state = (BandDevPair*)B.db[12];
-        d.row0 = (const uint64_t*)B.db[13];
-        d.g_tree = B.db[14];
-        d.g_score = (uint32_t*)B.db[15];
-        d.g_back = (int16_t*)B.db[16];
-        if ((rc = launch_band_match(d, st_build))) return rc;
-        if ((rc = launch_band_chain(d, st_build, 1))) return rc;
-        BG_HIP(hipEventRecord(B.set[n_chunk & 1].matched, st_build));
+            if ((rc = bg_reserve(&db[i], &db_cap[i], std::max<size_t>(need[i], 64)))) return rc;
+        d.head = (uint32_t*)db[0];
+        d.next = (uint32_t*)db[1];
+        d.hy = (uint64_t*)db[2];
+        d.mx = (uint32_t*)db[4];
+        d.my = (uint32_t*)db[5];
+        d.path = (uint32_t*)db[6];
+        d.qpos = (uint32_t*)db[7];
+        d.upos = (uint32_t*)db[8];
+        d.cont = (int32_t*)db[9];
+        d.col_start = (uint32_t*)db[10];
+        d.col_end = (uint32_t*)db[11];
+        d.state = (BandDevPair*)db[12];
+        d.row0 = (const uint64_t*)db[13];
+        d.g_tree = db[14];
+        d.g_score = (uint32_t*)db[15];
+        d.g_back = (int16_t*)db[16];
+        if ((rc = launch_band_match(d, st_join))) return rc;
+        if ((rc = launch_band_chain(d, st_join, 1))) return rc;
+        BG_HIP(hipEventRecord(B.set[n_chunk & 1].matched, st_join));
         P.d = d;
         P.p0 = p0;
         P.want = want;
@@ -615,7 +633,8 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
             d.rowc = (int2*)S.d_rowc;
             d.row_off = (uint32_t*)S.d_roff;
             if ((rc = pinned_reserve(&B.h_state, &B.h_state_cap, want * sizeof(BandDevPair)))) return rc;
-            BG_HIP(hipMemcpyAsync(B.db[13], row0.data(), (want + 1) * 8, hipMemcpyHostToDevice, st_build));
+            if (st_join != st_build) BG_HIP(hipStreamWaitEvent(st_build, S.matched, 0));
+            BG_HIP(hipMemcpyAsync((void*)d.row0, row0.data(), (want + 1) * 8, hipMemcpyHostToDevice, st_build));
             // The chaining of sub-batch c + 1 runs UNDER the fill of c: it mostly waits on memory and fits the registers
             // the fill leaves free — provided it starts after every block of the fill is resident
             // (launch_band_wait_started: the fill's grid is a single round of blocks, and a co-runner that is on a CU
@@ -630,6 +649,7 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
             if ((rc = launch_band_raster(d, st_build))) return rc;
             BG_HIP(hipMemcpyAsync(B.h_state, d.state, want * sizeof(BandDevPair), hipMemcpyDeviceToHost, st_build));
             BG_HIP(hipEventRecord(S.built, st_build));
+            S.built_valid = true;
             // The builder's own arrays are free again: the join and the chain preparation of the NEXT sub-batch go right
             // behind, without waiting for the host to learn this one's sizes (finish() used to issue them: 2 ms of round trip
             // on the builder's path, and they landed in the gap between two fills).  Speculative in one respect: the next
