@@ -778,7 +778,7 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
             if (!(N.matched && N.p0 == p0 + take))
                 if ((rc = issue_match(p0 + take, n_chunk + 1))) return rc;
             // Round 3: the fill waited for the join (124 KB of LDS per block: it could only run in a window between two
-            // fills).  With K3i on 32-byte rings (two blocks = 66 KB per CU) the join (91 KB) and the chaining's
+            // fills).  With K3i / K3p on 32-byte rings (two blocks = 66 KB per CU) the join (91 KB) and the chaining's
             // preparation (16 KB per wavefront) fit NEXT to a fill: no window, fills back to back.
             if (ctx->band_window) BG_HIP(hipStreamWaitEvent(st, B.set[(n_chunk + 1) & 1].matched, 0));
         }
@@ -787,7 +787,7 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
         // 16 384 pairs in flight); a small sub-batch — a whole small call, or the tail of a large one — finishes sooner
         // with one pair per wavefront (K3: 19 ms; measured cross-over between 2 048 and 4 096 pairs,
         // tools/exp/time_banded_small.py).  band_fill_v1: 1 always K3, -1 never (tests)
-        // (the remainder sub-batch of a large call runs first, under the next one's band construction: K3v2 / K3i there)
+        // (the remainder sub-batch of a large call runs first, under the next one's band construction: K3v2 / K3p there)
         const bool small_batch = take <= 2048 && ctx->band_fill_v1 >= 0 && n_pairs <= 2048;
         if (sm == SCORE_PARAMS && ctx->band_fill_v1 <= 0 && !small_batch) {
             a.started = on_device ? B.d_started : nullptr;
@@ -809,7 +809,7 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
                 a.redo_count = B.d_started + 1;
             }
             if (on_device) B.started_target += band_fill2_blocks(a.n_pairs);
-            // K3v2 / K3i: eight pairs per wavefront; the epilogue goes to the traceback stream, ahead of K4 — the fill
+            // K3v2 / K3p (K3i): eight pairs per wavefront; the epilogue goes to the traceback stream, ahead of K4 — the fill
             // stream goes straight on with the next sub-batch (event timing keeps everything on one stream)
             launch_band_fill2(a, narrow, st, S.fill_gone, ctx->timing || ctx->band_window ? nullptr : st_tb);
             S.fill_gone_valid = true;
