@@ -90,6 +90,7 @@ const char* bg_last_error(void); /* text of the last HIP failure on this thread 
  *                          65535 = every pair is flagged and recomputed by the int32 kernels (tests)
  *   band_tail_last / band_window / band_raster_late = 1  A/B switches of the banded pipeline's order (round-3 behaviour)
  *   band_join_serial = 1   the k-mer join of a sub-batch on the builder's stream instead of its own (A/B)
+ *   band_pre_serial = 1    a banded fill's preparation (pair table, waits, first strips) on the fill stream instead of its own (A/B)
  *   band_chain_global  chaining tree placement: 0 LDS, 1 global scratch, -1 by batch size (default)
  *   band_join_global = 1  k-mer join with its table in global memory even where the LDS flavour applies
  * Unknown keys return BG_ERR_INVALID_ARG. */

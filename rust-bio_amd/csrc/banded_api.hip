@@ -154,6 +154,7 @@ struct bg_band_scratch {
         hipEvent_t copied = nullptr, filled = nullptr, traced = nullptr, built = nullptr, matched = nullptr;
         bool built_valid = false;  // `built` has been recorded in this call
         hipEvent_t fill_gone = nullptr;  // the fill kernel itself is off the device (its epilogue may still run)
+        hipEvent_t pre_done = nullptr;   // ... and what pre_stream did for it is done
         hipEvent_t cleared = nullptr;    // the aux block has been zeroed (on aux_stream)
         bool busy = false, fill_gone_valid = false;
     } set[2];
@@ -162,6 +163,7 @@ struct bg_band_scratch {
     size_t db_cap[2][17] = {};
     hipStream_t build_stream = nullptr;
     hipStream_t join_stream = nullptr;  // k-mer join + chain preparation of the sub-batch after next
+    hipStream_t pre_stream = nullptr;   // what a fill needs before its long kernel: the pair table, the waits, K3v2's first strips
     hipEvent_t seq_ready = nullptr;
     void* h_state = nullptr;  // pinned copy of the builder's BandDevPair array
     size_t h_state_cap = 0;
@@ -206,6 +208,7 @@ void bg_band_scratch_free(bg_band_scratch* b) {
         if (s.built) hipEventDestroy(s.built);
         if (s.matched) hipEventDestroy(s.matched);
         if (s.fill_gone) hipEventDestroy(s.fill_gone);
+        if (s.pre_done) hipEventDestroy(s.pre_done);
         if (s.cleared) hipEventDestroy(s.cleared);
     }
     for (void* p : b->io) hipFree(p);
@@ -217,6 +220,7 @@ void bg_band_scratch_free(bg_band_scratch* b) {
     for (auto& set : b->db)
         for (void* p : set) hipFree(p);
     if (b->join_stream) hipStreamDestroy(b->join_stream);
+    if (b->pre_stream) hipStreamDestroy(b->pre_stream);
     hipHostFree(b->h_state);
     hipHostFree(b->h_ops);
     if (b->tb_stream) hipStreamDestroy(b->tb_stream);
@@ -498,6 +502,15 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
     hipStream_t st_join = ctx->band_join_serial ? st_build : B.join_stream;
     for (auto& s : B.set) s.built_valid = false;
     uint64_t waited_join = 0;
+    // The preparation of a fill — the pair table's upload, the waits for the band, the cleared aux block and the sequences,
+    // and K3v2's phase 1 (the strips before the interior runs) — does not depend on the fill before it, but on the fill
+    // stream it queued behind it: 2 ms between two long kernels, every cycle.  On a stream of its own it runs under the
+    // previous fill's tail (`band_pre_serial` = 1: on the fill stream as before; event timing keeps one stream).
+    if (!B.pre_stream) BG_HIP(hipStreamCreateWithFlags(&B.pre_stream, hipStreamNonBlocking));
+    for (auto& s : B.set)
+        if (!s.pre_done) BG_HIP(hipEventCreateWithFlags(&s.pre_done, hipEventDisableTiming));
+    const bool use_pre = dev_kw != nullptr && !ctx->band_on_host && !ctx->timing && !ctx->band_window && !ctx->band_pre_serial;
+    uint64_t waited_pre = 0;
     if (!B.d_started) BG_HIP(hipMalloc((void**)&B.d_started, 64));
     BG_HIP(hipMemsetAsync(B.d_started, 0, 8, st));  // [0] blocks started, [1] pairs K3p flagged
     B.started_target = 0;
@@ -689,6 +702,7 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
         uint32_t* h_roff = (uint32_t*)S.h_roff;
         BandPair* dp = (BandPair*)S.h_pairs;
         int rc = BG_OK;
+        hipStream_t sp = use_pre && on_device ? B.pre_stream : st;  // (see use_pre)
         if (on_device) {
             BG_HIP(hipEventSynchronize(S.built));
             lap("band build (device)");
@@ -719,8 +733,8 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
                 });
                 for (uint64_t q : redo) {
                     const size_t nr = (size_t)hp[q].m + 1;
-                    BG_HIP(hipMemcpyAsync((int2*)S.d_rowc + row0[q], h_rowc + row0[q], nr * sizeof(int2), hipMemcpyHostToDevice, st));
-                    BG_HIP(hipMemcpyAsync((uint32_t*)S.d_roff + row0[q], h_roff + row0[q], nr * 4, hipMemcpyHostToDevice, st));
+                    BG_HIP(hipMemcpyAsync((int2*)S.d_rowc + row0[q], h_rowc + row0[q], nr * sizeof(int2), hipMemcpyHostToDevice, sp));
+                    BG_HIP(hipMemcpyAsync((uint32_t*)S.d_roff + row0[q], h_roff + row0[q], nr * 4, hipMemcpyHostToDevice, sp));
                 }
                 if (trace) fprintf(stderr, "[bg banded] %zu of %llu pairs rebuilt on the host\n", redo.size(), (unsigned long long)want);
             }
@@ -751,19 +765,19 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
         if ((rc = bg_reserve(&S.d_roff, &S.dc_roff, std::max<size_t>(rows * 4, 64)))) return rc;
         if ((rc = bg_reserve(&S.d_tb, &S.dc_tb, std::max<size_t>(tbb, 64)))) return rc;
         if ((rc = bg_reserve(&S.d_aux, &S.dc_aux, std::max<size_t>(auxw * 4, 64)))) return rc;
-        BG_HIP(hipMemcpyAsync(S.d_pairs, dp, take * sizeof(BandPair), hipMemcpyHostToDevice, st));
+        BG_HIP(hipMemcpyAsync(S.d_pairs, dp, take * sizeof(BandPair), hipMemcpyHostToDevice, sp));
         if (!on_device) {
             BG_HIP(hipMemcpyAsync(S.d_rowc, h_rowc, rows * sizeof(int2), hipMemcpyHostToDevice, st));
             BG_HIP(hipMemcpyAsync(S.d_roff, h_roff, rows * 4, hipMemcpyHostToDevice, st));
         }
-        BG_HIP(hipEventRecord(S.copied, st));
+        BG_HIP(hipEventRecord(S.copied, sp));
         // the aux block is cleared on a stream of its own: 7 GB per sub-batch, 1.8 ms that used to sit between two fills
         // (the set's previous user, K4 of two sub-batches ago, is done: issue() waited for it)
         if (!B.aux_stream) BG_HIP(hipStreamCreateWithFlags(&B.aux_stream, hipStreamNonBlocking));
         if (!S.cleared) BG_HIP(hipEventCreateWithFlags(&S.cleared, hipEventDisableTiming));
         BG_HIP(hipMemsetAsync(S.d_aux, 0, auxw * 4, B.aux_stream));
         BG_HIP(hipEventRecord(S.cleared, B.aux_stream));
-        BG_HIP(hipStreamWaitEvent(st, S.cleared, 0));
+        BG_HIP(hipStreamWaitEvent(sp, S.cleared, 0));
         a.pairs = (const BandPair*)S.d_pairs;
         a.rowc = (const int2*)S.d_rowc;
         a.row_off = (const uint32_t*)S.d_roff;
@@ -771,8 +785,8 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
         a.aux = (int32_t*)S.d_aux;
         a.pair0 = p0;
         a.n_pairs = (uint32_t)take;
-        if ((rc = need_seq(st, waited_fill, p0 + take))) return rc;
-        if (on_device) BG_HIP(hipStreamWaitEvent(st, S.built, 0));
+        if ((rc = sp == st ? need_seq(st, waited_fill, p0 + take) : need_seq(sp, waited_pre, p0 + take))) return rc;
+        if (on_device) BG_HIP(hipStreamWaitEvent(sp, S.built, 0));
         if (on_device && p0 + take < n_pairs) {  // the next sub-batch's k-mer join goes first (see issue_match)
             const Plan& N = plan[(n_chunk + 1) & 1];
             if (!(N.matched && N.p0 == p0 + take))
@@ -811,12 +825,16 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
             if (on_device) B.started_target += band_fill2_blocks(a.n_pairs);
             // K3v2 / K3p (K3i): eight pairs per wavefront; the epilogue goes to the traceback stream, ahead of K4 — the fill
             // stream goes straight on with the next sub-batch (event timing keeps everything on one stream)
-            launch_band_fill2(a, narrow, st, S.fill_gone, ctx->timing || ctx->band_window ? nullptr : st_tb);
+            launch_band_fill2(a, narrow, st, S.fill_gone, ctx->timing || ctx->band_window ? nullptr : st_tb, sp != st ? sp : nullptr, S.pre_done);
             S.fill_gone_valid = true;
         }
         else {
             a.tb_flip = 0;
             a.split = 0;  // (K4 reads it too)
+            if (sp != st) {
+                BG_HIP(hipEventRecord(S.pre_done, sp));
+                BG_HIP(hipStreamWaitEvent(st, S.pre_done, 0));
+            }
             fill<<<dim3((unsigned)((take + 3) / 4)), dim3(256), 0, st>>>(a);
             S.fill_gone_valid = false;
         }

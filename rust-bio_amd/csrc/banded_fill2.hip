@@ -304,8 +304,17 @@ uint32_t band_fill2_blocks(uint32_t n_pairs) {
     return (jobs + 3) / 4;
 }
 
-bool launch_band_fill2(const BandArgs& a0, bool narrow, hipStream_t st, hipEvent_t after_fill, hipStream_t epi) {
+bool launch_band_fill2(const BandArgs& a0, bool narrow, hipStream_t st, hipEvent_t after_fill, hipStream_t epi, hipStream_t pre,
+                       hipEvent_t pre_done) {
     // epi: the epilogue runs there, behind after_fill (so that `st` can go on with the fill of the next sub-batch); null: on st
+    // pre: the stream that prepared this sub-batch (banded_api.hip); phase 1 of a split fill runs there too — under the tail
+    //      of the previous sub-batch's long kernel instead of behind it — and `st` takes over behind pre_done; null: all on st
+    auto join_pre = [&]() {
+        if (pre) {
+            (void)hipEventRecord(pre_done, pre);
+            (void)hipStreamWaitEvent(st, pre_done, 0);
+        }
+    };
     constexpr int LP = BF2_LP, PW = 64 / LP;
     BandArgs a = a0;
     const uint32_t jobs = (a.n_pairs + PW - 1) / PW;
@@ -316,6 +325,7 @@ bool launch_band_fill2(const BandArgs& a0, bool narrow, hipStream_t st, hipEvent
         const bool split = a.split && a.sc.xp <= NEG / 2;
         uint32_t* const started = a.started;
         if (!split) {
+            join_pre();
             a.phase = 0;
             a.split = 0;
             if (a.sc.xp > NEG / 2) launch_fill2_narrow_xp(a, grid, st);
@@ -323,7 +333,8 @@ bool launch_band_fill2(const BandArgs& a0, bool narrow, hipStream_t st, hipEvent
         } else {
             a.started = nullptr;  // whoever waits for "the fill is resident" means the long launch
             a.phase = 1;
-            launch_fill2_narrow(a, grid, st);
+            launch_fill2_narrow(a, grid, pre ? pre : st);
+            join_pre();
             a.started = started;
             if (a.packed) {
                 // K3p first (two pairs per lane group, 16-bit keys relative to a per-strip base); the pairs it flags — a
@@ -348,6 +359,7 @@ bool launch_band_fill2(const BandArgs& a0, bool narrow, hipStream_t st, hipEvent
         if (epi && after_fill) (void)hipStreamWaitEvent(epi, after_fill, 0);
         banded_epilogue_kernel<2, true><<<dim3((a.n_pairs + 3) / 4), dim3(256), 0, epi && after_fill ? epi : st>>>(a);
     } else {
+        join_pre();
         a.phase = 0;
         a.split = 0;
         launch_fill2_wide(a, grid, st);

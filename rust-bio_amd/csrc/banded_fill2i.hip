@@ -1,11 +1,13 @@
-// K3i — banded_fill2i_kernel<R, LP>: the INTERIOR run of every pair of a K3v2 sub-batch (band_split, banded_kernels.h).
+// K3i — banded_fill2i_kernel<R, LP>: the INTERIOR run of every pair of a K3v2 sub-batch (band_split, banded_kernels.h) in
+// int32.  Since K3p (banded_fill2p.hip: the same run, two pairs per lane group in 16-bit keys) this kernel runs the pairs K3p
+// flags (BandArgs::redo) and the scorings / lengths K3p does not take.
 //
 // Same geometry, same domain (scores scaled by 16, candidate priority in the low bits), same memory formats as K3v2
 // (banded_fill2.inc: LP = 8 lanes own a pair, R = 4 rows per lane, strips of 32 rows; traceback bytes staged in per-row LDS
 // rings and handed over in whole 16-byte groups; strips talk through bnd / gSn / gLy) — so K3v2 runs the strips before the
 // run (phase 1), this kernel the run, K3v2 the strips behind it (phase 2), and nothing in between has to be converted.
-// What an interior strip does not have (reference: banded.rs:556-680):
 // The traceback rings are indexed by step here (K3v2: by column): conflict-free byte writes, hand-overs realign.
+// What an interior strip does not have (reference: banded.rs:556-680):
 //   * x clips: no x-prefix-clip candidate (564-572, 625-631), and the x-suffix-clip fold S[curr][m] / Lx[j] (648-653) is
 //     MIN_SCORE + something that never wins (band_split's conditions) — not computed, not published;
 //   * column n: no Sn[i-1] + go candidate (590-596), no last-column records;

@@ -1,9 +1,11 @@
 // K3p — banded_fill2p_kernel<R, LP>: the interior runs of K3i (banded_fill2i.hip) with TWO pairs per lane group.
 //
-// K3i is bound by VALU issue (a cell of ~24 lane-instructions, no HBM or LDS limit anywhere near), so the lever is the one
+// K3i spends ~24 lane-instructions per cell, no HBM or LDS limit anywhere near — and, as this kernel's first measurements
+// showed, most of its time waiting for its own dependency chain (a dependent vector instruction issues 8.7 cycles behind
+// its producer on this chip: tools/microbench/ub_dep; notes at issue_chunk / hand_over below).  The lever on the count is the one
 // K1p pulled for the short reads (sw_fill_pk16.inc): every VGPR of the recurrence holds the values of two pairs, 16 bits each,
 // and the packed-math VALU (v_pk_sub_u16 clamp, v_pk_max_u16, v_pk_mad_u16) advances a cell of both pairs per instruction.
-// Same geometry as K3i (LP lanes x R rows per strip of 32 rows, columns skewed by one step per lane), same memory formats on
+// K3i's strips of 32 rows as 16 lanes x 2 rows (a lane group is one DPP row; columns skewed by one step per lane), same memory formats on
 // every side (bnd / gSn / gLy in K3v2's int32 domain, the interior traceback byte of tb_cell_norm), so K3v2's phases 1 and 2
 // (banded_fill2.inc) and K4 do not know which of the two kernels ran.
 //

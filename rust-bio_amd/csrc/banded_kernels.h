@@ -127,7 +127,8 @@ typedef void (*band_fill_fn)(const BandArgs);
 band_fill_fn get_band_fill(int sm);
 // K3v2 (banded_fill2.hip): LP lanes per pair, R rows per lane, MatchParams scoring; the last-column
 // epilogue runs in its own kernel.  Returns false if the geometry is not instantiated.
-bool launch_band_fill2(const BandArgs& a, bool narrow, hipStream_t st, hipEvent_t after_fill = nullptr, hipStream_t epi = nullptr);
+bool launch_band_fill2(const BandArgs& a, bool narrow, hipStream_t st, hipEvent_t after_fill = nullptr, hipStream_t epi = nullptr,
+                       hipStream_t pre = nullptr, hipEvent_t pre_done = nullptr);
 void launch_fill2i(const BandArgs& a, dim3 grid, hipStream_t st);  // banded_fill2i.hip: the interior runs
 void launch_fill2p(const BandArgs& a, hipStream_t st);             // banded_fill2p.hip: the same, two pairs per lane group
 uint32_t band_fill2_blocks(uint32_t n_pairs);  // thread blocks launch_band_fill2 starts for n_pairs

@@ -71,6 +71,7 @@ struct bg_ctx {
     bool band_interior_off = false;  // tests: K3v2 takes its general step in every strip (no reduced step in interior strips)
     bool band_packed_off = false;    // tests, A/B: interior runs on K3i (int32) only, no packed-int16 K3p in front of it
     int64_t band_packed_thresh = 0;  // tests: K3p's redo threshold in key units (0: derived from the scoring; 0xffff: every pair is redone)
+    bool band_pre_serial = false;    // A/B: a fill's preparation (pair table, waits, K3v2 phase 1) on the fill stream, behind the previous fill
     bool band_join_serial = false;   // A/B: the k-mer join of a sub-batch on the builder's stream, behind the previous sub-batch's row ranges (one chain)
     bool band_tail_last = false;   // A/B: the remainder sub-batch of a large banded call runs last (round 3) instead of first
     bool band_window = false;      // A/B: K3i on 64-byte rings, and the fill waits for the next sub-batch's join + preparation (round 3's window between two fills)

@@ -218,6 +218,10 @@ extern "C" int bg_set_option(bg_ctx* ctx, const char* key, int64_t value) {
         ctx->band_packed_thresh = value;
         return BG_OK;
     }
+    if (!strcmp(key, "band_pre_serial")) {
+        ctx->band_pre_serial = value != 0;
+        return BG_OK;
+    }
     if (!strcmp(key, "band_join_serial")) {
         ctx->band_join_serial = value != 0;
         return BG_OK;
