@@ -466,3 +466,40 @@ def test_several_sub_batches_and_the_remainder_first(opts):
                  d_ops.data_ptr(), stride)
     rec = d_out.view(torch.int32).view(len(xs), 16).cpu().numpy()
     assert (rec[:, 0] == out["score"]).all()
+
+
+def test_many_small_sub_batches_equal_one_sub_batch():
+    """The pipeline's streams (join two sub-batches ahead on its own stream and arrays, chaining / raster / row ranges, a fill's
+    preparation under the previous fill, epilogue and traceback behind it) over 47 sub-batches of 32 pairs against the same
+    1 500 pairs as one sub-batch: every record and every operation, twice (scratch reused), through the device-resident entry."""
+    import torch
+    from rust_bio_amd.banded import Aligner as BAligner
+    P, L = 1500, 700
+    x, off, y, _ = synth.sw_pairs(P, L, seed=123, sub=0.06, ins=0.02, dele=0.02)
+    al = BAligner.with_scoring(Scoring.from_scores(-5, -1, 1, -1), 10, 12)
+    dev = torch.device("cuda:0")
+    dx, dy = torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev)
+    doff = torch.from_numpy(off.astype(np.int64)).to(dev)
+    stride = 2 * L + 8
+    outs = []
+    for chunk in (0, 32, 32, 100, 0):
+        al.ctx.set_option("chunk_pairs", chunk)
+        d_out = torch.zeros(P * 64, dtype=torch.uint8, device=dev)
+        d_ops = torch.zeros(P * stride, dtype=torch.uint8, device=dev)
+        al.align_dev(2, P, dx.data_ptr(), doff.data_ptr(), dy.data_ptr(), doff.data_ptr(), d_out.data_ptr(), d_ops.data_ptr(), stride)
+        torch.cuda.synchronize()
+        outs.append((d_out.cpu().numpy().view(_lib.ALN_DTYPE).copy(), d_ops.cpu().numpy().copy()))
+    al.ctx.set_option("chunk_pairs", 0)
+    ref_rec, ref_ops = outs[0]
+    assert (ref_rec["status"] == 0).all()
+    for rec, ops in outs[1:]:
+        for f in ("score", "xstart", "xend", "ystart", "yend", "n_ops", "status", "ops_off"):
+            assert (rec[f] == ref_rec[f]).all(), f
+        for p in range(0, P, 7):
+            k_ = int(rec["n_ops"][p])
+            assert (ops[(p + 1) * stride - k_:(p + 1) * stride] == ref_ops[(p + 1) * stride - k_:(p + 1) * stride]).all(), p
+    # and a handful against the oracle
+    osc = orc.make_scoring(-5, -1, 1, -1)
+    for p in range(0, P, 250):
+        want = orc.banded_align(osc, "semiglobal", 10, 12, bytes(x[int(off[p]):int(off[p + 1])]), bytes(y[int(off[p]):int(off[p + 1])]))
+        assert int(ref_rec["score"][p]) == want["score"]
