@@ -498,15 +498,19 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
     // chain per sub-batch — join, preparation, chaining, raster, row ranges — and under the fill that chain, not the fill,
     // was the cycle (44 ms per 16 384 pairs, 14 of them the join).  With the builder's arrays twice the join of c + 2 runs
     // next to the chaining of c + 1 (`band_join_serial` = 1: one stream, as before).
-    if (!B.join_stream) BG_HIP(hipStreamCreateWithFlags(&B.join_stream, hipStreamNonBlocking));
-    hipStream_t st_join = ctx->band_join_serial ? st_build : B.join_stream;
+    // (no stream of its own: the process maps its streams onto a handful of hardware queues, and two more of them cost the
+    //  full bench — a dozen streams by then — 12 % of this leg where the leg alone gained 3 %; the join shares the stream of
+    //  the host-buffer flavour's sequence uploads, which it waits for anyway)
+    if (!B.copy_stream) BG_HIP(hipStreamCreateWithFlags(&B.copy_stream, hipStreamNonBlocking));
+    hipStream_t st_join = ctx->band_join_serial ? st_build : B.copy_stream;
     for (auto& s : B.set) s.built_valid = false;
     uint64_t waited_join = 0;
     // The preparation of a fill — the pair table's upload, the waits for the band, the cleared aux block and the sequences,
     // and K3v2's phase 1 (the strips before the interior runs) — does not depend on the fill before it, but on the fill
     // stream it queued behind it: 2 ms between two long kernels, every cycle.  On a stream of its own it runs under the
     // previous fill's tail (`band_pre_serial` = 1: on the fill stream as before; event timing keeps one stream).
-    if (!B.pre_stream) BG_HIP(hipStreamCreateWithFlags(&B.pre_stream, hipStreamNonBlocking));
+    // (it shares the stream that clears the aux block: the clear is one of the things it waits for)
+    if (!B.aux_stream) BG_HIP(hipStreamCreateWithFlags(&B.aux_stream, hipStreamNonBlocking));
     for (auto& s : B.set)
         if (!s.pre_done) BG_HIP(hipEventCreateWithFlags(&s.pre_done, hipEventDisableTiming));
     const bool use_pre = dev_kw != nullptr && !ctx->band_on_host && !ctx->timing && !ctx->band_window && !ctx->band_pre_serial;
@@ -702,7 +706,7 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
         uint32_t* h_roff = (uint32_t*)S.h_roff;
         BandPair* dp = (BandPair*)S.h_pairs;
         int rc = BG_OK;
-        hipStream_t sp = use_pre && on_device ? B.pre_stream : st;  // (see use_pre)
+        hipStream_t sp = use_pre && on_device ? B.aux_stream : st;  // (see use_pre)
         if (on_device) {
             BG_HIP(hipEventSynchronize(S.built));
             lap("band build (device)");
