@@ -47,3 +47,15 @@ def unpack_dev(d_packed, n, codes=DNA_CODES, ctx=None, stream=0):
     cb = (C.c_uint8 * 4)(*bytes(codes))
     _lib.check(_lib.lib().bg_unpack2_dev(ctx.h, d_packed.data_ptr(), n, cb, out.data_ptr(), stream), "bg_unpack2_dev")
     return out
+
+
+def pack_host(seq, codes=DNA_CODES):
+    """bg_pack2_host: the same layout packed by the library on the host (no GPU; AVX2 where the CPU has it) ->
+    (uint32 array of words_for(n) dwords — the last one zero, like pack_numpy's —, True if every byte was a code)"""
+    seq = np.ascontiguousarray(seq, dtype=np.uint8)
+    out = np.zeros(words_for(len(seq)), dtype=np.uint32)
+    cb = np.frombuffer(bytes(codes), dtype=np.uint8)
+    rc = _lib.lib().bg_pack2_host(seq.ctypes.data if len(seq) else None, len(seq), cb.ctypes.data, out.ctypes.data)
+    if rc < 0:
+        _lib.check(rc, "bg_pack2_host")
+    return out, rc == 1

@@ -68,3 +68,14 @@ def test_bad_arguments():
     assert L.bg_pack2_host(b.ctypes.data, 4, same.ctypes.data, out.ctypes.data) < 0
     assert L.bg_pack2_host(b.ctypes.data, 4, None, out.ctypes.data) < 0
     assert L.bg_pack2_host(None, 0, b.ctypes.data, None) == 1
+
+
+def test_python_wrapper_equals_the_numpy_statement_of_the_layout():
+    from rust_bio_amd import pack2
+    rng = np.random.default_rng(8)
+    s = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=1003)]
+    got, ok = pack2.pack_host(s)
+    assert ok and (got == pack2.pack_numpy(s)).all()
+    s2 = s.copy()
+    s2[500] = ord("N")
+    assert not pack2.pack_host(s2)[1]
