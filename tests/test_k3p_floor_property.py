@@ -174,3 +174,59 @@ def test_unflagged_strips_are_exact_and_flags_fire_when_a_cell_sinks_to_the_floo
             assert pk_last[j][0] == ex_last[j][0], ("last row S", j)
     # the sample holds both kinds, and enough cells to mean something
     assert n_ok >= 300 and n_flag >= 150 and n_cells >= 200_000, (n_ok, n_flag, n_cells)
+
+
+def test_strips_chained_through_the_hand_over_row():
+    """Several strips of one pair, each started from what the strip above handed on: the exact model from its own exact row, the
+    16-bit model from ITS row — S plus shift, I plus shift with "minus infinity" arriving as the floor of the strip that wrote it —
+    re-based on the exact maximum of that row.  A floor value resurrected by a falling base must not change a cell the kernel does
+    not flag (both candidates of the next cell's I move by the same amount: the strip above checked its S against the threshold
+    in the frame the I was written in)."""
+    rng = random.Random(99)
+    n_pairs_ok = n_strips_ok = 0
+    for _ in range(250):
+        st = make_strip(rng)
+        if st["ge"] <= -40:
+            continue
+        ex_st, pk_st = dict(st), dict(st)
+        ok = True
+        for k in range(4):
+            ex, ex_last = exact(ex_st)
+            pk, pk_last, flagged, shift, bound_rel, thresh = packed(pk_st)
+            if flagged:
+                ok = False
+                break
+            for key, (s_true, byte_true) in ex.items():
+                s_rel, byte = pk[key]
+                assert s_rel + shift == s_true << 4 and (byte & 0xE) == (byte_true & 0xE), (k, key)
+            n_strips_ok += 1
+            # the next strip: the band goes on to the right, new symbols, the clip candidate keeps falling
+            last_lo, last_hi = st["cf"][ROWS - 1], st["cl"][ROWS - 1]
+            width = last_hi - last_lo
+            cf, cl, a = [], [], last_lo
+            for r in range(ROWS):
+                if rng.random() < 0.8:
+                    a += 1
+                cf.append(a)
+                cl.append(a + max(3, width + rng.randint(-1, 1)))
+            for r in range(1, ROWS):
+                cf[r], cl[r] = max(cf[r], cf[r - 1]), max(cl[r], cl[r - 1])
+            ncols = cl[-1] + 2
+            x = [rng.randint(0, 3) for _ in range(ROWS)]
+            y = [rng.randint(0, 3) for _ in range(ncols + 2)]
+            for r in range(ROWS):
+                if rng.random() < rng.choice([0.2, 0.9]):  # stretches that lose score: the base falls
+                    y[min(ncols, cf[r] + 1)] = x[r]
+            ycl = [st["ycl"][-1] + st["ge"] * (ROWS * k + r + 1) for r in range(ROWS)]
+            common = dict(st, cf=cf, cl=cl, ncols=ncols, x=x, y=y, ycl=ycl, above=(last_lo, last_hi))
+            ex_st = dict(common, S_above={j: ex_last[j][0] >> 4 for j in range(last_lo, last_hi + 1)},
+                         I_above={j: (NEG if ex_last[j][1] < -(1 << 38) else ex_last[j][1] >> 4) for j in range(last_lo, last_hi + 1)})
+            ex_st["base"] = max(ex_st["S_above"].values())
+            # the 16-bit model's own hand-over: absolute keys, a clean I, nothing marks a floor value as one
+            pk_st = dict(common, S_above={j: pk_last[j][0] >> 4 for j in range(last_lo, last_hi + 1)},
+                         I_above={j: pk_last[j][1] >> 4 for j in range(last_lo, last_hi + 1)})
+            pk_st["base"] = max(pk_st["S_above"].values())
+            assert pk_st["base"] == ex_st["base"]
+            st = common
+        n_pairs_ok += ok
+    assert n_pairs_ok >= 60 and n_strips_ok >= 400, (n_pairs_ok, n_strips_ok)
