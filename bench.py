@@ -217,24 +217,35 @@ def gather_ceiling(footprint_bytes, line_bytes=64):
     return val
 
 
-def fm_gather_fields(fm, n_q, pat, off, bufs, stream, launch_ms, block_bytes):
-    """requested block loads of one launch (the counting instantiation of K5, outside the timed region) against the gather
-    ceiling at the footprint of the blocks the search really reads: the 2-step rank blocks (128-byte lines, n bytes) when
-    the index has them, the 1-step blocks (64-byte lines, n / 3 bytes) otherwise"""
+def fm_gather_fields(fm, n_q, pat, off, bufs, stream, launch_ms, block_bytes, pattern_bytes, with_ceiling=True):
+    """The FM legs' roofline.  Numerator = the bytes this kernel MUST move per launch with the block layout it runs on:
+    the rank-block lines it has to fetch — counted exactly by the counting instantiation of K5 (outside the timed region):
+    one line per (l - 1, r) block access, one when both ranks fall into the same block; 128-byte lines answering two LF steps
+    with the 2-step blocks, 64-byte lines otherwise — x the line size, + the pattern bytes + 24 result bytes per query.
+    (SURVEY.md §8(d)'s figure — two 64-byte lines per LF step — described the round-1 kernel; it is kept as the informational
+    `alg_bytes_survey_per_query`, no fraction is formed from it: the 2-step kernel fetches a quarter of those lines.)
+    `frac_of_gather_ceiling`: the same line rate against the chip's measured rate for this access shape
+    (tools/microbench/ub_gather64 / ub_gather128) at the footprint of the blocks the search really reads."""
     d_tag, d_lo, d_hi, d_ml = bufs
     lines = fm.backward_search_count_lines_dev(n_q, pat.data_ptr(), off.data_ptr(), d_tag.data_ptr(), d_lo.data_ptr(), d_hi.data_ptr(),
                                                d_ml.data_ptr(), stream)
     s2 = fm.step2_bytes()
     line_bytes = 128 if s2 else 64
     foot = s2 if s2 else block_bytes
-    ceil_g = gather_ceiling(foot, line_bytes)
     rate = lines / (launch_ms * 1e-3) / 1e9
-    return {"requested_lines_per_launch": lines, "line_bytes": line_bytes, "lf_steps_per_block_access": 2 if s2 else 1,
-            "glines_per_s": round(rate, 2), "requested_gb_per_s": round(rate * line_bytes, 1),
-            "gather_ceiling_glines_per_s": ceil_g,
-            "frac_of_gather_ceiling": round(rate / ceil_g, 4) if ceil_g else None,
-            "gather_ceiling_source": f"tools/microbench/{'ub_gather128 (w128x4' if s2 else 'ub_gather64 ('}two dependent random "
-                                     f"{line_bytes}-B lines per quad-step, 8 waves/SIMD) on a {round(foot / 1e6)} MB table, run beside this leg"}
+    alg = float(lines) * line_bytes + float(pattern_bytes) + 24.0 * n_q
+    ach = alg / (launch_ms * 1e-3) / 1e9
+    out = {"achieved": round(ach, 2), "frac": round(ach / HBM_PEAK_GBS, 5), "alg_bytes_per_query": round(alg / n_q, 1),
+           "alg_bytes_definition": "requested rank-block lines (counted) x line_bytes + pattern bytes + 24 B of results per query",
+           "requested_lines_per_launch": lines, "line_bytes": line_bytes, "lf_steps_per_block_access": 2 if s2 else 1,
+           "glines_per_s": round(rate, 2), "requested_gb_per_s": round(rate * line_bytes, 1)}
+    if with_ceiling:
+        ceil_g = gather_ceiling(foot, line_bytes)
+        out.update({"gather_ceiling_glines_per_s": ceil_g,
+                    "frac_of_gather_ceiling": round(rate / ceil_g, 4) if ceil_g else None,
+                    "gather_ceiling_source": f"tools/microbench/{'ub_gather128 (w128x4' if s2 else 'ub_gather64 ('}two dependent random "
+                                             f"{line_bytes}-B lines per quad-step, 8 waves/SIMD) on a {round(foot / 1e6)} MB table, run beside this leg"})
+    return out
 
 
 def timed_steps(fn, steps, warmup, device):
@@ -688,9 +699,8 @@ def fm_legs(args, ctx, dev, stream, rank, world, do_cpu, orc, threads, parity, r
     fm_ms = tm["fm_ms"] / max(1, tm["fm_launches"])
     ml = d_ml.to(torch.int64)
     steps_exec = int((ml + (d_tag == 1).to(torch.int64) + (d_tag == 2).to(torch.int64)).sum().item())
-    # algorithmic bytes per query: |P| + 24 + 128 x LF steps executed
-    alg_bytes = float(n_q) * (P + 24) + 128.0 * steps_exec
-    fm_ach = alg_bytes / (fm_ms * 1e-3) / 1e9
+    # SURVEY.md §8(d)'s per-query figure (|P| + 24 + 128 x LF steps executed: two 64-byte lines per step) — informational only
+    survey_bytes = float(n_q) * (P + 24) + 128.0 * steps_exec
     fm_res = {"value": round(qps, 1), "unit": "queries/s", "ms_per_step": round(fm_t / args.steps * 1e3, 3), "scaling": "weak",
               "config": {"workload": f"FMIndex over {args.genome} bp synthetic genome + '$' (n_alphabet, Occ k=128), "
                                      f"{n_q} x {P} bp backward_search per GPU (BASELINE configs[2])",
@@ -700,17 +710,17 @@ def fm_legs(args, ctx, dev, stream, rank, world, do_cpu, orc, threads, parity, r
                                         "blocks (bg_suffix_array_dev, bg_bwt_dev, bg_sa_sample_dev, bg_fm_build_dev)"},
               "tags": {"complete": int((d_tag == 0).sum().item()), "partial": int((d_tag == 1).sum().item()),
                        "absent": int((d_tag == 2).sum().item())},
-              "roofline": {"bound": "hbm", "kernel": "fm_search_fast_kernel", "achieved": round(fm_ach, 2),
-                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(fm_ach / HBM_PEAK_GBS, 5),
+              "roofline": {"bound": "hbm", "kernel": "fm_search_fast_kernel", "achieved": None,
+                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
                            "traffic": pmc_traffic("fm_search_fast_kernel", "fm_queries_per_launch", n_q),
                            "launch_ms": round(fm_ms, 4), "queries_per_launch": n_q,
-                           "alg_bytes_per_query": round(alg_bytes / n_q, 1),
+                           "alg_bytes_survey_per_query": round(survey_bytes / n_q, 1),
                            "note": "the 33 MB block index of a 100 Mbp text sits in the 256 MiB Infinity Cache: see fm_big "
                                    "for an index that cannot"}}
 
     block_bytes = (args.genome + 1 + 191) // 192 * 64
-    if rank == 0:
-        fm_res["roofline"].update(fm_gather_fields(fm, n_q, pat, off, (d_tag, d_lo, d_hi, d_ml), stream, fm_ms, block_bytes))
+    fm_res["roofline"].update(fm_gather_fields(fm, n_q, pat, off, (d_tag, d_lo, d_hi, d_ml), stream, fm_ms, block_bytes,
+                                               float(n_q) * P, with_ceiling=rank == 0))
     if not args.skip_packed:
         fm_res["packed2"] = fm_packed_leg(args, ctx, dev, stream, world, fm, n_q, pat, off, (d_tag, d_lo, d_hi, d_ml), fm_ms, parity, "fm")
     # strong scaling on configs[2]: the SAME n_q queries in total, split over the ranks, gathered inside the step
@@ -812,7 +822,7 @@ def fm_big_leg(args, ctx, dev, stream, rank, world, do_cpu, orc, threads, parity
     tm = kernel_timing(ctx, step)
     ms = tm["fm_ms"] / max(1, tm["fm_launches"])
     steps_exec = int((d_ml.to(torch.int64) + (d_tag == 1).to(torch.int64) + (d_tag == 2).to(torch.int64)).sum().item())
-    alg = float(n_q) * (P + 24) + 128.0 * steps_exec
+    survey_bytes = float(n_q) * (P + 24) + 128.0 * steps_exec  # SURVEY.md §8(d)'s figure: informational (fm_gather_fields)
     leg = {"value": round(world * float(n_q) * args.steps / t, 1), "unit": "queries/s", "ms_per_step": round(t / args.steps * 1e3, 3),
            "scaling": "weak",
            "config": {"workload": f"FMIndex over {n_g} bp synthetic genome + '$', {n_q} x {P} bp backward_search per GPU, "
@@ -822,12 +832,13 @@ def fm_big_leg(args, ctx, dev, stream, rank, world, do_cpu, orc, threads, parity
                       "bwt_samples_blocks_s": round(bt["bwt_samples_blocks_s"], 2),
                       "host_peak_rss_gb": round(resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6, 1)},
            "tags": {"complete": int((d_tag == 0).sum().item()), "partial": int((d_tag == 1).sum().item())},
-           "roofline": {"bound": "hbm", "kernel": "fm_search_fast_kernel", "achieved": round(alg / (ms * 1e-3) / 1e9, 2),
-                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+           "roofline": {"bound": "hbm", "kernel": "fm_search_fast_kernel", "achieved": None,
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
                         "traffic": fm_big_traffic(n_q, fm.device_bytes()),
-                        "launch_ms": round(ms, 4), "queries_per_launch": n_q, "alg_bytes_per_query": round(alg / n_q, 1)}}
-    if rank == 0:
-        leg["roofline"].update(fm_gather_fields(fm, n_q, pat, off, (d_tag, d_lo, d_hi, d_ml), stream, ms, (n_g + 1 + 191) // 192 * 64))
+                        "launch_ms": round(ms, 4), "queries_per_launch": n_q,
+                        "alg_bytes_survey_per_query": round(survey_bytes / n_q, 1)}}
+    leg["roofline"].update(fm_gather_fields(fm, n_q, pat, off, (d_tag, d_lo, d_hi, d_ml), stream, ms, (n_g + 1 + 191) // 192 * 64,
+                                            float(n_q) * P, with_ceiling=rank == 0))
     if not args.skip_packed:
         leg["packed2"] = fm_packed_leg(args, ctx, dev, stream, world, fm, n_q, pat, off, (d_tag, d_lo, d_hi, d_ml), ms, parity, "fm_big")
     if do_cpu:

@@ -1,10 +1,13 @@
 """Summarise the rocprofv3 PMC passes written by collect_profiles.sh.
 
 FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB per dispatch (summed over the XCDs).  The
-calibration kernels (tools/pmc_calib.hip) have exactly known traffic, so the ratio printed for them is
-the correction to apply on this chip/driver: on gfx950 + ROCm 7.2 both came out at 1.00 for the access
-shapes the engine uses (16 B/lane gathers of 64-byte blocks, 8 B/lane coalesced stores), i.e. NO
-extra factor is applied; single-byte strided stores are the known outlier (6.3x write amplification).
+calibration kernels (tools/pmc_calib.hip) move exactly known byte counts in the access shapes of the engine
+(random 64-byte blocks per quad, random 128-byte lines per quad / per 8 lanes, coalesced 4 / 8 / 16 B per lane
+loads and stores); the ratio reported / moved of each shape is measured in the same collection run and the
+engine kernels of that shape are corrected by 1 / ratio (KERNEL_SHAPES below; MI355X_MICROARCH.md "HBM": gfx950
+tallies 128-byte read requests at 64 B).  Every entry keeps `raw_bytes` (what rocprofv3 said), the shape and the
+ratio applied; `mean_bytes` is the corrected figure bench.py reports as roofline.traffic.  Kernels without a
+listed shape are left uncorrected and say so.  Single-byte strided stores are the known outlier (6.3x).
 The SQ_* counters are plain event counts per dispatch (wave instructions, cycles).
 """
 import collections
@@ -58,20 +61,83 @@ for p in passes:
     counters.update(per_kernel(p))
 shape = launch_shape(os.path.join(out, "pmc_1.log")) if passes else {}
 
+# ---- calibration (first: the traffic figures below are corrected with it)
+cal_lines = []
+CAL = {}  # (calibration kernel, counter) -> reported / moved
+expect = {}
+for f in glob.glob(os.path.join(out, "cal_*.log")):
+    for ln in open(f):
+        if ln.startswith("EXPECT"):
+            _, name, counter, nbytes = ln.split()
+            expect[(name, counter)] = float(nbytes)
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    for f in glob.glob(os.path.join(out, "cal_" + c, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            agg[r["Kernel_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"]) * 1024.0
+    for k, v in agg.items():
+        base = k.split("(")[0].replace("void ", "").strip()
+        for (name, counter), nbytes in expect.items():
+            if counter == c and name == base:
+                mean = sum(v.values()) / len(v)
+                CAL[(name, c)] = mean / nbytes
+                cal_lines.append(f"{name:24s} {c:10s} measured {mean/1e9:9.4f} GB  expected {nbytes/1e9:9.4f} GB  ratio {mean/nbytes:6.3f}")
+if cal_lines:
+    open(os.path.join(out, tag + "_pmc_calibration.txt"), "w").write("\n".join(sorted(cal_lines)) + "\n")
+    print("\n".join(sorted(cal_lines)))
+
+# access shape of the engine kernels that carry a roofline: (kernel substring, FETCH shape, WRITE shape); first match wins
+KERNEL_SHAPES = [
+    ("fm_search_fast_kernel<STEP2>", "k_gather128x4", "k_store8"),  # the last template argument: 128-byte lines, two LF steps each
+    ("fm_search_fast_kernel", "k_quadload", "k_store8"),                                  # 1-step blocks: 64-byte lines
+    ("fm_backward_search_kernel", "k_quadload", "k_store8"),
+    ("sa_sampled_get", "k_quadload", "k_store8"), ("fmd_smems", "k_quadload", "k_store4"),
+    ("banded_fill2p_kernel", "k_load16", "k_store16"),  # uint4 chunk loads, uint4 traceback lines
+    ("banded_fill2i_kernel", "k_load16", "k_store16"), ("banded_fill2_kernel", "k_load16", "k_store16"),
+    ("banded_traceback_kernel", "k_quadload", "k_store8"), ("banded_epilogue_kernel", "k_load16", "k_store8"),
+    ("band_rows_kernel", "k_load4", "k_store4"),
+    ("sw_fill_pk16_kernel", "k_load4", "k_store8"), ("sw_fill_kernel", "k_load4", "k_store8"),
+    ("sw_traceback_kernel", "k_quadload", "k_store8"),
+    ("fq_gather_kernel", "k_load16", "k_store16"), ("fq_count_newlines", "k_load16", "k_store4"),
+    ("fq_line_starts", "k_load16", "k_store8"), ("fq_line_info", "k_load8", "k_store8"), ("fq_measure", "k_load16", "k_store4"),
+]
+
+
+def corrected(kernel, counter, raw):
+    """raw bytes of one counter -> (bytes, {"shape", "ratio"} or None)"""
+    step2 = "fm_search_fast_kernel<" in kernel and kernel.strip().endswith(", true>")
+    for sub, fs, ws in KERNEL_SHAPES:
+        if (sub == "fm_search_fast_kernel<STEP2>" and step2) or sub in kernel:
+            shape = fs if counter == "FETCH_SIZE" else ws
+            ratio = CAL.get((shape, counter))
+            if ratio and ratio > 0:
+                return raw / ratio, {"shape": shape, "ratio": round(ratio, 4)}
+            return raw, None
+    return raw, None
+
+
+def entry(kernel, counter, vals):
+    raw = sum(vals) * 1024.0 / len(vals)
+    cor, how = corrected(kernel, counter, raw)
+    return {"launches": len(vals), "mean_bytes": cor, "raw_bytes": raw, "calibration": how}
+
+
 # ---- HBM traffic
-res = {"unit": "bytes per launch (mean over launches)", "csrc_sha": SHA, "kernels": {}, "launch_shape": shape}
+res = {"unit": "bytes per launch (mean over launches); mean_bytes = raw_bytes / the measured ratio of the kernel's access shape "
+               "(tools/pmc_calib.hip, <tag>_pmc_calibration.txt); calibration null = no listed shape, uncorrected",
+       "csrc_sha": SHA, "calibration": {f"{n} {c}": round(r, 4) for (n, c), r in sorted(CAL.items())}, "kernels": {}, "launch_shape": shape}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for k, v in counters.get(c, {}).items():
-        res["kernels"].setdefault(k, {})[c] = {"launches": len(v), "mean_bytes": sum(v) * 1024.0 / len(v)}
+        res["kernels"].setdefault(k, {})[c] = entry(k, c, v)
 # FASTQ ingest is many short kernels per call: bytes of all of them per bg_fastq_parse_dev call (the leg makes 4 calls)
-fq = sum(sum(v) * 1024.0 for c in ("FETCH_SIZE", "WRITE_SIZE") for k, v in counters.get(c, {}).items() if k.startswith("fq_"))
+fq = sum(corrected(k, c, sum(v) * 1024.0)[0] for c in ("FETCH_SIZE", "WRITE_SIZE") for k, v in counters.get(c, {}).items() if k.startswith("fq_"))
 res["ingest_bytes_per_call"] = fq / 4.0
 # the FM search kernel on the index beyond the Infinity Cache (its own passes)
 big = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
-    vals = [v for k, vs in per_kernel(os.path.join(out, "big_" + c)).get(c, {}).items() if "fm_search_fast_kernel" in k for v in vs]
-    if vals:
-        big[c] = {"launches": len(vals), "mean_bytes": sum(vals) * 1024.0 / len(vals)}
+    for k, vs in per_kernel(os.path.join(out, "big_" + c)).get(c, {}).items():
+        if "fm_search_fast_kernel" in k and "fm_search_fast_kernel<true" not in k and (c not in big or len(vs) > big[c]["launches"]):
+            big[c] = entry(k, c, vs)   # the byte flavour of the whole-pattern search (the SEEDS flavour belongs to seed_extend)
 logf = os.path.join(out, "big_FETCH_SIZE.log")
 if big and os.path.exists(logf):
     for ln in open(logf):
@@ -89,8 +155,10 @@ tot_bytes = 0.0
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for k, vs in per_kernel(os.path.join(out, "big_" + c)).get(c, {}).items():
         if not k.startswith(("at::", "void at::", "elementwise_kernel", "rocprim", "void rocprim")) and any(t in k for t in SE_KERNELS):
-            se["kernels"].setdefault(k, {})[c] = {"launches": len(vs), "mean_bytes": sum(vs) * 1024.0 / len(vs), "total_bytes": sum(vs) * 1024.0}
-            tot_bytes += sum(vs) * 1024.0
+            e = entry(k, c, vs)
+            e["total_bytes"] = e["mean_bytes"] * len(vs)
+            se["kernels"].setdefault(k, {})[c] = e
+            tot_bytes += e["total_bytes"]
 if se["kernels"] and os.path.exists(logf):
     for ln in open(logf):
         if ln.startswith("{") and '"seed_extend"' in ln:
@@ -132,24 +200,3 @@ with open(os.path.join(out, tag + "_lds_counters.txt"), "w") as f:
                                                   "-" if c["conflict_over_active"] is None else "%.1f %%" % (100 * c["conflict_over_active"])))
 print(json.dumps({"traffic_kernels": len(res["kernels"]), "sq_kernels": len(sq["kernels"]), "lds_kernels": len(lds["kernels"])}))
 
-# ---- calibration
-lines = []
-expect = {}
-for f in glob.glob(os.path.join(out, "cal_*.log")):
-    for ln in open(f):
-        if ln.startswith("EXPECT"):
-            _, name, counter, nbytes = ln.split()
-            expect[(name, counter)] = float(nbytes)
-for c in ("FETCH_SIZE", "WRITE_SIZE"):
-    agg = collections.defaultdict(list)
-    for f in glob.glob(os.path.join(out, "cal_" + c, "**", "*counter_collection.csv"), recursive=True):
-        for r in csv.DictReader(open(f)):
-            agg[r["Kernel_Name"]].append(float(r["Counter_Value"]) * 1024.0)
-    for k, v in agg.items():
-        for (name, counter), nbytes in expect.items():
-            if counter == c and name in k:
-                mean = sum(v) / len(v)
-                lines.append(f"{name:24s} {c:10s} measured {mean/1e9:9.4f} GB  expected {nbytes/1e9:9.4f} GB  ratio {mean/nbytes:6.3f}")
-if lines:
-    open(os.path.join(out, tag + "_pmc_calibration.txt"), "w").write("\n".join(lines) + "\n")
-    print("\n".join(lines))
