@@ -517,7 +517,15 @@ int bg_pretty_batch(bg_ctx* ctx, uint64_t n, const bg_alignment_t* aln, const ui
  *                      a ctx-less host communicator) and receives all of them in rank order in `all` (capacity: the sum
  *                      of the counts); counts_out (optional, host, world entries) says how many each rank brought.  RCCL:
  *                      one ncclAllGather on `stream` when the shards are equal, grouped broadcasts when they are ragged;
- *                      the call returns when the collective is queued (the counts cost one stream synchronisation). */
+ *                      the call returns when the collective is queued (the counts cost one stream synchronisation).
+ *   bg_gather_records_cap  the same with the size of `all` stated in records: the counts (and every rank's all_cap) travel
+ *                      first, and when the ranks' records together exceed the smallest all_cap EVERY rank returns
+ *                      BG_ERR_OPS_CAP before a single record has moved.
+ * The host-staged flavour never leaves a rank behind: a local failure (segment, mapping, copy) is published in the control
+ * block and all ranks return it together after the call's last barrier; a barrier that is not completed within 120 s (a
+ * rank is gone) returns BG_ERR_HIP with the data segment unmapped and unlinked.  bg_comm_init_host survives a control
+ * segment of the same name left behind by a crashed or earlier run (ranks confirm with a nonce that the segment they
+ * mapped is the one this run's rank 0 created, and attach again otherwise). */
 #define BG_COMM_ID_BYTES 128
 typedef struct bg_comm bg_comm;
 int bg_shard_range(uint64_t n_units, int rank, int world, uint64_t* lo, uint64_t* hi);
@@ -527,9 +535,11 @@ int bg_comm_init(bg_ctx* ctx, int rank, int world, const uint8_t* id /* BG_COMM_
 int bg_comm_init_host(bg_ctx* ctx, int rank, int world, const char* name, bg_comm** out);
 int bg_gather_records(bg_comm* comm, const void* local, uint64_t n_local, uint32_t rec_bytes, void* all, uint64_t* counts_out,
                       void* stream);
-/* ... for records in HOST memory (the results of the host-buffer entry points): staged through device scratch for an
- * RCCL communicator, through the shared segment for a host-staged one; all_cap = records `all` can hold (BG_ERR_OPS_CAP
- * if the ranks bring more).  Synchronous. */
+int bg_gather_records_cap(bg_comm* comm, const void* local, uint64_t n_local, uint32_t rec_bytes, void* all, uint64_t all_cap,
+                          uint64_t* counts_out, void* stream);
+/* ... for records in HOST memory (the results of the host-buffer entry points): staged through device scratch (sized from
+ * the gathered counts) for an RCCL communicator, through the shared segment for a host-staged one; all_cap = records `all`
+ * can hold: BG_ERR_OPS_CAP on every rank, nothing written, if the ranks bring more.  Synchronous. */
 int bg_gather_records_host(bg_comm* comm, const void* local, uint64_t n_local, uint32_t rec_bytes, void* all, uint64_t all_cap,
                            uint64_t* counts_out);
 int bg_comm_free(bg_comm* comm);

@@ -95,7 +95,7 @@ SYMBOLS = ["bg_device_count", "bg_init", "bg_free", "bg_strerror", "bg_last_erro
            "bg_pack2_dev", "bg_unpack2_dev", "bg_fm_pattern_codes", "bg_fm_backward_search_packed_dev",
            "bg_fm_backward_search_count_lines_dev", "bg_align_batch_packed_dev", "bg_fm_step2_bytes",
            "bg_shard_range", "bg_shard_balanced", "bg_comm_unique_id", "bg_comm_init", "bg_comm_init_host",
-           "bg_gather_records", "bg_gather_records_host", "bg_comm_free"]
+           "bg_gather_records", "bg_gather_records_cap", "bg_gather_records_host", "bg_comm_free"]
 
 
 def build(force=False):
@@ -142,6 +142,7 @@ def lib():
         L.bg_comm_init.argtypes = [vp, i32, i32, vp, C.POINTER(vp)]
         L.bg_comm_init_host.argtypes = [vp, i32, i32, C.c_char_p, C.POINTER(vp)]
         L.bg_gather_records.argtypes = [vp, vp, u64, u32, vp, vp, vp]
+        L.bg_gather_records_cap.argtypes = [vp, vp, u64, u32, vp, u64, vp, vp]
         L.bg_gather_records_host.argtypes = [vp, vp, u64, u32, vp, u64, vp]
         L.bg_comm_free.argtypes = [vp]
         L.bg_fm_backward_search_batch.argtypes = [vp, u64, vp, vp, vp, vp, vp, vp]

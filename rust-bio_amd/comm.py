@@ -48,21 +48,28 @@ class Comm:
                    "bg_comm_init_host")
         return cls(h, rank, world, ctx)
 
-    def gather_ptr(self, local_ptr, n_local, rec_bytes, all_ptr, stream=0):
-        """device (or, for a ctx-less host communicator, host) pointers; returns the per-rank record counts"""
+    def gather_ptr(self, local_ptr, n_local, rec_bytes, all_ptr, stream=0, all_cap=None):
+        """device (or, for a ctx-less host communicator, host) pointers; returns the per-rank record counts.
+        all_cap: records `all_ptr` can hold — checked on every rank before anything moves (bg_gather_records_cap)"""
         counts = np.zeros(self.world, dtype=np.uint64)
-        _lib.check(_lib.lib().bg_gather_records(self.h, local_ptr, n_local, rec_bytes, all_ptr, counts.ctypes.data, stream),
-                   "bg_gather_records")
+        if all_cap is None:
+            _lib.check(_lib.lib().bg_gather_records(self.h, local_ptr, n_local, rec_bytes, all_ptr, counts.ctypes.data, stream),
+                       "bg_gather_records")
+        else:
+            _lib.check(_lib.lib().bg_gather_records_cap(self.h, local_ptr, n_local, rec_bytes, all_ptr, all_cap, counts.ctypes.data, stream),
+                       "bg_gather_records_cap")
         return counts
 
     def gather_host(self, local, total_records):
-        """numpy records [n_local, ...] of a ctx-less host communicator -> all records in rank order"""
+        """numpy records [n_local, ...] in host memory -> all records in rank order (bg_gather_records_host: through the shared
+        segment for a host communicator, staged through device scratch for an RCCL one); total_records = the room of the result"""
         local = np.ascontiguousarray(local)
         rec_bytes = local.dtype.itemsize * int(np.prod(local.shape[1:], dtype=np.int64))
         out = np.zeros((total_records,) + local.shape[1:], dtype=local.dtype)
-        counts = self.gather_ptr(local.ctypes.data, local.shape[0], rec_bytes, out.ctypes.data)
-        assert int(counts.sum()) == total_records
-        return out, counts
+        counts = np.zeros(self.world, dtype=np.uint64)
+        _lib.check(_lib.lib().bg_gather_records_host(self.h, local.ctypes.data, local.shape[0], rec_bytes, out.ctypes.data, total_records,
+                                                     counts.ctypes.data), "bg_gather_records_host")
+        return out[:int(counts.sum())], counts
 
     def free(self):
         if self.h:

@@ -21,6 +21,7 @@
 
 #include <atomic>
 #include <chrono>
+#include <random>
 #include <string>
 #include <vector>
 
@@ -65,7 +66,13 @@ struct ShmCtrl {
     std::atomic<uint32_t> arrived;  // ranks attached (init)
     std::atomic<uint32_t> count;    // barrier: arrivals of the current phase
     std::atomic<uint32_t> sense;    // barrier: flips when a phase completes
+    std::atomic<int32_t> err;       // first error of the current gather: every rank fails together (rank 0 clears it afterwards)
     uint64_t n_rec[kMaxRanks];      // records each rank brings to the current gather
+    uint64_t cap[kMaxRanks];        // records each rank's `all` can hold (~0: unchecked)
+    // attach handshake: rank k writes a fresh nonce into hello[k]; the rank 0 of THIS run copies it into ack[k].  A segment
+    // left behind by a crashed or earlier run of the same name never answers a fresh nonce, so a rank that opened it before
+    // rank 0 replaced it notices (the name's inode changes) and attaches again
+    std::atomic<uint64_t> hello[kMaxRanks], ack[kMaxRanks];
 };
 
 }  // namespace
@@ -165,7 +172,7 @@ extern "C" int bg_comm_init(bg_ctx* ctx, int rank, int world, const uint8_t* id,
         delete c;
         return BG_ERR_HIP;
     }
-    if (hipMalloc((void**)&c->d_counts, (size_t)world * 8 + 8) != hipSuccess) {
+    if (hipMalloc((void**)&c->d_counts, (size_t)world * 16 + 16) != hipSuccess) {
         r.destroy(c->nccl);
         delete c;
         return BG_ERR_OOM;
@@ -182,44 +189,76 @@ extern "C" int bg_comm_init_host(bg_ctx* ctx, int rank, int world, const char* n
     c->world = world;
     c->name = std::string("/bg_") + name;
     const std::string ctl = c->name + "_ctl";
-    int fd = -1;
+    const auto t0 = std::chrono::steady_clock::now();
+    auto late = [&] { return std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120); };
+    auto fail = [&](int rc) {
+        if (c->ctrl) munmap(c->ctrl, sizeof(ShmCtrl));
+        delete c;
+        return rc;
+    };
     if (rank == 0) {
-        shm_unlink(ctl.c_str());
-        fd = shm_open(ctl.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+        shm_unlink(ctl.c_str());  // whatever an earlier run of this name left behind
+        int fd = shm_open(ctl.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
         if (fd < 0 || ftruncate(fd, sizeof(ShmCtrl)) != 0) {
             if (fd >= 0) close(fd);
-            delete c;
-            return BG_ERR_HIP;
+            return fail(BG_ERR_HIP);
         }
-    } else {
-        const auto t0 = std::chrono::steady_clock::now();
+        void* m = mmap(nullptr, sizeof(ShmCtrl), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        close(fd);
+        if (m == MAP_FAILED) {
+            shm_unlink(ctl.c_str());
+            return fail(BG_ERR_HIP);
+        }
+        c->ctrl = (ShmCtrl*)m;  // (a fresh segment is zero-filled: counters, sense, error flag and nonces start at 0)
+        c->ctrl->arrived.fetch_add(1, std::memory_order_acq_rel);
+        while (c->ctrl->arrived.load(std::memory_order_acquire) < (uint32_t)world) {
+            sched_yield();
+            if (late()) {
+                shm_unlink(ctl.c_str());
+                return fail(BG_ERR_HIP);
+            }
+        }
+        for (int k = 1; k < world; k++) c->ctrl->ack[k].store(c->ctrl->hello[k].load(std::memory_order_acquire), std::memory_order_release);
+        *out = c;
+        return BG_OK;
+    }
+    std::random_device rd;
+    for (;;) {  // attach; again if the segment turns out to be a stale one
+        int fd = -1;
         struct stat sb;
         while ((fd = shm_open(ctl.c_str(), O_RDWR, 0600)) < 0 || fstat(fd, &sb) != 0 || (size_t)sb.st_size < sizeof(ShmCtrl)) {
             if (fd >= 0) close(fd);
             fd = -1;
-            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) {
-                delete c;
-                return BG_ERR_HIP;
-            }
+            if (late()) return fail(BG_ERR_HIP);
             usleep(1000);
         }
-    }
-    c->ctrl = (ShmCtrl*)mmap(nullptr, sizeof(ShmCtrl), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-    close(fd);
-    if (c->ctrl == MAP_FAILED) {
-        delete c;
-        return BG_ERR_HIP;
-    }
-    // (a fresh segment is zero-filled: counters, sense and counts start at 0)
-    c->ctrl->arrived.fetch_add(1, std::memory_order_acq_rel);
-    const auto t0 = std::chrono::steady_clock::now();
-    while (c->ctrl->arrived.load(std::memory_order_acquire) < (uint32_t)world) {
-        sched_yield();
-        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) {
-            munmap(c->ctrl, sizeof(ShmCtrl));
-            delete c;
-            return BG_ERR_HIP;
+        void* m = mmap(nullptr, sizeof(ShmCtrl), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        close(fd);
+        if (m == MAP_FAILED) return fail(BG_ERR_HIP);
+        c->ctrl = (ShmCtrl*)m;
+        uint64_t nonce = ((uint64_t)rd() << 32) ^ rd() ^ ((uint64_t)getpid() << 20);
+        nonce |= 1;  // never 0
+        c->ctrl->hello[rank].store(nonce, std::memory_order_release);
+        c->ctrl->arrived.fetch_add(1, std::memory_order_acq_rel);
+        bool stale = false;
+        for (uint32_t spin = 0; c->ctrl->ack[rank].load(std::memory_order_acquire) != nonce; spin++) {
+            sched_yield();
+            if (late()) return fail(BG_ERR_HIP);
+            if ((spin & 1023) == 1023) {  // is the name still the segment this rank mapped?
+                struct stat now;
+                const int f2 = shm_open(ctl.c_str(), O_RDWR, 0600);
+                const bool same = f2 >= 0 && fstat(f2, &now) == 0 && now.st_ino == sb.st_ino && now.st_dev == sb.st_dev;
+                if (f2 >= 0) close(f2);
+                if (!same) {
+                    stale = true;
+                    break;
+                }
+            }
         }
+        if (!stale) break;
+        munmap(c->ctrl, sizeof(ShmCtrl));
+        c->ctrl = nullptr;
+        usleep(1000);
     }
     *out = c;
     return BG_OK;
@@ -237,111 +276,197 @@ extern "C" int bg_comm_free(bg_comm* c) {
     return BG_OK;
 }
 
-extern "C" int bg_gather_records(bg_comm* c, const void* local, uint64_t n_local, uint32_t rec_bytes, void* all, uint64_t* counts_out,
-                                 void* stream) {
-    if (!c || !rec_bytes || (n_local && !local) || !all) return BG_ERR_INVALID_ARG;
+namespace {
+
+constexpr uint64_t kNoCap = ~0ull;
+
+// The counts of every rank — and the smallest `all` any rank brought: whether the records fit is decided BEFORE anything
+// moves, and identically on every rank (a rank that left the collective alone would hang the others).
+int rccl_counts(bg_comm* c, uint64_t n_local, uint64_t cap, std::vector<uint64_t>& counts, uint64_t& min_cap, hipStream_t st) {
+    Rccl& r = rccl();
+    const int W = c->world;
+    uint64_t mine[2] = {n_local, cap};
+    std::vector<uint64_t> got((size_t)2 * W, 0);
+    BG_HIP(hipMemcpyAsync(c->d_counts + 2 * W, mine, 16, hipMemcpyHostToDevice, st));
+    if (r.all_gather(c->d_counts + 2 * W, c->d_counts, 16, ncclUint8, c->nccl, st) != ncclSuccess) return BG_ERR_HIP;
+    BG_HIP(hipMemcpyAsync(got.data(), c->d_counts, (size_t)W * 16, hipMemcpyDeviceToHost, st));
+    BG_HIP(hipStreamSynchronize(st));
+    min_cap = kNoCap;
+    for (int k = 0; k < W; k++) {
+        counts[k] = got[2 * k];
+        min_cap = std::min(min_cap, got[2 * k + 1]);
+    }
+    return BG_OK;
+}
+
+int rccl_records(bg_comm* c, const void* local, uint32_t rec_bytes, void* all, const std::vector<uint64_t>& counts, hipStream_t st) {
+    Rccl& r = rccl();
+    const int W = c->world;
+    bool equal = true;
+    for (int k = 1; k < W; k++) equal = equal && counts[k] == counts[0];
+    if (equal) {  // one all-gather when the shards are equal
+        if (counts[0] && r.all_gather(local, all, (size_t)counts[0] * rec_bytes, ncclUint8, c->nccl, st) != ncclSuccess) return BG_ERR_HIP;
+        return BG_OK;
+    }
+    if (r.group_start() != ncclSuccess) return BG_ERR_HIP;  // ragged: one grouped broadcast per rank
+    uint64_t off = 0;
+    for (int k = 0; k < W; k++) {
+        const size_t bytes = (size_t)counts[k] * rec_bytes;
+        if (bytes && r.broadcast(k == c->rank ? local : nullptr, (uint8_t*)all + off, bytes, ncclUint8, k, c->nccl, st) != ncclSuccess) {
+            r.group_end();
+            return BG_ERR_HIP;
+        }
+        off += bytes;
+    }
+    return r.group_end() != ncclSuccess ? BG_ERR_HIP : BG_OK;
+}
+
+// host-staged flavour.  Every rank passes the same barriers whatever fails locally: a failure is published in the control
+// block's error flag and every rank returns it together, after the last barrier — nobody is left spinning, and the barrier
+// state stays usable for the next call.  (A barrier that times out means a rank is gone: the communicator is dead then;
+// the data segment is unmapped, closed and unlinked on the way out all the same.)
+int shm_gather(bg_comm* c, bg_ctx* ctx, const void* local, uint64_t n_local, uint32_t rec_bytes, void* all, uint64_t cap,
+               std::vector<uint64_t>& counts) {
+    ShmCtrl* s = c->ctrl;
+    const int W = c->world;
+    s->n_rec[c->rank] = n_local;
+    s->cap[c->rank] = cap;
+    int rc = shm_barrier(c);
+    if (rc) return rc;
+    uint64_t total = 0, my_off = 0, min_cap = kNoCap;
+    for (int k = 0; k < W; k++) {
+        counts[k] = s->n_rec[k];
+        min_cap = std::min(min_cap, s->cap[k]);
+        if (k < c->rank) my_off += counts[k];
+        total += counts[k];
+    }
+    if (total > min_cap) {  // every rank sees the same numbers and leaves here; nothing was moved
+        rc = shm_barrier(c);  // (the counts are read: the next call may overwrite them)
+        return rc ? rc : BG_ERR_OPS_CAP;
+    }
+    const size_t bytes = std::max<size_t>((size_t)total * rec_bytes, 16);
+    const std::string dn = c->name + "_d" + std::to_string(c->seq++);
+    auto publish = [&](int e) {
+        int32_t none = 0;
+        if (e) s->err.compare_exchange_strong(none, e, std::memory_order_acq_rel);
+    };
+    int fd = -1;
+    uint8_t* data = nullptr;
+    auto cleanup = [&] {
+        if (data) munmap(data, bytes);
+        if (fd >= 0) close(fd);
+        if (c->rank == 0) shm_unlink(dn.c_str());
+    };
+    if (c->rank == 0) {
+        shm_unlink(dn.c_str());
+        fd = shm_open(dn.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (fd < 0 || ftruncate(fd, (off_t)bytes) != 0) publish(BG_ERR_OOM);
+    }
+    if ((rc = shm_barrier(c))) {  // the data segment exists (or the error flag says why not)
+        cleanup();
+        return rc;
+    }
+    if (!s->err.load(std::memory_order_acquire)) {
+        if (c->rank != 0 && (fd = shm_open(dn.c_str(), O_RDWR, 0600)) < 0) publish(BG_ERR_HIP);
+        if (fd >= 0) {
+            void* m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+            if (m == MAP_FAILED)
+                publish(BG_ERR_OOM);
+            else
+                data = (uint8_t*)m;
+        }
+        if (data) publish(copy_any(ctx, data + my_off * rec_bytes, local, (size_t)n_local * rec_bytes, hipMemcpyDeviceToHost));
+    }
+    if ((rc = shm_barrier(c))) {  // every slice is in place
+        cleanup();
+        return rc;
+    }
+    int e = s->err.load(std::memory_order_acquire);
+    if (!e && data) e = copy_any(ctx, all, data, (size_t)total * rec_bytes, hipMemcpyHostToDevice);
+    rc = shm_barrier(c);  // everybody has read the segment and the flag: both can go
+    cleanup();
+    if (c->rank == 0) s->err.store(0, std::memory_order_release);  // (the others touch it again only behind the next call's first barrier)
+    return rc ? rc : e;
+}
+
+int gather_any(bg_comm* c, const void* local, uint64_t n_local, uint32_t rec_bytes, void* all, uint64_t cap, uint64_t* counts_out,
+               hipStream_t st) {
     const int W = c->world;
     std::vector<uint64_t> counts((size_t)W, 0);
+    int rc;
     if (c->nccl) {
-        Rccl& r = rccl();
-        hipStream_t st = (hipStream_t)stream;
         BG_HIP(hipSetDevice(c->ctx->device));
-        // the counts first (8 bytes per rank), then the records: one all-gather when the shards are equal
-        BG_HIP(hipMemcpyAsync(c->d_counts + W, &n_local, 8, hipMemcpyHostToDevice, st));
-        if (r.all_gather(c->d_counts + W, c->d_counts, 8, ncclUint8, c->nccl, st) != ncclSuccess) return BG_ERR_HIP;
-        BG_HIP(hipMemcpyAsync(counts.data(), c->d_counts, (size_t)W * 8, hipMemcpyDeviceToHost, st));
-        BG_HIP(hipStreamSynchronize(st));
-        bool equal = true;
-        for (int k = 1; k < W; k++) equal = equal && counts[k] == counts[0];
-        if (equal) {
-            if (counts[0] && r.all_gather(local, all, (size_t)counts[0] * rec_bytes, ncclUint8, c->nccl, st) != ncclSuccess) return BG_ERR_HIP;
-        } else {
-            if (r.group_start() != ncclSuccess) return BG_ERR_HIP;
-            uint64_t off = 0;
-            for (int k = 0; k < W; k++) {
-                const size_t bytes = (size_t)counts[k] * rec_bytes;
-                if (bytes && r.broadcast(k == c->rank ? local : nullptr, (uint8_t*)all + off, bytes, ncclUint8, k, c->nccl, st) != ncclSuccess) {
-                    r.group_end();
-                    return BG_ERR_HIP;
-                }
-                off += bytes;
-            }
-            if (r.group_end() != ncclSuccess) return BG_ERR_HIP;
-        }
+        uint64_t min_cap = kNoCap, total = 0;
+        if ((rc = rccl_counts(c, n_local, cap, counts, min_cap, st))) return rc;
+        for (uint64_t k : counts) total += k;
+        if (total > min_cap) return BG_ERR_OPS_CAP;
+        if ((rc = rccl_records(c, local, rec_bytes, all, counts, st))) return rc;
     } else {
         if (!c->ctrl) return BG_ERR_INVALID_ARG;
         if (c->ctx) {
             BG_HIP(hipSetDevice(c->ctx->device));
-            BG_HIP(hipStreamSynchronize((hipStream_t)stream));  // the records are results of work queued there
+            BG_HIP(hipStreamSynchronize(st));  // the records are results of work queued there
         }
-        c->ctrl->n_rec[c->rank] = n_local;
-        int rc = shm_barrier(c);
-        if (rc) return rc;
-        uint64_t total = 0, my_off = 0;
-        for (int k = 0; k < W; k++) {
-            counts[k] = c->ctrl->n_rec[k];
-            if (k < c->rank) my_off += counts[k];
-            total += counts[k];
-        }
-        const size_t bytes = std::max<size_t>((size_t)total * rec_bytes, 16);
-        const std::string dn = c->name + "_d" + std::to_string(c->seq++);
-        int fd = -1;
-        if (c->rank == 0) {
-            shm_unlink(dn.c_str());
-            fd = shm_open(dn.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
-            if (fd < 0 || ftruncate(fd, (off_t)bytes) != 0) return BG_ERR_OOM;
-        }
-        if ((rc = shm_barrier(c))) return rc;  // the data segment exists
-        if (c->rank != 0 && (fd = shm_open(dn.c_str(), O_RDWR, 0600)) < 0) return BG_ERR_HIP;
-        uint8_t* data = (uint8_t*)mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-        close(fd);
-        if (data == MAP_FAILED) return BG_ERR_OOM;
-        rc = copy_any(c->ctx, data + my_off * rec_bytes, local, (size_t)n_local * rec_bytes, hipMemcpyDeviceToHost);
-        const int rc2 = shm_barrier(c);  // every slice is in place
-        if (!rc && !rc2) rc = copy_any(c->ctx, all, data, (size_t)total * rec_bytes, hipMemcpyHostToDevice);
-        const int rc3 = shm_barrier(c);  // everybody has read: the segment can go
-        munmap(data, bytes);
-        if (c->rank == 0) shm_unlink(dn.c_str());
-        if (rc || rc2 || rc3) return rc ? rc : (rc2 ? rc2 : rc3);
+        if ((rc = shm_gather(c, c->ctx, local, n_local, rec_bytes, all, cap, counts))) return rc;
     }
     if (counts_out)
         for (int k = 0; k < W; k++) counts_out[k] = counts[k];
     return BG_OK;
 }
 
+}  // namespace
+
+extern "C" int bg_gather_records(bg_comm* c, const void* local, uint64_t n_local, uint32_t rec_bytes, void* all, uint64_t* counts_out,
+                                 void* stream) {
+    if (!c || !rec_bytes || (n_local && !local) || !all) return BG_ERR_INVALID_ARG;
+    return gather_any(c, local, n_local, rec_bytes, all, kNoCap, counts_out, (hipStream_t)stream);
+}
+
+// The same with the size of `all` stated (records): BG_ERR_OPS_CAP on EVERY rank, before any record moves, when the ranks'
+// records together exceed the smallest `all_cap` any rank passed
+extern "C" int bg_gather_records_cap(bg_comm* c, const void* local, uint64_t n_local, uint32_t rec_bytes, void* all, uint64_t all_cap,
+                                     uint64_t* counts_out, void* stream) {
+    if (!c || !rec_bytes || (n_local && !local) || !all) return BG_ERR_INVALID_ARG;
+    return gather_any(c, local, n_local, rec_bytes, all, all_cap, counts_out, (hipStream_t)stream);
+}
+
 // The same for records that sit in HOST memory (what the host-buffer entry points return: bg_align_batch's bg_alignment_t
 // headers, bg_fm_backward_search_batch's arrays): staged through device scratch for an RCCL communicator (the collective
-// itself runs over xGMI), straight through the shared segment for a host-staged one.  `all_cap`: records `all` can hold.
+// itself runs over xGMI), straight through the shared segment for a host-staged one.  `all_cap`: records `all` can hold —
+// checked against the gathered counts before a single record is written (BG_ERR_OPS_CAP on every rank).
 extern "C" int bg_gather_records_host(bg_comm* c, const void* local, uint64_t n_local, uint32_t rec_bytes, void* all, uint64_t all_cap,
                                       uint64_t* counts_out) {
     if (!c || !rec_bytes || (n_local && !local) || !all) return BG_ERR_INVALID_ARG;
-    if (!c->nccl) {
-        bg_ctx* const keep = c->ctx;
-        c->ctx = nullptr;  // host pointers: plain copies
-        const int rc = bg_gather_records(c, local, n_local, rec_bytes, all, counts_out, nullptr);
-        c->ctx = keep;
-        return rc;
-    }
-    BG_HIP(hipSetDevice(c->ctx->device));
-    hipStream_t st = c->ctx->stream;
-    void *d_loc = nullptr, *d_all = nullptr;
-    BG_HIP(hipMalloc(&d_loc, std::max<size_t>((size_t)n_local * rec_bytes, 16)));
-    if (hipMalloc(&d_all, std::max<size_t>((size_t)all_cap * rec_bytes, 16)) != hipSuccess) {
-        hipFree(d_loc);
-        return BG_ERR_OOM;
-    }
-    std::vector<uint64_t> counts((size_t)c->world, 0);
+    const int W = c->world;
+    std::vector<uint64_t> counts((size_t)W, 0);
     int rc = BG_OK;
-    if (n_local && hipMemcpyAsync(d_loc, local, (size_t)n_local * rec_bytes, hipMemcpyHostToDevice, st) != hipSuccess) rc = BG_ERR_HIP;
-    if (!rc) rc = bg_gather_records(c, d_loc, n_local, rec_bytes, d_all, counts.data(), st);
-    uint64_t total = 0;
-    for (uint64_t k : counts) total += k;
-    if (!rc && total > all_cap) rc = BG_ERR_OPS_CAP;
-    if (!rc && total && hipMemcpyAsync(all, d_all, (size_t)total * rec_bytes, hipMemcpyDeviceToHost, st) != hipSuccess) rc = BG_ERR_HIP;
-    if (hipStreamSynchronize(st) != hipSuccess && !rc) rc = BG_ERR_HIP;
-    hipFree(d_loc);
-    hipFree(d_all);
+    if (!c->nccl) {
+        if (!c->ctrl) return BG_ERR_INVALID_ARG;
+        rc = shm_gather(c, nullptr, local, n_local, rec_bytes, all, all_cap, counts);  // host pointers: plain copies
+    } else {
+        BG_HIP(hipSetDevice(c->ctx->device));
+        hipStream_t st = c->ctx->stream;
+        uint64_t min_cap = kNoCap, total = 0;
+        if ((rc = rccl_counts(c, n_local, all_cap, counts, min_cap, st))) return rc;
+        for (uint64_t k : counts) total += k;
+        if (total > min_cap) return BG_ERR_OPS_CAP;
+        void *d_loc = nullptr, *d_all = nullptr;  // sized from the gathered counts
+        BG_HIP(hipMalloc(&d_loc, std::max<size_t>((size_t)n_local * rec_bytes, 16)));
+        if (hipMalloc(&d_all, std::max<size_t>((size_t)total * rec_bytes, 16)) != hipSuccess) {
+            // (every rank allocates the same amount: they fail or succeed alike on like GPUs; a lone failure leaves the
+            // others in the collective until RCCL's own watchdog ends it)
+            hipFree(d_loc);
+            return BG_ERR_OOM;
+        }
+        if (n_local && hipMemcpyAsync(d_loc, local, (size_t)n_local * rec_bytes, hipMemcpyHostToDevice, st) != hipSuccess) rc = BG_ERR_HIP;
+        const int rc2 = rccl_records(c, d_loc, rec_bytes, d_all, counts, st);  // entered even after a failed upload: the peers are in it
+        if (!rc) rc = rc2;
+        if (!rc && total && hipMemcpyAsync(all, d_all, (size_t)total * rec_bytes, hipMemcpyDeviceToHost, st) != hipSuccess) rc = BG_ERR_HIP;
+        if (hipStreamSynchronize(st) != hipSuccess && !rc) rc = BG_ERR_HIP;
+        hipFree(d_loc);
+        hipFree(d_all);
+    }
     if (!rc && counts_out)
-        for (int k = 0; k < c->world; k++) counts_out[k] = counts[k];
+        for (int k = 0; k < W; k++) counts_out[k] = counts[k];
     return rc;
 }

@@ -24,6 +24,18 @@ def test_rccl_world_of_one_runs_the_collective():
     counts = c.gather_ptr(local.data_ptr(), 5, 28, out.data_ptr())
     torch.cuda.synchronize()
     assert counts.tolist() == [5] and torch.equal(out, local)
+    # an `all` that is too small is refused BEFORE the collective writes (device and host flavours)
+    small = torch.full((2 + 6, 7), -1, dtype=torch.int32, device="cuda:0")
+    cnt = np.zeros(1, dtype=np.uint64)
+    rc = _lib.lib().bg_gather_records_cap(c.h, local.data_ptr(), 5, 28, small.data_ptr(), 2, cnt.ctypes.data, 0)
+    torch.cuda.synchronize()
+    assert rc == -9 and bool((small == -1).all())  # BG_ERR_OPS_CAP, not a byte written
+    hloc = local.cpu().numpy()
+    hsmall = np.full((1 + 6, 7), -1, dtype=np.int32)
+    rc = _lib.lib().bg_gather_records_host(c.h, hloc.ctypes.data, 5, 28, hsmall.ctypes.data, 1, cnt.ctypes.data)
+    assert rc == -9 and (hsmall == -1).all()
+    hall, cnt2 = c.gather_host(hloc, 5)  # ... and with room: staged through device scratch sized from the counts
+    assert cnt2.tolist() == [5] and (hall == hloc).all()
     c.free()
 
 
