@@ -105,6 +105,67 @@ from rust_bio_amd.pairwise import Aligner, Scoring  # noqa: E402
 from rust_bio_amd.suffix_array import suffix_array  # noqa: E402
 
 
+class Gatherer:
+    """The one collective of a sharded step — the all-gather of fixed-size result records — through the PRODUCT's entry
+    point (include/biogpu.h: bg_gather_records_cap, csrc/comm.hip): an RCCL communicator per rank when every rank owns a
+    device (the unique id travels from rank 0 over the torch.distributed store), the host-staged flavour (POSIX shared memory)
+    when several ranks share one GPU (BENCH_SINGLE_GPU=1, the one-GPU test box).  torch.distributed (shard.py) only carries
+    the rendezvous, the barrier and the max-over-ranks of the timing — and stays as the cross-check: `check()` gathers one
+    tensor both ways and compares.  If the communicator cannot be made (no librccl.so), the legs fall back to shard.py and
+    say so in `collective`."""
+
+    def __init__(self, ctx, rank, world, stream):
+        from rust_bio_amd import comm
+        self.rank, self.world, self.stream, self.comm, self.kind = rank, world, stream, None, "none (1 GPU)"
+        self.why = None
+        if world == 1:
+            return
+        import torch.distributed as dist
+        try:
+            if shard.single_gpu_mode():
+                name = "bench%s" % os.environ.get("MASTER_PORT", "0")
+                self.comm = comm.Comm.host(ctx, rank, world, name)
+                self.kind = "bg_gather_records (host-staged)"
+            else:
+                box = [comm.unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(box, src=0)
+                self.comm = comm.Comm.rccl(ctx, rank, world, box[0])
+                self.kind = "bg_gather_records (RCCL: one ncclAllGather per step; grouped ncclBroadcast when shards are ragged)"
+        except Exception as e:  # noqa: BLE001 — reported, not hidden: the line says which collective ran
+            self.comm, self.why = None, repr(e)
+            self.kind = "torch.distributed all_gather (fallback: %s)" % self.why
+        # every rank must have taken the same route
+        ok = torch.tensor([1 if self.comm is not None else 0], dtype=torch.int64)
+        flags = shard.gather_records(ok.view(1, 1).to(torch.device("cuda", torch.cuda.current_device()))).cpu().view(-1).tolist()
+        if self.comm is not None and not all(flags):
+            self.comm.free()
+            self.comm, self.kind = None, "torch.distributed all_gather (fallback: a rank has no communicator)"
+
+    def gather(self, local, counts):
+        """local: contiguous CUDA tensor [n_local, ...]; counts: records of every rank.  All records in rank order."""
+        if self.world == 1:
+            return local
+        if self.comm is None:
+            return shard.gather_records(local, counts=counts)
+        total = int(sum(counts))
+        out = torch.empty((total,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        rec_bytes = local.element_size() * int(np.prod(local.shape[1:], dtype=np.int64))
+        got = self.comm.gather_ptr(local.data_ptr(), int(local.shape[0]), rec_bytes, out.data_ptr(), self.stream, all_cap=total)
+        assert [int(c) for c in got] == [int(c) for c in counts], (got, counts)
+        return out
+
+    def check(self, local, counts):
+        """the same records through torch.distributed: must be identical"""
+        if self.world == 1 or self.comm is None:
+            return None
+        a = self.gather(local, counts)
+        torch.cuda.synchronize()
+        return bool(torch.equal(a, shard.gather_records(local, counts=counts)))
+
+
+GATHER = None
+
+
 def host_cores():
     """cores this process may actually run on (cgroup / affinity aware)"""
     try:
@@ -340,6 +401,8 @@ def main():
     dev = torch.device("cuda", local_rank)
     ctx = _lib.Context(local_rank)
     stream = torch.cuda.current_stream().cuda_stream
+    global GATHER
+    GATHER = Gatherer(ctx, rank, world, stream)
     L = args.read_len
     n_pairs = args.pairs
     do_cpu = rank == 0 and world == 1 and not args.skip_cpu
@@ -361,7 +424,7 @@ def main():
                           L, L, d_out.data_ptr(), d_ops.data_ptr(), stride, stream)
         if world > 1:  # the single collective: scores + coordinates of every pair
             rec = d_out.view(torch.int32).view(n_pairs, 16)[:, :5].contiguous()
-            shard.gather_records(rec, counts=[n_pairs] * world)
+            GATHER.gather(rec, [n_pairs] * world)
 
     sw_t = timed_steps(sw_step, args.steps, args.warmup, dev)
     gcups = world * float(n_pairs) * L * L * args.steps / sw_t / 1e9
@@ -691,7 +754,7 @@ def fm_legs(args, ctx, dev, stream, rank, world, do_cpu, orc, threads, parity, r
         fm.backward_search_dev(n_q, pat.data_ptr(), off.data_ptr(), d_tag.data_ptr(),
                                d_lo.data_ptr(), d_hi.data_ptr(), d_ml.data_ptr(), stream)
         if world > 1:  # the single collective: intervals of every query
-            shard.gather_records(torch.stack((d_lo, d_hi), dim=1), counts=[n_q] * world)
+            GATHER.gather(torch.stack((d_lo, d_hi), dim=1), [n_q] * world)
 
     fm_t = timed_steps(fm_step, args.steps, args.warmup, dev)
     qps = world * float(n_q) * args.steps / fm_t
@@ -739,14 +802,28 @@ def fm_legs(args, ctx, dev, stream, rank, world, do_cpu, orc, threads, parity, r
         fm.backward_search_dev(my, s_pat.data_ptr(), s_off.data_ptr(), d_tag.data_ptr(), d_lo.data_ptr(),
                                d_hi.data_ptr(), d_ml.data_ptr(), stream)
         rec = torch.stack((d_lo[:my], d_hi[:my], d_ml[:my].to(torch.int64) | (d_tag[:my].to(torch.int64) << 32)), dim=1)
-        holder["all"] = shard.gather_records(rec, counts=counts)  # 24-byte records {lower, upper, tag|matched_len}
+        holder["rec"] = rec
+        holder["all"] = GATHER.gather(rec, counts)  # 24-byte records {lower, upper, tag|matched_len}
 
     st_t = timed_steps(fm_strong_step, args.steps, args.warmup, dev)
     fm_res["strong"] = {"value": round(float(n_q) * args.steps / st_t, 1), "unit": "queries/s", "scaling": "strong",
                         "ms_per_step": round(st_t / args.steps * 1e3, 3), "queries_total": n_q, "queries_per_gpu": my,
-                        "collective": "one all-gather of 24-byte records per step (RCCL)" if world > 1 else "none (1 GPU)",
+                        "collective": GATHER.kind, "record_bytes": 24,
                         "gathered_records": int(holder["all"].shape[0])}
+    if world == 1 and n_q >= 8:
+        # an eighth of the queries in one call: what one GPU of eight sees of configs[2] in the strong leg — bounds the 8-GPU
+        # strong-scaling efficiency of this leg from one GPU (launch of 1.25 M queries against the steady rate of 10 M)
+        qe = n_q // 8
+
+        def eighth_step():
+            fm.backward_search_dev(qe, pat.data_ptr(), off.data_ptr(), d_tag.data_ptr(), d_lo.data_ptr(), d_hi.data_ptr(), d_ml.data_ptr(), stream)
+
+        te = timed_steps(eighth_step, args.steps, args.warmup, dev)
+        fm_res["strong"]["eighth_of_the_batch"] = {"queries": qe, "ms": round(te / args.steps * 1e3, 3), "queries_per_s": round(qe * args.steps / te, 1),
+                                                   "frac_of_full_batch_rate": round((qe * args.steps / te) / (float(n_q) * args.steps / st_t), 3)}
+        fm_step()  # the full batch's results back for the checks below
     if world > 1:  # the gathered records of the sharded run must be the unsharded answer
+        fm_res["strong"]["capi_gather_equals_torch_gather"] = GATHER.check(holder["rec"], counts)
         fm.backward_search_dev(n_q, pat_s.data_ptr(), off_s.data_ptr(), d_tag.data_ptr(), d_lo.data_ptr(),
                                d_hi.data_ptr(), d_ml.data_ptr(), stream)
         full = torch.stack((d_lo, d_hi, d_ml.to(torch.int64) | (d_tag.to(torch.int64) << 32)), dim=1)
@@ -816,7 +893,7 @@ def fm_big_leg(args, ctx, dev, stream, rank, world, do_cpu, orc, threads, parity
         fm.backward_search_dev(n_q, pat.data_ptr(), off.data_ptr(), d_tag.data_ptr(), d_lo.data_ptr(), d_hi.data_ptr(),
                                d_ml.data_ptr(), stream)
         if world > 1:
-            shard.gather_records(torch.stack((d_lo, d_hi), dim=1), counts=[n_q] * world)
+            GATHER.gather(torch.stack((d_lo, d_hi), dim=1), [n_q] * world)
 
     t = timed_steps(step, args.steps, args.warmup, dev)
     tm = kernel_timing(ctx, step)
@@ -883,7 +960,7 @@ def seed_extend_leg(args, ctx, dev, stream, rank, world, do_cpu, orc, threads, p
                         stream, tot)
         if world > 1:  # the single collective: score + reference span of every read (24-byte records)
             h64 = d_hits.view(torch.int64).view(Rp, 12)
-            shard.gather_records(torch.stack((h64[:, 0] & 0xFFFFFFFF, h64[:, 9], h64[:, 10]), dim=1), counts=[Rp] * world)
+            GATHER.gather(torch.stack((h64[:, 0] & 0xFFFFFFFF, h64[:, 9], h64[:, 10]), dim=1), [Rp] * world)
 
     pipe_t = timed_steps(pipe_step, args.steps, args.warmup, dev)
     tm = kernel_timing(ctx, pipe_step, reps=1)
@@ -936,16 +1013,18 @@ def seed_extend_leg(args, ctx, dev, stream, rank, world, do_cpu, orc, threads, p
         def strong_step():
             seed_extend_dev(fm, sc, my, s_reads.data_ptr(), s_roff.data_ptr(), L, s_hits.data_ptr(), s_ops.data_ptr(), stride, prm, stream, None)
             h64 = s_hits.view(torch.int64).view(-1, 12)[:my]
-            holder["all"] = shard.gather_records(torch.stack((h64[:, 0] & 0xFFFFFFFF, h64[:, 9], h64[:, 10]), dim=1), counts=counts)
+            holder["rec"] = torch.stack((h64[:, 0] & 0xFFFFFFFF, h64[:, 9], h64[:, 10]), dim=1)
+            holder["all"] = GATHER.gather(holder["rec"], counts)
 
         st_t = timed_steps(strong_step, s_steps, s_warm, dev)
         leg["strong"] = {"value": round(float(Rt) * s_steps / st_t, 1), "unit": "reads/s", "scaling": "strong",
                          "ms_per_step": round(st_t / s_steps * 1e3, 3), "steps": s_steps, "reads_total": Rt, "reads_per_gpu": my,
-                         "collective": "one all-gather of 24-byte records per step (RCCL)" if world > 1 else "none (1 GPU)",
+                         "collective": GATHER.kind, "record_bytes": 24,
                          "gathered_records": int(holder["all"].shape[0]),
                          "note": "records only (score + reference span); the winners' operations stay on the rank that "
                                  "computed them (INTEGRATION.md section 3)"}
         if world > 1:  # the gathered records of the sharded run must be the unsharded answer
+            leg["strong"]["capi_gather_equals_torch_gather"] = GATHER.check(holder["rec"], counts)
             f_roff = torch.arange(Rt + 1, dtype=torch.int64, device=dev) * L
             f_hits = torch.empty(Rt * 96, dtype=torch.uint8, device=dev)
             seed_extend_dev(fm, sc, Rt, g_reads.data_ptr(), f_roff.data_ptr(), L, f_hits.data_ptr(), 0, 0, prm, stream, None)
@@ -1029,7 +1108,7 @@ def banded_leg(args, ctx, dev, rank, world, do_cpu, orc, threads, parity):
     bal.align_dev(2, Pb, bx.data_ptr(), d_boff.data_ptr(), by.data_ptr(), d_boff.data_ptr(), d_bout.data_ptr(),
                   d_bops.data_ptr(), bstride)
     if world > 1:  # the single collective: scores + coordinates of every pair
-        shard.gather_records(d_bout.view(torch.int32).view(Pb, 16)[:, :5].contiguous(), counts=[Pb] * world)
+        GATHER.gather(d_bout.view(torch.int32).view(Pb, 16)[:, :5].contiguous(), [Pb] * world)
     torch.cuda.synchronize()
     bt_dev = shard.max_over_ranks(time.perf_counter() - t0, dev)
     dev_ok = bool((d_bout.view(torch.int32).view(Pb, 16)[:, 0].cpu().numpy() == bout["score"]).all())
@@ -1066,7 +1145,8 @@ def banded_leg(args, ctx, dev, rank, world, do_cpu, orc, threads, parity):
         def strong_step():
             holder["cells"] = bal.align_dev(2, my, sx.data_ptr(), d_boff.data_ptr(), sy.data_ptr(), d_boff.data_ptr(),
                                             d_bout.data_ptr(), d_bops.data_ptr(), bstride, want_cells=True)
-            holder["all"] = shard.gather_records(d_bout.view(torch.int32).view(Pb, 16)[:my, :5].contiguous(), counts=counts)
+            holder["rec"] = d_bout.view(torch.int32).view(Pb, 16)[:my, :5].contiguous()
+            holder["all"] = GATHER.gather(holder["rec"], counts)
 
         strong_step()
         my_cells = torch.tensor([float(holder["cells"].sum())], dtype=torch.float64, device=dev)
@@ -1083,7 +1163,8 @@ def banded_leg(args, ctx, dev, rank, world, do_cpu, orc, threads, parity):
         torch.cuda.synchronize()
         strong = {"value": round(tot_cells / st_t / 1e9, 3), "unit": "GCUPS (band cells)", "scaling": "strong",
                   "pairs_total": Pb, "pairs_per_gpu": my, "pairs_per_s": round(Pb / st_t, 1),
-                  "collective": "one all-gather of 20-byte records per step (RCCL)",
+                  "collective": GATHER.kind, "record_bytes": 20,
+                  "capi_gather_equals_torch_gather": GATHER.check(holder["rec"], counts),
                   "sharded_equals_unsharded": bool((sharded == d_bout.view(torch.int32).view(Pb, 16)[:, :5]).all().item())}
         del gx, gy, sx, sy
     del d_bout, d_bops, bx, by

@@ -188,6 +188,7 @@ extern "C" int bg_band_redo_pairs(bg_ctx* ctx, uint64_t* out) {
     if (!ctx || !out) return BG_ERR_INVALID_ARG;
     *out = 0;
     if (!ctx->band || !ctx->band->d_started) return BG_OK;
+    BG_HIP(hipSetDevice(ctx->device));  // (the caller's current device may be another one: several contexts, torch elsewhere)
     BG_HIP(hipDeviceSynchronize());
     uint32_t v = 0;
     BG_HIP(hipMemcpy(&v, ctx->band->d_started + 1, 4, hipMemcpyDeviceToHost));
@@ -345,7 +346,6 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
     if (sc->matrix) {
         const int A = bg_compact_matrix(sc->matrix, code_map, table);
         sm = A <= kMaxLdsAlphabet ? SCORE_LDS : SCORE_GLOBAL;
-        ctx->table_hash = 0;  // (sw_api.hip keeps its compacted matrix here between calls)
         if ((rc = bg_reserve(&ctx->table, &ctx->table_bytes, 256 + table.size() * 4))) return rc;
         BG_HIP(hipMemcpy((uint8_t*)ctx->table + 256, table.data(), table.size() * 4, hipMemcpyHostToDevice));
         BG_HIP(hipMemcpy(ctx->table, code_map.data(), 256, hipMemcpyHostToDevice));
@@ -473,7 +473,18 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
         return BG_OK;
     };
     if ((rc = need_seq(st, waited_fill, std::min<uint64_t>(n_pairs, chunk_pairs)))) return rc;  // the first slice
-    const uint64_t budget = 40ull << 30;  // traceback + aux per scratch set (two sets, of 288 GB HBM)
+    // traceback + aux per scratch set (two sets): 40 GB each on an otherwise empty 288 GB part — but no more than a third of
+    // what the device has free now plus what the sets already hold (a smaller or shared GPU, a torch caching allocator next
+    // to the engine): a smaller budget cuts the sub-batches (`take < want` below) instead of failing bg_reserve with OOM
+    uint64_t budget = 40ull << 30;
+    {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            uint64_t held = 0;
+            for (auto& s : B.set) held += s.dc_tb + s.dc_aux;
+            budget = std::min<uint64_t>(budget, std::max<uint64_t>(((uint64_t)free_b + held) / 3, 1ull << 30));
+        }
+    }
     const uint64_t grain = std::max<uint64_t>(1, std::min<uint64_t>(64, 65536 / (max_x + max_y + 1)));
     // Two sub-batches are in flight: while K3/K4 of one run, the band of the next one is being built —
     // by band_device.hip on its own stream, or by the host threads.

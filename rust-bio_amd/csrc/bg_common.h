@@ -51,8 +51,13 @@ struct bg_ctx {
     size_t unpk_cap[2] = {};
     void* table = nullptr;  // compacted scoring table + code map
     size_t table_bytes = 0;
-    uint64_t table_hash = 0;  // hash of the score matrix whose compacted form `table` holds (0: none / the banded path's)
-    int table_alpha = 0;      // ... and its number of classes
+    // the full aligner's compacted matrix stays on the device between calls, in a buffer of its own (the banded path
+    // writes `table`); a call recognises its matrix by hash AND by comparing the 256 KB kept on the host
+    void* sw_table = nullptr;
+    size_t sw_table_bytes = 0;
+    uint64_t table_hash = 0;  // hash of the score matrix whose compacted form `sw_table` holds (0: none)
+    int table_alpha = 0;      // ... its number of classes
+    int32_t* table_matrix = nullptr;  // ... and the matrix itself (65 536 entries, host)
     bg_band_scratch* band = nullptr;  // persistent scratch of the banded pipeline
     bg_host_pipe* pipe = nullptr;     // persistent staging of bg_align_batch's pipelined path
     bg_seed_scratch* seed = nullptr;  // persistent scratch of the seed-and-extend pipeline

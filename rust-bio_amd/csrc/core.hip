@@ -146,6 +146,8 @@ extern "C" int bg_free(bg_ctx* ctx) {
     hipFree(ctx->aux);
     hipFree(ctx->bnd);
     hipFree(ctx->table);
+    hipFree(ctx->sw_table);
+    free(ctx->table_matrix);
     hipFree(ctx->unpk[0]);
     hipFree(ctx->unpk[1]);
     for (void* p : ctx->io) hipFree(p);

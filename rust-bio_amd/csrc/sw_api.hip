@@ -263,7 +263,9 @@ static int align_batch_dev_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, u
     if (sc->matrix) {
         // The compacted table stays on the device between calls: a caller aligns batch after batch under one matrix
         // (`Aligner::with_scoring` once, `local()` per pair), and compacting 65 536 entries, two copies and a
-        // synchronisation per call were 3 ms next to a 31 ms step.  Recognised by a hash of the 256 KB.
+        // synchronisation per call were 3 ms next to a 31 ms step.  Recognised by a hash of the 256 KB, confirmed by comparing
+        // the matrix with the copy kept on the host (a 64-bit non-cryptographic hash alone could, once in 2^64 calls, align
+        // under the wrong matrix); the device copy has a buffer of its own that no other path writes.
         uint64_t h = 0xcbf29ce484222325ull;
         {
             const uint64_t* w = (const uint64_t*)sc->matrix;
@@ -276,24 +278,26 @@ static int align_batch_dev_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, u
             h ^= h2;
             if (h == 0) h = 1;
         }
-        if (ctx->table_hash != h) {
+        if (ctx->table_hash != h || !ctx->table_matrix || memcmp(ctx->table_matrix, sc->matrix, 65536 * sizeof(int32_t)) != 0) {
             std::vector<uint8_t> code_map;
             std::vector<int32_t> table;
             const int A = compact_matrix(sc->matrix, code_map, table);
             const size_t bytes = 256 + table.size() * 4;
             ctx->table_hash = 0;
-            if ((rc = bg_reserve(&ctx->table, &ctx->table_bytes, bytes))) return rc;
-            BG_HIP(hipMemcpyAsync((uint8_t*)ctx->table + 256, table.data(), table.size() * 4,
+            if (!ctx->table_matrix && !(ctx->table_matrix = (int32_t*)malloc(65536 * sizeof(int32_t)))) return BG_ERR_OOM;
+            if ((rc = bg_reserve(&ctx->sw_table, &ctx->sw_table_bytes, bytes))) return rc;
+            BG_HIP(hipMemcpyAsync((uint8_t*)ctx->sw_table + 256, table.data(), table.size() * 4,
                                   hipMemcpyHostToDevice, st));
-            BG_HIP(hipMemcpyAsync(ctx->table, code_map.data(), 256, hipMemcpyHostToDevice, st));
+            BG_HIP(hipMemcpyAsync(ctx->sw_table, code_map.data(), 256, hipMemcpyHostToDevice, st));
             BG_HIP(hipStreamSynchronize(st));  // the host vectors go out of scope
+            memcpy(ctx->table_matrix, sc->matrix, 65536 * sizeof(int32_t));
             ctx->table_hash = h;
             ctx->table_alpha = A;
         }
         const int A = ctx->table_alpha;
         sm = A <= kMaxLdsAlphabet ? SCORE_LDS : SCORE_GLOBAL;
-        a.code_map = (const uint8_t*)ctx->table;
-        a.table = (const int32_t*)((uint8_t*)ctx->table + 256);
+        a.code_map = (const uint8_t*)ctx->sw_table;
+        a.table = (const int32_t*)((uint8_t*)ctx->sw_table + 256);
         a.alpha = A;
     }
 

@@ -408,3 +408,37 @@ def test_two_streams_one_ctx_do_not_share_scratch_in_flight():
         oout, _, _ = orc.align_batch(orc.make_scoring(-5, -1, 1, -1), "local", x, xo, y, yo, threads=8, want_ops=False)
         for f in ("score", "xstart", "xend", "ystart", "yend", "n_ops"):
             assert (rec[f].astype(np.int64) == oout[f].astype(np.int64)).all(), f
+
+
+def test_cached_matrix_is_invalidated_across_alternating_matrices_and_banded_calls():
+    """the compacted matrix stays on the device between calls (own buffer, recognised by hash + a comparison with
+    the host copy).  One ctx: matrix A, a banded call under matrix B (the banded path has its own table), matrix A again,
+    then B and A back to back — every call must align under ITS matrix."""
+    from rust_bio_amd.banded import Aligner as BAligner
+    rng = np.random.default_rng(11)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    xs = [acgt[rng.integers(0, 4, size=int(rng.integers(20, 90)))].tobytes() for _ in range(96)]
+    ys = [acgt[rng.integers(0, 4, size=int(rng.integers(20, 90)))].tobytes() for _ in range(96)]
+    fa = MatchParams(2, -3)
+    fb = lambda a, b: (5 if a == b else (-1 if {a, b} in ({65, 71}, {67, 84}) else -4))  # transitions cheaper: different scores
+    clips = dict(xclip_prefix=MIN_SCORE, xclip_suffix=MIN_SCORE, yclip_prefix=MIN_SCORE, yclip_suffix=MIN_SCORE)
+    ctx = _lib.Context(0)
+    x, xo = _lib.concat(xs)
+    y, yo = _lib.concat(ys)
+
+    def run(fn):
+        kw = dict(gap_open=-5, gap_extend=-1, matrix=fn, **clips)
+        al = Aligner.with_scoring(engine_scoring(kw), ctx=ctx)
+        out, _ = al.align_arrays(MODES["local"], x, xo, y, yo)
+        oout, _, _ = orc.align_batch(orc.make_scoring(**kw), "local", x, xo, y, yo, threads=4)
+        assert (out["score"] == oout["score"]).all(), fn
+        return out["score"].copy()
+
+    sa = run(fa.score if hasattr(fa, "score") else fa)
+    bal = BAligner.with_scoring(engine_scoring(dict(gap_open=-5, gap_extend=-1, matrix=fb, **clips)), 6, 8, ctx=ctx)
+    bal.align_arrays(MODES["local"], x, xo, y, yo)
+    assert (run(fa.score if hasattr(fa, "score") else fa) == sa).all()
+    sb = run(fb)
+    assert (sb != sa).any()
+    assert (run(fa.score if hasattr(fa, "score") else fa) == sa).all()
+    assert (run(fb) == sb).all()

@@ -141,3 +141,8 @@ def test_bench_launches_its_own_ranks():
     bs, ss = d["banded"]["strong"], d["seed_extend"]["strong"]
     assert bs["pairs_total"] == 97 and bs["pairs_per_gpu"] == 48 and bs["sharded_equals_unsharded"] is True
     assert ss["reads_total"] == 5001 and ss["gathered_records"] == 5001 and ss["sharded_equals_unsharded"] is True
+    # the collective of every strong leg is the PRODUCT's (bg_gather_records behind the C ABI; host-staged here: two ranks
+    # share the one GPU), cross-checked against torch.distributed's gather of the same records — equal and ragged shards
+    for leg in (d["fm"]["strong"], bs, ss):
+        assert leg["collective"] == "bg_gather_records (host-staged)", leg["collective"]
+        assert leg["capi_gather_equals_torch_gather"] is True
