@@ -36,6 +36,7 @@ struct BandDevArgs {
     uint32_t table_size, table_bits, cap_matches;
     uint32_t chain_min, chain_cap;
     int32_t join_global;   // 1: kmer_match_kernel (table in global memory) even where kmer_match_lds_kernel applies
+    int32_t chain_rows;    // 1: the global-tree event loop runs four pairs per wavefront (chain_rows_kernel); 0: one (chain_kernel<false, 2>)
     int32_t chain_global;  // 1 / 0: force the global / LDS tree variant of chain_kernel, -1: by batch size  // chain_kernel: the range of match counts this launch handles
     // scratch, one slice per pair
     uint32_t* head;   // [table_size]

@@ -581,6 +581,201 @@ __global__ __launch_bounds__(64) void chain_kernel(const BandDevArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------- B2, four pairs per wavefront
+// chain_rows_kernel: the event loop + path of chain_kernel<false, 2> with ONE PAIR PER DPP ROW OF 16 LANES (round 5).
+// The loop above is one dependent memory round trip per event, ~3 600 events per 10 kb pair, and of its 64 lanes thirteen
+// touch the tree; its throughput is the number of pairs in flight.  Next to a K3p fill (2 x 188 VGPRs per SIMD) a wavefront
+// slot is what is scarce: four pairs per wavefront put the 16 384 pairs of a sub-batch in flight at once instead of a
+// third of them (the chaining was the longest kernel of the builder's chain, and the builder's chain the cycle of the
+// pipeline: profiles/r04_banded_timeline_k3p.txt).  Same events in the same order per pair, same tree operations, same
+// tie-breaking — only where a pair's lanes sit changes:
+//   * lanes 0..12 of a row read / raise the Fenwick nodes (row_max is a DPP row operation already), lane 15 — where the
+//     row_shr maximum lands — is the row's scalar lane: it computes the start event's score, stores score / back and keeps
+//     the running best;
+//   * the current start / end records come out of 16-record windows (one record per lane of the row) with ds_bpermute
+//     instead of a wave-uniform readlane; a window is reloaded every 16 events of its kind;
+//   * the four rows take different branches at one step: both event bodies are predicated (exec-masked per row), each is
+//     skipped when no row wants it.
+// Per-pair arrays are addressed as 32-bit element offsets from the kernel arguments (scalar bases): 31 VGPRs.
+__device__ __forceinline__ uint32_t row_pick(uint32_t v, uint32_t idx) {  // lane (row, idx & 15) of v, per row
+    return (uint32_t)__builtin_amdgcn_ds_bpermute((int)((((uint32_t)threadIdx.x & 48u) | (idx & 15u)) << 2), (int)v);
+}
+
+__global__ __launch_bounds__(64) void chain_rows_kernel(const BandDevArgs a) {
+    __builtin_amdgcn_s_setprio(3);  // (see chain_kernel)
+    const uint32_t lane = threadIdx.x, rl = lane & 15u;
+    const uint32_t pair = blockIdx.x * 4u + (lane >> 4);
+    uint32_t nm = 0;
+    if (pair < a.n_pairs) {
+        const BandDevPair* st = a.state + pair;
+        if (st->flags == BP_OK) {
+            nm = st->n_matches;
+            if (nm == 0 && rl == 0) a.state[pair].n_path = 0;
+            if (nm < a.chain_min || nm > a.chain_cap) nm = 0;  // another launch (LDS size class) owns this pair
+        }
+    }
+    if (__builtin_amdgcn_ballot_w64(nm != 0) == 0) return;
+    const uint32_t eb = pair * a.cap_matches;         // element offset of this pair's slices (nm == 0: never dereferenced)
+    const uint32_t tb = pair * (a.cap_matches + 1u);  // ... of its tree
+    const uint32_t* const g_mx = a.mx;
+    const uint32_t* const g_my = a.my;
+    const uint32_t* const g_qpos = a.qpos;
+    const uint32_t* const g_upos = a.upos;
+    const int32_t* const g_cont = a.cont;
+    Frag* const g_tree = (Frag*)a.g_tree;
+    uint32_t* const g_score = a.g_score;
+    int16_t* const g_back = a.g_back;
+    const uint32_t k = a.k, ms = a.match_score;
+    const uint32_t go = (uint32_t)(-(int64_t)a.gap_open), ge = (uint32_t)(-(int64_t)a.gap_extend);
+    uint32_t best_score = k;  // (k, 0): sparse.rs:234 — kept by the row's lane 15
+    int32_t best_idx = 0;
+    auto better = [](uint32_t s1, int32_t i1, uint32_t s2, int32_t i2) { return s1 > s2 || (s1 == s2 && i1 > i2); };
+    uint32_t s = 0, e = 0;
+    uint32_t ws_x = 0, ws_y = 0, ws_q = 0, we_x = 0, we_y = 0, we_u = 0;
+    int32_t we_c = -1;
+    auto load_s = [&](uint32_t base) {  // (callers are predicated per row)
+        const uint32_t i = base + rl;
+        if (i < nm) {
+            ws_x = g_mx[eb + i];
+            ws_y = g_my[eb + i];
+            ws_q = g_qpos[eb + i];
+        }
+    };
+    auto load_e = [&](uint32_t base) {
+        const uint32_t i = base + rl;
+        if (i < nm) {
+            we_x = g_mx[eb + i] + k;
+            we_y = g_my[eb + i] + k;
+            we_u = g_upos[eb + i];
+            we_c = g_cont[eb + i];
+        }
+    };
+    // maximum of the 128-bit keys of a row's lanes 0..15 in its lane 15 (four row_shr steps; the other lanes hold prefixes)
+    auto row_max15 = [&](Frag v) -> Frag {
+#define BG_SHR(x, ctl) (uint32_t) __builtin_amdgcn_update_dpp(0, (int)(x), ctl, 0xf, 0xf, true)
+        uint32_t h1 = (uint32_t)(v.hi >> 32), h0 = (uint32_t)v.hi, l1 = (uint32_t)(v.lo >> 32), l0 = (uint32_t)v.lo;
+#define BG_STEP(ctl)                                                                                       \
+        {                                                                                                      \
+            const uint32_t q1 = BG_SHR(h1, ctl), q0 = BG_SHR(h0, ctl), r1 = BG_SHR(l1, ctl), r0 = BG_SHR(l0, ctl); \
+            const uint64_t qh = (uint64_t)q1 << 32 | q0, ql = (uint64_t)r1 << 32 | r0;                         \
+            const uint64_t vh = (uint64_t)h1 << 32 | h0, vl = (uint64_t)l1 << 32 | l0;                         \
+            if (vh < qh || (vh == qh && vl < ql)) {                                                            \
+                h1 = q1;                                                                                       \
+                h0 = q0;                                                                                       \
+                l1 = r1;                                                                                       \
+                l0 = r0;                                                                                       \
+            }                                                                                                  \
+        }
+        BG_STEP(0x111) BG_STEP(0x112) BG_STEP(0x114) BG_STEP(0x118)
+#undef BG_STEP
+#undef BG_SHR
+        return Frag{(uint64_t)h1 << 32 | h0, (uint64_t)l1 << 32 | l0};
+    };
+    load_s(0);
+    load_e(0);
+    while (__builtin_amdgcn_ballot_w64(e < nm) != 0) {
+        const bool on = e < nm;
+        // Events in (x, y, tag) order: ends before starts at equal coordinates; both lists are sorted: a merge of two cursors
+        const uint32_t ex = row_pick(we_x, e), ey = row_pick(we_y, e);
+        const uint32_t sx = row_pick(ws_x, s), sy = row_pick(ws_y, s);
+        const bool take_start = on && s < nm && (sx < ex || (sx == ex && sy < ey));
+        const bool take_end = on && !take_start;
+        if (__builtin_amdgcn_ballot_w64(take_start) != 0) {
+            // prefix maximum over tree[1 .. pos]: one node per set bit b of pos (pos with the bits below b cleared); lane b reads it
+            const uint32_t i = row_pick(ws_q, s);
+            Frag bp{0, 0};
+            if (take_start && rl < 13 && ((i >> rl) & 1u)) bp = g_tree[tb + (i & ~((1u << rl) - 1u))];
+            bp = row_max15(bp);  // (DPP moves run for every row; rows that are not at a start event carry zeros)
+            if (take_start && rl == 15) {
+                const uint32_t p = s;
+                uint32_t sc = k * ms;
+                int32_t bk = -1;
+                const uint32_t bscore = (uint32_t)bp.hi;
+                if (bscore > 0) {
+                    const uint32_t bid = ((uint32_t)bp.lo >> 20) & 0xFFFu, d = (uint32_t)(bp.lo >> 32);
+                    const uint32_t bx = (uint32_t)bp.lo & 0xFFFFFu, by = d - bx;
+                    const uint32_t gap = max(sx - bx, sy - by);
+                    const uint32_t pen = gap > 0 ? go + gap * ge : 0;
+                    const uint32_t sum = bscore + k * ms;
+                    const uint32_t ns = sum > pen ? sum - pen : 0;
+                    if (better(ns, (int32_t)bid, sc, bk)) {
+                        sc = ns;
+                        bk = (int32_t)bid;
+                    }
+                    if (better(sc, (int32_t)p, best_score, best_idx)) {
+                        best_score = sc;
+                        best_idx = (int32_t)p;
+                    }
+                }
+                g_score[eb + p] = sc;
+                g_back[eb + p] = (int16_t)bk;
+            }
+            if (take_start) {
+                s++;
+                if ((s & 15u) == 0) load_s(s);
+            }
+        }
+        if (__builtin_amdgcn_ballot_w64(take_end) != 0) {
+            const int32_t c = (int32_t)row_pick((uint32_t)we_c, e);
+            const uint32_t i = row_pick(we_u, e);
+            if (take_end) {
+                const uint32_t p = e;
+                uint32_t sc = g_score[eb + p];  // (every lane of the row reads the same words: one request)
+                int32_t bk = g_back[eb + p];
+                if (c >= 0) {
+                    const uint32_t cs = g_score[eb + (uint32_t)c] + ms;
+                    if (better(cs, c, sc, bk)) {
+                        sc = cs;
+                        bk = c;
+                    }
+                    if (rl == 15) {
+                        if (better(sc, (int32_t)p, best_score, best_idx)) {
+                            best_score = sc;
+                            best_idx = (int32_t)p;
+                        }
+                        g_score[eb + p] = sc;
+                        g_back[eb + p] = (int16_t)bk;
+                    }
+                }
+                const uint32_t d = ex + ey;
+                Frag f;
+                f.hi = (uint64_t)(uint32_t)(sc + d * ge) << 32 | sc;
+                f.lo = (uint64_t)d << 32 | (uint64_t)p << 20 | ex;
+                // raise tree[pos], tree[pos + lowbit(pos)], ...: lane b takes the round-up of pos to a multiple of 2^b if it
+                // differs from the one for b - 1
+                if (rl < 13) {
+                    const uint32_t cb = ((i - 1) | ((1u << rl) - 1u)) + 1u;
+                    const uint32_t cp = rl ? ((i - 1) | ((1u << (rl - 1)) - 1u)) + 1u : 0u;
+                    if (cb != cp && cb <= nm && frag_less(g_tree[tb + cb], f)) g_tree[tb + cb] = f;
+                }
+                e++;
+                if ((e & 15u) == 0) load_e(e);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();  // one wavefront, its memory operations stay in order: only keep the order
+    }
+    // the chain, last element first (the row's lane 15 walks it), then reversed in place by the row
+    uint32_t len = 0;
+    if (nm != 0 && rl == 15) {
+        uint32_t* const path = a.path + eb;
+        for (int32_t q = best_idx; q >= 0; q = g_back[eb + (uint32_t)q]) path[len++] = (uint32_t)q;
+        a.state[pair].n_path = len;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    len = row_pick(len, 15);
+    if (nm != 0) {
+        uint32_t* const path = a.path + eb;
+        for (uint32_t t = rl; t < len / 2; t += 16) {
+            const uint32_t u = path[t];
+            path[t] = path[len - 1 - t];
+            path[len - 1 - t] = u;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------- B3
 // One tile of the per-column ranges in LDS: columns [j0, j0 + kBandTile) — 2048 columns, 16 KB: measured per 16 384
 // 10 kb pairs 12.2 ms with 8192 columns (two blocks per CU), 7.6 ms with 4096, 7.4 ms with 2048 (the path is walked once
@@ -1026,7 +1221,13 @@ int launch_band_chain(const BandDevArgs& a, hipStream_t st, int part) {
     if (a.chain_global > 0 || (a.chain_global < 0 && a.n_pairs >= kChainGlobalMinPairs)) {
         // enough pairs to hide memory latency with occupancy: tree in global scratch, 16 KB of LDS per pair
         if (part != 2) chain_kernel<false, 1><<<dim3(a.n_pairs), dim3(64), 4 * (size_t)(kMaxChainMatches + 1), st>>>(c);
-        if (part != 1) chain_kernel<false, 2><<<dim3(a.n_pairs), dim3(64), 0, st>>>(c);
+        if (part != 1) {
+            // rows: four pairs per wavefront (chain_rows_kernel); 0: one pair per wavefront (round 2 .. 4, kept for A/B and tests)
+            if (a.chain_rows)
+                chain_rows_kernel<<<dim3((a.n_pairs + 3) / 4), dim3(64), 0, st>>>(c);
+            else
+                chain_kernel<false, 2><<<dim3(a.n_pairs), dim3(64), 0, st>>>(c);
+        }
     } else if (part != 1) {
         static bool attr_set = false;
         if (!attr_set) {

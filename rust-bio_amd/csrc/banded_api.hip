@@ -589,6 +589,7 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
         d.table_size = 1u << d.table_bits;
         d.cap_matches = kMaxChainMatches + 1;
         d.chain_global = ctx->band_chain_global;
+        d.chain_rows = ctx->band_chain_rows ? 1 : 0;
         d.join_global = ctx->band_join_global ? 1 : 0;
         const size_t need[17] = {(size_t)want * d.table_size * 4, (size_t)want * d.max_n * 4, (size_t)want * d.max_n * 8,
                                  (size_t)64 /* (unused) */, (size_t)want * d.cap_matches * 4,

@@ -199,6 +199,10 @@ extern "C" int bg_set_option(bg_ctx* ctx, const char* key, int64_t value) {
         ctx->band_join_global = value != 0;
         return BG_OK;
     }
+    if (!strcmp(key, "band_chain_rows")) {
+        ctx->band_chain_rows = value != 0;
+        return BG_OK;
+    }
     if (!strcmp(key, "band_chain_global")) {
         ctx->band_chain_global = (int)value;
         return BG_OK;

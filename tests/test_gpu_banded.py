@@ -268,8 +268,11 @@ def test_device_band_builder_equals_host_builder():
             except Exception as e:  # noqa: BLE001 - statuses are compared below
                 out_h, ops_h, cells_h = al.last_out.copy(), al.last_ops.copy(), al.last_cells.copy()
             al.ctx.set_option("band_on_host", 0)
-            for chain_global, join_global in ((0, 0), (1, 0), (1, 1)):  # both placements of the chaining kernel's tree, both k-mer joins
+            # both placements of the chaining kernel's tree (the global one with four pairs per wavefront — chain_rows_kernel,
+            # 96 pairs of ragged match counts: rows that finish early, a last block with live rows only — and with one), both k-mer joins
+            for chain_global, join_global, chain_rows in ((0, 0, 1), (1, 0, 1), (1, 0, 0), (1, 1, 1)):
                 al.ctx.set_option("band_chain_global", chain_global)
+                al.ctx.set_option("band_chain_rows", chain_rows)
                 al.ctx.set_option("band_join_global", join_global)
                 try:
                     out_d, ops_d = al.align_arrays(mode, x, xo, y, yo)
@@ -282,6 +285,7 @@ def test_device_band_builder_equals_host_builder():
                     if out_h["status"][p] == 0:
                         assert decode_ops(out_d[p], ops_d) == decode_ops(out_h[p], ops_h), (mode, k, w, p, chain_global)
             al.ctx.set_option("band_chain_global", -1)
+            al.ctx.set_option("band_chain_rows", 1)
             al.ctx.set_option("band_join_global", 0)
 
 
@@ -296,14 +300,18 @@ def test_device_band_builder_large_batch_10kb():
     out_h, ops_h = al.align_arrays(2, x, off, y, off)
     cells_h = al.last_cells.copy()
     al.ctx.set_option("band_on_host", 0)
-    for join_global in (0, 1):  # k-mer join in LDS (what a 10 kb batch gets) and with its table in global memory
+    # k-mer join in LDS (what a 10 kb batch gets) and with its table in global memory; the chaining's event loop with four
+    # pairs per wavefront (the default) and with one
+    for join_global, chain_rows in ((0, 1), (1, 1), (0, 0)):
         al.ctx.set_option("band_join_global", join_global)
+        al.ctx.set_option("band_chain_rows", chain_rows)
         out_d, ops_d = al.align_arrays(2, x, off, y, off)
-        assert (al.last_cells == cells_h).all(), join_global
+        assert (al.last_cells == cells_h).all(), (join_global, chain_rows)
         for f in ("score", "xstart", "xend", "ystart", "yend", "n_ops", "status", "ops_off"):
-            assert (out_d[f] == out_h[f]).all(), (f, join_global)
-        assert (ops_d[:int(out_d["n_ops"].sum())] == ops_h[:int(out_h["n_ops"].sum())]).all(), join_global
+            assert (out_d[f] == out_h[f]).all(), (f, join_global, chain_rows)
+        assert (ops_d[:int(out_d["n_ops"].sum())] == ops_h[:int(out_h["n_ops"].sum())]).all(), (join_global, chain_rows)
     al.ctx.set_option("band_join_global", 0)
+    al.ctx.set_option("band_chain_rows", 1)
 
 
 def test_fill_kernel_variants_agree():

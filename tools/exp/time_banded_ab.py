@@ -1,4 +1,5 @@
 """A/B of a banded ctx option on the device-resident path: python tools/exp/time_banded_ab.py <pairs> <option> [<option> ...]
+An option may be written name=value:restore (e.g. band_chain_rows=0:1 for an option that defaults to 1).
 Every option is timed at 0 and at 1 (wall of a call, event-timed fill and traceback) and the records of the two runs are compared."""
 import os, sys, time
 R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -37,9 +38,13 @@ def measure(tag):
 base = measure("default")
 print("   redo pairs:", ctx.band_redo_pairs(), flush=True)
 for o in opts:
-    ctx.set_option(o, 1)
-    got = measure(o + "=1")
+    name, val, back = o, 1, 0
+    if "=" in o:
+        name, rest = o.split("=")
+        val, back = (int(v) for v in rest.split(":"))
+    ctx.set_option(name, val)
+    got = measure("%s=%d" % (name, val))
     print("   redo pairs:", ctx.band_redo_pairs(), flush=True)
-    ctx.set_option(o, 0)
+    ctx.set_option(name, back)
     rec_a, rec_b = base[0].view(torch.int32).view(Pb, 16), got[0].view(torch.int32).view(Pb, 16)
     print("   records equal:", bool((rec_a == rec_b).all().item()), " ops equal:", bool((base[1] == got[1]).all().item()), flush=True)
