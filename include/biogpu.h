@@ -34,9 +34,17 @@
  * Operation lists are variable-length and ops_off indexes the buffer of the process that made them: they stay where
  * they are unless the caller gathers byte counts (ops_used) and bytes itself and re-bases ops_off.
  *
- * Limits that rust-bio does not have (it indexes with usize): an FM index, its suffix arrays and `less` hold uint32
- * positions — texts of 2^32 - 1 symbols or more are refused with BG_ERR_TOO_LARGE (a 3.1 Gbp genome fits; the same
- * genome followed by its reverse complement does not); a sequence of an aligner call may have up to 2^24 symbols.
+ * Text positions are 64-bit at the boundary, like the reference's usize (fmindex.rs:70-71, bwt.rs:94, suffix_array.rs:
+ * 264).  Inside, an index below 2^32 - 1 symbols keeps the uint32 layout of rounds 1-4 (and its speed); from 2^32 - 1
+ * symbols on — T$R$ of a human genome for an FMD index is 6.2 G — bg_fm_build / bg_fm_build_dev lay the SAME rank blocks
+ * out with superblock-relative counters and 64-bit bases (csrc/fm_wide.hip) and bg_fm_backward_search_batch[_dev],
+ * bg_fm_set_[sampled_]suffix_array, bg_sa_get_batch[_dev] and bg_interval_occ_batch[_dev] work on them unchanged;
+ * bg_suffix_array_dev64 / bg_bwt_dev64 / bg_sa_sample_dev64 build the 64-bit suffix array in HBM.  BG_ERR_TOO_LARGE only
+ * beyond 2^40 symbols.  What a 64-bit index does NOT offer (BG_ERR_UNSUPPORTED): the 2-bit packed pattern entry points
+ * and bg_fm_pattern_codes (the byte entry points answer the same queries), bg_fm_set_text / seed-and-extend, the FMD
+ * kernels (their interval records are uint32 in this ABI), and BWTs with more than 1024 positions outside their four most
+ * frequent bytes (protein texts: they would need rank bit vectors with 64-bit bases).
+ * A sequence of an aligner call may have up to 2^24 symbols.
  */
 #ifndef BIOGPU_H
 #define BIOGPU_H
@@ -55,7 +63,7 @@ typedef enum {
     BG_ERR_SENTINEL = -5,        /* suffix_array.rs:431-437 assert: last byte must be the smallest */
     BG_ERR_POSITIVE_PENALTY = -6,/* pairwise/mod.rs:265-266,292-293,554-571 asserts */
     BG_ERR_OUT_OF_ALPHABET = -7, /* fmindex.rs:229 / bwt.rs:114,158 index-out-of-bounds panics */
-    BG_ERR_TOO_LARGE = -8,       /* text >= 2^32-1 symbols or sequence too long for the engine */
+    BG_ERR_TOO_LARGE = -8,       /* text > 2^40 symbols (>= 2^32 - 1 for the uint32 suffix-array flavours), or sequence too long for the engine */
     BG_ERR_OPS_CAP = -9,         /* caller's ops buffer too small (ops_used reports the need) */
     BG_ERR_TRACEBACK = -10,      /* traceback did not terminate (reference would loop forever) */
     BG_ERR_UNSUPPORTED = -11     /* legal for rust-bio, not yet covered by the device layout */
@@ -116,14 +124,20 @@ int bg_less(const uint8_t* bwt, uint64_t n, const uint8_t* alphabet, uint32_t n_
  * ceil(n / rate) entries, extra rows come back sorted, *n_extra says how many; BG_ERR_OPS_CAP beyond extra_cap).
  * The results equal the host functions' (the suffix array of the transformed text is unique), also for texts whose
  * sentinel byte occurs several times — several sequences, or T$R$ for an FMD index (fmindex.rs:312-340): the sentinels
- * rank by position, the last occurrence smallest (transform_text, suffix_array.rs:444-466).  Texts are limited to
- * 2^32 - 2 symbols (BG_ERR_TOO_LARGE; the reference indexes with usize).  About 29 bytes of device scratch per symbol;
- * synchronous. */
+ * rank by position, the last occurrence smallest (transform_text, suffix_array.rs:444-466).  The uint32 flavours take
+ * texts up to 2^32 - 2 symbols (BG_ERR_TOO_LARGE beyond) with about 29 bytes of device scratch per symbol; the *64
+ * flavours are the same algorithm on uint64 positions (suffix_array.rs:264: usize) for texts up to 2^40 symbols, 49 bytes
+ * of scratch per symbol (a 4.4 G-symbol text: 216 GB next to its 35 GB suffix array on the 288 GB part).  Synchronous. */
 int bg_suffix_array_dev(bg_ctx* ctx, const uint8_t* d_text, uint64_t n, uint32_t* d_sa, void* stream);
 int bg_bwt_dev(bg_ctx* ctx, const uint8_t* d_text, const uint32_t* d_sa, uint64_t n, uint8_t* d_bwt, void* stream);
 int bg_sa_sample_dev(bg_ctx* ctx, const uint32_t* d_sa, const uint8_t* d_bwt, uint64_t n, uint32_t sampling_rate,
                      uint8_t sentinel, uint64_t* sample, uint64_t* extra_rows, uint64_t* extra_pos, uint64_t extra_cap,
                      uint64_t* n_extra, void* stream);
+int bg_suffix_array_dev64(bg_ctx* ctx, const uint8_t* d_text, uint64_t n, uint64_t* d_sa, void* stream);
+int bg_bwt_dev64(bg_ctx* ctx, const uint8_t* d_text, const uint64_t* d_sa, uint64_t n, uint8_t* d_bwt, void* stream);
+int bg_sa_sample_dev64(bg_ctx* ctx, const uint64_t* d_sa, const uint8_t* d_bwt, uint64_t n, uint32_t sampling_rate,
+                       uint8_t sentinel, uint64_t* sample, uint64_t* extra_rows, uint64_t* extra_pos, uint64_t extra_cap,
+                       uint64_t* n_extra, void* stream);
 
 /* ------------------------------------------------------------------ FM index
  * bg_fm_build replaces `Occ::new(&bwt, k, &alphabet)` + `FMIndex::new(bwt, less, occ)`

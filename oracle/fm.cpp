@@ -520,3 +520,75 @@ extern "C" int orc_fmd_interval(const uint8_t* bwt, uint64_t n, const uint64_t* 
         return -1;
     }
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Interval of a pattern BY DEFINITION, without a suffix array (test infrastructure for texts the restatement above cannot
+// sort in test time: the 4.4 G-symbol run of tools/exp/fm_wide_big.py).  The interval backward_search returns for a pattern
+// that occurs — Interval { lower, upper } over the suffix array, fmindex.rs:63-79, 100-102, 144-208 — is the range of
+// suffixes that start with it; in a suffix array sorted like suffix_array.rs:264-284 sorts (plain byte order; the text
+// ends in a unique smallest sentinel) that is
+//      lower = #{ i : text[i..] < P },   upper = lower + #{ i : P is a prefix of text[i..] }
+// and the positions Interval::occ yields are those i.  One pass over the text for a batch of patterns, `threads` slices;
+// pos_out[p * pos_cap ..] receives up to pos_cap occurrence positions of pattern p, ascending.
+// Pinned: tests/test_oracle_fm.py compares it with orc_backward_search + orc_suffix_array on small texts.
+extern "C" void orc_intervals_by_scan(const uint8_t* text, uint64_t n, uint64_t n_pat, const uint8_t* pat, const uint64_t* pat_off,
+                                      uint64_t* lower, uint64_t* upper, uint64_t* pos_out, uint64_t pos_cap, uint64_t* n_pos,
+                                      int threads) {
+    if (threads < 1) threads = 1;
+    struct Part {
+        std::vector<uint64_t> less, pref;
+        std::vector<std::vector<uint64_t>> pos;
+        uint64_t hist[256];
+    };
+    std::vector<Part> parts(threads);
+    std::vector<std::vector<uint32_t>> bucket(256);  // patterns by first byte
+    for (uint64_t p = 0; p < n_pat; p++)
+        if (pat_off[p + 1] > pat_off[p]) bucket[pat[pat_off[p]]].push_back((uint32_t)p);
+    auto work = [&](int t) {
+        Part& P = parts[t];
+        P.less.assign(n_pat, 0);
+        P.pref.assign(n_pat, 0);
+        P.pos.assign(n_pat, {});
+        std::fill(P.hist, P.hist + 256, 0);
+        const uint64_t lo = n * (uint64_t)t / (uint64_t)threads, hi = n * (uint64_t)(t + 1) / (uint64_t)threads;
+        for (uint64_t i = lo; i < hi; i++) {
+            const uint8_t c = text[i];
+            P.hist[c]++;
+            for (uint32_t p : bucket[c]) {  // first bytes agree: compare on
+                const uint8_t* q = pat + pat_off[p];
+                const uint64_t m = pat_off[p + 1] - pat_off[p];
+                uint64_t k = 1;
+                while (k < m && i + k < n && text[i + k] == q[k]) k++;
+                if (k == m) {
+                    P.pref[p]++;
+                    if (P.pos[p].size() < pos_cap) P.pos[p].push_back(i);
+                } else if (i + k >= n || text[i + k] < q[k]) {  // the suffix ended (a proper prefix of P) or its byte is smaller
+                    P.less[p]++;
+                }
+            }
+        }
+    };
+    if (threads == 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < threads; t++) th.emplace_back(work, t);
+        for (auto& x : th) x.join();
+    }
+    for (uint64_t p = 0; p < n_pat; p++) {
+        const uint64_t m = pat_off[p + 1] - pat_off[p];
+        uint64_t less = 0, pref = 0, np = 0;
+        for (int t = 0; t < threads; t++) {
+            less += parts[t].less[p];
+            pref += parts[t].pref[p];
+            if (m)
+                for (int c = 0; c < pat[pat_off[p]]; c++) less += parts[t].hist[c];  // suffixes with a smaller first byte
+            for (uint64_t v : parts[t].pos[p])
+                if (np < pos_cap) pos_out[p * pos_cap + np++] = v;
+        }
+        if (m == 0) pref = n;  // every suffix starts with the empty pattern
+        lower[p] = less;
+        upper[p] = less + pref;
+        n_pos[p] = np;
+    }
+}

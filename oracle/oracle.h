@@ -119,6 +119,11 @@ void orc_backward_search_batch(const uint8_t* bwt, uint64_t n, const uint64_t* l
                                const uint8_t* pat, const uint64_t* pat_off, uint8_t* tag,
                                uint64_t* lower, uint64_t* upper, uint64_t* matched_len,
                                int threads);
+/* The interval of a pattern by definition, without a suffix array (fmindex.rs:63-79,100-102: the suffixes that start with
+ * it; suffix_array.rs:264-284: in plain byte order) — lower = #suffixes < P, upper = lower + #suffixes with prefix P — and
+ * up to pos_cap occurrence positions per pattern.  For texts too large to sort in test time (tools/exp/fm_wide_big.py). */
+void orc_intervals_by_scan(const uint8_t* text, uint64_t n, uint64_t n_pat, const uint8_t* pat, const uint64_t* pat_off,
+                           uint64_t* lower, uint64_t* upper, uint64_t* pos_out, uint64_t pos_cap, uint64_t* n_pos, int threads);
 
 
 /* SampledSuffixArray (suffix_array.rs:86-184): sample() and get().  orc_sampled_sa_get returns 0,

@@ -87,6 +87,9 @@ def lib():
                                                 C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
                                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                 C.c_int]
+        L.orc_intervals_by_scan.restype = None
+        L.orc_intervals_by_scan.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_uint64, C.c_void_p, C.c_int]
         for name, res, args in [
             ("orc_banded_align", C.c_int,
              [C.POINTER(Scoring), C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64,
@@ -389,6 +392,19 @@ def backward_search_batch(bwt_arr, less_arr, occ, pat, pat_off, threads=1):
                                     p.ctypes.data, off.ctypes.data, tag.ctypes.data,
                                     lo.ctypes.data, hi.ctypes.data, ml.ctypes.data, threads)
     return tag, lo, hi, ml
+
+
+def intervals_by_scan(text, pat, pat_off, pos_cap=64, threads=1):
+    """The interval of every pattern by definition (fm.cpp: orc_intervals_by_scan) — lower = suffixes smaller than the pattern,
+    upper = lower + suffixes that start with it — and up to pos_cap occurrence positions each; no suffix array involved."""
+    t, p = _buf(text), _buf(pat)
+    off = np.ascontiguousarray(pat_off, dtype=np.uint64)
+    n = len(off) - 1
+    lo, hi, npos = np.zeros(n, dtype=np.uint64), np.zeros(n, dtype=np.uint64), np.zeros(n, dtype=np.uint64)
+    pos = np.zeros(max(1, n * pos_cap), dtype=np.uint64)
+    lib().orc_intervals_by_scan(t.ctypes.data, len(t), n, p.ctypes.data, off.ctypes.data, lo.ctypes.data, hi.ctypes.data,
+                                pos.ctypes.data, pos_cap, npos.ctypes.data, threads)
+    return lo, hi, [pos[k * pos_cap:k * pos_cap + int(npos[k])] for k in range(n)]
 
 
 class SampledSuffixArray:

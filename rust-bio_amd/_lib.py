@@ -91,7 +91,7 @@ SYMBOLS = ["bg_device_count", "bg_init", "bg_free", "bg_strerror", "bg_last_erro
            "bg_align_banded_bands_batch", "bg_band_from_matches_batch", "bg_sparse_find_kmer_matches", "bg_sparse_sdpkpp",
            "bg_sparse_lcskpp", "bg_sparse_sdpkpp_union_lcskpp_path", "bg_sparse_expand_kmer_matches", "bg_fastq_parse",
            "bg_fastq_parse_dev", "bg_cigar_batch", "bg_cigar_batch_dev", "bg_get_timing", "bg_enable_timing", "bg_band_redo_pairs", "bg_pack2_host",
-           "bg_pretty_batch", "bg_suffix_array_dev", "bg_bwt_dev", "bg_sa_sample_dev", "bg_fm_build_dev", "bg_fm_set_text", "bg_fm_set_text_dev", "bg_seed_extend_batch", "bg_seed_extend_batch_dev",
+           "bg_pretty_batch", "bg_suffix_array_dev", "bg_bwt_dev", "bg_sa_sample_dev", "bg_suffix_array_dev64", "bg_bwt_dev64", "bg_sa_sample_dev64", "bg_fm_build_dev", "bg_fm_set_text", "bg_fm_set_text_dev", "bg_seed_extend_batch", "bg_seed_extend_batch_dev",
            "bg_pack2_dev", "bg_unpack2_dev", "bg_fm_pattern_codes", "bg_fm_backward_search_packed_dev",
            "bg_fm_backward_search_count_lines_dev", "bg_align_batch_packed_dev", "bg_fm_step2_bytes",
            "bg_shard_range", "bg_shard_balanced", "bg_comm_unique_id", "bg_comm_init", "bg_comm_init_host",
@@ -183,6 +183,9 @@ def lib():
         L.bg_suffix_array_dev.argtypes = [vp, vp, u64, vp, vp]
         L.bg_bwt_dev.argtypes = [vp, vp, vp, u64, vp, vp]
         L.bg_sa_sample_dev.argtypes = [vp, vp, vp, u64, u32, C.c_uint8, vp, vp, vp, u64, C.POINTER(u64), vp]
+        L.bg_suffix_array_dev64.argtypes = [vp, vp, u64, vp, vp]
+        L.bg_bwt_dev64.argtypes = [vp, vp, vp, u64, vp, vp]
+        L.bg_sa_sample_dev64.argtypes = [vp, vp, vp, u64, u32, C.c_uint8, vp, vp, vp, u64, C.POINTER(u64), vp]
         L.bg_fm_set_text.argtypes = [vp, vp, u64]
         L.bg_fm_set_text_dev.argtypes = [vp, vp, u64]
         L.bg_seed_extend_batch.argtypes = [vp, C.POINTER(ScoringC), C.POINTER(SeedParamsC), u64, vp, vp, vp, vp, u64, C.POINTER(u64)]

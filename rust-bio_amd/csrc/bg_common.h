@@ -62,6 +62,8 @@ struct bg_ctx {
     bg_host_pipe* pipe = nullptr;     // persistent staging of bg_align_batch's pipelined path
     bg_seed_scratch* seed = nullptr;  // persistent scratch of the seed-and-extend pipeline
     bg_fm_pipe* fm_pipe = nullptr;    // persistent pinned / device staging of bg_fm_backward_search_batch
+    uint64_t fm_wide_from = 0xFFFFFFFFull;  // texts of this many symbols or more get the 64-bit FM layout (tests: lower it)
+    uint32_t fm_wide_sb_shift = 17;         // ... with superblocks of 2^this blocks (tests: a few blocks, so that bases matter)
     bool fm_host_bytes = false;       // tests, A/B: bg_fm_backward_search_batch stages the pattern bytes (no 2-bit packing on the host)
     int64_t host_chunk_pairs = 0;     // pairs per pipeline stage of bg_align_batch (0 = default)
     int64_t chunk_pairs = 0;  // 0 = default

@@ -199,6 +199,15 @@ extern "C" int bg_set_option(bg_ctx* ctx, const char* key, int64_t value) {
         ctx->band_join_global = value != 0;
         return BG_OK;
     }
+    if (!strcmp(key, "fm_wide_from")) {  // tests: indexes of this many symbols or more take the 64-bit layout (0: the default, 2^32 - 1)
+        ctx->fm_wide_from = value > 0 ? (uint64_t)value : 0xFFFFFFFFull;
+        return BG_OK;
+    }
+    if (!strcmp(key, "fm_wide_sb_shift")) {
+        if (value < 0 || value > 24) return BG_ERR_INVALID_ARG;  // (2^24 blocks of 192 symbols: relative counts stay below 2^32)
+        ctx->fm_wide_sb_shift = (uint32_t)value;
+        return BG_OK;
+    }
     if (!strcmp(key, "band_chain_rows")) {
         ctx->band_chain_rows = value != 0;
         return BG_OK;

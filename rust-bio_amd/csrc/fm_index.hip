@@ -629,7 +629,18 @@ extern "C" int bg_fm_build(bg_ctx* ctx, const uint8_t* bwt, uint64_t n, const ui
                            uint32_t n_sym, bg_fm** out) {
     if (!ctx || !bwt || !less || !alphabet || !out || n == 0 || n_sym == 0 || occ_k == 0)
         return BG_ERR_INVALID_ARG;
-    if (n >= 0xFFFFFFFFull) return BG_ERR_TOO_LARGE;
+    if (n > (1ull << 40)) return BG_ERR_TOO_LARGE;
+    if (n >= fm_wide_threshold(ctx)) {
+        // 64-bit positions (fm_wide.hip): the BWT goes up and the device builder lays the index out (the caller's less[] kept)
+        BG_HIP(hipSetDevice(ctx->device));
+        uint8_t* d_b = nullptr;
+        BG_HIP(hipMalloc((void**)&d_b, n));
+        int rcw = bg_copy_pieces(d_b, bwt, n, hipMemcpyHostToDevice, ctx->stream) == hipSuccess ? BG_OK : BG_ERR_HIP;
+        if (!rcw) rcw = fm_wide_build_dev(ctx, d_b, n, alphabet, n_sym, less, less_len, nullptr, out, ctx->stream);
+        hipStreamSynchronize(ctx->stream);
+        hipFree(d_b);
+        return rcw;
+    }
     // Alphabet (alphabets/mod.rs:49-60): set of bytes; m = max_symbol + 1 (bwt.rs:96-99)
     bool in_alpha[256] = {};
     uint32_t max_symbol = 0;
@@ -878,7 +889,9 @@ __global__ __launch_bounds__(256) void fmb_sparse_kernel(const uint8_t* __restri
 extern "C" int bg_fm_build_dev(bg_ctx* ctx, const uint8_t* d_bwt, uint64_t n, uint32_t occ_k, const uint8_t* alphabet, uint32_t n_sym,
                                uint64_t* less_out, bg_fm** out, void* stream) {
     if (!ctx || !d_bwt || !alphabet || !out || n == 0 || n_sym == 0 || occ_k == 0) return BG_ERR_INVALID_ARG;
-    if (n >= 0xFFFFFFFFull) return BG_ERR_TOO_LARGE;
+    if (n > (1ull << 40)) return BG_ERR_TOO_LARGE;
+    if (n >= fm_wide_threshold(ctx))  // 64-bit positions (fm_wide.hip)
+        return fm_wide_build_dev(ctx, d_bwt, n, alphabet, n_sym, nullptr, 0, less_out, out, (hipStream_t)stream);
     hipStream_t st = (hipStream_t)stream;
     BG_HIP(hipSetDevice(ctx->device));
     bool in_alpha[256] = {};
@@ -1053,6 +1066,7 @@ extern "C" int bg_fm_build_dev(bg_ctx* ctx, const uint8_t* d_bwt, uint64_t n, ui
 extern "C" int bg_fm_free(bg_fm* fm) {
     if (!fm) return BG_OK;
     hipFree(fm->d_blocks);
+    hipFree(fm->d_sb);
     hipFree(fm->d_blocks2);
     hipFree(fm->d_exc_pos);
     hipFree(fm->d_exc_sym_pos);
@@ -1073,7 +1087,7 @@ extern "C" int bg_fm_free(bg_fm* fm) {
 
 extern "C" uint64_t bg_fm_device_bytes(const bg_fm* fm) { return fm ? fm->bytes : 0; }
 extern "C" uint64_t bg_fm_step2_bytes(const bg_fm* fm) {
-    return fm && fm->dev2.blocks2 && !fm->no_step2 ? ((uint64_t)fm->dev.n + kSym2PerBlock - 1) / kSym2PerBlock * 128 : 0;
+    return fm && !fm->wide && fm->dev2.blocks2 && !fm->no_step2 ? ((uint64_t)fm->dev.n + kSym2PerBlock - 1) / kSym2PerBlock * 128 : 0;
 }
 
 // the four 2-bit codes all stand for symbols and no symbol is ranked by a bit vector: the packed / fast kernels apply
@@ -1119,6 +1133,20 @@ extern "C" int bg_fm_backward_search_batch_dev(bg_fm* fm, uint64_t n_q, const ui
     if (n_q == 0) return BG_OK;
     bg_ctx* ctx = fm->ctx;
     hipStream_t st = (hipStream_t)stream;
+    if (fm->wide) {  // 64-bit positions: fm_wide.hip
+        if (ctx->timing) BG_HIP(hipEventRecord(ctx->ev[0], st));
+        const int rcw = fm_wide_search_dev(fm, n_q, d_pat, d_pat_off, d_tag, d_lower, d_upper, d_matched_len, st);
+        if (rcw) return rcw;
+        if (ctx->timing) {
+            BG_HIP(hipEventRecord(ctx->ev[1], st));
+            BG_HIP(hipEventSynchronize(ctx->ev[1]));
+            float ms = 0;
+            BG_HIP(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+            ctx->last.fm_ms += ms;
+            ctx->last.fm_launches += 1;
+        }
+        return BG_OK;
+    }
     const uint64_t quads_per_block = 64;
     uint64_t blocks = (n_q + quads_per_block - 1) / quads_per_block;
     blocks = std::min<uint64_t>(blocks, 256 * 8);  // 8 resident 256-thread blocks per CU
@@ -1202,6 +1230,7 @@ int bg_fm_search_seeds_dev(bg_fm* fm, uint64_t n_reads, const uint8_t* d_reads, 
                            uint32_t stride, uint32_t seed_len, uint8_t* d_tag, uint64_t* d_lower, uint64_t* d_upper,
                            uint32_t* d_matched_len, hipStream_t st) {
     const uint64_t n_q = n_reads * S;
+    if (fm->wide) return BG_ERR_UNSUPPORTED;  // (seed-and-extend runs on 32-bit positions: biogpu.h)
     if (n_q == 0) return BG_OK;
     const uint64_t blocks = std::min<uint64_t>((n_q + 63) / 64, 256 * 8);
     SeedSrc src = fm_codes(fm);
@@ -1238,7 +1267,7 @@ extern "C" int bg_fm_pattern_codes(const bg_fm* fm, uint8_t codes[4]) {
     if (!fm || !codes) return BG_ERR_INVALID_ARG;
     // the four 2-bit codes must all stand for symbols of the text (a DNA-like BWT): with dense symbols code 0 means
     // "something else", and an index over fewer than four letters has codes no pattern symbol may use
-    if (fm->dev.n_dense || fm->n_codes != 4) return BG_ERR_UNSUPPORTED;
+    if (fm->wide || fm->dev.n_dense || fm->n_codes != 4) return BG_ERR_UNSUPPORTED;  // (wide: byte patterns only)
     for (int c = 0; c < 4; c++) codes[c] = fm->code_byte[c];
     return BG_OK;
 }
@@ -1247,7 +1276,7 @@ extern "C" int bg_fm_backward_search_packed_dev(bg_fm* fm, uint64_t n_q, const u
                                                 uint8_t* d_tag, uint64_t* d_lower, uint64_t* d_upper, uint32_t* d_matched_len,
                                                 void* stream) {
     if (!fm || (n_q && (!d_packed || !d_sym_off || !d_tag || !d_lower || !d_upper || !d_matched_len))) return BG_ERR_INVALID_ARG;
-    if (fm->dev.n_dense || fm->n_codes != 4) return BG_ERR_UNSUPPORTED;
+    if (fm->wide || fm->dev.n_dense || fm->n_codes != 4) return BG_ERR_UNSUPPORTED;
     if (n_q == 0) return BG_OK;
     bg_ctx* ctx = fm->ctx;
     hipStream_t st = (hipStream_t)stream;
@@ -1285,6 +1314,7 @@ extern "C" int bg_fm_backward_search_count_lines_dev(bg_fm* fm, uint64_t n_q, co
                                                      uint32_t* d_matched_len, uint64_t* lines_out, void* stream) {
     if (!fm || !lines_out || (n_q && (!d_pat_off || !d_tag || !d_lower || !d_upper || !d_matched_len))) return BG_ERR_INVALID_ARG;
     *lines_out = 0;
+    if (fm->wide) return BG_ERR_UNSUPPORTED;  // (a measurement aid of the 32-bit kernels)
     if (n_q == 0) return BG_OK;
     hipStream_t st = (hipStream_t)stream;
     BG_HIP(hipSetDevice(fm->ctx->device));

@@ -168,6 +168,37 @@ __device__ __forceinline__ uint4 bv_load(const FmDev& fm, uint32_t d, uint32_t r
     return fm.bitvecs[((uint64_t)d * fm.nbv_blocks + b) * 4 + t];
 }
 
+// ---- 64-bit positions (round 5, fm_wide.hip) ------------------------------------------------------------------------------
+// The reference indexes texts with usize (fmindex.rs:70-71 Interval, bwt.rs:94 Occ, suffix_array.rs:264); the layout above
+// counts in uint32.  A text of 2^32 - 1 symbols or more (T$R$ of a human genome for an FMD index: 6.2 G) gets the SAME 64-byte
+// blocks with counters RELATIVE to a superblock of 2^sb_shift blocks, plus one absolute 64-bit count per code and
+// superblock (2^17 blocks = 25 M symbols: 8 KB of bases for 6.2 G symbols, cache-resident) — Occ::get is still one 64-byte
+// line, one more load and a 64-bit add; l, r, less[] and the exception positions are 64-bit.  DNA-like BWTs only (four
+// 2-bit codes + at most kMaxExcLds other positions): a text that needs rank bit vectors (protein) and 64-bit positions is
+// refused with BG_ERR_UNSUPPORTED.
+struct FmWideDev {
+    const uint4* blocks;           // cnt[4] relative to the block's superblock + 192 symbols
+    const uint64_t* sb;            // [n_superblocks][4]: occurrences of code c before the superblock
+    const uint64_t* exc_pos;       // sparse exception positions, sorted
+    const uint64_t* exc_sym_pos;   // per sparse symbol, sorted, concatenated
+    const uint32_t* sparse_off;    // [n_sparse + 1]
+    const uint16_t* sym_class;     // [256]
+    const uint64_t* less;          // [256]
+    uint64_t n;
+    uint32_t n_exc;
+    uint32_t sb_shift;             // blocks per superblock = 1 << sb_shift
+};
+__device__ __forceinline__ uint32_t count_le64(const uint64_t* arr, uint32_t lo, uint32_t hi, uint64_t r) {
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (arr[mid] <= r)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+
 }  // namespace bgfm
 
 struct bg_fm {
@@ -209,7 +240,20 @@ struct bg_fm {
     int n_codes = 0;         // distinct bytes with a 2-bit code (<= 4)
     uint32_t less_len = 0;
     bool fmd_ok = false;  // the BWT is a word over dna::n_alphabet() + '$' (FMDIndex::from, fmindex.rs:323-327)
+    // 64-bit positions (fm_wide.hip): `wdev` instead of `dev` / `dev2`; the suffix array attached to it is uint64
+    bool wide = false;
+    bgfm::FmWideDev wdev = {};
+    void* d_sb = nullptr;
 };
+
+// fm_wide.hip: the index with 64-bit positions (built from a BWT in HBM; `less` null: the BWT's own cumulative counts)
+int fm_wide_build_dev(bg_ctx* ctx, const uint8_t* d_bwt, uint64_t n, const uint8_t* alphabet, uint32_t n_sym, const uint64_t* less,
+                      uint32_t less_len, uint64_t* less_out, bg_fm** out, hipStream_t st);
+int fm_wide_search_dev(bg_fm* fm, uint64_t n_q, const uint8_t* d_pat, const uint64_t* d_pat_off, uint8_t* d_tag, uint64_t* d_lower,
+                       uint64_t* d_upper, uint32_t* d_matched_len, hipStream_t st);
+int fm_wide_sa_get(bg_fm* fm, uint64_t n, const uint64_t* d_index, uint64_t* d_pos, hipStream_t st);
+// texts from this many symbols on take the 64-bit layout (tests lower it through the ctx option "fm_wide_from")
+uint64_t fm_wide_threshold(const bg_ctx* ctx);
 
 // fm_step2.hip: builds fm->dev2 behind a finished index (best effort; synchronises the stream)
 void fm_build_step2(bg_fm* fm, hipStream_t st);

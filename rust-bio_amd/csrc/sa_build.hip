@@ -19,6 +19,13 @@
 // scans and compaction are rocPRIM's (rocprim::radix_sort_pairs / inclusive_scan / select): plain library primitives,
 // like rust-bio's own use of a library suffix sorter; the kernels around them are below.  Memory: 29 bytes per symbol
 // of scratch.
+//
+// Round 5: every kernel and the driver are templates over the position type P.  P = uint32_t is the builder of rounds
+// 2-4 (texts below 2^32 - 1 symbols, bg_suffix_array_dev).  P = uint64_t (bg_suffix_array_dev64: the reference indexes with
+// usize, suffix_array.rs:264) lifts that limit: positions, ranks and group heads are 64-bit, and a doubling round — whose
+// key (rank[i], rank[i + h]) no longer fits one 64-bit radix key — is two stable passes, by the second rank and then by
+// the first (LSD), over the bits a rank below n needs.  49 bytes of scratch per symbol: a 4.4 G-symbol text takes 216 GB
+// of the 288 GB part next to its 35 GB suffix array.
 #include <cstring>
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -48,8 +55,9 @@ __global__ __launch_bounds__(256) void sab_presence_kernel(const uint8_t* __rest
 // key of suffix i: its first K symbols, b bits each, most significant first, up to and including its first sentinel
 // (code 0): what follows a sentinel counts as 0 — a comparison never goes past one (transform_text makes every
 // sentinel a symbol of its own) — and so do symbols past the end
+template <typename P>
 __global__ __launch_bounds__(256) void sab_init_keys_kernel(const uint8_t* __restrict__ t, uint64_t n, CodeMap cm, uint32_t b, uint32_t K,
-                                                            uint64_t* __restrict__ key, uint32_t* __restrict__ val) {
+                                                            uint64_t* __restrict__ key, P* __restrict__ val) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint64_t k = 0;
@@ -61,7 +69,7 @@ __global__ __launch_bounds__(256) void sab_init_keys_kernel(const uint8_t* __res
         k = (k << b) | c;
     }
     key[i] = k;
-    val[i] = (uint32_t)i;
+    val[i] = (P)i;
 }
 
 __global__ __launch_bounds__(256) void sab_count_byte_kernel(const uint8_t* __restrict__ t, uint64_t n, uint32_t byte,
@@ -76,96 +84,124 @@ __global__ __launch_bounds__(256) void sab_count_byte_kernel(const uint8_t* __re
 // The c suffixes that start with a sentinel are the c smallest of the text, the last occurrence first
 // (suffix_array.rs:454-458): the sorted list holds them in rows 0 .. c - 1 in ascending position (stable sort of equal
 // keys): `sent` keeps that list (next-sentinel lookups), rows / ranks are rewritten in descending position
-__global__ __launch_bounds__(256) void sab_sentinel_rows_kernel(const uint32_t* __restrict__ suf, uint64_t c, uint32_t* __restrict__ sent,
-                                                                uint32_t* __restrict__ rank, uint32_t* __restrict__ sa,
+template <typename P>
+__global__ __launch_bounds__(256) void sab_sentinel_rows_kernel(const P* __restrict__ suf, uint64_t c, P* __restrict__ sent,
+                                                                P* __restrict__ rank, P* __restrict__ sa,
                                                                 uint8_t* __restrict__ active) {
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= c) return;
     sent[j] = suf[j];
-    const uint32_t i = suf[c - 1 - j];
-    rank[i] = (uint32_t)j;
+    const P i = suf[c - 1 - j];
+    rank[i] = (P)j;
     sa[j] = i;
     active[j] = 0;
 }
 
 // hp[j] = j where a new group starts (else 0): an inclusive max-scan turns it into "start of my group"
-__global__ __launch_bounds__(256) void sab_heads_kernel(const uint64_t* __restrict__ key, uint64_t n, uint32_t* __restrict__ hp) {
+template <typename P>
+__global__ __launch_bounds__(256) void sab_heads_kernel(const uint64_t* __restrict__ key, uint64_t n, P* __restrict__ hp) {
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
-    hp[j] = (j == 0 || key[j] != key[j - 1]) ? (uint32_t)j : 0u;
+    hp[j] = (j == 0 || key[j] != key[j - 1]) ? (P)j : (P)0;
 }
 
 // round 0: rank of every suffix, the array itself, and which suffixes are still in a group of several
-__global__ __launch_bounds__(256) void sab_round0_kernel(const uint32_t* __restrict__ suf, const uint32_t* __restrict__ grp, uint64_t n,
-                                                         uint32_t* __restrict__ rank, uint32_t* __restrict__ sa, uint8_t* __restrict__ active) {
+template <typename P>
+__global__ __launch_bounds__(256) void sab_round0_kernel(const P* __restrict__ suf, const P* __restrict__ grp, uint64_t n,
+                                                         P* __restrict__ rank, P* __restrict__ sa, uint8_t* __restrict__ active) {
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
-    const uint32_t i = suf[j], g = grp[j];
+    const P i = suf[j], g = grp[j];
     rank[i] = g;
     sa[j] = i;
-    const bool head = g == (uint32_t)j, next_head = j + 1 == n || grp[j + 1] == (uint32_t)(j + 1);
+    const bool head = g == (P)j, next_head = j + 1 == n || grp[j + 1] == (P)(j + 1);
     active[j] = !(head && next_head);
 }
 
 // second key of an active suffix: the rank of the suffix h symbols on — or of its first sentinel, if that comes first:
 // the members of a group are equal up to there, sentinel included, and the sentinels' own ranks (unique from the
 // start) decide (sent: the c sentinel positions, ascending; c == 1: the text's last byte, never before i + h)
-__global__ __launch_bounds__(256) void sab_round_keys_kernel(const uint32_t* __restrict__ act, uint64_t A, const uint32_t* __restrict__ rank,
-                                                             uint64_t n, uint64_t h, const uint32_t* __restrict__ sent, uint32_t c,
-                                                             uint64_t* __restrict__ key) {
-    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= A) return;
-    const uint64_t i = act[p];
+// rank of the suffix h symbols behind suffix i, or of i's first sentinel if that comes first (see above)
+template <typename P>
+__device__ __forceinline__ P sab_second_rank(uint64_t i, const P* __restrict__ rank, uint64_t n, uint64_t h, const P* __restrict__ sent, uint64_t c) {
     uint64_t at = i + h;
     if (c > 1) {  // first sentinel at or after i (there always is one: the text ends in one)
-        uint32_t lo = 0, hi = c - 1;
+        uint64_t lo = 0, hi = c - 1;
         while (lo < hi) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (sent[mid] >= i)
+            const uint64_t mid = (lo + hi) >> 1;
+            if ((uint64_t)sent[mid] >= i)
                 hi = mid;
             else
                 lo = mid + 1;
         }
         at = min(at, (uint64_t)sent[lo]);
     }
-    const uint32_t r2 = at < n ? rank[at] : 0u;  // at >= n cannot happen for an active suffix (it would hold the last sentinel)
-    key[p] = (uint64_t)rank[i] << 32 | r2;
+    return at < n ? rank[at] : (P)0;  // at >= n cannot happen for an active suffix (it would hold the last sentinel)
 }
-
-__global__ __launch_bounds__(256) void sab_round_heads_kernel(const uint64_t* __restrict__ key, uint64_t A, uint32_t* __restrict__ hpH,
-                                                              uint32_t* __restrict__ hpF) {
+// P = uint32_t: key = rank[i] << 32 | second rank (one sort).  P = uint64_t, FIRST == false: key = second rank (the first of
+// two stable passes); FIRST == true: key = rank[i] (the second pass, over the list the first one left)
+template <typename P, bool FIRST>
+__global__ __launch_bounds__(256) void sab_round_keys_kernel(const P* __restrict__ act, uint64_t A, const P* __restrict__ rank,
+                                                             uint64_t n, uint64_t h, const P* __restrict__ sent, uint64_t c,
+                                                             uint64_t* __restrict__ key) {
     const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= A) return;
-    const uint64_t k = key[p], kp = p ? key[p - 1] : ~k;
-    hpH[p] = (p == 0 || (k >> 32) != (kp >> 32)) ? (uint32_t)p : 0u;
-    hpF[p] = (p == 0 || k != kp) ? (uint32_t)p : 0u;
+    const uint64_t i = act[p];
+    if (sizeof(P) == 4)
+        key[p] = (uint64_t)rank[i] << 32 | (uint64_t)sab_second_rank<P>(i, rank, n, h, sent, c);
+    else
+        key[p] = FIRST ? (uint64_t)rank[i] : (uint64_t)sab_second_rank<P>(i, rank, n, h, sent, c);
 }
 
-// rewrite every group in the order of the second rank, give its members their refined ranks, mark what stays active
-__global__ __launch_bounds__(256) void sab_round_apply_kernel(const uint64_t* __restrict__ key, const uint32_t* __restrict__ suf, uint64_t A,
-                                                              const uint32_t* __restrict__ firstH, const uint32_t* __restrict__ firstF,
-                                                              uint32_t* __restrict__ rank, uint32_t* __restrict__ sa,
+// group heads of the sorted active list: hpH by the first rank, hpF by both.  P = uint64_t: `key` holds the first rank only
+// (the second pass's key); the second one is looked up again for p and p - 1
+template <typename P>
+__global__ __launch_bounds__(256) void sab_round_heads_kernel(const uint64_t* __restrict__ key, const P* __restrict__ suf, uint64_t A,
+                                                              const P* __restrict__ rank, uint64_t n, uint64_t h, const P* __restrict__ sent,
+                                                              uint64_t c, P* __restrict__ hpH, P* __restrict__ hpF) {
+    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= A) return;
+    bool newH, newF;
+    if (sizeof(P) == 4) {
+        const uint64_t k = key[p], kp = p ? key[p - 1] : ~k;
+        newH = p == 0 || (k >> 32) != (kp >> 32);
+        newF = p == 0 || k != kp;
+    } else {
+        newH = p == 0 || key[p] != key[p - 1];
+        newF = newH || sab_second_rank<P>(suf[p], rank, n, h, sent, c) != sab_second_rank<P>(suf[p - 1], rank, n, h, sent, c);
+    }
+    hpH[p] = newH ? (P)p : (P)0;
+    hpF[p] = newF ? (P)p : (P)0;
+}
+
+// the refined rank of every member (rank writes must not race with the heads kernel's rank reads: a launch of its own)
+template <typename P>
+__global__ __launch_bounds__(256) void sab_round_apply_kernel(const uint64_t* __restrict__ key, const P* __restrict__ suf, uint64_t A,
+                                                              const P* __restrict__ firstH, const P* __restrict__ firstF,
+                                                              P* __restrict__ rank, P* __restrict__ sa,
                                                               uint8_t* __restrict__ active) {
     const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= A) return;
-    const uint32_t g = (uint32_t)(key[p] >> 32), i = suf[p];
-    const uint32_t fH = firstH[p], fF = firstF[p];
+    const P g = sizeof(P) == 4 ? (P)(key[p] >> 32) : (P)key[p], i = suf[p];
+    const P fH = firstH[p], fF = firstF[p];
     sa[(uint64_t)g + (p - fH)] = i;
     rank[i] = g + (fF - fH);
-    const bool head = fF == (uint32_t)p, next_head = p + 1 == A || firstF[p + 1] == (uint32_t)(p + 1);
+    const bool head = fF == (P)p, next_head = p + 1 == A || firstF[p + 1] == (P)(p + 1);
     active[p] = !(head && next_head);
 }
 
-__global__ __launch_bounds__(256) void sab_bwt_kernel(const uint8_t* __restrict__ t, const uint32_t* __restrict__ sa, uint64_t n,
+template <typename P>
+__global__ __launch_bounds__(256) void sab_bwt_kernel(const uint8_t* __restrict__ t, const P* __restrict__ sa, uint64_t n,
                                                       uint8_t* __restrict__ bwt) {
     const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
-    const uint32_t p = sa[r];
+    const P p = sa[r];
     bwt[r] = p > 0 ? t[p - 1] : t[n - 1];  // bwt.rs:43-47
 }
 
 // RawSuffixArray::sample (suffix_array.rs:86-120): every rate-th entry, plus the rows whose BWT byte is the sentinel
-__global__ __launch_bounds__(256) void sab_sample_kernel(const uint32_t* __restrict__ sa, const uint8_t* __restrict__ bwt, uint64_t n,
+template <typename P>
+__global__ __launch_bounds__(256) void sab_sample_kernel(const P* __restrict__ sa, const uint8_t* __restrict__ bwt, uint64_t n,
                                                          uint32_t rate, uint32_t sentinel, uint64_t* __restrict__ sample,
                                                          uint64_t* __restrict__ extra, uint32_t extra_cap, uint32_t* __restrict__ n_extra) {
     const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -181,18 +217,19 @@ __global__ __launch_bounds__(256) void sab_sample_kernel(const uint32_t* __restr
     }
 }
 
-struct MaxU32 {
-    __host__ __device__ uint32_t operator()(uint32_t a, uint32_t b) const { return a > b ? a : b; }
+template <typename P>
+struct MaxOf {
+    __host__ __device__ P operator()(P a, P b) const { return a > b ? a : b; }
 };
 
 inline unsigned nblk(uint64_t n) { return (unsigned)((n + 255) / 256); }
 
 }  // namespace
 
-extern "C" int bg_suffix_array_dev(bg_ctx* ctx, const uint8_t* d_text, uint64_t n, uint32_t* d_sa, void* stream) {
-    if (!ctx || !d_text || !d_sa || n == 0) return BG_ERR_INVALID_ARG;
-    if (n >= 0xFFFFFFFFull) return BG_ERR_TOO_LARGE;
-    hipStream_t st = (hipStream_t)stream;
+namespace {
+
+template <typename P>
+int sa_build_impl(bg_ctx* ctx, const uint8_t* d_text, uint64_t n, P* d_sa, hipStream_t st) {
     BG_HIP(hipSetDevice(ctx->device));
     // ---- alphabet: bytes that occur, the sentinel (last byte) must be the unique smallest one
     uint32_t* d_cnt = nullptr;
@@ -238,45 +275,50 @@ extern "C" int bg_suffix_array_dev(bg_ctx* ctx, const uint8_t* d_text, uint64_t 
     uint32_t b = 1;
     while ((1u << b) < sigma) b++;
     const uint32_t K = 64 / b;
+    constexpr bool WIDE = sizeof(P) == 8;
+    unsigned rank_bits = 1;  // bits of a rank below n (the radix passes of the 64-bit flavour's rounds)
+    while (rank_bits < 64 && (n >> rank_bits)) rank_bits++;
 
     uint64_t *keyA = nullptr, *keyB = nullptr;
-    uint32_t *valA = nullptr, *valB = nullptr, *rank = nullptr;
+    P *valA = nullptr, *valB = nullptr, *rank = nullptr;
     uint8_t* active = nullptr;
     void* tmp = nullptr;
     uint64_t* d_count = nullptr;
-    uint32_t* d_sent = nullptr;
+    P* d_sent = nullptr;
     auto run = [&]() -> int {
-        BG_HIP(hipMalloc((void**)&d_sent, n_sent * 4));
+        BG_HIP(hipMalloc((void**)&d_sent, n_sent * sizeof(P)));
         BG_HIP(hipMalloc((void**)&keyA, n * 8));
         BG_HIP(hipMalloc((void**)&keyB, n * 8));
-        BG_HIP(hipMalloc((void**)&valA, n * 4));
-        BG_HIP(hipMalloc((void**)&valB, n * 4));
-        BG_HIP(hipMalloc((void**)&rank, n * 4));
+        BG_HIP(hipMalloc((void**)&valA, n * sizeof(P)));
+        BG_HIP(hipMalloc((void**)&valB, n * sizeof(P)));
+        BG_HIP(hipMalloc((void**)&rank, n * sizeof(P)));
         BG_HIP(hipMalloc((void**)&active, n));
         BG_HIP(hipMalloc((void**)&d_count, 8));
         rocprim::double_buffer<uint64_t> keys(keyA, keyB);
-        rocprim::double_buffer<uint32_t> vals(valA, valB);
+        rocprim::double_buffer<P> vals(valA, valB);
         size_t t_sort = 0, t_scan = 0, t_sel = 0;
         BG_HIP(rocprim::radix_sort_pairs(nullptr, t_sort, keys, vals, n, 0, 64, st));
-        BG_HIP(rocprim::inclusive_scan(nullptr, t_scan, (uint32_t*)nullptr, (uint32_t*)nullptr, n, MaxU32(), st));
-        BG_HIP(rocprim::select(nullptr, t_sel, (uint32_t*)nullptr, (uint8_t*)nullptr, (uint32_t*)nullptr, d_count, n, st));
+        BG_HIP(rocprim::inclusive_scan(nullptr, t_scan, (P*)nullptr, (P*)nullptr, n, MaxOf<P>(), st));
+        BG_HIP(rocprim::select(nullptr, t_sel, (P*)nullptr, (uint8_t*)nullptr, (P*)nullptr, d_count, n, st));
         size_t tmp_bytes = std::max(std::max(t_sort, t_scan), t_sel);
         BG_HIP(hipMalloc(&tmp, std::max<size_t>(tmp_bytes, 256)));
 
         // ---- round 0
-        sab_init_keys_kernel<<<dim3(nblk(n)), dim3(256), 0, st>>>(d_text, n, cm, b, K, keys.current(), vals.current());
+        sab_init_keys_kernel<P><<<dim3(nblk(n)), dim3(256), 0, st>>>(d_text, n, cm, b, K, keys.current(), vals.current());
         BG_HIP(hipGetLastError());
         BG_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, vals, n, 0, (unsigned)(b * K), st));
-        uint32_t* hp = (uint32_t*)keys.alternate();  // the sort's other key buffer is free now: two uint32 arrays fit
-        uint32_t* grp = hp + n;
-        sab_heads_kernel<<<dim3(nblk(n)), dim3(256), 0, st>>>(keys.current(), n, hp);
-        BG_HIP(rocprim::inclusive_scan(tmp, tmp_bytes, hp, grp, n, MaxU32(), st));
-        sab_round0_kernel<<<dim3(nblk(n)), dim3(256), 0, st>>>(vals.current(), grp, n, rank, d_sa, active);
+        // group heads and their scan: 32-bit positions — two arrays in the sort's other key buffer; 64-bit positions — one
+        // there and one in the other value buffer (free until the active list is selected into it)
+        P* hp = (P*)keys.alternate();
+        P* grp = WIDE ? vals.alternate() : hp + n;
+        sab_heads_kernel<P><<<dim3(nblk(n)), dim3(256), 0, st>>>(keys.current(), n, hp);
+        BG_HIP(rocprim::inclusive_scan(tmp, tmp_bytes, hp, grp, n, MaxOf<P>(), st));
+        sab_round0_kernel<P><<<dim3(nblk(n)), dim3(256), 0, st>>>(vals.current(), grp, n, rank, d_sa, active);
         // rows 0 .. n_sent - 1 (key 0): the sentinel suffixes, final from here on
-        sab_sentinel_rows_kernel<<<dim3(nblk(n_sent)), dim3(256), 0, st>>>(vals.current(), n_sent, d_sent, rank, d_sa, active);
+        sab_sentinel_rows_kernel<P><<<dim3(nblk(n_sent)), dim3(256), 0, st>>>(vals.current(), n_sent, d_sent, rank, d_sa, active);
         BG_HIP(hipGetLastError());
         // active suffixes, in array order
-        uint32_t* act = vals.alternate();
+        P* act = vals.alternate();
         BG_HIP(rocprim::select(tmp, tmp_bytes, vals.current(), active, act, d_count, n, st));
         uint64_t A = 0;
         BG_HIP(hipMemcpyAsync(&A, d_count, 8, hipMemcpyDeviceToHost, st));
@@ -287,22 +329,34 @@ extern "C" int bg_suffix_array_dev(bg_ctx* ctx, const uint8_t* d_text, uint64_t 
         for (uint64_t h = K; A > 0; h *= 2) {
             // every suffix is unique within n symbols (a group that is tied up to its sentinels needs one round whatever h is)
             if (h > 2 * n && h > 2 * (uint64_t)K) return BG_ERR_HIP;  // cannot happen
-            sab_round_keys_kernel<<<dim3(nblk(A)), dim3(256), 0, st>>>(vals.current(), A, rank, n, h, d_sent, (uint32_t)n_sent, keys.current());
-            BG_HIP(hipGetLastError());
-            BG_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, vals, A, 0, 64, st));
-            uint32_t* hpH = (uint32_t*)keys.alternate();
-            uint32_t* hpF = hpH + A;
-            // firstH / firstF need their own storage: the other value buffer and the (idle) first half of ... `active`
-            // is bytes; use two fresh slices of the alternate key buffer instead when A is small, else allocate
-            uint32_t *firstH = nullptr, *firstF = nullptr;
-            BG_HIP(hipMalloc((void**)&firstH, A * 4));
-            BG_HIP(hipMalloc((void**)&firstF, A * 4));
+            if (!WIDE) {
+                sab_round_keys_kernel<P, false><<<dim3(nblk(A)), dim3(256), 0, st>>>(vals.current(), A, rank, n, h, d_sent, n_sent, keys.current());
+                BG_HIP(hipGetLastError());
+                BG_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, vals, A, 0, 64, st));
+            } else {  // (first rank, second rank) as two stable passes, least significant first
+                sab_round_keys_kernel<P, false><<<dim3(nblk(A)), dim3(256), 0, st>>>(vals.current(), A, rank, n, h, d_sent, n_sent, keys.current());
+                BG_HIP(hipGetLastError());
+                BG_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, vals, A, 0, rank_bits, st));
+                sab_round_keys_kernel<P, true><<<dim3(nblk(A)), dim3(256), 0, st>>>(vals.current(), A, rank, n, h, d_sent, n_sent, keys.current());
+                BG_HIP(hipGetLastError());
+                BG_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, vals, A, 0, rank_bits, st));
+            }
+            P *hpH = nullptr, *hpF = nullptr, *firstH = nullptr, *firstF = nullptr;
+            if (!WIDE) {  // two 32-bit arrays fit the sort's other key buffer
+                hpH = (P*)keys.alternate();
+                hpF = hpH + A;
+            } else {
+                hpH = (P*)keys.alternate();
+                BG_HIP(hipMalloc((void**)&hpF, A * sizeof(P)));
+            }
+            BG_HIP(hipMalloc((void**)&firstH, A * sizeof(P)));
+            BG_HIP(hipMalloc((void**)&firstF, A * sizeof(P)));
             int rr = BG_OK;
             auto round = [&]() -> int {
-                sab_round_heads_kernel<<<dim3(nblk(A)), dim3(256), 0, st>>>(keys.current(), A, hpH, hpF);
-                BG_HIP(rocprim::inclusive_scan(tmp, tmp_bytes, hpH, firstH, A, MaxU32(), st));
-                BG_HIP(rocprim::inclusive_scan(tmp, tmp_bytes, hpF, firstF, A, MaxU32(), st));
-                sab_round_apply_kernel<<<dim3(nblk(A)), dim3(256), 0, st>>>(keys.current(), vals.current(), A, firstH, firstF, rank, d_sa, active);
+                sab_round_heads_kernel<P><<<dim3(nblk(A)), dim3(256), 0, st>>>(keys.current(), vals.current(), A, rank, n, h, d_sent, n_sent, hpH, hpF);
+                BG_HIP(rocprim::inclusive_scan(tmp, tmp_bytes, hpH, firstH, A, MaxOf<P>(), st));
+                BG_HIP(rocprim::inclusive_scan(tmp, tmp_bytes, hpF, firstF, A, MaxOf<P>(), st));
+                sab_round_apply_kernel<P><<<dim3(nblk(A)), dim3(256), 0, st>>>(keys.current(), vals.current(), A, firstH, firstF, rank, d_sa, active);
                 BG_HIP(hipGetLastError());
                 BG_HIP(rocprim::select(tmp, tmp_bytes, vals.current(), active, vals.alternate(), d_count, A, st));
                 BG_HIP(hipMemcpyAsync(&A, d_count, 8, hipMemcpyDeviceToHost, st));
@@ -310,6 +364,7 @@ extern "C" int bg_suffix_array_dev(bg_ctx* ctx, const uint8_t* d_text, uint64_t 
                 return BG_OK;
             };
             rr = round();
+            if (WIDE) hipFree(hpF);
             hipFree(firstH);
             hipFree(firstF);
             if (rr) return rr;
@@ -330,18 +385,43 @@ extern "C" int bg_suffix_array_dev(bg_ctx* ctx, const uint8_t* d_text, uint64_t 
     return rc;
 }
 
+}  // namespace
+
+extern "C" int bg_suffix_array_dev(bg_ctx* ctx, const uint8_t* d_text, uint64_t n, uint32_t* d_sa, void* stream) {
+    if (!ctx || !d_text || !d_sa || n == 0) return BG_ERR_INVALID_ARG;
+    if (n >= 0xFFFFFFFFull) return BG_ERR_TOO_LARGE;  // 64-bit positions: bg_suffix_array_dev64
+    return sa_build_impl<uint32_t>(ctx, d_text, n, d_sa, (hipStream_t)stream);
+}
+
+// the same with 64-bit positions (suffix_array.rs:264: the reference's usize): texts of 2^32 - 1 symbols and more, up to 2^40
+extern "C" int bg_suffix_array_dev64(bg_ctx* ctx, const uint8_t* d_text, uint64_t n, uint64_t* d_sa, void* stream) {
+    if (!ctx || !d_text || !d_sa || n == 0) return BG_ERR_INVALID_ARG;
+    if (n > (1ull << 40)) return BG_ERR_TOO_LARGE;
+    return sa_build_impl<uint64_t>(ctx, d_text, n, d_sa, (hipStream_t)stream);
+}
+
 extern "C" int bg_bwt_dev(bg_ctx* ctx, const uint8_t* d_text, const uint32_t* d_sa, uint64_t n, uint8_t* d_bwt, void* stream) {
     if (!ctx || !d_text || !d_sa || !d_bwt) return BG_ERR_INVALID_ARG;
     if (n == 0) return BG_OK;
     BG_HIP(hipSetDevice(ctx->device));
-    sab_bwt_kernel<<<dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream>>>(d_text, d_sa, n, d_bwt);
+    sab_bwt_kernel<uint32_t><<<dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream>>>(d_text, d_sa, n, d_bwt);
+    BG_HIP(hipGetLastError());
+    return BG_OK;
+}
+extern "C" int bg_bwt_dev64(bg_ctx* ctx, const uint8_t* d_text, const uint64_t* d_sa, uint64_t n, uint8_t* d_bwt, void* stream) {
+    if (!ctx || !d_text || !d_sa || !d_bwt) return BG_ERR_INVALID_ARG;
+    if (n == 0) return BG_OK;
+    BG_HIP(hipSetDevice(ctx->device));
+    sab_bwt_kernel<uint64_t><<<dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream>>>(d_text, d_sa, n, d_bwt);
     BG_HIP(hipGetLastError());
     return BG_OK;
 }
 
-extern "C" int bg_sa_sample_dev(bg_ctx* ctx, const uint32_t* d_sa, const uint8_t* d_bwt, uint64_t n, uint32_t sampling_rate,
-                                uint8_t sentinel, uint64_t* sample, uint64_t* extra_rows, uint64_t* extra_pos, uint64_t extra_cap,
-                                uint64_t* n_extra, void* stream) {
+namespace {
+template <typename P>
+int sa_sample_impl(bg_ctx* ctx, const P* d_sa, const uint8_t* d_bwt, uint64_t n, uint32_t sampling_rate,
+                   uint8_t sentinel, uint64_t* sample, uint64_t* extra_rows, uint64_t* extra_pos, uint64_t extra_cap,
+                   uint64_t* n_extra, void* stream) {
     if (!ctx || !d_sa || !d_bwt || !sample || !n_extra || sampling_rate == 0 || n == 0) return BG_ERR_INVALID_ARG;
     hipStream_t st = (hipStream_t)stream;
     BG_HIP(hipSetDevice(ctx->device));
@@ -356,7 +436,7 @@ extern "C" int bg_sa_sample_dev(bg_ctx* ctx, const uint32_t* d_sa, const uint8_t
         BG_HIP(hipMalloc((void**)&d_extra, std::max<uint64_t>(cap, 1) * 16));
         BG_HIP(hipMalloc((void**)&d_ne, 4));
         BG_HIP(hipMemsetAsync(d_ne, 0, 4, st));
-        sab_sample_kernel<<<dim3(nblk(n)), dim3(256), 0, st>>>(d_sa, d_bwt, n, sampling_rate, sentinel, d_sample, d_extra, cap, d_ne);
+        sab_sample_kernel<P><<<dim3(nblk(n)), dim3(256), 0, st>>>(d_sa, d_bwt, n, sampling_rate, sentinel, d_sample, d_extra, cap, d_ne);
         BG_HIP(hipGetLastError());
         BG_HIP(hipMemcpyAsync(sample, d_sample, ns * 8, hipMemcpyDeviceToHost, st));
         BG_HIP(hipMemcpyAsync(&ne, d_ne, 4, hipMemcpyDeviceToHost, st));
@@ -381,4 +461,16 @@ extern "C" int bg_sa_sample_dev(bg_ctx* ctx, const uint32_t* d_sa, const uint8_t
         if (extra_pos) extra_pos[k] = v[k].second;
     }
     return BG_OK;
+}
+}  // namespace
+
+extern "C" int bg_sa_sample_dev(bg_ctx* ctx, const uint32_t* d_sa, const uint8_t* d_bwt, uint64_t n, uint32_t sampling_rate,
+                                uint8_t sentinel, uint64_t* sample, uint64_t* extra_rows, uint64_t* extra_pos, uint64_t extra_cap,
+                                uint64_t* n_extra, void* stream) {
+    return sa_sample_impl<uint32_t>(ctx, d_sa, d_bwt, n, sampling_rate, sentinel, sample, extra_rows, extra_pos, extra_cap, n_extra, stream);
+}
+extern "C" int bg_sa_sample_dev64(bg_ctx* ctx, const uint64_t* d_sa, const uint8_t* d_bwt, uint64_t n, uint32_t sampling_rate,
+                                  uint8_t sentinel, uint64_t* sample, uint64_t* extra_rows, uint64_t* extra_pos, uint64_t extra_cap,
+                                  uint64_t* n_extra, void* stream) {
+    return sa_sample_impl<uint64_t>(ctx, d_sa, d_bwt, n, sampling_rate, sentinel, sample, extra_rows, extra_pos, extra_cap, n_extra, stream);
 }

@@ -153,6 +153,7 @@ __global__ __launch_bounds__(256) void sa_sampled_get_kernel(FmDev fm, SaDev sa,
 
 int launch_get(bg_fm* fm, uint64_t n, const uint64_t* d_index, uint64_t* d_pos, hipStream_t st) {
     if (n == 0) return BG_OK;
+    if (fm->wide) return fm_wide_sa_get(fm, n, d_index, d_pos, st);  // 64-bit positions: fm_wide.hip
     if (fm->sa_kind == 1) {
         sa_raw_get_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>((const uint32_t*)fm->d_sa, fm->dev.n, n,
                                                                                 d_index, d_pos);
@@ -174,6 +175,19 @@ int launch_get(bg_fm* fm, uint64_t n, const uint64_t* d_index, uint64_t* d_pos, 
     return BG_OK;
 }
 
+// 64-bit index: the entries stay uint64 (checked against the text's length like the narrow ones)
+int upload64(void** dptr, const uint64_t* src, uint64_t count, uint64_t limit, uint64_t* bytes) {
+    for (uint64_t i = 0; i < count; i++)
+        if (src[i] >= limit) return BG_ERR_INVALID_ARG;
+    hipFree(*dptr);
+    *dptr = nullptr;
+    BG_HIP(hipMalloc(dptr, std::max<uint64_t>(count * 8, 16)));
+    if (count) BG_HIP(hipMemcpy(*dptr, src, count * 8, hipMemcpyHostToDevice));
+    *bytes += std::max<uint64_t>(count * 8, 16);
+    return BG_OK;
+}
+inline uint64_t fm_len(const bg_fm* fm) { return fm->wide ? fm->wdev.n : (uint64_t)fm->dev.n; }
+
 int upload32(void** dptr, const uint64_t* src, uint64_t count, uint64_t limit, uint64_t* bytes) {
     std::vector<uint32_t> tmp(count);
     for (uint64_t i = 0; i < count; i++) {
@@ -191,9 +205,9 @@ int upload32(void** dptr, const uint64_t* src, uint64_t count, uint64_t limit, u
 }  // namespace
 
 extern "C" int bg_fm_set_suffix_array(bg_fm* fm, const uint64_t* sa, uint64_t n) {
-    if (!fm || !sa || n != fm->dev.n) return BG_ERR_INVALID_ARG;
+    if (!fm || !sa || n != fm_len(fm)) return BG_ERR_INVALID_ARG;
     BG_HIP(hipSetDevice(fm->ctx->device));
-    int rc = upload32(&fm->d_sa, sa, n, n, &fm->bytes);
+    int rc = (fm->wide ? upload64 : upload32)(&fm->d_sa, sa, n, n, &fm->bytes);
     if (rc) return rc;
     fm->sa_kind = 1;
     return BG_OK;
@@ -203,15 +217,16 @@ extern "C" int bg_fm_set_sampled_suffix_array(bg_fm* fm, const uint64_t* sample,
                                               uint8_t sentinel, const uint64_t* extra_rows, const uint64_t* extra_pos,
                                               uint64_t n_extra) {
     if (!fm || !sample || sampling_rate == 0 || (n_extra && (!extra_rows || !extra_pos))) return BG_ERR_INVALID_ARG;
-    const uint64_t n = fm->dev.n;
+    const uint64_t n = fm_len(fm);
     if (n_sample != (n + sampling_rate - 1) / sampling_rate) return BG_ERR_INVALID_ARG;
     for (uint64_t i = 1; i < n_extra; i++)
         if (extra_rows[i] <= extra_rows[i - 1]) return BG_ERR_INVALID_ARG;  // sorted, unique
     BG_HIP(hipSetDevice(fm->ctx->device));
     int rc;
-    if ((rc = upload32(&fm->d_sa, sample, n_sample, n, &fm->bytes))) return rc;
-    if ((rc = upload32(&fm->d_extra_row, extra_rows, n_extra, n, &fm->bytes))) return rc;
-    if ((rc = upload32(&fm->d_extra_pos, extra_pos, n_extra, n, &fm->bytes))) return rc;
+    auto up = fm->wide ? upload64 : upload32;
+    if ((rc = up(&fm->d_sa, sample, n_sample, n, &fm->bytes))) return rc;
+    if ((rc = up(&fm->d_extra_row, extra_rows, n_extra, n, &fm->bytes))) return rc;
+    if ((rc = up(&fm->d_extra_pos, extra_pos, n_extra, n, &fm->bytes))) return rc;
     fm->n_sample = n_sample;
     fm->n_extra = n_extra;
     fm->sa_rate = sampling_rate;
@@ -268,7 +283,7 @@ extern "C" int bg_interval_occ_batch(bg_fm* fm, uint64_t n_iv, const uint64_t* l
     uint64_t total = 0;
     for (uint64_t v = 0; v < n_iv; v++) {
         // "Interval out of range of suffix array" (fmindex.rs:77) — an empty range yields no rows
-        if (upper[v] > lower[v] && upper[v] > fm->dev.n) return BG_ERR_INVALID_ARG;
+        if (upper[v] > lower[v] && upper[v] > fm_len(fm)) return BG_ERR_INVALID_ARG;
         out_off[v] = total;
         total += upper[v] > lower[v] ? upper[v] - lower[v] : 0;
     }

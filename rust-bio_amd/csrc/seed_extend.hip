@@ -228,6 +228,7 @@ __global__ __launch_bounds__(256) void se_best_kernel(uint64_t n_reads, uint64_t
 }  // namespace
 
 extern "C" int bg_fm_set_text(bg_fm* fm, const uint8_t* text, uint64_t n) {
+    if (fm && fm->wide) return BG_ERR_UNSUPPORTED;  // seed-and-extend runs on 32-bit positions (biogpu.h)
     if (!fm || !text || n != fm->dev.n) return BG_ERR_INVALID_ARG;
     BG_HIP(hipSetDevice(fm->ctx->device));
     if (fm->text_owned) hipFree(fm->d_text);
@@ -242,6 +243,7 @@ extern "C" int bg_fm_set_text(bg_fm* fm, const uint8_t* text, uint64_t n) {
 }
 
 extern "C" int bg_fm_set_text_dev(bg_fm* fm, const uint8_t* d_text, uint64_t n) {
+    if (fm && fm->wide) return BG_ERR_UNSUPPORTED;
     if (!fm || !d_text || n != fm->dev.n) return BG_ERR_INVALID_ARG;
     if (fm->text_owned) hipFree(fm->d_text);
     fm->d_text = (void*)d_text;
@@ -255,6 +257,7 @@ extern "C" int bg_seed_extend_batch_dev(bg_fm* fm, const bg_scoring_t* sc, const
                                         bg_seed_hit_t* d_hits, uint8_t* d_ops, uint64_t ops_stride, uint64_t* totals,
                                         void* stream) {
     if (!fm || !sc || !prm_in || (n_reads && (!d_read_off || !d_hits))) return BG_ERR_INVALID_ARG;
+    if (fm->wide) return BG_ERR_UNSUPPORTED;
     if (!fm->d_text || fm->sa_kind == 0) return BG_ERR_INVALID_ARG;  // needs bg_fm_set_text + a suffix array
     if (prm_in->seed_len == 0 || prm_in->stride == 0 || prm_in->max_occ == 0) return BG_ERR_INVALID_ARG;
     if (max_read_len > 65535 || prm_in->pad > 65535) return BG_ERR_TOO_LARGE;

@@ -84,13 +84,20 @@ class RawSuffixArray:
 NONE = 0xFFFFFFFFFFFFFFFF
 
 
-def suffix_array_dev(d_text, ctx=None, stream=0):
+def suffix_array_dev(d_text, ctx=None, stream=0, wide=None):
     """`suffix_array` for a text that lives in HBM (a uint8 cuda tensor ending in a unique, smallest sentinel):
     returns the suffix array as a cuda tensor of n uint32 values (dtype torch.int32 holds the bits; view it as
-    torch.uint32 or widen with `.to(torch.int64) & 0xFFFFFFFF`).  bg_suffix_array_dev."""
+    torch.uint32 or widen with `.to(torch.int64) & 0xFFFFFFFF`).  bg_suffix_array_dev.
+    wide (default: n >= 2^32 - 1): 64-bit positions — a torch.int64 tensor, bg_suffix_array_dev64 (suffix_array.rs:264: usize)."""
     import torch
     ctx = ctx or _lib.default_context()
     n = d_text.numel()
+    if wide is None:
+        wide = n >= 0xFFFFFFFF
+    if wide:
+        d_sa = torch.empty(n, dtype=torch.int64, device=d_text.device)
+        _lib.check(_lib.lib().bg_suffix_array_dev64(ctx.h, d_text.data_ptr(), n, d_sa.data_ptr(), stream), "suffix_array (device, 64-bit)")
+        return d_sa
     d_sa = torch.empty(n, dtype=torch.int32, device=d_text.device)
     _lib.check(_lib.lib().bg_suffix_array_dev(ctx.h, d_text.data_ptr(), n, d_sa.data_ptr(), stream), "suffix_array (device)")
     return d_sa
@@ -102,7 +109,8 @@ def bwt_dev(d_text, d_sa, ctx=None, stream=0):
     ctx = ctx or _lib.default_context()
     n = d_text.numel()
     d_bwt = torch.empty(n, dtype=torch.uint8, device=d_text.device)
-    _lib.check(_lib.lib().bg_bwt_dev(ctx.h, d_text.data_ptr(), d_sa.data_ptr(), n, d_bwt.data_ptr(), stream), "bwt (device)")
+    fn = _lib.lib().bg_bwt_dev64 if d_sa.dtype == torch.int64 else _lib.lib().bg_bwt_dev  # (the suffix array's width says which)
+    _lib.check(fn(ctx.h, d_text.data_ptr(), d_sa.data_ptr(), n, d_bwt.data_ptr(), stream), "bwt (device)")
     return d_bwt
 
 
@@ -117,7 +125,9 @@ def sample_dev(d_sa, d_bwt, sentinel_byte, sampling_rate, ctx=None, stream=0):
     cap = 1 << 16
     rows, pos = np.zeros(cap, dtype=np.uint64), np.zeros(cap, dtype=np.uint64)
     ne = C.c_uint64(0)
-    _lib.check(_lib.lib().bg_sa_sample_dev(ctx.h, d_sa.data_ptr(), d_bwt.data_ptr(), n, s.s, s.sentinel, s.sample.ctypes.data,
+    import torch
+    fn = _lib.lib().bg_sa_sample_dev64 if d_sa.dtype == torch.int64 else _lib.lib().bg_sa_sample_dev
+    _lib.check(fn(ctx.h, d_sa.data_ptr(), d_bwt.data_ptr(), n, s.s, s.sentinel, s.sample.ctypes.data,
                                            rows.ctypes.data, pos.ctypes.data, cap, C.byref(ne), stream), "RawSuffixArray::sample (device)")
     s.extra_rows, s.extra_pos = rows[:ne.value].copy(), pos[:ne.value].copy()
     return s

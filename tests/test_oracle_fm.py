@@ -155,3 +155,37 @@ def test_backward_search_vs_bruteforce():
                 occs = sorted(int(sa[i]) for i in range(lo, hi))
                 want = sorted(i for i in range(len(t)) if t.startswith(suf, i))
                 assert occs == want
+
+
+def test_intervals_by_scan_equal_backward_search_and_the_suffix_array():
+    """orc_intervals_by_scan — the definition-level checker of the 4.4 G-symbol run (no suffix array) — pinned to the pinned
+    restatement: for every pattern that occurs, (lower, upper) = backward_search's Complete interval and the positions are
+    the suffix array's entries of that interval; for one that does not, an empty range at the pattern's insertion point"""
+    import oracle_py as orc
+    rng = np.random.default_rng(12)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    text = np.append(acgt[rng.integers(0, 4, size=20_000)], np.uint8(ord("$")))
+    text[rng.integers(0, 20_000, size=30)] = ord("N")
+    sa = np.asarray(orc.suffix_array(text), dtype=np.uint64)
+    b = np.frombuffer(bytes(orc.bwt(text, sa)), dtype=np.uint8)
+    alpha = b"ACGTN$"
+    ls = orc.less(b, alpha)
+    occ = orc.Occ(b, 3, alpha)
+    pats = [text[s:s + L].tobytes() for s, L in zip(rng.integers(0, 19_000, size=300), rng.integers(1, 14, size=300))]
+    pats += [acgt[rng.integers(0, 4, size=int(L))].tobytes() for L in rng.integers(6, 16, size=200)] + [b"A", b"T", b"N", b"TTTTTTTTTTTTTTTTTTTT"]
+    buf = np.frombuffer(b"".join(pats), dtype=np.uint8)
+    off = np.zeros(len(pats) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(p) for p in pats])
+    tag, lo, hi, ml = orc.backward_search_batch(b, ls, occ, buf, off)
+    for threads in (1, 3):
+        slo, shi, spos = orc.intervals_by_scan(text, buf, off, pos_cap=100_000, threads=threads)
+        for k, p in enumerate(pats):
+            if tag[k] == 0:
+                assert (int(slo[k]), int(shi[k])) == (int(lo[k]), int(hi[k])), p
+                assert sorted(int(v) for v in sa[int(lo[k]):int(hi[k])]) == [int(v) for v in spos[k]]
+            else:
+                assert slo[k] == shi[k] and len(spos[k]) == 0
+                # the insertion point: every suffix below it is smaller than the pattern, every one from it on larger
+                r = int(slo[k])
+                suf = lambda i: text[int(sa[i]):].tobytes()
+                assert (r == 0 or suf(r - 1) < p) and (r == len(sa) or suf(r) > p)

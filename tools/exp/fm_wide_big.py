@@ -1,0 +1,199 @@
+"""An FM index over a text of MORE THAN 2^32 SYMBOLS on one MI355X ("a synthetic 4.4 G-symbol text indexes on
+the 288 GB part, a seeded sample of intervals and positions equals the oracle's"):
+    python tools/exp/fm_wide_big.py [symbols=4400000000] [queries=10000000] > gpurun_out/r05_fm_wide_4g4.json
+  1. the text in HBM: random ACGT (SplitMix64, synth_gpu.genome) with a 2 Mbp segment copied three times further on (real work
+     for the prefix doubling: groups that stay tied for 2 M symbols) and a hundred N, '$' at the end;
+  2. bg_suffix_array_dev64 -> bg_bwt_dev64 -> bg_sa_sample_dev64 (rate 32) -> bg_fm_build_dev (the 64-bit layout, fm_wide.hip)
+     -> bg_fm_set_sampled_suffix_array: nothing text-sized leaves the device except the samples;
+  3. `queries` 100 bp patterns (half cut from the text — some from the copied segment: several occurrences — half random)
+     through bg_fm_backward_search_batch_dev: the rate of the 64-bit kernel;
+  4. parity, three ways:
+     a. ORACLE BY DEFINITION on a seeded sample (oracle/fm.cpp: orc_intervals_by_scan — lower = #suffixes < P, upper = lower +
+        #suffixes with prefix P, and the occurrence positions, by one pass over the 4.4 GB text on the host threads; no suffix
+        array on the host): Complete intervals equal, Partial results equal the interval of the matched suffix and the suffix one
+        symbol longer does not occur, located positions (K6 on 64-bit samples) equal the scan's;
+     b. every position K6 returns for 200 000 Complete queries is an occurrence (the text is compared on the device) and a
+        query cut from position p finds p;
+     c. positions and interval bounds beyond 2^32 occur (counted), i.e. the run exercises what uint32 could not hold."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tools")):
+    sys.path.insert(0, p)
+import oracle_py as orc  # noqa: E402
+from csrc_hash import csrc_sha  # noqa: E402
+from rust_bio_amd import _lib, synth_gpu  # noqa: E402
+from rust_bio_amd.fmindex import FMIndex  # noqa: E402
+from rust_bio_amd.suffix_array import bwt_dev, sample_dev, suffix_array_dev  # noqa: E402
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 4_400_000_000
+NQ = int(sys.argv[2]) if len(sys.argv) > 2 else 10_000_000
+P = 100
+dev = torch.device("cuda:0")
+ctx = _lib.Context(0)
+threads = len(os.sched_getaffinity(0))
+res = {"symbols": N + 1, "beyond_2_32": N + 1 > 1 << 32, "csrc_sha": csrc_sha(ROOT)}
+
+
+def sync():
+    torch.cuda.synchronize()
+    return time.perf_counter()
+
+
+# ---- 1. text
+t0 = sync()
+g = synth_gpu.genome(N, 91, dev)
+SEG = min(2_000_000, N // 16)
+for k in range(1, 4):  # the same segment four times in all
+    dst = (N // 5) * k + 12345
+    g[dst:dst + SEG] = g[777:777 + SEG]
+npos = torch.arange(100, dtype=torch.int64, device=dev) * (N // 101) + 31
+g[npos] = ord("N")
+res["text_s"] = round(sync() - t0, 2)
+torch.cuda.empty_cache()
+free0, total = torch.cuda.mem_get_info()
+res["hbm_total_gb"] = round(total / 1e9, 1)
+
+# ---- 2. suffix array, BWT, samples, index
+t0 = sync()
+d_sa = suffix_array_dev(g, ctx=ctx, wide=True)
+res["suffix_array_s"] = round(sync() - t0, 2)
+t0 = sync()
+d_b = bwt_dev(g, d_sa, ctx=ctx)
+samples = sample_dev(d_sa, d_b, ord("$"), 32, ctx=ctx)
+res["bwt_and_samples_s"] = round(sync() - t0, 2)
+t0 = sync()
+fm = FMIndex.from_device(d_b, 128, b"ACGTNacgtn", ctx=ctx)
+samples.attach(fm)
+res["index_s"] = round(sync() - t0, 2)
+res["index_bytes"] = fm.device_bytes()
+res["less"] = {chr(c): int(fm._less[c]) for c in b"$ACGNT"}
+# the suffix array itself is not needed any more (35 GB): K6 locates through the samples
+sa_probe = d_sa[torch.tensor([0, 1, N // 2, N], device=dev)].cpu().tolist()
+res["sa_probe_rows_0_1_mid_last"] = sa_probe
+del d_sa
+torch.cuda.empty_cache()
+
+# ---- 3. queries
+rng = np.random.default_rng(5)
+z = synth_gpu.splitmix64(1234, NQ, dev)
+start = torch.remainder(z & ((1 << 62) - 1), N - P)  # (non-negative 62-bit draws)
+in_seg = torch.arange(NQ, device=dev) % 50 == 0       # 2 %: inside the copied segment (four occurrences at least)
+start = torch.where(in_seg, 777 + torch.remainder(start, SEG - P), start)
+is_rand = torch.arange(NQ, device=dev) % 2 == 1
+ar = torch.arange(P, dtype=torch.int64, device=dev)
+pat = torch.empty((NQ, P), dtype=torch.uint8, device=dev)
+CH = 1 << 20
+for s in range(0, NQ, CH):
+    e = min(NQ, s + CH)
+    pat[s:e] = g[start[s:e].view(-1, 1) + ar.view(1, -1)]
+for s in range(0, NQ, CH):  # every second pattern: random symbols instead (most of them end Partial after ~16 steps)
+    e = min(NQ, s + CH)
+    rnd = synth_gpu.random_dna((e - s) * P, 77, dev, start=s * P).view(e - s, P)
+    m = is_rand[s:e]
+    pat[s:e][m] = rnd[m]
+    del rnd
+pat = pat.view(-1)
+off = torch.arange(NQ + 1, dtype=torch.int64, device=dev) * P
+d_tag = torch.empty(NQ, dtype=torch.uint8, device=dev)
+d_lo = torch.empty(NQ, dtype=torch.int64, device=dev)
+d_hi = torch.empty(NQ, dtype=torch.int64, device=dev)
+d_ml = torch.empty(NQ, dtype=torch.int32, device=dev)
+
+
+def search():
+    fm.backward_search_dev(NQ, pat.data_ptr(), off.data_ptr(), d_tag.data_ptr(), d_lo.data_ptr(), d_hi.data_ptr(), d_ml.data_ptr())
+
+
+search()
+t0 = sync()
+for _ in range(3):
+    search()
+dt = (sync() - t0) / 3
+res["search"] = {"queries": NQ, "pattern_len": P, "ms": round(dt * 1e3, 2), "queries_per_s": round(NQ / dt, 1),
+                 "complete": int((d_tag == 0).sum()), "partial": int((d_tag == 1).sum()), "absent": int((d_tag == 2).sum()),
+                 "kernel": "fmw_search_kernel (64-bit positions, 1-step blocks, byte patterns)"}
+res["intervals_with_a_bound_beyond_2_32"] = int(((d_hi > (1 << 32)) & (d_tag < 2)).sum())
+
+# ---- 4b. located positions are occurrences; a query cut from p finds p
+NL = min(NQ // 2, 200_000)
+sel = torch.nonzero((d_tag == 0) & ~is_rand)[:NL].view(-1)
+lo_s, hi_s = d_lo[sel], d_hi[sel]
+cnt = (hi_s - lo_s).clamp(max=64)  # (the copied segment's patterns have four rows; cap anything odd)
+out_off = torch.zeros(sel.numel() + 1, dtype=torch.int64, device=dev)
+out_off[1:] = torch.cumsum(cnt, 0)
+total = int(out_off[-1])
+d_pos = torch.empty(total, dtype=torch.int64, device=dev)
+t0 = sync()
+fm.interval_occ_dev(sel.numel(), lo_s.data_ptr(), out_off.data_ptr(), total, d_pos.data_ptr())
+res["locate"] = {"intervals": int(sel.numel()), "positions": total, "ms": round((sync() - t0) * 1e3, 2)}
+owner = torch.repeat_interleave(torch.arange(sel.numel(), device=dev), cnt)
+ok_occ = True
+found_self = torch.zeros(sel.numel(), dtype=torch.bool, device=dev)
+for s in range(0, total, CH):
+    e = min(total, s + CH)
+    q = sel[owner[s:e]]
+    got = g[d_pos[s:e].view(-1, 1) + ar.view(1, -1)]
+    ok_occ = ok_occ and bool((got == pat.view(NQ, P)[q]).all())
+    hit = d_pos[s:e] == start[q]
+    found_self[owner[s:e][hit]] = True
+res["locate"]["every_position_is_an_occurrence"] = ok_occ
+res["locate"]["every_query_finds_where_it_was_cut"] = bool(found_self[(hi_s - lo_s) <= 64].all())
+res["locate"]["positions_beyond_2_32"] = int((d_pos >= (1 << 32)).sum())
+
+# ---- 4a. the oracle by definition on a seeded sample
+NS = 96
+pick = torch.cat([torch.nonzero((d_tag == 0) & ~is_rand)[:40].view(-1), torch.nonzero((d_tag == 0) & in_seg & ~is_rand)[:8].view(-1),
+                  torch.nonzero(d_tag == 1)[:NS - 48].view(-1)])
+h_pat = pat.view(NQ, P)[pick].cpu().numpy()
+h_tag, h_lo, h_hi, h_ml = d_tag[pick].cpu().numpy(), d_lo[pick].cpu().numpy().astype(np.uint64), d_hi[pick].cpu().numpy().astype(np.uint64), d_ml[pick].cpu().numpy()
+scan_pats, kinds = [], []
+for k in range(len(pick)):
+    if h_tag[k] == 0:
+        scan_pats.append(h_pat[k].tobytes()); kinds.append(("complete", k))
+    else:  # Partial(pl, pr + 1, ml): the interval of the last ml symbols; one symbol more does not occur (fmindex.rs:160-182)
+        ml = int(h_ml[k])
+        scan_pats.append(h_pat[k][P - ml:].tobytes()); kinds.append(("partial", k))
+        scan_pats.append(h_pat[k][P - ml - 1:].tobytes()); kinds.append(("longer", k))
+buf = np.frombuffer(b"".join(scan_pats), dtype=np.uint8)
+soff = np.zeros(len(scan_pats) + 1, dtype=np.uint64)
+soff[1:] = np.cumsum([len(p) for p in scan_pats])
+t0 = time.perf_counter()
+h_text = g.cpu().numpy()
+res["text_download_s"] = round(time.perf_counter() - t0, 2)
+t0 = time.perf_counter()
+slo, shi, spos = orc.intervals_by_scan(h_text, buf, soff, pos_cap=64, threads=threads)
+res["oracle_scan_s"] = round(time.perf_counter() - t0, 1)
+bad = 0
+n_c = n_p = 0
+loc_lo, loc_hi, loc_want = [], [], []
+for j, (kind, k) in enumerate(kinds):
+    if kind == "complete":
+        n_c += 1
+        bad += (int(slo[j]), int(shi[j])) != (int(h_lo[k]), int(h_hi[k]))
+        loc_lo.append(int(h_lo[k])); loc_hi.append(int(h_hi[k])); loc_want.append(sorted(int(v) for v in spos[j]))
+    elif kind == "partial":
+        n_p += 1
+        bad += (int(slo[j]), int(shi[j])) != (int(h_lo[k]), int(h_hi[k]))
+    else:
+        bad += int(shi[j]) != int(slo[j])
+_, pos = fm.interval_occ_arrays(np.array(loc_lo, dtype=np.uint64), np.array(loc_hi, dtype=np.uint64))
+o = 0
+bad_pos = 0
+for lo_, hi_, want in zip(loc_lo, loc_hi, loc_want):
+    got = sorted(int(v) for v in pos[o:o + hi_ - lo_])
+    o += hi_ - lo_
+    bad_pos += got != want
+res["oracle_sample"] = {"patterns": len(pick), "complete": n_c, "partial": n_p, "scans": len(scan_pats), "oracle_threads": threads,
+                        "interval_mismatches": int(bad), "position_list_mismatches": int(bad_pos),
+                        "max_interval_size": int(max(h - l for l, h in zip(loc_lo, loc_hi))),
+                        "intervals_beyond_2_32": int(sum(1 for l in loc_lo if l >= (1 << 32)))}
+res["bit_exact"] = bool(bad == 0 and bad_pos == 0 and ok_occ and res["locate"]["every_query_finds_where_it_was_cut"])
+res["hbm_free_before_the_suffix_array_gb"] = round(free0 / 1e9, 1)
+print(json.dumps(res))
