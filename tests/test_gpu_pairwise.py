@@ -419,8 +419,11 @@ def test_cached_matrix_is_invalidated_across_alternating_matrices_and_banded_cal
     acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
     xs = [acgt[rng.integers(0, 4, size=int(rng.integers(20, 90)))].tobytes() for _ in range(96)]
     ys = [acgt[rng.integers(0, 4, size=int(rng.integers(20, 90)))].tobytes() for _ in range(96)]
-    fa = MatchParams(2, -3)
-    fb = lambda a, b: (5 if a == b else (-1 if {a, b} in ({65, 71}, {67, 84}) else -4))  # transitions cheaper: different scores
+    fa = np.fromfunction(lambda a, b: np.where(a == b, 2, -3), (256, 256), dtype=np.int64).astype(np.int32)
+    fb = np.full((256, 256), -4, dtype=np.int32)  # transitions cheaper: different scores under the same gaps
+    np.fill_diagonal(fb, 5)
+    for u, v in ((65, 71), (67, 84)):
+        fb[u, v] = fb[v, u] = -1
     clips = dict(xclip_prefix=MIN_SCORE, xclip_suffix=MIN_SCORE, yclip_prefix=MIN_SCORE, yclip_suffix=MIN_SCORE)
     ctx = _lib.Context(0)
     x, xo = _lib.concat(xs)
@@ -431,14 +434,14 @@ def test_cached_matrix_is_invalidated_across_alternating_matrices_and_banded_cal
         al = Aligner.with_scoring(engine_scoring(kw), ctx=ctx)
         out, _ = al.align_arrays(MODES["local"], x, xo, y, yo)
         oout, _, _ = orc.align_batch(orc.make_scoring(**kw), "local", x, xo, y, yo, threads=4)
-        assert (out["score"] == oout["score"]).all(), fn
+        assert (out["score"] == oout["score"]).all()
         return out["score"].copy()
 
-    sa = run(fa.score if hasattr(fa, "score") else fa)
+    sa = run(fa)
     bal = BAligner.with_scoring(engine_scoring(dict(gap_open=-5, gap_extend=-1, matrix=fb, **clips)), 6, 8, ctx=ctx)
     bal.align_arrays(MODES["local"], x, xo, y, yo)
-    assert (run(fa.score if hasattr(fa, "score") else fa) == sa).all()
+    assert (run(fa) == sa).all()
     sb = run(fb)
     assert (sb != sa).any()
-    assert (run(fa.score if hasattr(fa, "score") else fa) == sa).all()
+    assert (run(fa) == sa).all()
     assert (run(fb) == sb).all()

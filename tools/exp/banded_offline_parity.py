@@ -25,6 +25,12 @@ chunk = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 Lb, kb, wb = 10_000, 16, 32
 dev = torch.device("cuda:0")
 threads = len(os.sched_getaffinity(0))
+try:  # cgroup CPU quota: threads beyond it are only throttled (run A: 256 "cores" on a 16-CPU quota made the oracle 2.5 x slower)
+    quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+    if quota != "max":
+        threads = min(threads, max(1, -(-int(quota) // int(period))))
+except (OSError, ValueError):
+    pass
 bx, _, by, _ = synth_gpu.sw_pairs_big(Pb, Lb, seed=4, device=dev, sub=0.06, ins=0.02, dele=0.02, chunk=64)
 hx, hy = bx.cpu().numpy(), by.cpu().numpy()
 hoff = np.arange(Pb + 1, dtype=np.uint64) * np.uint64(Lb)
