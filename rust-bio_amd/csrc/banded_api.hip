@@ -635,16 +635,34 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
         if (build_on_device && !(P.matched && P.p0 == p0))
             if ((rc = issue_match(p0, n_chunk))) return rc;
         P.p0 = p0;
-        if (S.busy) {  // its staging and device buffers were last used two sub-batches ago
-            BG_HIP(hipEventSynchronize(S.traced));
-            S.busy = false;
-        }
         const uint64_t want = want_at(p0);
         P.want = want;
         hp.assign(want, HostPair());
         row0.resize(want + 1);
         row0[0] = 0;
         for (uint64_t q = 0; q < want; q++) row0[q + 1] = row0[q] + (x_off[p0 + q + 1] - x_off[p0 + q]) + 1;
+        // The set's staging and device buffers were last used two sub-batches ago — by K4 of sub-batch c - 2, which ends
+        // ~14 ms after ITS fill.  Rounds 2-4 waited for that on the HOST, here, before launching anything of sub-batch c: the
+        // chaining of c then started 5 ms into the fill of c - 1 it is meant to run under (profiles/
+        // r05_banded_timeline_chain_rows.txt: chain_rows 68.85 behind K4's end at 68.79, the fill at 63.55), and the builder's
+        // chain — not the fill — timed the cycle.  The chaining touches none of the set's buffers (the builder's own arrays are
+        // double-buffered by parity and guarded by `built`): only the raster, which writes the set's row ranges, has to wait,
+        // and it can do so on the device; the host waits in finish(), before it writes the pinned staging.  (A buffer that has
+        // to GROW is freed and allocated anew: then, and for host-built bands, the host waits here as before.)
+        auto set_idle = [&]() -> int {
+            if (S.busy) {
+                BG_HIP(hipEventSynchronize(S.traced));
+                S.busy = false;
+            }
+            return BG_OK;
+        };
+        {
+            const size_t need_rc = std::max<size_t>(row0[want] * sizeof(int2), 64), need_ro = std::max<size_t>(row0[want] * 4, 64);
+            const bool grows = S.hc_rowc < need_rc || S.hc_roff < need_ro || S.hc_pairs < want * sizeof(BandPair) || S.dc_rowc < need_rc ||
+                               S.dc_roff < need_ro || B.h_state_cap < want * sizeof(BandDevPair);
+            if (grows || !build_on_device || ctx->band_host_sync)
+                if ((rc = set_idle())) return rc;
+        }
         if ((rc = pinned_reserve(&S.h_rowc, &S.hc_rowc, std::max<size_t>(row0[want] * sizeof(int2), 64)))) return rc;
         if ((rc = pinned_reserve(&S.h_roff, &S.hc_roff, std::max<size_t>(row0[want] * 4, 64)))) return rc;
         if ((rc = pinned_reserve(&S.h_pairs, &S.hc_pairs, want * sizeof(BandPair)))) return rc;
@@ -675,6 +693,7 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
                 bg_band_scratch::Set& prev = B.set[(n_chunk - 1) & 1];
                 BG_HIP(hipStreamWaitEvent(st_build, prev.fill_gone_valid ? prev.fill_gone : prev.filled, 0));
             }
+            if (S.busy) BG_HIP(hipStreamWaitEvent(st_build, S.traced, 0));  // the raster writes the set's row ranges: K4 of c - 2 has read them
             if ((rc = launch_band_raster(d, st_build))) return rc;
             BG_HIP(hipMemcpyAsync(B.h_state, d.state, want * sizeof(BandDevPair), hipMemcpyDeviceToHost, st_build));
             BG_HIP(hipEventRecord(S.built, st_build));
@@ -719,6 +738,10 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
         BandPair* dp = (BandPair*)S.h_pairs;
         int rc = BG_OK;
         hipStream_t sp = use_pre && on_device ? B.aux_stream : st;  // (see use_pre)
+        if (S.busy) {  // (issue() left this wait to the device: the host writes the set's pinned staging from here on)
+            BG_HIP(hipEventSynchronize(S.traced));
+            S.busy = false;
+        }
         if (on_device) {
             BG_HIP(hipEventSynchronize(S.built));
             lap("band build (device)");
