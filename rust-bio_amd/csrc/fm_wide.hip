@@ -84,12 +84,13 @@ __global__ __launch_bounds__(256) void fmw_heads_kernel(uint64_t nblk, uint32_t 
 // sparse exceptions: (position, byte) appended in any order; the host sorts the few of them
 __global__ __launch_bounds__(256) void fmw_sparse_kernel(const uint8_t* __restrict__ b, uint64_t n, const uint8_t* __restrict__ is_sparse,
                                                          uint32_t cap, uint32_t* __restrict__ n_out, ulonglong2* __restrict__ out) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint8_t ch = b[i];
-    if (is_sparse[ch]) {
-        const uint32_t k = atomicAdd(n_out, 1u);
-        if (k < cap) out[k] = make_ulonglong2(i, ch);
+    // (grid-stride: a launch may not exceed 2^32 threads)
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint8_t ch = b[i];
+        if (is_sparse[ch]) {
+            const uint32_t k = atomicAdd(n_out, 1u);
+            if (k < cap) out[k] = make_ulonglong2(i, ch);
+        }
     }
 }
 
@@ -444,7 +445,7 @@ int fm_wide_build_dev(bg_ctx* ctx, const uint8_t* d_bwt, uint64_t n, const uint8
         if ((rc = dalloc((void**)&d_ns, 4))) return rc;
         if ((rc = dalloc((void**)&d_sp, (size_t)(kWideMaxExc + 8) * 16))) return rc;
         BG_HIP(hipMemsetAsync(d_ns, 0, 4, st));
-        fmw_sparse_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(d_bwt, n, d_sparse, kWideMaxExc + 8, d_ns, d_sp);
+        fmw_sparse_kernel<<<dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 1u << 22)), dim3(256), 0, st>>>(d_bwt, n, d_sparse, kWideMaxExc + 8, d_ns, d_sp);
         BG_HIP(hipGetLastError());
         uint32_t ns = 0;
         BG_HIP(hipMemcpyAsync(&ns, d_ns, 4, hipMemcpyDeviceToHost, st));

@@ -58,18 +58,19 @@ __global__ __launch_bounds__(256) void sab_presence_kernel(const uint8_t* __rest
 template <typename P>
 __global__ __launch_bounds__(256) void sab_init_keys_kernel(const uint8_t* __restrict__ t, uint64_t n, CodeMap cm, uint32_t b, uint32_t K,
                                                             uint64_t* __restrict__ key, P* __restrict__ val) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint64_t k = 0;
-    bool open = true;
-    for (uint32_t u = 0; u < K; u++) {
-        const uint64_t p = i + u;
-        const uint64_t c = (open && p < n) ? (uint64_t)cm.code[t[p]] : 0ull;
-        open = open && c != 0;
-        k = (k << b) | c;
+    // (grid-stride: a launch may not exceed 2^32 threads, and texts here do)
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t k = 0;
+        bool open = true;
+        for (uint32_t u = 0; u < K; u++) {
+            const uint64_t p = i + u;
+            const uint64_t c = (open && p < n) ? (uint64_t)cm.code[t[p]] : 0ull;
+            open = open && c != 0;
+            k = (k << b) | c;
+        }
+        key[i] = k;
+        val[i] = (P)i;
     }
-    key[i] = k;
-    val[i] = (P)i;
 }
 
 __global__ __launch_bounds__(256) void sab_count_byte_kernel(const uint8_t* __restrict__ t, uint64_t n, uint32_t byte,
@@ -88,34 +89,37 @@ template <typename P>
 __global__ __launch_bounds__(256) void sab_sentinel_rows_kernel(const P* __restrict__ suf, uint64_t c, P* __restrict__ sent,
                                                                 P* __restrict__ rank, P* __restrict__ sa,
                                                                 uint8_t* __restrict__ active) {
-    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= c) return;
-    sent[j] = suf[j];
-    const P i = suf[c - 1 - j];
-    rank[i] = (P)j;
-    sa[j] = i;
-    active[j] = 0;
+    // (grid-stride: a launch may not exceed 2^32 threads, and texts here do)
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < c; j += (uint64_t)gridDim.x * blockDim.x) {
+        sent[j] = suf[j];
+        const P i = suf[c - 1 - j];
+        rank[i] = (P)j;
+        sa[j] = i;
+        active[j] = 0;
+    }
 }
 
 // hp[j] = j where a new group starts (else 0): an inclusive max-scan turns it into "start of my group"
 template <typename P>
 __global__ __launch_bounds__(256) void sab_heads_kernel(const uint64_t* __restrict__ key, uint64_t n, P* __restrict__ hp) {
-    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
-    hp[j] = (j == 0 || key[j] != key[j - 1]) ? (P)j : (P)0;
+    // (grid-stride: a launch may not exceed 2^32 threads, and texts here do)
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (uint64_t)gridDim.x * blockDim.x) {
+        hp[j] = (j == 0 || key[j] != key[j - 1]) ? (P)j : (P)0;
+    }
 }
 
 // round 0: rank of every suffix, the array itself, and which suffixes are still in a group of several
 template <typename P>
 __global__ __launch_bounds__(256) void sab_round0_kernel(const P* __restrict__ suf, const P* __restrict__ grp, uint64_t n,
                                                          P* __restrict__ rank, P* __restrict__ sa, uint8_t* __restrict__ active) {
-    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
-    const P i = suf[j], g = grp[j];
-    rank[i] = g;
-    sa[j] = i;
-    const bool head = g == (P)j, next_head = j + 1 == n || grp[j + 1] == (P)(j + 1);
-    active[j] = !(head && next_head);
+    // (grid-stride: a launch may not exceed 2^32 threads, and texts here do)
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (uint64_t)gridDim.x * blockDim.x) {
+        const P i = suf[j], g = grp[j];
+        rank[i] = g;
+        sa[j] = i;
+        const bool head = g == (P)j, next_head = j + 1 == n || grp[j + 1] == (P)(j + 1);
+        active[j] = !(head && next_head);
+    }
 }
 
 // second key of an active suffix: the rank of the suffix h symbols on — or of its first sentinel, if that comes first:
@@ -144,13 +148,14 @@ template <typename P, bool FIRST>
 __global__ __launch_bounds__(256) void sab_round_keys_kernel(const P* __restrict__ act, uint64_t A, const P* __restrict__ rank,
                                                              uint64_t n, uint64_t h, const P* __restrict__ sent, uint64_t c,
                                                              uint64_t* __restrict__ key) {
-    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= A) return;
-    const uint64_t i = act[p];
-    if (sizeof(P) == 4)
-        key[p] = (uint64_t)rank[i] << 32 | (uint64_t)sab_second_rank<P>(i, rank, n, h, sent, c);
-    else
-        key[p] = FIRST ? (uint64_t)rank[i] : (uint64_t)sab_second_rank<P>(i, rank, n, h, sent, c);
+    // (grid-stride: a launch may not exceed 2^32 threads, and texts here do)
+    for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < A; p += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t i = act[p];
+        if (sizeof(P) == 4)
+            key[p] = (uint64_t)rank[i] << 32 | (uint64_t)sab_second_rank<P>(i, rank, n, h, sent, c);
+        else
+            key[p] = FIRST ? (uint64_t)rank[i] : (uint64_t)sab_second_rank<P>(i, rank, n, h, sent, c);
+    }
 }
 
 // group heads of the sorted active list: hpH by the first rank, hpF by both.  P = uint64_t: `key` holds the first rank only
@@ -159,19 +164,20 @@ template <typename P>
 __global__ __launch_bounds__(256) void sab_round_heads_kernel(const uint64_t* __restrict__ key, const P* __restrict__ suf, uint64_t A,
                                                               const P* __restrict__ rank, uint64_t n, uint64_t h, const P* __restrict__ sent,
                                                               uint64_t c, P* __restrict__ hpH, P* __restrict__ hpF) {
-    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= A) return;
-    bool newH, newF;
-    if (sizeof(P) == 4) {
-        const uint64_t k = key[p], kp = p ? key[p - 1] : ~k;
-        newH = p == 0 || (k >> 32) != (kp >> 32);
-        newF = p == 0 || k != kp;
-    } else {
-        newH = p == 0 || key[p] != key[p - 1];
-        newF = newH || sab_second_rank<P>(suf[p], rank, n, h, sent, c) != sab_second_rank<P>(suf[p - 1], rank, n, h, sent, c);
+    // (grid-stride: a launch may not exceed 2^32 threads, and texts here do)
+    for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < A; p += (uint64_t)gridDim.x * blockDim.x) {
+        bool newH, newF;
+        if (sizeof(P) == 4) {
+            const uint64_t k = key[p], kp = p ? key[p - 1] : ~k;
+            newH = p == 0 || (k >> 32) != (kp >> 32);
+            newF = p == 0 || k != kp;
+        } else {
+            newH = p == 0 || key[p] != key[p - 1];
+            newF = newH || sab_second_rank<P>(suf[p], rank, n, h, sent, c) != sab_second_rank<P>(suf[p - 1], rank, n, h, sent, c);
+        }
+        hpH[p] = newH ? (P)p : (P)0;
+        hpF[p] = newF ? (P)p : (P)0;
     }
-    hpH[p] = newH ? (P)p : (P)0;
-    hpF[p] = newF ? (P)p : (P)0;
 }
 
 // the refined rank of every member (rank writes must not race with the heads kernel's rank reads: a launch of its own)
@@ -180,23 +186,25 @@ __global__ __launch_bounds__(256) void sab_round_apply_kernel(const uint64_t* __
                                                               const P* __restrict__ firstH, const P* __restrict__ firstF,
                                                               P* __restrict__ rank, P* __restrict__ sa,
                                                               uint8_t* __restrict__ active) {
-    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= A) return;
-    const P g = sizeof(P) == 4 ? (P)(key[p] >> 32) : (P)key[p], i = suf[p];
-    const P fH = firstH[p], fF = firstF[p];
-    sa[(uint64_t)g + (p - fH)] = i;
-    rank[i] = g + (fF - fH);
-    const bool head = fF == (P)p, next_head = p + 1 == A || firstF[p + 1] == (P)(p + 1);
-    active[p] = !(head && next_head);
+    // (grid-stride: a launch may not exceed 2^32 threads, and texts here do)
+    for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < A; p += (uint64_t)gridDim.x * blockDim.x) {
+        const P g = sizeof(P) == 4 ? (P)(key[p] >> 32) : (P)key[p], i = suf[p];
+        const P fH = firstH[p], fF = firstF[p];
+        sa[(uint64_t)g + (p - fH)] = i;
+        rank[i] = g + (fF - fH);
+        const bool head = fF == (P)p, next_head = p + 1 == A || firstF[p + 1] == (P)(p + 1);
+        active[p] = !(head && next_head);
+    }
 }
 
 template <typename P>
 __global__ __launch_bounds__(256) void sab_bwt_kernel(const uint8_t* __restrict__ t, const P* __restrict__ sa, uint64_t n,
                                                       uint8_t* __restrict__ bwt) {
-    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n) return;
-    const P p = sa[r];
-    bwt[r] = p > 0 ? t[p - 1] : t[n - 1];  // bwt.rs:43-47
+    // (grid-stride: a launch may not exceed 2^32 threads, and texts here do)
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (uint64_t)gridDim.x * blockDim.x) {
+        const P p = sa[r];
+        bwt[r] = p > 0 ? t[p - 1] : t[n - 1];  // bwt.rs:43-47
+    }
 }
 
 // RawSuffixArray::sample (suffix_array.rs:86-120): every rate-th entry, plus the rows whose BWT byte is the sentinel
@@ -204,15 +212,16 @@ template <typename P>
 __global__ __launch_bounds__(256) void sab_sample_kernel(const P* __restrict__ sa, const uint8_t* __restrict__ bwt, uint64_t n,
                                                          uint32_t rate, uint32_t sentinel, uint64_t* __restrict__ sample,
                                                          uint64_t* __restrict__ extra, uint32_t extra_cap, uint32_t* __restrict__ n_extra) {
-    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n) return;
-    if (r % rate == 0) {
-        sample[r / rate] = sa[r];
-    } else if (bwt[r] == sentinel) {
-        const uint32_t k = atomicAdd(n_extra, 1u);
-        if (k < extra_cap) {
-            extra[2 * (uint64_t)k] = r;
-            extra[2 * (uint64_t)k + 1] = sa[r];
+    // (grid-stride: a launch may not exceed 2^32 threads, and texts here do)
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (uint64_t)gridDim.x * blockDim.x) {
+        if (r % rate == 0) {
+            sample[r / rate] = sa[r];
+        } else if (bwt[r] == sentinel) {
+            const uint32_t k = atomicAdd(n_extra, 1u);
+            if (k < extra_cap) {
+                extra[2 * (uint64_t)k] = r;
+                extra[2 * (uint64_t)k + 1] = sa[r];
+            }
         }
     }
 }
@@ -222,7 +231,9 @@ struct MaxOf {
     __host__ __device__ P operator()(P a, P b) const { return a > b ? a : b; }
 };
 
-inline unsigned nblk(uint64_t n) { return (unsigned)((n + 255) / 256); }
+// blocks of 256 threads for n elements, capped: every kernel above strides over its elements (HIP refuses launches of
+// 2^32 threads or more — a 4.4 G-symbol text has more elements than that)
+inline unsigned nblk(uint64_t n) { return (unsigned)std::min<uint64_t>((n + 255) / 256, 1u << 22); }
 
 }  // namespace
 
