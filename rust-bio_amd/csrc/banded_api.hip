@@ -289,6 +289,20 @@ extern "C" int bg_band_create_batch(const bg_scoring_t* sc, int mode, uint32_t k
 using BandMaker = std::function<bool(uint64_t, bgband::Band&, bgband::Workspace&)>;
 
 // device-resident flavour: sequences, offsets, records and (strided) operation slots stay in HBM
+// Streams of the pipeline by queue priority.  The runtime maps a process's streams onto a few hardware queues PER PRIORITY
+// LEVEL, and a hardware queue hands out its packets in order: a short kernel queued behind a long, starved one (the k-mer
+// join under a fill) waits for that one's last block to be dispatched, whatever streams the two were launched on
+// (profiles/r05_banded_timeline_hostsync.txt: the next fill's preparation started 1.3 ms after the join two sub-batches
+// ahead ended, every cycle).  So the join goes to the low-priority queues, a fill's preparation to the high-priority
+// ones, and neither can sit in front of the other or of the fill.  BG_BAND_STREAM_PRIO=0: all normal (rounds 2-4).
+int band_stream_create(hipStream_t* s, int level) {
+    static const int on = [] { const char* e = getenv("BG_BAND_STREAM_PRIO"); return e ? atoi(e) : 1; }();
+    int lo = 0, hi = 0;
+    if (!on || level == 0 || hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess || lo == hi)
+        return hipStreamCreateWithFlags(s, hipStreamNonBlocking) == hipSuccess ? BG_OK : BG_ERR_HIP;
+    return hipStreamCreateWithPriority(s, hipStreamNonBlocking, level > 0 ? hi : lo) == hipSuccess ? BG_OK : BG_ERR_HIP;
+}
+
 struct BandDevIO {
     const uint8_t* d_x;
     const uint64_t* d_xo;
@@ -441,7 +455,7 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
     const uint64_t n_slices = dio ? 0 : (n_pairs + chunk_pairs - 1) / chunk_pairs;
     uint64_t slices_up = 0, waited_fill = 0, waited_build = 0;
     (void)waited_build;
-    if (n_slices && !B.copy_stream) BG_HIP(hipStreamCreateWithFlags(&B.copy_stream, hipStreamNonBlocking));
+    if (n_slices && !B.copy_stream && (rc = band_stream_create(&B.copy_stream, -1))) return rc;
     auto upload_slices = [&](uint64_t upto) -> int {  // slices [slices_up, upto)
         for (; slices_up < std::min(upto, n_slices); slices_up++) {
             const uint64_t q0 = slices_up * chunk_pairs, q1 = std::min(n_pairs, q0 + chunk_pairs);
@@ -512,7 +526,7 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
     // (no stream of its own: the process maps its streams onto a handful of hardware queues, and two more of them cost the
     //  full bench — a dozen streams by then — 12 % of this leg where the leg alone gained 3 %; the join shares the stream of
     //  the host-buffer flavour's sequence uploads, which it waits for anyway)
-    if (!B.copy_stream) BG_HIP(hipStreamCreateWithFlags(&B.copy_stream, hipStreamNonBlocking));
+    if (!B.copy_stream && (rc = band_stream_create(&B.copy_stream, -1))) return rc;
     hipStream_t st_join = ctx->band_join_serial ? st_build : B.copy_stream;
     for (auto& s : B.set) s.built_valid = false;
     uint64_t waited_join = 0;
@@ -521,7 +535,7 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
     // stream it queued behind it: 2 ms between two long kernels, every cycle.  On a stream of its own it runs under the
     // previous fill's tail (`band_pre_serial` = 1: on the fill stream as before; event timing keeps one stream).
     // (it shares the stream that clears the aux block: the clear is one of the things it waits for)
-    if (!B.aux_stream) BG_HIP(hipStreamCreateWithFlags(&B.aux_stream, hipStreamNonBlocking));
+    if (!B.aux_stream && (rc = band_stream_create(&B.aux_stream, 1))) return rc;
     for (auto& s : B.set)
         if (!s.pre_done) BG_HIP(hipEventCreateWithFlags(&s.pre_done, hipEventDisableTiming));
     const bool use_pre = dev_kw != nullptr && !ctx->band_on_host && !ctx->timing && !ctx->band_window && !ctx->band_pre_serial;
@@ -812,7 +826,7 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
         BG_HIP(hipEventRecord(S.copied, sp));
         // the aux block is cleared on a stream of its own: 7 GB per sub-batch, 1.8 ms that used to sit between two fills
         // (the set's previous user, K4 of two sub-batches ago, is done: issue() waited for it)
-        if (!B.aux_stream) BG_HIP(hipStreamCreateWithFlags(&B.aux_stream, hipStreamNonBlocking));
+        if (!B.aux_stream && (rc = band_stream_create(&B.aux_stream, 1))) return rc;
         if (!S.cleared) BG_HIP(hipEventCreateWithFlags(&S.cleared, hipEventDisableTiming));
         BG_HIP(hipMemsetAsync(S.d_aux, 0, auxw * 4, B.aux_stream));
         BG_HIP(hipEventRecord(S.cleared, B.aux_stream));
