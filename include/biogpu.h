@@ -101,6 +101,10 @@ const char* bg_last_error(void); /* text of the last HIP failure on this thread 
  *   band_pre_serial = 1    a banded fill's preparation (pair table, waits, first strips) on the fill stream instead of its own (A/B)
  *   band_chain_global  chaining tree placement: 0 LDS, 1 global scratch, -1 by batch size (default)
  *   band_join_global = 1  k-mer join with its table in global memory even where the LDS flavour applies
+ *   band_join_late = 1    the k-mer join of a sub-batch waits for the chaining of the one before it (A/B: measured slower)
+ *   band_p_block512 = 1   K3p in blocks of eight wavefronts compiled for 168 VGPRs instead of four at 187 (A/B: measured slower)
+ *   band_budget_gb     traceback + aux bytes per scratch set of the banded pipeline, in GB (0 = default: 40, and never more
+ *                      than a third of the device's free memory); a sub-batch that does not fit is cut
  * Unknown keys return BG_ERR_INVALID_ARG. */
 int bg_set_option(bg_ctx* ctx, const char* key, int64_t value);
 

@@ -165,6 +165,8 @@ struct bg_band_scratch {
     hipStream_t join_stream = nullptr;  // k-mer join + chain preparation of the sub-batch after next
     hipStream_t pre_stream = nullptr;   // what a fill needs before its long kernel: the pair table, the waits, K3v2's first strips
     hipEvent_t seq_ready = nullptr;
+    hipEvent_t chained = nullptr;  // the chaining's event loop of the sub-batch being built has left the device
+    bool chained_valid = false;    // ... recorded in this call, under a running fill
     void* h_state = nullptr;  // pinned copy of the builder's BandDevPair array
     size_t h_state_cap = 0;
     void* io[6] = {};  // x, y, x_off, y_off, out, ops on the device
@@ -229,6 +231,7 @@ void bg_band_scratch_free(bg_band_scratch* b) {
     if (b->copy_stream) hipStreamDestroy(b->copy_stream);
     if (b->build_stream) hipStreamDestroy(b->build_stream);
     if (b->seq_ready) hipEventDestroy(b->seq_ready);
+    if (b->chained) hipEventDestroy(b->chained);
     delete b;
 }
 
@@ -294,7 +297,10 @@ using BandMaker = std::function<bool(uint64_t, bgband::Band&, bgband::Workspace&
 // join under a fill) waits for that one's last block to be dispatched, whatever streams the two were launched on
 // (profiles/r05_banded_timeline_hostsync.txt: the next fill's preparation started 1.3 ms after the join two sub-batches
 // ahead ended, every cycle).  So the join goes to the low-priority queues, a fill's preparation to the high-priority
-// ones, and neither can sit in front of the other or of the fill.  BG_BAND_STREAM_PRIO=0: all normal (rounds 2-4).
+// ones, and neither can sit in front of the other or of the fill: the gap between two fills drops from 10.8 to 1.9 ms
+// (profiles/r05_banded_timeline_prio.txt) — and the call gains nothing, because the join that used to run in that gap now
+// starves under two fills in a row and the chaining behind it starts late (profiles/r05_banded_pipeline_experiments.txt).
+// BG_BAND_STREAM_PRIO=0: all normal (rounds 2-4).
 int band_stream_create(hipStream_t* s, int level) {
     static const int on = [] { const char* e = getenv("BG_BAND_STREAM_PRIO"); return e ? atoi(e) : 1; }();
     int lo = 0, hi = 0;
@@ -490,7 +496,7 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
     // traceback + aux per scratch set (two sets): 40 GB each on an otherwise empty 288 GB part — but no more than a third of
     // what the device has free now plus what the sets already hold (a smaller or shared GPU, a torch caching allocator next
     // to the engine): a smaller budget cuts the sub-batches (`take < want` below) instead of failing bg_reserve with OOM
-    uint64_t budget = 40ull << 30;
+    uint64_t budget = (ctx->band_budget_gb > 0 ? (uint64_t)ctx->band_budget_gb : 40ull) << 30;
     {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
@@ -512,6 +518,7 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
     if (!B.build_stream) {
         BG_HIP(hipStreamCreateWithFlags(&B.build_stream, hipStreamNonBlocking));
         BG_HIP(hipEventCreateWithFlags(&B.seq_ready, hipEventDisableTiming));
+        BG_HIP(hipEventCreateWithFlags(&B.chained, hipEventDisableTiming));
         for (auto& s : B.set) {
             BG_HIP(hipEventCreateWithFlags(&s.built, hipEventDisableTiming));
             BG_HIP(hipEventCreateWithFlags(&s.matched, hipEventDisableTiming));
@@ -529,6 +536,7 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
     if (!B.copy_stream && (rc = band_stream_create(&B.copy_stream, -1))) return rc;
     hipStream_t st_join = ctx->band_join_serial ? st_build : B.copy_stream;
     for (auto& s : B.set) s.built_valid = false;
+    B.chained_valid = false;
     uint64_t waited_join = 0;
     // The preparation of a fill — the pair table's upload, the waits for the band, the cleared aux block and the sequences,
     // and K3v2's phase 1 (the strips before the interior runs) — does not depend on the fill before it, but on the fill
@@ -573,6 +581,12 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
         if ((rc = need_seq(st_join, waited_join, p0 + want))) return rc;
         // this parity's arrays were last read by the raster of two sub-batches ago
         if (st_join != st_build && n_chunk >= 2 && B.set[n_chunk & 1].built_valid) BG_HIP(hipStreamWaitEvent(st_join, B.set[n_chunk & 1].built, 0));
+        // `band_join_late` = 1 (A/B, round 5): this join starts when the chaining of the sub-batch before it has left the
+        // device.  Under a running fill the registers two fill wavefronts per SIMD leave hold EITHER that chaining OR this
+        // join plus a part of it, and whichever is dispatched first keeps the other one in rounds.  Measured: ordering them
+        // costs more than the race (279 against 265 ms per 100 000 pairs: the join then starves behind the raster and K4
+        // instead, and the next chaining starts late) — the default leaves the dispatch order to the hardware.
+        if (st_join != st_build && B.chained_valid && ctx->band_join_late) BG_HIP(hipStreamWaitEvent(st_join, B.chained, 0));
         void** db = B.db[n_chunk & 1];
         size_t* db_cap = B.db_cap[n_chunk & 1];
         uint32_t max_m = 0, max_n = 0;
@@ -703,6 +717,10 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
             // overlap K4 of sub-batch c.
             if (B.started_target) launch_band_wait_started(B.d_started, B.started_target, st_build);
             if ((rc = launch_band_chain(d, st_build, 2))) return rc;
+            if (B.started_target) {
+                BG_HIP(hipEventRecord(B.chained, st_build));
+                B.chained_valid = true;
+            }
             if (ctx->band_raster_late && n_chunk >= 1 && B.set[(n_chunk - 1) & 1].busy) {  // (the raster does not have to wait for the fill's epilogue)
                 bg_band_scratch::Set& prev = B.set[(n_chunk - 1) & 1];
                 BG_HIP(hipStreamWaitEvent(st_build, prev.fill_gone_valid ? prev.fill_gone : prev.filled, 0));
@@ -874,6 +892,7 @@ static int banded_batch_impl(bg_ctx* ctx, const bg_scoring_t* sc, int mode, uint
                             max_y < 65536 && target - thresh >= (1 << 14)) ? 1 : 0;
                 a.pk_thresh = (int32_t)ctx->band_packed_thresh;
                 a.redo_count = B.d_started + 1;
+                a.p_block512 = ctx->band_p_block512 ? 1 : 0;
             }
             if (on_device) B.started_target += band_fill2_blocks(a.n_pairs);
             // K3v2 / K3p (K3i): eight pairs per wavefront; the epilogue goes to the traceback stream, ahead of K4 — the fill

@@ -63,8 +63,16 @@ __device__ __forceinline__ pk row_shr1_first(pk first, pk v) {
 // 0xffff in every half that is non-zero
 __device__ __forceinline__ pk nz_mask(pk v, pk one) { return pk_sub(pk_subs(one, v), one); }
 
-template <int R, int LP>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void banded_fill2p_kernel(const BandArgs a) {
+// WB: wavefronts per block.  4: round 4's launch (187 VGPRs, two blocks per CU) — the default.  8 (`band_p_block512`): ONE
+// block per CU compiled for 168 VGPRs (the compiler parks 14 values of the strip prologue in scratch; the step loops are
+// the same instructions), so that two fill wavefronts per SIMD leave 176 VGPRs and the chaining of the next sub-batch
+// (chain_rows_kernel: 40 VGPRs, four wavefronts per SIMD for 16 384 pairs) is resident as a whole next to the fill instead
+// of three wavefronts in four.  Measured in round 5 (profiles/r05_banded_pipeline_experiments.txt): the chaining does
+// drop from 22 to 16 ms under the fill, the fill itself runs 3 % longer, and the call does not gain — what runs next to a
+// fill (chaining, raster, join, K4: ~7 900 VGPR-ms per SIMD and sub-batch) does not fit the registers a fill leaves
+// (176 x 30 ms) whatever the order; the rest runs in the gap between two fills, which is what the cycle already does.
+template <int R, int LP, int WB>
+__global__ __launch_bounds__(64 * WB) __attribute__((amdgpu_waves_per_eu(WB == 8 ? 3 : 2, WB == 8 ? 3 : 2))) void banded_fill2p_kernel(const BandArgs a) {
     constexpr int RING = 32;   // bytes of LDS per row and pair, indexed by step (banded_fill2i.hip)
     constexpr int FLUSH = 16;  // steps between two hand-overs of complete 16-byte groups == the blocks of the Sn / Ly merge
     static_assert(LP == 16, "a block of 16 steps is one chunk: lane ll prepares / hands over step t0 + ll");
@@ -72,12 +80,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // ((h * R + r) * 8 + d) * 256 + L * 4 of the wavefront's 8 KB — whatever dword the lanes touch, lane L is in bank L (no
     // padding: two blocks are 68 KB, and the 91 KB k-mer join of the next sub-batch fits next to them, banded_api.hip)
     constexpr int WAVE_LDS = 64 * 2 * R * RING;
-    __shared__ __align__(16) uint8_t s_tb_all[4 * WAVE_LDS];
+    __shared__ __align__(16) uint8_t s_tb_all[WB * WAVE_LDS];
     uint8_t* const s_row = s_tb_all + (threadIdx.x >> 6) * WAVE_LDS + (threadIdx.x & 63) * 4;
     auto ring_at = [&](int hr, uint32_t byte) -> uint8_t* { return s_row + ((uint32_t)hr * 8u + (byte >> 2)) * 256u + (byte & 3u); };
     // the strip's last row on its way to bnd: (S, I) of both pairs per step, eight steps per lane group (33 KB per block in
     // all, what K3i takes: the LDS of a CU is handed out in pieces, and one more of them per block keeps the join out)
-    __shared__ uint2 s_hand_all[256 / LP][8];
+    __shared__ uint2 s_hand_all[64 * WB / LP][8];
     constexpr int32_t NEGS = kNarrowFloor * 16;
     auto to_s = [](int32_t v) -> int32_t {  // the reference's integers -> the scaled domain (K3v2's map)
         if (v <= NEG / 2) return NEGS + (int32_t)((uint32_t)(max(v, NEG - (1 << 20)) - NEG) << 4);
@@ -92,7 +100,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int g = lane / LP, ll = lane % LP;
     uint2* const s_hand = s_hand_all[threadIdx.x / LP];
     // (the host counts K3i-sized blocks of 32 pairs: launch_band_wait_started)
-    if (a.started && threadIdx.x == 0) atomicAdd(a.started, (uint32_t)(8 * PW / 32));
+    if (a.started && threadIdx.x == 0) atomicAdd(a.started, (uint32_t)(2 * WB * PW / 32));
     const uint32_t job = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if ((uint64_t)job * 2 * PW >= a.n_pairs) return;  // wave-uniform
     const SwScoring sc = a.sc;
@@ -500,8 +508,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 void launch_fill2p(const BandArgs& a, hipStream_t st) {
     // 16 lanes x 2 rows per pair couple: 8 pairs per wavefront, K3i's grid (two wavefronts per SIMD at 16 384 pairs)
-    constexpr uint32_t per_block = 4 * 2 * (64 / 16);
-    banded_fill2p_kernel<2, 16><<<dim3((a.n_pairs + per_block - 1) / per_block), dim3(256), 0, st>>>(a);
+    if (a.p_block512) {
+        constexpr uint32_t per_block = 8 * 2 * (64 / 16);
+        banded_fill2p_kernel<2, 16, 8><<<dim3((a.n_pairs + per_block - 1) / per_block), dim3(512), 0, st>>>(a);
+    } else {
+        constexpr uint32_t per_block = 4 * 2 * (64 / 16);
+        banded_fill2p_kernel<2, 16, 4><<<dim3((a.n_pairs + per_block - 1) / per_block), dim3(256), 0, st>>>(a);
+    }
 }
 
 }  // namespace bgband_dev

@@ -97,6 +97,7 @@ struct BandArgs {
     int32_t redo;       // K3v2 phase 1 / K3i: only the pairs K3p flagged (aux[5] != 0)
     int32_t pk_thresh;  // K3p: the threshold a band cell's key has to exceed (0: derived from the scoring; tests raise it)
     uint32_t* redo_count;  // K3p counts the pairs it flags here (nullptr: nobody asks)
+    int32_t p_block512;    // K3p in blocks of eight wavefronts at 168 VGPRs (banded_fill2p.hip) instead of four at 187
 };
 
 // Interior run of a pair: the strips [s_a, s_b) of RS rows each that banded_fill2i_kernel takes with its reduced cell.

@@ -85,6 +85,9 @@ struct bg_ctx {
     bool band_tail_last = false;   // A/B: the remainder sub-batch of a large banded call runs last (round 3) instead of first
     bool band_window = false;      // A/B: K3i on 64-byte rings, and the fill waits for the next sub-batch's join + preparation (round 3's window between two fills)
     bool band_raster_late = false; // A/B: the raster of sub-batch c + 1 waits for fill c to leave the device (round 3)
+    bool band_join_late = false;  // A/B: the k-mer join of sub-batch c + 2 waits for the chaining of c + 1 to leave the device (round 5: measured slower)
+    bool band_p_block512 = false;  // A/B: K3p in blocks of eight wavefronts compiled for 168 VGPRs instead of four at 187 (round 5: measured 3 % slower)
+    int64_t band_budget_gb = 0;  // traceback + aux bytes per scratch set of the banded pipeline, in GB (0: 40)
     bool band_on_host = false;  // build bands with the host builder (band_host.cpp) instead of band_device.hip
     // the scratch above is one set per ctx: a *_dev call arriving on another stream than the previous one first
     // waits (on the device) for that call's last kernel — see bg_scratch_guard

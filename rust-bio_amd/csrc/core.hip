@@ -257,6 +257,19 @@ extern "C" int bg_set_option(bg_ctx* ctx, const char* key, int64_t value) {
         ctx->band_raster_late = value != 0;
         return BG_OK;
     }
+    if (!strcmp(key, "band_join_late")) {
+        ctx->band_join_late = value != 0;
+        return BG_OK;
+    }
+    if (!strcmp(key, "band_p_block512")) {
+        ctx->band_p_block512 = value != 0;
+        return BG_OK;
+    }
+    if (!strcmp(key, "band_budget_gb")) {
+        if (value < 0 || value > 256) return BG_ERR_INVALID_ARG;
+        ctx->band_budget_gb = value;
+        return BG_OK;
+    }
     if (!strcmp(key, "band_on_host")) {
         ctx->band_on_host = value != 0;
         return BG_OK;

@@ -11,9 +11,12 @@ from rust_bio_amd import synth_gpu
 from rust_bio_amd.pairwise import Scoring
 from rust_bio_amd.banded import Aligner as BandedAligner
 Pb = int(sys.argv[2]) if len(sys.argv) > 2 else 16384
+OPTS = [a.split("=") for a in sys.argv[3:]]  # ctx options, name=value
 Lb, kb, wb = 10_000, 16, 32
 dev = torch.device("cuda:0")
 ctx = _lib.Context(0)
+for k_, v_ in OPTS:
+    ctx.set_option(k_, int(v_))
 bx, bxo, by, byo = synth_gpu.sw_pairs_big(Pb, Lb, seed=4, device=dev, sub=0.06, ins=0.02, dele=0.02, chunk=64)
 bal = BandedAligner.with_scoring(Scoring.from_scores(-5, -1, 1, -1), kb, wb, ctx=ctx)
 d_boff = torch.arange(Pb + 1, dtype=torch.int64, device=dev) * Lb
