@@ -546,6 +546,235 @@ __global__ __launch_bounds__(256) void fm_search_fast_kernel(FmDev fm, uint64_t 
     if (COUNT && t == 0 && n_lines) atomicAdd(seeds.lines, (unsigned long long)n_lines);
 }
 
+// K5x — fm_search_fast2x_kernel: fm_search_fast_kernel<STEP2> with TWO queries per quad (round 5).  With its requests
+// halved the search waits neither for memory throughput nor for the vector unit (0.60 of the 128-byte gather rate at
+// 3 Gbp, VALU 31 % busy, eight wavefronts per SIMD — the most the hardware holds): it waits for the latency of one block
+// access per step, and the only parallelism left to add is inside a wavefront.  Every quad walks two independent queries:
+// phase A computes the block addresses of both and issues their loads — all of them unconditional and in one basic block,
+// so that the second query's requests leave before the first one's data is waited for (the line of l - 1 is requested even
+// where it is the line of r: a hit in the vector cache) — phase B ranks and updates both.  Stream (quad, u) takes queries
+// (quad * 2 + u) + k * (quads * 2); results, deferral and LDS pattern slots as in fm_search_fast_kernel.
+// Measured (profiles/r05_fm_ilp.txt, 10 M x 100 bp): 846 -> 1076 M queries/s on the 100 Mbp index, 608 -> 794 M at 3 Gbp
+// (packed patterns 908 -> 1121 and 657 -> 860).  86 VGPRs: five wavefronts per SIMD, ten queries in flight per SIMD-slot
+// against eight.  More is not better: three queries per quad (116 VGPRs, four wavefronts: twelve) reach 988 / 752, four
+// (147: three wavefronts) 838 / 673, and the same two queries compiled for six wavefronts (80 VGPRs, three values in
+// scratch) 1006 / 715 — the optimum is where this kernel sits.
+template <bool SEEDS, bool COUNT, bool PACKED, int U>
+__global__ __launch_bounds__(256) void fm_search_fast2x_kernel(FmDev fm, uint64_t n_q, const uint8_t* __restrict__ pat,
+                                                               const uint64_t* __restrict__ pat_off, uint8_t* __restrict__ tag,
+                                                               uint64_t* __restrict__ lower, uint64_t* __restrict__ upper,
+                                                               uint32_t* __restrict__ matched_len, const SeedSrc seeds, const Fm2Dev f2) {
+    constexpr uint32_t SLOT = kFastSyms / 16;  // dwords per pattern slot
+    __shared__ uint16_t s_class[256];
+    __shared__ uint32_t s_less4[4];
+    __shared__ uint32_t s_pk[64 * U * SLOT + 1];  // (+1: the 2-step funnel reads one dword past a slot's last)
+    __shared__ uint32_t s_c2[16], s_e2pos[kMaxExc2], s_e2nib[kMaxExc2];
+    for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) s_class[i] = fm.sym_class[i];
+    if (threadIdx.x < 4) s_less4[threadIdx.x] = fm.less[(seeds.code_bytes >> (8 * threadIdx.x)) & 0xFFu];
+    if (threadIdx.x == 0) s_pk[64 * U * SLOT] = 0;
+    if (threadIdx.x < 16) s_c2[threadIdx.x] = f2.c2[threadIdx.x];
+    if (threadIdx.x < kMaxExc2) {
+        s_e2pos[threadIdx.x] = f2.exc_pos[threadIdx.x];
+        s_e2nib[threadIdx.x] = f2.exc_nib[threadIdx.x];
+    }
+    __syncthreads();
+
+    const uint32_t t = threadIdx.x & 3;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t n_streams = (uint64_t)gridDim.x * (blockDim.x >> 2) * U;
+    struct St {
+        uint64_t q;
+        uint32_t pos, l, r, matched;
+        bool active, need, force1;
+    };
+    St S[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        S[u].q = ((uint64_t)blockIdx.x * (blockDim.x >> 2) + (threadIdx.x >> 2)) * U + u;
+        S[u].pos = S[u].l = S[u].r = S[u].matched = 0;
+        S[u].active = false;
+        S[u].need = true;
+        S[u].force1 = false;
+    }
+    uint32_t n_lines = 0;
+
+    // taking the next query of stream u: a job of the whole wavefront, one waiting quad at a time (fm_search_fast_kernel)
+    auto fetch_all = [&](St& s, const int u) {
+        uint64_t waiting = __ballot(s.need && t == 0);
+        while (waiting) {
+            const uint32_t leader = (uint32_t)__ffsll((unsigned long long)waiting) - 1u;
+            const bool mine = (lane >> 2) == (leader >> 2);
+            const uint64_t qs = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(s.q >> 32), leader) << 32) |
+                                (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)s.q, leader);
+            if (qs >= n_q) {
+                if (mine) {
+                    s.need = false;
+                    s.active = false;
+                }
+                waiting &= waiting - 1;
+                continue;
+            }
+            uint64_t off;
+            uint32_t len;
+            if (SEEDS) {
+                const uint64_t rd = qs / seeds.S;
+                const uint32_t k = (uint32_t)(qs - rd * seeds.S);
+                const uint64_t o = pat_off[rd];
+                off = o + (uint64_t)k * seeds.stride;
+                len = (uint64_t)k * seeds.stride + seeds.seed_len <= pat_off[rd + 1] - o ? seeds.seed_len : 0u;
+            } else {
+                off = pat_off[qs];
+                const uint64_t len64 = pat_off[qs + 1] - off;
+                len = len64 > kFastSyms ? kFastSyms + 1 : (uint32_t)len64;
+            }
+            bool bad = len > kFastSyms;
+            uint32_t* const dst = s_pk + ((((threadIdx.x >> 6) * 16) + (leader >> 2)) * U + u) * SLOT;
+            if (PACKED && len && !bad) {
+                const uint32_t* pk = (const uint32_t*)pat;
+                if (lane < ((len + 15u) >> 4)) {
+                    const uint64_t w0 = (off >> 4) + lane;
+                    const uint32_t sh = 2u * ((uint32_t)off & 15u);
+                    const uint32_t lo = pk[w0], hi = pk[w0 + 1];  // the stream is padded by one dword
+                    dst[lane] = sh ? (lo >> sh) | (hi << (32u - sh)) : lo;
+                }
+            } else if (len && !bad) {
+                for (uint32_t base = 0; base < len; base += 64) {
+                    const uint32_t idx = base + lane;
+                    uint32_t c = 0;
+                    if (idx < len) {
+                        c = s_class[pat[off + idx]];
+                        bad = bad || c >= 4;
+                    }
+                    uint32_t word = (c & 3u) << (2 * (lane & 15u));
+                    word |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)word, 0x111 /*row_shr:1*/, 0xf, 0xf, true);
+                    word |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)word, 0x112 /*row_shr:2*/, 0xf, 0xf, true);
+                    word |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)word, 0x114 /*row_shr:4*/, 0xf, 0xf, true);
+                    word |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)word, 0x118 /*row_shr:8*/, 0xf, 0xf, true);
+                    if ((lane & 15u) == 15u && base + (lane & ~15u) < len) dst[(base >> 4) + (lane >> 4)] = word;
+                }
+                bad = __any(bad);
+            }
+            if (len == 0 || bad) {  // empty: Absent (fmindex.rs:185-207); a byte without a code / too long: the generic kernel's
+                if (lane == leader) {
+                    if (len == 0) {
+                        tag[qs] = (uint8_t)BG_FM_ABSENT;
+                        lower[qs] = 0;
+                        upper[qs] = 0;
+                        matched_len[qs] = 0;
+                    } else {
+                        tag[qs] = kTagDeferred;
+                    }
+                }
+                if (mine) s.q += n_streams;  // the same stream takes the next one in the next turn of this loop
+                continue;
+            }
+            if (mine) {
+                s.pos = len;
+                s.l = 0;
+                s.r = fm.n - 1;  // fmindex.rs:148
+                s.matched = 0;
+                s.active = true;
+                s.need = false;
+                s.force1 = false;
+            }
+            waiting &= waiting - 1;
+        }
+    };
+    auto emit = [&](uint64_t q, uint32_t tg, uint32_t lo, uint32_t hi, uint32_t ml) {
+        if (t == 0) {
+            tag[q] = (uint8_t)tg;
+            lower[q] = lo;
+            upper[q] = hi;
+            matched_len[q] = ml;
+        }
+    };
+    for (;;) {
+        bool any_active = false;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (__any(S[u].need)) fetch_all(S[u], u);
+            any_active |= S[u].active;
+        }
+        if (!__any(any_active)) break;
+        // ---- phase A: the symbols and the block loads of both streams (a stream without a query reads block 0)
+        uint4 rc[U], rs[U], lc[U], ls[U];
+        uint32_t c[U], p2[U], orr[U], ol[U], lm1[U];
+        bool single[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const St& s = S[u];
+            single[u] = s.force1 || s.pos == 1;
+            p2[u] = s.active ? s.pos - (single[u] ? 1u : 2u) : 0u;
+            const uint32_t* const slot = s_pk + ((threadIdx.x >> 2) * U + u) * SLOT;
+            const uint32_t ix = p2[u] >> 4;
+            const uint32_t cc = __builtin_amdgcn_alignbit(slot[ix + 1], slot[ix], 2 * (p2[u] & 15u));
+            c[u] = single[u] ? (cc & 3u) << 2 : (cc & 15u);
+            lm1[u] = s.l ? s.l - 1 : 0u;
+            const uint32_t r_ = s.active ? s.r : 0u, l_ = s.active ? lm1[u] : 0u;
+            const uint32_t br = r_ / kSym2PerBlock, bl = l_ / kSym2PerBlock;
+            orr[u] = r_ % kSym2PerBlock;
+            ol[u] = l_ % kSym2PerBlock;
+            rc[u] = f2.blocks2[(uint64_t)br * 8 + t];
+            rs[u] = f2.blocks2[(uint64_t)br * 8 + 4 + t];
+            lc[u] = f2.blocks2[(uint64_t)bl * 8 + t];
+            ls[u] = f2.blocks2[(uint64_t)bl * 8 + 4 + t];
+            if (COUNT && s.active) n_lines += bl != br ? 2u : 1u;
+        }
+        // ---- phase B: fmindex.rs:160-182, twice per block access (see fm_search_fast_kernel<STEP2>)
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            St& s = S[u];
+            if (!s.active) continue;
+            const uint32_t k = single[u] ? 1u : 2u;
+            const uint32_t base = single[u] ? s_less4[c[u] >> 2] : s_c2[c[u]];
+            const Pair2Key key2 = pair2_key(c[u], single[u]);
+            uint32_t occ_r = quad_sum(block2_part(rc[u], rs[u], t, orr[u], c[u], single[u], key2));
+            uint32_t occ_l = quad_sum(block2_part(lc[u], ls[u], t, ol[u], c[u], single[u], key2));
+            {
+                const uint32_t key = single[u] ? 16u : c[u];
+                const uint32_t e0 = f2.exc_pos[0], n0 = single[u] ? (f2.exc_nib[0] & 16u) | (c[u] ? 32u : 0u) : (f2.exc_nib[0] & 15u);
+                const uint32_t e1 = f2.exc_pos[1], n1 = single[u] ? (f2.exc_nib[1] & 16u) | (c[u] ? 32u : 0u) : (f2.exc_nib[1] & 15u);
+                occ_r -= (n0 == key && e0 <= s.r) ? 1u : 0u;
+                occ_l -= (n0 == key && e0 <= lm1[u]) ? 1u : 0u;
+                occ_r -= (n1 == key && e1 <= s.r) ? 1u : 0u;
+                occ_l -= (n1 == key && e1 <= lm1[u]) ? 1u : 0u;
+                for (uint32_t e = 2; e < f2.n_exc; e++) {  // (uniform)
+                    const uint32_t pe = s_e2pos[e], ne = s_e2nib[e];
+                    const uint32_t nk = single[u] ? (ne & 16u) | (c[u] ? 32u : 0u) : (ne & 15u);
+                    occ_r -= (nk == key && pe <= s.r) ? 1u : 0u;
+                    occ_l -= (nk == key && pe <= lm1[u]) ? 1u : 0u;
+                }
+            }
+            occ_l = s.l ? occ_l : 0u;
+            const bool empty = occ_r == occ_l;
+            if (empty && !single[u]) {
+                s.force1 = true;  // nothing changes: the two single steps that follow say how the query ends
+            } else if (empty) {
+                if (s.matched)
+                    emit(s.q, BG_FM_PARTIAL, s.l, s.r + 1, s.matched);
+                else
+                    emit(s.q, BG_FM_ABSENT, 0, 0, 0);
+                s.need = true;
+            } else {
+                s.l = base + occ_l;  // fmindex.rs:171 (twice for a double step)
+                s.r = base + occ_r - 1;
+                s.pos = p2[u];
+                s.matched += k;
+                if (s.pos == 0) {
+                    emit(s.q, BG_FM_COMPLETE, s.l, s.r + 1, s.matched);
+                    s.need = true;
+                }
+            }
+            if (s.need) {
+                s.q += n_streams;
+                s.active = false;
+                s.force1 = false;
+            }
+        }
+    }
+    if (COUNT && t == 0 && n_lines) atomicAdd(seeds.lines, (unsigned long long)n_lines);
+}
+
 // jump-table construction: every kJumpK-mer over the four coded bytes as a pattern ...
 __global__ __launch_bounds__(256) void fm_jump_patterns_kernel(uint32_t code_byte, uint8_t* pat, uint64_t* pat_off) {
     const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1094,6 +1323,16 @@ extern "C" uint64_t bg_fm_step2_bytes(const bg_fm* fm) {
 static bool fm_fast_ok(const bg_fm* fm) { return !fm->dev.n_dense && fm->n_codes == 4 && !fm->no_fast; }
 // ... and the index has 2-step rank blocks (fm_step2.hip): the fast kernels take two symbols per block access
 static bool fm_step2_ok(const bg_fm* fm) { return fm->dev2.blocks2 != nullptr && !fm->no_step2; }
+// grid of fm_search_fast2x_kernel: persistent blocks, as many as are resident (its registers decide), 128 queries each
+template <typename K>
+static uint64_t fm_2x_blocks(K kernel, uint64_t n_q, int u) {
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+    return std::min<uint64_t>((n_q + 64 * (uint64_t)u - 1) / (64 * (uint64_t)u), 256ull * (uint64_t)per_cu);
+}
+#define FM_LAUNCH_2X(SEEDS, COUNT, PACKED, ...)                                                                                  \
+    fm_search_fast2x_kernel<SEEDS, COUNT, PACKED, 2><<<dim3((unsigned)fm_2x_blocks(fm_search_fast2x_kernel<SEEDS, COUNT, PACKED, 2>, n_q, 2)), \
+                                                       dim3(256), 0, st>>>(__VA_ARGS__)
 static SeedSrc fm_codes(const bg_fm* fm) {
     SeedSrc ex{};
     ex.code_bytes = (uint32_t)fm->code_byte[0] | (uint32_t)fm->code_byte[1] << 8 | (uint32_t)fm->code_byte[2] << 16 |
@@ -1105,6 +1344,11 @@ extern "C" int bg_fm_set_option(bg_fm* fm, const char* key, int64_t value) {
     if (!fm || !key) return BG_ERR_INVALID_ARG;
     if (!strcmp(key, "no_step2")) {  // searches take single steps only, whether the index has 2-step blocks or not (tests, A/B)
         fm->no_step2 = value != 0;
+        return BG_OK;
+    }
+    if (!strcmp(key, "ilp")) {  // queries per quad of the 2-step search: 1 fm_search_fast_kernel, 2 fm_search_fast2x_kernel (A/B)
+        if (value != 1 && value != 2) return BG_ERR_INVALID_ARG;
+        fm->ilp = (int)value;
         return BG_OK;
     }
     if (!strcmp(key, "jump_min_queries")) {  // batch size from which K5 builds / uses its jump table; < 0: never (default)
@@ -1201,7 +1445,9 @@ extern "C" int bg_fm_backward_search_batch_dev(bg_fm* fm, uint64_t n_q, const ui
     } else if (fm_fast_ok(fm)) {
         // DNA-like index: patterns become 2-bit codes in LDS when a quad takes them; what that path cannot hold (a byte
         // outside the four codes, more than kFastSyms symbols) is left to the generic kernel behind it
-        if (fm_step2_ok(fm))
+        if (fm_step2_ok(fm) && fm->ilp >= 2)
+            FM_LAUNCH_2X(false, false, false, fm->dev, n_q, d_pat, d_pat_off, d_tag, d_lower, d_upper, d_matched_len, fm_codes(fm), fm->dev2);
+        else if (fm_step2_ok(fm))
             fm_search_fast_kernel<false, false, false, true><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(
                 fm->dev, n_q, d_pat, d_pat_off, d_tag, d_lower, d_upper, d_matched_len, fm_codes(fm), fm->dev2);
         else
@@ -1238,7 +1484,9 @@ int bg_fm_search_seeds_dev(bg_fm* fm, uint64_t n_reads, const uint8_t* d_reads, 
     bg_ctx* ctx = fm->ctx;
     if (ctx && ctx->timing) BG_HIP(hipEventRecord(ctx->ev[0], st));
     if (fm_fast_ok(fm) && seed_len <= kFastSyms) {
-        if (fm_step2_ok(fm))
+        if (fm_step2_ok(fm) && fm->ilp >= 2)
+            FM_LAUNCH_2X(true, false, false, fm->dev, n_q, d_reads, d_read_off, d_tag, d_lower, d_upper, d_matched_len, src, fm->dev2);
+        else if (fm_step2_ok(fm))
             fm_search_fast_kernel<true, false, false, true><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(fm->dev, n_q, d_reads, d_read_off, d_tag,
                                                                                                          d_lower, d_upper, d_matched_len, src, fm->dev2);
         else
@@ -1284,7 +1532,9 @@ extern "C" int bg_fm_backward_search_packed_dev(bg_fm* fm, uint64_t n_q, const u
     const SeedSrc ex = fm_codes(fm);
     if (ctx->timing) BG_HIP(hipEventRecord(ctx->ev[0], st));
     if (!fm->no_fast) {  // the LDS-slot kernel; patterns beyond its 256 symbols are left to the generic packed kernel
-        if (fm_step2_ok(fm))
+        if (fm_step2_ok(fm) && fm->ilp >= 2)
+            FM_LAUNCH_2X(false, false, true, fm->dev, n_q, (const uint8_t*)d_packed, d_sym_off, d_tag, d_lower, d_upper, d_matched_len, ex, fm->dev2);
+        else if (fm_step2_ok(fm))
             fm_search_fast_kernel<false, false, true, true><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(
                 fm->dev, n_q, (const uint8_t*)d_packed, d_sym_off, d_tag, d_lower, d_upper, d_matched_len, ex, fm->dev2);
         else
@@ -1327,7 +1577,9 @@ extern "C" int bg_fm_backward_search_count_lines_dev(bg_fm* fm, uint64_t n_q, co
         SeedSrc ex = fm_codes(fm);
         ex.lines = d_cnt;
         if (fm_fast_ok(fm)) {
-            if (fm_step2_ok(fm))
+            if (fm_step2_ok(fm) && fm->ilp >= 2)
+            FM_LAUNCH_2X(false, true, false, fm->dev, n_q, d_pat, d_pat_off, d_tag, d_lower, d_upper, d_matched_len, ex, fm->dev2);
+            else if (fm_step2_ok(fm))
                 fm_search_fast_kernel<false, true, false, true><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(fm->dev, n_q, d_pat, d_pat_off, d_tag,
                                                                                                             d_lower, d_upper, d_matched_len, ex, fm->dev2);
             else

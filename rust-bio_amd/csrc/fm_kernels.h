@@ -207,6 +207,7 @@ struct bg_fm {
     bgfm::Fm2Dev dev2 = {};      // 2-step rank blocks (fm_kernels.h), built behind the index by fm_build_step2
     void* d_blocks2 = nullptr;
     bool no_step2 = false;       // option "no_step2": searches take single steps only (tests, A/B)
+    int ilp = 2;                 // option "ilp": queries per quad of the 2-step search (1: fm_search_fast_kernel; 2-4: fm_search_fast2x_kernel)
     void* d_blocks = nullptr;
     void* d_exc_pos = nullptr;
     void* d_exc_sym_pos = nullptr;

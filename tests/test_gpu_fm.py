@@ -296,25 +296,34 @@ def test_two_step_rank_blocks_equal_single_steps_and_the_oracle(text_kind):
             p[-2] = acgt[(int(np.searchsorted(acgt, p[-2])) + 2) % 4]
         elif kind == 5:
             p = p[:int(rng.integers(1, 3))]  # one or two symbols
+        elif kind == 6 and q % 40 == 6:
+            p = p[:0]                        # empty: Absent without a search
+        elif kind == 7 and q % 40 == 7:
+            p[int(rng.integers(0, ln))] = ord("N")  # a byte without a 2-bit code: left to the generic kernel
         pats.append(bytes(p))
     pat, off = _lib.concat(pats)
     d_pat = torch.from_numpy(pat.copy()).to("cuda:0")
     d_off = torch.from_numpy(off.astype(np.int64)).to("cuda:0")
     n_q = len(pats)
 
-    def run(no_step2):
+    def run(no_step2, ilp=1):
         fm.set_option("no_step2", no_step2)
+        fm.set_option("ilp", ilp)
         tag = torch.full((n_q,), 77, dtype=torch.uint8, device="cuda:0")
         lo, hi = torch.zeros(n_q, dtype=torch.int64, device="cuda:0"), torch.zeros(n_q, dtype=torch.int64, device="cuda:0")
         ml = torch.zeros(n_q, dtype=torch.int32, device="cuda:0")
         fm.backward_search_dev(n_q, d_pat.data_ptr(), d_off.data_ptr(), tag.data_ptr(), lo.data_ptr(), hi.data_ptr(), ml.data_ptr())
         torch.cuda.synchronize()
         fm.set_option("no_step2", 0)
+        fm.set_option("ilp", 2)
         return tag.cpu().numpy(), lo.cpu().numpy(), hi.cpu().numpy(), ml.cpu().numpy()
 
     two, one = run(0), run(1)
     for a, c in zip(two, one):
         assert (a == c).all()
+    for ilp in (2,):  # two queries per quad (fm_search_fast2x_kernel; the default)
+        for a, e in zip(two, run(0, ilp=ilp)):
+            assert (a == e).all(), ilp
     otag, olo, ohi, oml = orc.backward_search_batch(b, ls, orc.Occ(b, 64, alpha), pat, off, threads=8)
     tag, lo, hi, ml = two
     assert (tag == otag).all() and (lo == olo.astype(np.int64)).all() and (hi == ohi.astype(np.int64)).all()

@@ -66,7 +66,8 @@ def test_backward_search_on_packed_patterns_equals_the_byte_flavour_and_the_orac
     pk, bad = pack2.pack_dev(d_pat, codes=codes)
     assert bad == 0
     outs = []
-    for packed in (False, True):
+    for packed, ilp in ((False, 1), (True, 1), (False, 2), (True, 2)):  # (ilp: queries per quad, fm_search_fast2x_kernel from 2 on)
+        fm.set_option("ilp", ilp)
         tag = torch.empty(n_q, dtype=torch.uint8, device=DEV)
         lo, hi = torch.empty(n_q, dtype=torch.int64, device=DEV), torch.empty(n_q, dtype=torch.int64, device=DEV)
         ml = torch.empty(n_q, dtype=torch.int32, device=DEV)
@@ -76,8 +77,8 @@ def test_backward_search_on_packed_patterns_equals_the_byte_flavour_and_the_orac
             fm.backward_search_dev(n_q, d_pat.data_ptr(), d_off.data_ptr(), tag.data_ptr(), lo.data_ptr(), hi.data_ptr(), ml.data_ptr())
         torch.cuda.synchronize()
         outs.append((tag.cpu().numpy(), lo.cpu().numpy(), hi.cpu().numpy(), ml.cpu().numpy()))
-    for a, c in zip(*outs):
-        assert (a == c).all()
+    for cols in zip(*outs):
+        assert all((cols[0] == c).all() for c in cols[1:])
     otag, olo, ohi, oml = orc.backward_search_batch(b, ls, orc.Occ(b, 128, b"ACGTNacgtn"), pat, off, threads=8)
     t, lo, hi, ml = outs[1]
     assert (t == otag).all() and (lo.astype(np.uint64) == olo).all() and (hi.astype(np.uint64) == ohi).all() and (ml.astype(np.uint64) == oml).all()
@@ -85,7 +86,10 @@ def test_backward_search_on_packed_patterns_equals_the_byte_flavour_and_the_orac
     tag = torch.empty(n_q, dtype=torch.uint8, device=DEV)
     lo_t, hi_t = torch.empty(n_q, dtype=torch.int64, device=DEV), torch.empty(n_q, dtype=torch.int64, device=DEV)
     ml_t = torch.empty(n_q, dtype=torch.int32, device=DEV)
+    fm.set_option("ilp", 2)
     lines = fm.backward_search_count_lines_dev(n_q, d_pat.data_ptr(), d_off.data_ptr(), tag.data_ptr(), lo_t.data_ptr(), hi_t.data_ptr(), ml_t.data_ptr())
+    fm.set_option("ilp", 1)
+    assert lines == fm.backward_search_count_lines_dev(n_q, d_pat.data_ptr(), d_off.data_ptr(), tag.data_ptr(), lo_t.data_ptr(), hi_t.data_ptr(), ml_t.data_ptr())
     assert (tag.cpu().numpy() == otag).all() and (lo_t.cpu().numpy().astype(np.uint64) == olo).all()
     steps = int(oml.sum()) + int((otag != 0).sum())
     # (an index with 2-step rank blocks — this one — takes two LF steps per block access)
