@@ -773,9 +773,9 @@ def fm_legs(args, ctx, dev, stream, rank, world, do_cpu, orc, threads, parity, r
                                         "blocks (bg_suffix_array_dev, bg_bwt_dev, bg_sa_sample_dev, bg_fm_build_dev)"},
               "tags": {"complete": int((d_tag == 0).sum().item()), "partial": int((d_tag == 1).sum().item()),
                        "absent": int((d_tag == 2).sum().item())},
-              "roofline": {"bound": "hbm", "kernel": "fm_search_fast_kernel", "achieved": None,
+              "roofline": {"bound": "hbm", "kernel": "fm_search_fast2x_kernel", "achieved": None,
                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
-                           "traffic": pmc_traffic("fm_search_fast_kernel", "fm_queries_per_launch", n_q),
+                           "traffic": pmc_traffic("fm_search_fast2x_kernel", "fm_queries_per_launch", n_q),
                            "launch_ms": round(fm_ms, 4), "queries_per_launch": n_q,
                            "alg_bytes_survey_per_query": round(survey_bytes / n_q, 1),
                            "note": "the 33 MB block index of a 100 Mbp text sits in the 256 MiB Infinity Cache: see fm_big "
@@ -909,7 +909,7 @@ def fm_big_leg(args, ctx, dev, stream, rank, world, do_cpu, orc, threads, parity
                       "bwt_samples_blocks_s": round(bt["bwt_samples_blocks_s"], 2),
                       "host_peak_rss_gb": round(resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6, 1)},
            "tags": {"complete": int((d_tag == 0).sum().item()), "partial": int((d_tag == 1).sum().item())},
-           "roofline": {"bound": "hbm", "kernel": "fm_search_fast_kernel", "achieved": None,
+           "roofline": {"bound": "hbm", "kernel": "fm_search_fast2x_kernel", "achieved": None,
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
                         "traffic": fm_big_traffic(n_q, fm.device_bytes()),
                         "launch_ms": round(ms, 4), "queries_per_launch": n_q,

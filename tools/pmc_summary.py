@@ -88,6 +88,7 @@ if cal_lines:
 
 # access shape of the engine kernels that carry a roofline: (kernel substring, FETCH shape, WRITE shape); first match wins
 KERNEL_SHAPES = [
+    ("fm_search_fast2x_kernel", "k_gather128x4", "k_store8"),       # two queries per quad on the 2-step blocks (round 5: the default)
     ("fm_search_fast_kernel<STEP2>", "k_gather128x4", "k_store8"),  # the last template argument: 128-byte lines, two LF steps each
     ("fm_search_fast_kernel", "k_quadload", "k_store8"),                                  # 1-step blocks: 64-byte lines
     ("fm_backward_search_kernel", "k_quadload", "k_store8"),
@@ -136,7 +137,7 @@ res["ingest_bytes_per_call"] = fq / 4.0
 big = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for k, vs in per_kernel(os.path.join(out, "big_" + c)).get(c, {}).items():
-        if "fm_search_fast_kernel" in k and "fm_search_fast_kernel<true" not in k and (c not in big or len(vs) > big[c]["launches"]):
+        if ("fm_search_fast_kernel" in k or "fm_search_fast2x_kernel" in k) and "_kernel<true" not in k and (c not in big or len(vs) > big[c]["launches"]):
             big[c] = entry(k, c, vs)   # the byte flavour of the whole-pattern search (the SEEDS flavour belongs to seed_extend)
 logf = os.path.join(out, "big_FETCH_SIZE.log")
 if big and os.path.exists(logf):
@@ -148,7 +149,7 @@ if big and os.path.exists(logf):
             big["alg_bytes_per_launch"] = fb["roofline"]["alg_bytes_per_query"] * fb["roofline"]["queries_per_launch"]
     res["fm_big"] = big
 # the seed-and-extend leg of the same passes: every kernel of bg_seed_extend_batch_dev, bytes per call
-SE_KERNELS = ("se_", "sa_sampled_get", "sa_raw", "interval_rows", "fm_search_fast_kernel<true", "fm_backward_search_kernel<false, true",
+SE_KERNELS = ("se_", "sa_sampled_get", "sa_raw", "interval_rows", "fm_search_fast_kernel<true", "fm_search_fast2x_kernel<true", "fm_backward_search_kernel<false, true",
               "semiglobal", "sw_fill_pk16", "sw_traceback_kernel")
 se = {"kernels": {}}
 tot_bytes = 0.0
