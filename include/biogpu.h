@@ -66,7 +66,8 @@ typedef enum {
     BG_ERR_TOO_LARGE = -8,       /* text > 2^40 symbols (>= 2^32 - 1 for the uint32 suffix-array flavours), or sequence too long for the engine */
     BG_ERR_OPS_CAP = -9,         /* caller's ops buffer too small (ops_used reports the need) */
     BG_ERR_TRACEBACK = -10,      /* traceback did not terminate (reference would loop forever) */
-    BG_ERR_UNSUPPORTED = -11     /* legal for rust-bio, not yet covered by the device layout */
+    BG_ERR_UNSUPPORTED = -11,    /* legal for rust-bio, not yet covered by the device layout */
+    BG_ERR_IO = -12              /* bg_fm_save / bg_fm_load: the file cannot be opened, is truncated, or fails its checksum */
 } bg_status;
 
 #define BG_MIN_SCORE (-858993459) /* pairwise::MIN_SCORE, mod.rs:174 */
@@ -162,6 +163,15 @@ int bg_fm_build_dev(bg_ctx* ctx, const uint8_t* d_bwt, uint64_t n, uint32_t occ_
                     uint32_t n_sym, uint64_t* less_out, bg_fm** out, void* stream);
 int bg_fm_free(bg_fm* fm);
 uint64_t bg_fm_device_bytes(const bg_fm* fm);
+/* Index persistence.  The reference derives Serialize / Deserialize for Occ (bwt.rs:76), FMIndex (fmindex.rs:214) and
+ * SampledSuffixArray (suffix_array.rs:124): an index is built once per genome and loaded afterwards.  bg_fm_save writes what
+ * the reference's FMIndex holds — the BWT (read back out of the rank blocks), less, the alphabet and k — plus the suffix
+ * array attached to the handle (raw, or sampled with its extra rows) and the text if the handle owns a copy
+ * (bg_fm_set_text); bg_fm_load lays the index out again (the rank blocks are cheap: csrc/fm_persist.hip) and attaches
+ * them: the loaded handle answers every call like the saved one.  The file is the engine's own format (little-endian,
+ * checksummed), not serde's.  BG_ERR_IO: cannot open / truncated / altered. */
+int bg_fm_save(const bg_fm* fm, const char* path);
+int bg_fm_load(bg_ctx* ctx, const char* path, bg_fm** out);
 /* Bytes of the index's 2-step rank blocks (128-byte lines: 16 pair counters + 128 four-bit pair codes per 128 BWT
  * positions; built behind DNA-like indexes whose `less` is the BWT's own, fm_step2.hip) that the searches take two
  * pattern symbols per block access from; 0: single steps (no such blocks, or bg_fm_set_option "no_step2" = 1). */

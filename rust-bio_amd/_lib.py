@@ -13,7 +13,7 @@ CSRC = os.path.join(_HERE, "csrc")
 BG_OK = 0
 ERRORS = {-1: "INVALID_ARG", -2: "NO_DEVICE", -3: "HIP", -4: "OOM", -5: "SENTINEL",
           -6: "POSITIVE_PENALTY", -7: "OUT_OF_ALPHABET", -8: "TOO_LARGE", -9: "OPS_CAP",
-          -10: "TRACEBACK", -11: "UNSUPPORTED"}
+          -10: "TRACEBACK", -11: "UNSUPPORTED", -12: "IO"}
 MIN_SCORE = -858993459
 
 
@@ -95,7 +95,7 @@ SYMBOLS = ["bg_device_count", "bg_init", "bg_free", "bg_strerror", "bg_last_erro
            "bg_pack2_dev", "bg_unpack2_dev", "bg_fm_pattern_codes", "bg_fm_backward_search_packed_dev",
            "bg_fm_backward_search_count_lines_dev", "bg_align_batch_packed_dev", "bg_fm_step2_bytes",
            "bg_shard_range", "bg_shard_balanced", "bg_comm_unique_id", "bg_comm_init", "bg_comm_init_host",
-           "bg_gather_records", "bg_gather_records_cap", "bg_gather_records_host", "bg_comm_free"]
+           "bg_gather_records", "bg_gather_records_cap", "bg_gather_records_host", "bg_comm_free", "bg_fm_save", "bg_fm_load"]
 
 
 def build(force=False):
@@ -130,6 +130,8 @@ def lib():
         L.bg_less.argtypes = [vp, u64, vp, u32, vp, C.POINTER(u32)]
         L.bg_fm_build.argtypes = [vp, vp, u64, vp, u32, u32, vp, u32, C.POINTER(vp)]
         L.bg_fm_free.argtypes = [vp]
+        L.bg_fm_save.argtypes = [vp, C.c_char_p]
+        L.bg_fm_load.argtypes = [vp, C.c_char_p, C.POINTER(vp)]
         L.bg_fm_build_dev.argtypes = [vp, vp, u64, u32, vp, u32, vp, C.POINTER(vp), vp]
         L.bg_fm_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
         L.bg_fm_device_bytes.restype = u64

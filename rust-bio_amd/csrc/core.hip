@@ -179,6 +179,7 @@ extern "C" const char* bg_strerror(int s) {
         case BG_ERR_OPS_CAP: return "operations buffer too small";
         case BG_ERR_TRACEBACK: return "traceback did not terminate";
         case BG_ERR_UNSUPPORTED: return "not supported by the device layout";
+        case BG_ERR_IO: return "index file cannot be opened, is truncated or fails its checksum";
         default: return "unknown status";
     }
 }

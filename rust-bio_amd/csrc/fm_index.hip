@@ -853,9 +853,9 @@ static void assign_classes(const uint64_t hist[256], const bool in_alpha[256], F
     }
 }
 
-extern "C" int bg_fm_build(bg_ctx* ctx, const uint8_t* bwt, uint64_t n, const uint64_t* less,
-                           uint32_t less_len, uint32_t occ_k, const uint8_t* alphabet,
-                           uint32_t n_sym, bg_fm** out) {
+static int fm_build_host_impl(bg_ctx* ctx, const uint8_t* bwt, uint64_t n, const uint64_t* less,
+                              uint32_t less_len, uint32_t occ_k, const uint8_t* alphabet,
+                              uint32_t n_sym, bg_fm** out) {
     if (!ctx || !bwt || !less || !alphabet || !out || n == 0 || n_sym == 0 || occ_k == 0)
         return BG_ERR_INVALID_ARG;
     if (n > (1ull << 40)) return BG_ERR_TOO_LARGE;
@@ -1115,8 +1115,8 @@ __global__ __launch_bounds__(256) void fmb_sparse_kernel(const uint8_t* __restri
 
 }  // namespace
 
-extern "C" int bg_fm_build_dev(bg_ctx* ctx, const uint8_t* d_bwt, uint64_t n, uint32_t occ_k, const uint8_t* alphabet, uint32_t n_sym,
-                               uint64_t* less_out, bg_fm** out, void* stream) {
+static int fm_build_dev_impl(bg_ctx* ctx, const uint8_t* d_bwt, uint64_t n, uint32_t occ_k, const uint8_t* alphabet, uint32_t n_sym,
+                             uint64_t* less_out, bg_fm** out, void* stream) {
     if (!ctx || !d_bwt || !alphabet || !out || n == 0 || n_sym == 0 || occ_k == 0) return BG_ERR_INVALID_ARG;
     if (n > (1ull << 40)) return BG_ERR_TOO_LARGE;
     if (n >= fm_wide_threshold(ctx))  // 64-bit positions (fm_wide.hip)
@@ -1290,6 +1290,26 @@ extern "C" int bg_fm_build_dev(bg_ctx* ctx, const uint8_t* d_bwt, uint64_t n, ui
     fm_build_step2(fm, st);  // 2-step rank blocks (fm_step2.hip): less[] is this builder's own
     *out = fm;
     return BG_OK;
+}
+
+// the exported builders: the implementations above + what bg_fm_save needs to write the index out again (fm_persist.hip)
+extern "C" int bg_fm_build(bg_ctx* ctx, const uint8_t* bwt, uint64_t n, const uint64_t* less, uint32_t less_len, uint32_t occ_k,
+                           const uint8_t* alphabet, uint32_t n_sym, bg_fm** out) {
+    const int rc = fm_build_host_impl(ctx, bwt, n, less, less_len, occ_k, alphabet, n_sym, out);
+    if (rc == BG_OK && out && *out) fm_remember_inputs(*out, alphabet, n_sym, occ_k, less, less_len);
+    return rc;
+}
+extern "C" int bg_fm_build_dev(bg_ctx* ctx, const uint8_t* d_bwt, uint64_t n, uint32_t occ_k, const uint8_t* alphabet, uint32_t n_sym,
+                               uint64_t* less_out, bg_fm** out, void* stream) {
+    uint32_t max_symbol = 0;
+    for (uint32_t i = 0; alphabet && i < n_sym; i++) max_symbol = std::max<uint32_t>(max_symbol, alphabet[i]);
+    std::vector<uint64_t> less(max_symbol + 2, 0);
+    const int rc = fm_build_dev_impl(ctx, d_bwt, n, occ_k, alphabet, n_sym, less.data(), out, stream);
+    if (rc == BG_OK && out && *out) {
+        fm_remember_inputs(*out, alphabet, n_sym, occ_k, less.data(), (uint32_t)less.size());
+        if (less_out) memcpy(less_out, less.data(), less.size() * 8);
+    }
+    return rc;
 }
 
 extern "C" int bg_fm_free(bg_fm* fm) {

@@ -3,6 +3,7 @@
 #ifndef BG_FM_KERNELS_H
 #define BG_FM_KERNELS_H
 #include <mutex>
+#include <vector>
 
 #include "bg_common.h"
 
@@ -245,7 +246,12 @@ struct bg_fm {
     bool wide = false;
     bgfm::FmWideDev wdev = {};
     void* d_sb = nullptr;
+    // what the handle was built from, for bg_fm_save (fm_persist.hip): the reference's FMIndex holds the same
+    std::vector<uint8_t> alphabet;
+    std::vector<uint64_t> h_less;
+    uint32_t occ_k = 0;
 };
+void fm_remember_inputs(bg_fm* fm, const uint8_t* alphabet, uint32_t n_sym, uint32_t occ_k, const uint64_t* less, uint32_t less_len);
 
 // fm_wide.hip: the index with 64-bit positions (built from a BWT in HBM; `less` null: the BWT's own cumulative counts)
 int fm_wide_build_dev(bg_ctx* ctx, const uint8_t* d_bwt, uint64_t n, const uint8_t* alphabet, uint32_t n_sym, const uint64_t* less,

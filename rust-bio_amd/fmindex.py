@@ -1,5 +1,6 @@
 """FMIndex / backward_search — reference: src/data_structures/fmindex.rs:69-248."""
 import ctypes as C
+import os
 from dataclasses import dataclass
 
 import numpy as np
@@ -153,6 +154,23 @@ class FMIndex:
     def interval_occ_dev(self, n_iv, d_lower, d_out_off, total, d_pos, stream=0):
         _lib.check(_lib.lib().bg_interval_occ_batch_dev(self.h, n_iv, d_lower, d_out_off, total, d_pos, stream),
                    "Interval::occ (dev)")
+
+    def save(self, path):
+        """Serialize (the reference derives it for FMIndex / Occ / SampledSuffixArray: fmindex.rs:214, bwt.rs:76,
+        suffix_array.rs:124): bg_fm_save — BWT, less, alphabet, k, the attached suffix array, the owned text."""
+        _lib.check(_lib.lib().bg_fm_save(self.h, os.fsencode(path)), "FMIndex::serialize")
+
+    @classmethod
+    def load(cls, path, ctx=None):
+        """Deserialize: bg_fm_load — the handle answers like the saved one (search, Interval::occ, seed-and-extend)."""
+        self = cls.__new__(cls)
+        self.ctx = ctx or _lib.default_context()
+        self._bwt = None
+        self._less = None
+        self._d_bwt = None
+        self.h = C.c_void_p()
+        _lib.check(_lib.lib().bg_fm_load(self.ctx.h, os.fsencode(path), C.byref(self.h)), "FMIndex::deserialize")
+        return self
 
     def close(self):
         if self.h:

@@ -34,6 +34,22 @@ impl<'ctx> GpuFMIndex<'ctx> {
         GpuFMIndex { h, _ctx: std::marker::PhantomData }
     }
 
+    /// `Serialize` (the reference derives it for `FMIndex`, `Occ`, `SampledSuffixArray`: fmindex.rs:214, bwt.rs:76,
+    /// suffix_array.rs:124): BWT, less, alphabet, k, the attached suffix array and an owned text, in the engine's file format.
+    pub fn save(&self, path: &std::path::Path) -> std::io::Result<()> {
+        let c = std::ffi::CString::new(path.to_str().expect("path")).expect("path");
+        let rc = unsafe { sys::bg_fm_save(self.h, c.as_ptr()) };
+        if rc == 0 { Ok(()) } else { Err(std::io::Error::new(std::io::ErrorKind::Other, strerror(rc))) }
+    }
+
+    /// `Deserialize`: the loaded index answers every call like the saved one.
+    pub fn load(ctx: &'ctx Context, path: &std::path::Path) -> std::io::Result<Self> {
+        let c = std::ffi::CString::new(path.to_str().expect("path")).expect("path");
+        let mut h = std::ptr::null_mut();
+        let rc = unsafe { sys::bg_fm_load(ctx.raw, c.as_ptr(), &mut h) };
+        if rc == 0 { Ok(GpuFMIndex { h, _ctx: std::marker::PhantomData }) } else { Err(std::io::Error::new(std::io::ErrorKind::Other, strerror(rc))) }
+    }
+
     /// `backward_search` (fmindex.rs:144-208) for many patterns.
     pub fn backward_search_batch(&self, patterns: &[&[u8]]) -> Vec<BackwardSearchResult> {
         let (pat, off) = concat(patterns);

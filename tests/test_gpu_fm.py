@@ -371,3 +371,94 @@ def test_host_entry_packs_patterns_on_the_host_and_falls_back_per_stage():
     sub_off = off[:20001] - off[0]
     otag, olo, ohi, oml = orc.backward_search_batch(b, ls, occ, pat[:int(off[20000])], sub_off, threads=8)
     assert (tag_p[sel] == otag).all() and (lo_p[sel] == olo).all() and (hi_p[sel] == ohi).all() and (ml_p[sel].astype(np.uint64) == oml).all()
+
+
+@pytest.mark.parametrize("kind", ["dna_sampled_text", "dna_raw_sa", "protein_dense", "two_sentinels", "device_built", "wide"])
+def test_index_survives_save_and_load(kind, tmp_path):
+    """bg_fm_save / bg_fm_load (csrc/fm_persist.hip) — the reference derives Serialize / Deserialize for FMIndex, Occ and
+    SampledSuffixArray (fmindex.rs:214, bwt.rs:76, suffix_array.rs:124).  The file holds the BWT (read back out of the rank
+    blocks), less, alphabet, k, the attached suffix array and an owned text; the loaded handle answers backward_search,
+    Interval::occ and seed-and-extend like the saved one — and like the oracle.  Every index layout: 2-bit blocks with
+    listed exceptions, dense symbols (raw BWT kept), several sentinels, built on the device, 64-bit positions; a damaged
+    file is refused (BG_ERR_IO)."""
+    import torch
+    from rust_bio_amd import pipeline
+    from rust_bio_amd.pairwise import Scoring
+    from rust_bio_amd.suffix_array import RawSuffixArray, SampledSuffixArray
+    rng = np.random.default_rng(["dna_sampled_text", "dna_raw_sa", "protein_dense", "two_sentinels", "device_built", "wide"].index(kind) + 50)
+    ctx = _lib.Context(0)
+    alpha = b"ACGTNacgtn"
+    if kind == "wide":
+        ctx.set_option("fm_wide_from", 1)
+        ctx.set_option("fm_wide_sb_shift", 2)
+    if kind == "protein_dense":
+        alpha = b"ACDEFGHIKLMNPQRSTVWY"
+        g = np.append(np.frombuffer(alpha, dtype=np.uint8)[rng.integers(0, 20, size=40_000)], np.uint8(ord("$")))
+    elif kind == "two_sentinels":
+        acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+        fwd = acgt[rng.integers(0, 4, size=20_000)]
+        g = np.concatenate([fwd, np.frombuffer(b"$", np.uint8), np.frombuffer(b"TGCA", dtype=np.uint8)[np.searchsorted(acgt, fwd[::-1])],
+                            np.frombuffer(b"$", np.uint8)])
+    else:
+        g = synth.genome(120_000, 41)
+        g[5000:5040] = ord("N")  # listed exceptions next to the sentinel
+    sa = suffix_array(g)
+    b = bwt(g, sa)
+    ls = less(b, alpha)
+    if kind == "device_built":
+        fm = FMIndex.from_device(torch.from_numpy(np.ascontiguousarray(b)).to("cuda:0"), 32, alpha, ctx=ctx)
+    else:
+        fm = FMIndex(b, ls, Occ(b, 32, alpha), ctx=ctx)
+    if kind == "dna_raw_sa":
+        RawSuffixArray(sa, fm)
+    else:
+        SampledSuffixArray(sa, g, b, 16, fm)
+    with_text = kind == "dna_sampled_text"
+    if with_text:
+        pipeline.attach_text(fm, text=g)
+    path = str(tmp_path / "index.bgfm")
+    fm.save(path)
+    fm2 = FMIndex.load(path, ctx=ctx)
+
+    body = g[:20_000] if kind == "two_sentinels" else g[:-1]
+    pats = []
+    for q in range(3000):
+        ln = int(rng.integers(1, 50))
+        s0 = int(rng.integers(0, len(body) - ln))
+        p = body[s0:s0 + ln].copy()
+        if q % 3 == 1:
+            p[int(rng.integers(0, ln))] = alpha[int(rng.integers(0, 4))]
+        pats.append(bytes(p))
+    pat, off = _lib.concat(pats)
+    a, c = fm.backward_search_arrays(pat, off), fm2.backward_search_arrays(pat, off)
+    for x, y in zip(a, c):
+        assert (np.asarray(x) == np.asarray(y)).all()
+    otag, olo, ohi, oml = orc.backward_search_batch(b, ls, orc.Occ(b, 32, alpha), pat, off, threads=4)
+    tag, lo, hi, ml = c
+    assert (tag == otag).all() and (lo.astype(np.uint64) == olo).all() and (hi.astype(np.uint64) == ohi).all()
+    assert (tag == 0).any() and (tag == 1).any()
+    # Interval::occ through the loaded handle's suffix array = the host suffix array's rows
+    keep = np.nonzero(tag == 0)[0][:500]
+    o1, p1 = fm.interval_occ_arrays(lo[keep], hi[keep])
+    o2, p2 = fm2.interval_occ_arrays(lo[keep], hi[keep])
+    assert (o1 == o2).all() and (p1 == p2).all()
+    want = np.concatenate([np.asarray(sa[int(l):int(h)], dtype=np.uint64) for l, h in zip(lo[keep], hi[keep])])
+    assert (p2 == want).all()
+    if with_text:  # the owned text travelled too: seed-and-extend on the loaded handle
+        reads = [bytes(g[s:s + 100]) for s in rng.integers(0, len(g) - 200, size=200)]
+        rd, ro = _lib.concat(reads)
+        sc = Scoring.from_scores(-5, -1, 1, -1)
+        h1 = pipeline.seed_extend_arrays(fm, sc, rd, ro)
+        h2 = pipeline.seed_extend_arrays(fm2, sc, rd, ro)
+        for x, y in zip(h1, h2):
+            assert (np.asarray(x) == np.asarray(y)).all()
+    # a damaged file is refused: one byte flipped in the BWT section, and a truncated copy
+    raw = bytearray(open(path, "rb").read())
+    raw[len(raw) // 2] ^= 0x01
+    open(path + ".flip", "wb").write(raw)
+    open(path + ".cut", "wb").write(raw[:len(raw) - 16])
+    for bad in (path + ".flip", path + ".cut", path + ".missing"):
+        with pytest.raises(_lib.BiogpuError):
+            FMIndex.load(bad, ctx=ctx)
+    fm.close()
+    fm2.close()
