@@ -7,6 +7,8 @@ import numpy as np
 import torch
 torch.cuda.init()
 from rust_bio_amd import _lib, synth_gpu, pack2
+if os.environ.get("BG_SO"):  # a variant build of the library (A/B of compile-time choices)
+    _lib.SO_PATH = os.path.abspath(os.environ["BG_SO"])
 from rust_bio_amd.fmindex import FMIndex
 from rust_bio_amd.suffix_array import bwt_dev, suffix_array_dev
 n_g = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000_000
