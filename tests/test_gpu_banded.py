@@ -346,7 +346,8 @@ def test_fill_kernel_variants_agree():
         # band_interior_off: K3v2's general step in every strip (by default semiglobal-like scorings take a reduced step
         # in the strips that neither reach column n nor hold row m)
         for opts in ({"band_fill_v1": -1}, {"band_fill_v1": -1, "force_wide": 1}, {"band_fill_v1": 1}, {"band_fill_v1": 0},
-                     {"band_fill_v1": -1, "band_interior_off": 1}, {"band_fill_v1": -1, "band_packed_off": 1}):
+                     {"band_fill_v1": -1, "band_interior_off": 1}, {"band_fill_v1": -1, "band_packed_off": 1},
+                     {"band_fill_v1": -1, "band_p_block512": 1}):  # (round 5: K3p in 512-thread blocks compiled for 168 VGPRs)
             for k_, v_ in opts.items():
                 al.ctx.set_option(k_, v_)
             try:
@@ -440,8 +441,9 @@ def test_interior_runs_long_reads_vs_oracle(case):
             assert n >= 1, (opts, n)
 
 
-@pytest.mark.parametrize("opts", [{}, {"band_tail_last": 1}, {"band_window": 1, "band_raster_late": 1}],
-                         ids=["default", "tail-last", "round3-order"])
+@pytest.mark.parametrize("opts", [{}, {"band_tail_last": 1}, {"band_window": 1, "band_raster_late": 1},
+                                  {"band_join_late": 1, "band_p_block512": 1, "band_budget_gb": 1}],
+                         ids=["default", "tail-last", "round3-order", "round5-experiments"])
 def test_several_sub_batches_and_the_remainder_first(opts):
     """A batch that spans several sub-batches (chunk_pairs = 16, 70 pairs: the remainder of 6 runs first, then four full
     ones) through both entry points: same alignments as the oracle whatever the order of the pipeline's stages, and the
@@ -474,6 +476,8 @@ def test_several_sub_batches_and_the_remainder_first(opts):
     al.align_dev(MODES["custom"], len(xs), dx.data_ptr(), dxo.data_ptr(), dy.data_ptr(), dyo.data_ptr(), d_out.data_ptr(),
                  d_ops.data_ptr(), stride)
     rec = d_out.view(torch.int32).view(len(xs), 16).cpu().numpy()
+    for k_ in list(opts) + ["chunk_pairs"]:  # (the default ctx is shared between Aligners)
+        al.ctx.set_option(k_, 0)
     assert (rec[:, 0] == out["score"]).all()
 
 
