@@ -221,6 +221,152 @@ __global__ __launch_bounds__(256) void fmw_search_kernel(FmWideDev fm, uint64_t 
     }
 }
 
+// The same search with TWO queries per quad (round 5; what fm_search_fast2x_kernel is to the narrow index, fm_index.hip):
+// a step is one dependent block access, eight wavefronts per SIMD are all the hardware holds, and the parallelism left to
+// add is a second independent query inside the wavefront.  Phase A reads both streams' symbols and classes and issues
+// their block loads and superblock bases — unconditional, in one basic block (a stream without a coded symbol reads
+// block 0; the line of l - 1 is requested even where it is the line of r) — phase B ranks and updates both.  Stream
+// (quad, u) takes queries (2 quad + u) + k * 2 quads.  bg_fm_set_option("ilp", 1): the kernel above.
+__global__ __launch_bounds__(256) void fmw_search2x_kernel(FmWideDev fm, uint64_t n_q, const uint8_t* __restrict__ pat,
+                                                           const uint64_t* __restrict__ pat_off, uint8_t* __restrict__ tag,
+                                                           uint64_t* __restrict__ lower, uint64_t* __restrict__ upper,
+                                                           uint32_t* __restrict__ matched_len) {
+    constexpr int U = 2;
+    __shared__ uint16_t s_class[256];
+    __shared__ uint64_t s_less[256];
+    __shared__ uint64_t s_exc[kWideMaxExc];
+    for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) {
+        s_class[i] = fm.sym_class[i];
+        s_less[i] = fm.less[i];
+    }
+    for (uint32_t i = threadIdx.x; i < fm.n_exc; i += blockDim.x) s_exc[i] = fm.exc_pos[i];
+    __syncthreads();
+    const uint32_t t = threadIdx.x & 3;
+    const uint64_t n_streams = (uint64_t)gridDim.x * (blockDim.x >> 2) * U;
+    struct St {
+        uint64_t q, off, l, r;
+        uint32_t pos, matched, a_next;
+        bool active;
+    };
+    St S[U];
+    auto emit = [&](uint64_t q, uint32_t tg, uint64_t lo, uint64_t hi, uint32_t ml) {
+        if (t == 0) {
+            tag[q] = (uint8_t)tg;
+            lower[q] = lo;
+            upper[q] = hi;
+            matched_len[q] = ml;
+        }
+    };
+    auto fetch = [&](St& s) {  // the stream's next non-empty query; empty patterns are Absent at once (fmindex.rs:185-207)
+        s.active = false;
+        while (s.q < n_q) {
+            s.off = pat_off[s.q];
+            const uint32_t len = (uint32_t)(pat_off[s.q + 1] - s.off);
+            if (len) {
+                s.pos = len;
+                s.l = 0;
+                s.r = fm.n - 1;  // fmindex.rs:148
+                s.matched = 0;
+                s.a_next = pat[s.off + len - 1];
+                s.active = true;
+                return;
+            }
+            emit(s.q, BG_FM_ABSENT, 0, 0, 0);
+            s.q += n_streams;
+        }
+    };
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        S[u].q = ((uint64_t)blockIdx.x * (blockDim.x >> 2) + (threadIdx.x >> 2)) * U + u;
+        S[u].off = S[u].l = S[u].r = 0;
+        S[u].pos = S[u].matched = S[u].a_next = 0;
+        fetch(S[u]);
+    }
+    for (;;) {
+        bool any_active = false;
+#pragma unroll
+        for (int u = 0; u < U; u++) any_active |= S[u].active;
+        if (!__any(any_active)) break;
+        // ---- phase A
+        uint4 vr[U], vl[U];
+        uint64_t base_r[U], base_l[U], br[U], bl[U];
+        uint32_t orr[U], ol[U], a[U], cls[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            St& s = S[u];
+            a[u] = s.a_next;
+            const uint32_t p1 = s.active ? s.pos - 1u : 0u;
+            if (s.active && p1) s.a_next = pat[s.off + p1 - 1];  // (address independent of the ranks)
+            cls[u] = s_class[a[u]];
+            const bool coded = s.active && cls[u] < 4;
+            const uint64_t r_ = coded ? s.r : 0, l_ = coded && s.l ? s.l - 1 : 0;
+            br[u] = r_ / kSymPerBlock;
+            bl[u] = coded && s.l ? l_ / kSymPerBlock : br[u];
+            orr[u] = (uint32_t)(r_ - br[u] * kSymPerBlock);
+            ol[u] = (uint32_t)(l_ - bl[u] * kSymPerBlock);
+            const uint32_t code = coded ? cls[u] : 0u;
+            vr[u] = fm.blocks[br[u] * 4 + t];
+            vl[u] = fm.blocks[bl[u] * 4 + t];
+            base_r[u] = fm.sb[(br[u] >> fm.sb_shift) * 4 + code];
+            base_l[u] = fm.sb[(bl[u] >> fm.sb_shift) * 4 + code];
+        }
+        // ---- phase B: one iteration of the loop at fmindex.rs:160-182 per stream
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            St& s = S[u];
+            if (!s.active) continue;
+            s.pos -= 1;
+            const uint64_t less_a = s_less[a[u]];
+            uint64_t occ_r = 0, occ_l = 0;
+            bool stop = false;
+            uint32_t stop_tag = BG_FM_PARTIAL;
+            if (cls[u] == kClsPanic) {
+                stop = true;
+                stop_tag = BG_FM_PANIC;
+            } else if (cls[u] < 4) {
+                occ_r = base_r[u] + (uint64_t)quad_sum(block_part(vr[u], t, orr[u], cls[u]));
+                if (s.l > 0) occ_l = base_l[u] + (uint64_t)quad_sum(block_part(vl[u], t, ol[u], cls[u]));
+                if (cls[u] == 0 && fm.n_exc) {  // sparse exceptions sit in the stream as code 0
+                    occ_r -= count_le64(s_exc, 0u, fm.n_exc, s.r);
+                    if (s.l > 0) occ_l -= count_le64(s_exc, 0u, fm.n_exc, s.l - 1);
+                }
+            } else if (cls[u] >= kClsSparse) {  // (no dense symbols on a wide index)
+                const uint32_t e = cls[u] - kClsSparse;
+                const uint32_t lo = fm.sparse_off[e], hi = fm.sparse_off[e + 1];
+                occ_r = count_le64(fm.exc_sym_pos, lo, hi, s.r) - lo;
+                if (s.l > 0) occ_l = count_le64(fm.exc_sym_pos, lo, hi, s.l - 1) - lo;
+            }  // kClsZero: both stay 0
+            const uint64_t pl = s.l, pr = s.r;
+            if (!stop) {
+                if (occ_r == 0) {  // fmindex.rs:167-170
+                    stop = true;
+                } else {
+                    s.l = less_a + occ_l;  // fmindex.rs:171
+                    s.r = less_a + occ_r - 1;
+                    if (s.l > s.r)  // fmindex.rs:177-180
+                        stop = true;
+                    else
+                        s.matched += 1;
+                }
+            }
+            if (stop) {
+                if (stop_tag == BG_FM_PANIC)
+                    emit(s.q, BG_FM_PANIC, 0, 0, s.matched);
+                else if (s.matched)
+                    emit(s.q, BG_FM_PARTIAL, pl, pr + 1, s.matched);
+                else
+                    emit(s.q, BG_FM_ABSENT, 0, 0, 0);
+                s.q += n_streams;
+                fetch(s);
+            } else if (s.pos == 0) {
+                emit(s.q, BG_FM_COMPLETE, s.l, s.r + 1, s.matched);
+                s.q += n_streams;
+                fetch(s);
+            }
+        }
+    }
+}
+
 struct SaWideDev {
     const uint64_t* sa;         // raw SA or the samples
     const uint64_t* extra_row;  // sorted
@@ -504,8 +650,15 @@ int fm_wide_build_dev(bg_ctx* ctx, const uint8_t* d_bwt, uint64_t n, const uint8
 
 int fm_wide_search_dev(bg_fm* fm, uint64_t n_q, const uint8_t* d_pat, const uint64_t* d_pat_off, uint8_t* d_tag, uint64_t* d_lower,
                        uint64_t* d_upper, uint32_t* d_matched_len, hipStream_t st) {
-    const uint64_t blocks = std::min<uint64_t>((n_q + 63) / 64, 256 * 8);
-    fmw_search_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(fm->wdev, n_q, d_pat, d_pat_off, d_tag, d_lower, d_upper, d_matched_len);
+    if (fm->ilp >= 2) {  // two queries per quad (the default)
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fmw_search2x_kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+        const uint64_t blocks = std::min<uint64_t>((n_q + 127) / 128, 256ull * (uint64_t)per_cu);
+        fmw_search2x_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(fm->wdev, n_q, d_pat, d_pat_off, d_tag, d_lower, d_upper, d_matched_len);
+    } else {
+        const uint64_t blocks = std::min<uint64_t>((n_q + 63) / 64, 256 * 8);
+        fmw_search_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(fm->wdev, n_q, d_pat, d_pat_off, d_tag, d_lower, d_upper, d_matched_len);
+    }
     BG_HIP(hipGetLastError());
     return BG_OK;
 }

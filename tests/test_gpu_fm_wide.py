@@ -71,6 +71,15 @@ def check_search(fm, b, ls, alphabet, pats):
     torch.cuda.synchronize()
     assert (d_tag.cpu().numpy() == otag).all()
     assert (d_lo.cpu().numpy().astype(np.uint64)[ok] == olo[ok]).all() and (d_hi.cpu().numpy().astype(np.uint64)[ok] == ohi[ok]).all()
+    # ... which runs two queries per quad by default (fmw_search2x_kernel): the one-query kernel answers the same
+    fm.set_option("ilp", 1)
+    d_tag1, d_lo1, d_hi1, d_ml1 = torch.zeros_like(d_tag), torch.zeros_like(d_lo), torch.zeros_like(d_hi), torch.zeros_like(d_ml)
+    fm.backward_search_dev(nq, d_pat.data_ptr(), d_off.data_ptr(), d_tag1.data_ptr(), d_lo1.data_ptr(), d_hi1.data_ptr(), d_ml1.data_ptr())
+    torch.cuda.synchronize()
+    fm.set_option("ilp", 2)
+    assert torch.equal(d_tag, d_tag1) and torch.equal(d_ml, d_ml1)
+    okd = torch.from_numpy(ok).to(DEV)
+    assert torch.equal(d_lo[okd], d_lo1[okd]) and torch.equal(d_hi[okd], d_hi1[okd])
     return tag, lo, hi
 
 

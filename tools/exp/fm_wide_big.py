@@ -117,14 +117,27 @@ def search():
     fm.backward_search_dev(NQ, pat.data_ptr(), off.data_ptr(), d_tag.data_ptr(), d_lo.data_ptr(), d_hi.data_ptr(), d_ml.data_ptr())
 
 
+# the one-query-per-quad kernel first (fm option ilp = 1), then the default (two queries per quad): same arrays
+fm.set_option("ilp", 1)
+search()
+t0 = sync()
+for _ in range(3):
+    search()
+dt1 = (sync() - t0) / 3
+one = (d_tag.clone(), d_lo.clone(), d_hi.clone(), d_ml.clone())
+fm.set_option("ilp", 2)
 search()
 t0 = sync()
 for _ in range(3):
     search()
 dt = (sync() - t0) / 3
+same = bool(torch.equal(one[0], d_tag) and torch.equal(one[3], d_ml) and torch.equal(one[1][d_tag < 2], d_lo[d_tag < 2]) and
+            torch.equal(one[2][d_tag < 2], d_hi[d_tag < 2]))
+del one
 res["search"] = {"queries": NQ, "pattern_len": P, "ms": round(dt * 1e3, 2), "queries_per_s": round(NQ / dt, 1),
                  "complete": int((d_tag == 0).sum()), "partial": int((d_tag == 1).sum()), "absent": int((d_tag == 2).sum()),
-                 "kernel": "fmw_search_kernel (64-bit positions, 1-step blocks, byte patterns)"}
+                 "kernel": "fmw_search2x_kernel (64-bit positions, 1-step blocks, byte patterns, two queries per quad)",
+                 "one_query_per_quad": {"ms": round(dt1 * 1e3, 2), "queries_per_s": round(NQ / dt1, 1), "results_equal": same}}
 res["intervals_with_a_bound_beyond_2_32"] = int(((d_hi > (1 << 32)) & (d_tag < 2)).sum())
 
 # ---- 4b. located positions are occurrences; a query cut from p finds p
