@@ -184,7 +184,11 @@ enum { BG_FM_COMPLETE = 0, BG_FM_PARTIAL = 1, BG_FM_ABSENT = 2,
 /* Options of an index handle: "jump_min_queries" — batch size from which backward search builds (once,
  * 256 MB, synchronously on the first such call's stream, under a lock) and uses a table of the search state
  * after a pattern's last 12 symbols; < 0 disables it.  OFF by default: it buys 2.5 % on an index that sits in
- * the Infinity Cache and nothing on one that does not.  Results do not depend on it. */
+ * the Infinity Cache and nothing on one that does not.  Results do not depend on it.
+ * "ilp" — queries a quad of lanes walks at once in backward search: 2 (default: fm_search_fast2x_kernel on the 2-step blocks
+ * of a DNA-like index, fmw_search2x_kernel on a 64-bit index) or 1 (the round-4 kernels; A/B, tests).  "no_step2" = 1 —
+ * single LF steps even where the index has 2-step blocks; "no_fast" = 1 — every search through the generic kernel (tests).
+ * None of them changes a result. */
 int bg_fm_set_option(bg_fm* fm, const char* key, int64_t value);
 
 /* backward_search for n_q patterns (fmindex.rs:144-208).  Pattern q is
