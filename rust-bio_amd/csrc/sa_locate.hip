@@ -151,132 +151,6 @@ __global__ __launch_bounds__(256) void sa_sampled_get_kernel(FmDev fm, SaDev sa,
     }
 }
 
-// The same walk with TWO rows per quad (round 5; what fm_search_fast2x_kernel is to K5): a step of the walk is one
-// dependent block access, and a second independent row inside the wavefront hides it better than more wavefronts.  Phase A
-// issues both rows' loads — the block of rank(pos - 1, .) and the word (or raw byte) holding bwt[pos], unconditional, in one
-// basic block (a row without work reads block 0) — phase B resolves sampled / sentinel rows and takes the LF step.
-// Stream (quad, u) takes rows (2 quad + u) + k * 2 quads.  bg_fm_set_option("ilp", 1): the kernel above.
-__global__ __launch_bounds__(256) void sa_sampled_get2x_kernel(FmDev fm, SaDev sa, uint64_t n, const uint64_t* index, uint64_t* pos_out) {
-    constexpr int U = 2;
-    __shared__ uint16_t s_class[256];
-    __shared__ uint32_t s_less[256];
-    __shared__ uint32_t s_exc[kMaxExcLds];
-    for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) {
-        s_class[i] = fm.sym_class[i];
-        s_less[i] = fm.less[i];
-    }
-    for (uint32_t i = threadIdx.x; i < fm.n_exc; i += blockDim.x) s_exc[i] = fm.exc_pos[i];  // n_exc <= kMaxExcLds
-    __syncthreads();
-    const bool raw_bwt = fm.bwt_raw != nullptr;  // dense symbols exist: the stream's code 0 does not say which byte
-    const uint32_t t = threadIdx.x & 3;
-    const uint64_t n_streams = (uint64_t)gridDim.x * (blockDim.x >> 2) * U;
-    const uint32_t* blocks32 = (const uint32_t*)fm.blocks;
-    struct St {
-        uint64_t q;
-        uint32_t pos, offset;
-        bool active;
-    };
-    St S[U];
-    auto fetch = [&](St& s) {  // the stream's next row inside the text (SuffixArray::get -> None otherwise)
-        s.active = false;
-        while (s.q < n) {
-            const uint64_t r = index[s.q];
-            if (r < fm.n) {
-                s.pos = (uint32_t)r;
-                s.offset = 0;
-                s.active = true;
-                return;
-            }
-            if (t == 0) pos_out[s.q] = BG_SA_NONE;
-            s.q += n_streams;
-        }
-    };
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-        S[u].q = ((uint64_t)blockIdx.x * (blockDim.x >> 2) + (threadIdx.x >> 2)) * U + u;
-        S[u].pos = S[u].offset = 0;
-        fetch(S[u]);
-    }
-    for (;;) {
-        bool any_active = false;
-#pragma unroll
-        for (int u = 0; u < U; u++) any_active |= S[u].active;
-        if (!__any(any_active)) break;
-        // ---- phase A: loads of the rows that take a step
-        uint4 vr[U];
-        uint32_t word[U], ro[U];
-        bool walk[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const St& s = S[u];
-            walk[u] = s.active && (s.pos % sa.rate) != 0;  // (pos % rate != 0 implies pos >= 1)
-            const uint32_t p = walk[u] ? s.pos : 0u, p1 = walk[u] ? s.pos - 1u : 0u;  // (a row without a step reads position 0)
-            const uint32_t pb = p / kSymPerBlock, po = p - pb * kSymPerBlock;
-            const uint32_t rb = p1 / kSymPerBlock;
-            ro[u] = p1 - rb * kSymPerBlock;
-            vr[u] = fm.blocks[(uint64_t)rb * 4 + t];
-            word[u] = raw_bwt ? (uint32_t)fm.bwt_raw[p] : blocks32[(uint64_t)pb * 16 + 4 + (po >> 4)];
-        }
-        // ---- phase B
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            St& s = S[u];
-            if (!s.active) continue;
-            if (!walk[u]) {  // suffix_array.rs:162-164
-                if (t == 0) pos_out[s.q] = (uint64_t)sa.sa[s.pos / sa.rate] + s.offset;
-                s.q += n_streams;
-                fetch(s);
-                continue;
-            }
-            const uint32_t pos = s.pos;
-            uint32_t c;
-            if (raw_bwt) {
-                c = word[u];
-            } else {
-                const uint32_t po = pos % kSymPerBlock;
-                const uint32_t code = (word[u] >> (2 * (po & 15))) & 3u;
-                c = (sa.code_byte >> (8 * code)) & 255u;
-                if (code == 0 && fm.n_exc) {  // sparse exceptions sit in the stream as code 0
-                    const uint32_t e = count_le(s_exc, 0u, fm.n_exc, pos);
-                    if (e > 0 && s_exc[e - 1] == pos) c = sa.exc_byte[e - 1];
-                }
-            }
-            if (c == sa.sentinel) {  // suffix_array.rs:168-175
-                uint32_t lo = 0, hi = sa.n_extra;
-                while (lo < hi) {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    if (sa.extra_row[mid] < pos)
-                        lo = mid + 1;
-                    else
-                        hi = mid;
-                }
-                if (t == 0) pos_out[s.q] = lo < sa.n_extra && sa.extra_row[lo] == pos ? (uint64_t)sa.extra_pos[lo] + s.offset : BG_SA_PANIC;
-                s.q += n_streams;
-                fetch(s);
-                continue;
-            }
-            // pos = less[c] + occ.get(bwt, pos - 1, c)  (suffix_array.rs:177-178)
-            const uint32_t cls = s_class[c];
-            uint32_t occ = 0;
-            if (cls < 4) {
-                occ = quad_sum(block_part(vr[u], t, ro[u], cls));
-                if (cls == 0 && fm.n_exc) occ -= count_le(s_exc, 0u, fm.n_exc, pos - 1);
-            } else if (cls == kClsPanic) {
-            } else if (cls >= kClsDense) {
-                uint32_t o;
-                const uint4 v = bv_load(fm, cls - kClsDense, pos - 1, t, o);
-                occ = quad_sum(bv_part(v, t, o));
-            } else if (cls >= kClsSparse) {
-                const uint32_t e = cls - kClsSparse;
-                const uint32_t lo = fm.sparse_off[e], hi = fm.sparse_off[e + 1];
-                occ = count_le(fm.exc_sym_pos, lo, hi, pos - 1) - lo;
-            }
-            s.pos = s_less[c] + occ;
-            s.offset += 1;
-        }
-    }
-}
-
 int launch_get(bg_fm* fm, uint64_t n, const uint64_t* d_index, uint64_t* d_pos, hipStream_t st) {
     if (n == 0) return BG_OK;
     if (fm->wide) return fm_wide_sa_get(fm, n, d_index, d_pos, st);  // 64-bit positions: fm_wide.hip
@@ -294,15 +168,8 @@ int launch_get(bg_fm* fm, uint64_t n, const uint64_t* d_index, uint64_t* d_pos, 
         sa.sentinel = fm->sa_sentinel;
         sa.code_byte = (uint32_t)fm->code_byte[0] | (uint32_t)fm->code_byte[1] << 8 | (uint32_t)fm->code_byte[2] << 16 |
                        (uint32_t)fm->code_byte[3] << 24;
-        if (fm->ilp >= 2) {  // two rows per quad (the default)
-            int per_cu = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sa_sampled_get2x_kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
-            const uint64_t blocks = std::min<uint64_t>((n + 127) / 128, 256ull * (uint64_t)per_cu);
-            sa_sampled_get2x_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(fm->dev, sa, n, d_index, d_pos);
-        } else {
-            uint64_t blocks = std::min<uint64_t>((n + 63) / 64, 256 * 8);
-            sa_sampled_get_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(fm->dev, sa, n, d_index, d_pos);
-        }
+        uint64_t blocks = std::min<uint64_t>((n + 63) / 64, 256 * 8);
+        sa_sampled_get_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(fm->dev, sa, n, d_index, d_pos);
     }
     BG_HIP(hipGetLastError());
     return BG_OK;

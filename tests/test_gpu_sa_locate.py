@@ -78,11 +78,6 @@ def test_genome_locate_vs_oracle(rate):
     rows = rng.integers(0, len(sa), size=50_000).astype(np.uint64)
     got = ssa.get_batch(rows)
     assert (got == sa[rows.astype(np.intp)]).all()
-    fm.set_option("ilp", 1)  # one row per quad (sa_sampled_get_kernel); the default walks two (sa_sampled_get2x_kernel)
-    got1 = ssa.get_batch(np.append(rows, np.uint64(len(sa) + 5)))  # (+ a row beyond the array: None)
-    fm.set_option("ilp", 2)
-    got2 = ssa.get_batch(np.append(rows, np.uint64(len(sa) + 5)))
-    assert (got1 == got2).all() and (got1[:-1] == got).all() and int(got1[-1]) == 0xFFFFFFFFFFFFFFFF
     # a sample of the same rows through the oracle's restatement of SampledSuffixArray::get
     occ = orc.Occ(b, 32, ALPHA)
     ossa = orc.SampledSuffixArray(sa, text, b, ls, occ, rate)
