@@ -653,7 +653,17 @@ public:
     bg_fm* raw() const { return h_; }
     size_t len() const { return n_; }
 
+    // Serialize / Deserialize (the reference derives them for FMIndex, Occ, SampledSuffixArray: fmindex.rs:214, bwt.rs:76,
+    // suffix_array.rs:124): bg_fm_save / bg_fm_load — BWT, less, alphabet, k, the attached suffix array, an owned text.
+    void save(const std::string& path) const { check(bg_fm_save(h_, path.c_str()), "FMIndex::serialize"); }
+    static std::unique_ptr<FMIndex> load(const std::string& path, std::shared_ptr<Context> ctx = nullptr) {
+        std::unique_ptr<FMIndex> fm(new FMIndex(ctx ? std::move(ctx) : Context::shared_default()));
+        check(bg_fm_load(fm->ctx_->raw(), path.c_str(), &fm->h_), "FMIndex::deserialize");
+        return fm;
+    }
+
 private:
+    explicit FMIndex(std::shared_ptr<Context> ctx) : ctx_(std::move(ctx)), n_(0) {}
     std::shared_ptr<Context> ctx_;
     bg_fm* h_ = nullptr;
     size_t n_;

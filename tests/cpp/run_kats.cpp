@@ -287,6 +287,52 @@ static void kat_pretty_and_seed_extend() {
     }
 }
 
+// ---- Serialize / Deserialize (fmindex.rs:214, bwt.rs:76, suffix_array.rs:124: derived in the reference): a saved and
+// reloaded index answers backward_search, Interval::occ and seed-and-extend like the one that was saved
+static void kat_fmindex_save_and_load() {
+    Text g;
+    uint64_t s = 0x2545F4914F6CDD1Dull;
+    for (int i = 0; i < 6000; i++) {
+        s = s * 6364136223846793005ull + 1442695040888963407ull;
+        g.push_back("ACGT"[(s >> 33) & 3]);
+    }
+    g[1234] = 'N';
+    Text t = g;
+    t.push_back('$');
+    const auto alphabet = alphabets::dna::n_alphabet();
+    const auto sa = suffix_array::suffix_array(t);
+    const auto b = bwt::bwt(t, sa);
+    fmindex::FMIndex fm(b, bwt::less(b, alphabet), bwt::Occ(b, 3, alphabet));
+    fm.attach(sa);
+    fm.attach_text(t);
+    const std::string path = "/tmp/biogpu_kat_index.bgfm";
+    fm.save(path);
+    const auto fm2 = fmindex::FMIndex::load(path);
+    std::vector<Text> pats;
+    for (int q = 0; q < 200; q++) {
+        s = s * 6364136223846793005ull + 1442695040888963407ull;
+        const size_t at = (s >> 20) % 5900, len = 1 + (s >> 50) % 40;
+        Text p(g.begin() + at, g.begin() + at + len);
+        if (q % 3 == 0) p[len / 2] = p[len / 2] == 'A' ? 'C' : 'A';
+        pats.push_back(p);
+    }
+    const auto r1 = fm.backward_search_batch(pats), r2 = fm2->backward_search_batch(pats);
+    CHECK(r1 == r2);
+    std::vector<fmindex::Interval> ivs;
+    for (auto& r : r2)
+        if (r.kind == fmindex::BackwardSearchResult::Complete) ivs.push_back(r.interval);
+    CHECK(!ivs.empty());
+    CHECK(fm.occ_batch(ivs) == fm2->occ_batch(ivs));
+    for (auto& iv : ivs) CHECK(iv.occ(*fm2) == iv.occ(sa));
+    const auto scoring = pairwise::Scoring::from_scores(-5, -1, 1, -1);
+    const Text r0(g.begin() + 2000, g.begin() + 2100);
+    const auto h1 = fm.seed_extend_batch(scoring, {r0}), h2 = fm2->seed_extend_batch(scoring, {r0});
+    CHECK(h2[0].alignment && h1[0].alignment && h2[0].alignment->score == h1[0].alignment->score);
+    CHECK_EQ(h2[0].ref_start, (size_t)2000);
+    CHECK(panics([] { fmindex::FMIndex::load("/tmp/biogpu_kat_index.missing"); }));
+    std::remove(path.c_str());
+}
+
 int main(int argc, char** argv) {
     const char* filter = argc > 1 ? argv[1] : "";
     int ran = 0;
@@ -310,6 +356,7 @@ int main(int argc, char** argv) {
     run("kat_fmdindex_smems", kat_fmdindex_smems);
     run("kat_fastq_reader_and_cigar", kat_fastq_reader_and_cigar);
     run("kat_pretty_and_seed_extend", kat_pretty_and_seed_extend);
+    run("kat_fmindex_save_and_load", kat_fmindex_save_and_load);
     std::printf("%d tests, %d failed\n", ran, g_failed);
     return g_failed ? 1 : 0;
 }
