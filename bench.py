@@ -154,6 +154,28 @@ class Gatherer:
         assert [int(c) for c in got] == [int(c) for c in counts], (got, counts)
         return out
 
+    def proof(self, local=None, counts=None):
+        """What ran, read back from the library (bg_comm_world -> ncclCommCount / ncclCommUserRank, the path of the last gather)
+        and, given a leg's records, the gather alone timed with HIP events on the stream it is queued on: the line answers
+        "did RCCL see N ranks" and "what did the collective cost" by itself."""
+        if self.world == 1 or self.comm is None:
+            return {"rccl_ranks": 0, "why": self.why or "1 GPU"}
+        out = self.comm.world_info()
+        out["ragged_path_used"] = out["last_path"] == "grouped_broadcast"
+        if local is not None:
+            st = torch.cuda.ExternalStream(self.stream) if self.stream else torch.cuda.current_stream()
+            self.gather(local, counts)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record(st)
+            for _ in range(5):
+                self.gather(local, counts)
+            e1.record(st)
+            torch.cuda.synchronize()
+            out["gather_ms"] = round(e0.elapsed_time(e1) / 5, 4)
+            out["gather_bytes_per_rank_out"] = int(sum(counts)) * local.element_size() * int(np.prod(local.shape[1:], dtype=np.int64))
+        return out
+
     def check(self, local, counts):
         """the same records through torch.distributed: must be identical"""
         if self.world == 1 or self.comm is None:
@@ -477,6 +499,11 @@ def main():
                                      "affine-gap (-5,-1,+1,-1), score+coords+traceback ops (BASELINE configs[1])",
                          "pairs_per_gpu": n_pairs, "read_len": L, "parallelism": f"shard{world}"},
               "roofline": roofline}
+    if world > 1:  # the headline step's collective, proven from the library's side (bg_comm_world) and timed alone
+        rec5 = d_out.view(torch.int32).view(n_pairs, 16)[:, :5].contiguous()
+        result["collective"] = GATHER.kind
+        result["collective_proof"] = GATHER.proof(rec5, [n_pairs] * world)
+        del rec5
     if host_api:
         result["host_api"] = host_api
     # A/B: the same pairs as 2-bit streams (bg_pack2_dev + bg_align_batch_packed_dev: K1p loads codes instead of bytes)
@@ -809,7 +836,7 @@ def fm_legs(args, ctx, dev, stream, rank, world, do_cpu, orc, threads, parity, r
     fm_res["strong"] = {"value": round(float(n_q) * args.steps / st_t, 1), "unit": "queries/s", "scaling": "strong",
                         "ms_per_step": round(st_t / args.steps * 1e3, 3), "queries_total": n_q, "queries_per_gpu": my,
                         "collective": GATHER.kind, "record_bytes": 24,
-                        "gathered_records": int(holder["all"].shape[0])}
+                        "gathered_records": int(holder["all"].shape[0]), "collective_proof": GATHER.proof(holder["rec"], counts)}
     if world == 1 and n_q >= 8:
         # an eighth of the queries in one call: what one GPU of eight sees of configs[2] in the strong leg — bounds the 8-GPU
         # strong-scaling efficiency of this leg from one GPU (launch of 1.25 M queries against the steady rate of 10 M)
@@ -1020,7 +1047,7 @@ def seed_extend_leg(args, ctx, dev, stream, rank, world, do_cpu, orc, threads, p
         leg["strong"] = {"value": round(float(Rt) * s_steps / st_t, 1), "unit": "reads/s", "scaling": "strong",
                          "ms_per_step": round(st_t / s_steps * 1e3, 3), "steps": s_steps, "reads_total": Rt, "reads_per_gpu": my,
                          "collective": GATHER.kind, "record_bytes": 24,
-                         "gathered_records": int(holder["all"].shape[0]),
+                         "gathered_records": int(holder["all"].shape[0]), "collective_proof": GATHER.proof(holder["rec"], counts),
                          "note": "records only (score + reference span); the winners' operations stay on the rank that "
                                  "computed them (INTEGRATION.md section 3)"}
         if world > 1:  # the gathered records of the sharded run must be the unsharded answer
@@ -1163,7 +1190,7 @@ def banded_leg(args, ctx, dev, rank, world, do_cpu, orc, threads, parity):
         torch.cuda.synchronize()
         strong = {"value": round(tot_cells / st_t / 1e9, 3), "unit": "GCUPS (band cells)", "scaling": "strong",
                   "pairs_total": Pb, "pairs_per_gpu": my, "pairs_per_s": round(Pb / st_t, 1),
-                  "collective": GATHER.kind, "record_bytes": 20,
+                  "collective": GATHER.kind, "record_bytes": 20, "collective_proof": GATHER.proof(holder["rec"], counts),
                   "capi_gather_equals_torch_gather": GATHER.check(holder["rec"], counts),
                   "sharded_equals_unsharded": bool((sharded == d_bout.view(torch.int32).view(Pb, 16)[:, :5]).all().item())}
         del gx, gy, sx, sy

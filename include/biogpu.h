@@ -104,6 +104,15 @@ const char* bg_last_error(void); /* text of the last HIP failure on this thread 
  *   band_join_global = 1  k-mer join with its table in global memory even where the LDS flavour applies
  *   band_join_late = 1    the k-mer join of a sub-batch waits for the chaining of the one before it (A/B: measured slower)
  *   band_p_block512 = 1   K3p in blocks of eight wavefronts compiled for 168 VGPRs instead of four at 187 (A/B: measured slower)
+ *   band_chain_rows    global-tree chaining with four pairs per wavefront (chain_rows_kernel; default 1) or one (0: A/B, tests)
+ *   band_host_sync = 1 the chaining of a sub-batch is launched after a host wait for K4 of two sub-batches ago (rounds 2-4)
+ *                      instead of a stream wait (A/B)
+ *   fm_wide_from       texts of this many symbols or more get the 64-bit index layout (default 2^32 - 1; tests lower it so
+ *                      that small texts exercise csrc/fm_wide.hip); 0 restores the default
+ *   fm_wide_sb_shift   log2 of the rank blocks per superblock of the 64-bit layout (default 17; 0 .. 24; tests use small
+ *                      values so that short texts span many superblocks)
+ *   sa_chunk_symbols   suffixes sorted per pass of round 0 of bg_suffix_array_dev[64] (0 = derived from free device memory;
+ *                      tests use small values so that short texts take several passes)
  *   band_budget_gb     traceback + aux bytes per scratch set of the banded pipeline, in GB (0 = default: 40, and never more
  *                      than a third of the device's free memory); a sub-batch that does not fit is cut
  * Unknown keys return BG_ERR_INVALID_ARG. */
@@ -172,6 +181,16 @@ uint64_t bg_fm_device_bytes(const bg_fm* fm);
  * checksummed), not serde's.  BG_ERR_IO: cannot open / truncated / altered. */
 int bg_fm_save(const bg_fm* fm, const char* path);
 int bg_fm_load(bg_ctx* ctx, const char* path, bg_fm** out);
+/* What a handle says about itself — a loaded handle comes without the caller-side arrays it was built from, and the
+ * reference's FMDIndex::from(fmindex) (fmindex.rs:311-329) reads the BWT of whatever FMIndex it is given, deserialized
+ * or not.  bg_fm_len: the text length n (FMIndex's bwt.len()).  bg_fm_less: the `less` array the index answers with
+ * (less_out may be NULL to query *less_len = max_symbol + 2).  bg_fm_bwt / bg_fm_bwt_dev: the n BWT bytes, read back
+ * out of the rank blocks (2-bit codes -> bytes, listed exceptions put back) into host / device memory; the device
+ * flavour is asynchronous on `stream`. */
+int bg_fm_len(const bg_fm* fm, uint64_t* n);
+int bg_fm_less(const bg_fm* fm, uint64_t* less_out, uint32_t* less_len);
+int bg_fm_bwt(const bg_fm* fm, uint8_t* bwt);
+int bg_fm_bwt_dev(const bg_fm* fm, uint8_t* d_bwt, void* stream);
 /* Bytes of the index's 2-step rank blocks (128-byte lines: 16 pair counters + 128 four-bit pair codes per 128 BWT
  * positions; built behind DNA-like indexes whose `less` is the BWT's own, fm_step2.hip) that the searches take two
  * pattern symbols per block access from; 0: single steps (no such blocks, or bg_fm_set_option "no_step2" = 1). */
@@ -574,6 +593,12 @@ int bg_gather_records_cap(bg_comm* comm, const void* local, uint64_t n_local, ui
  * can hold: BG_ERR_OPS_CAP on every rank, nothing written, if the ranks bring more.  Synchronous. */
 int bg_gather_records_host(bg_comm* comm, const void* local, uint64_t n_local, uint32_t rec_bytes, void* all, uint64_t all_cap,
                            uint64_t* counts_out);
+/* What the communicator is, read back from the library that runs it — so that a multi-GPU line can prove "RCCL saw N
+ * ranks" instead of repeating what the caller asked for.  info (5 entries): [0] world as given to bg_comm_init*,
+ * [1] ncclCommCount() of the RCCL communicator (0 for a host-staged one: no RCCL involved), [2] ncclCommUserRank() (-1
+ * host-staged), [3] path of the last gather: 0 none yet, 1 one ncclAllGather, 2 grouped ncclBroadcasts (ragged shards),
+ * 3 host-staged through shared memory, [4] gathers done on this communicator. */
+int bg_comm_world(bg_comm* comm, int64_t* info);
 int bg_comm_free(bg_comm* comm);
 
 /* Timing of the last *_dev / batch call's kernels on this ctx, measured with HIP events on

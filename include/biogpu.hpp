@@ -659,7 +659,16 @@ public:
     static std::unique_ptr<FMIndex> load(const std::string& path, std::shared_ptr<Context> ctx = nullptr) {
         std::unique_ptr<FMIndex> fm(new FMIndex(ctx ? std::move(ctx) : Context::shared_default()));
         check(bg_fm_load(fm->ctx_->raw(), path.c_str(), &fm->h_), "FMIndex::deserialize");
+        uint64_t n = 0;
+        check(bg_fm_len(fm->h_, &n), "bg_fm_len");
+        fm->n_ = (size_t)n;
         return fm;
+    }
+    // the BWT the index was built over, read back out of the handle (bg_fm_bwt): a deserialized FMIndex has no other
+    bwt::BWT bwt() const {
+        bwt::BWT b(n_);
+        check(bg_fm_bwt(h_, b.data()), "bg_fm_bwt");
+        return b;
     }
 
 private:
@@ -688,11 +697,9 @@ public:
         BiInterval interval;
         size_t position, length;
     };
-    explicit FMDIndex(const FMIndex& fm, const bwt::BWT& b) : fm_(&fm) {
-        for (uint8_t c : b)
-            if (!c || !std::char_traits<char>::find("ACGTNacgtn$", 11, (char)c))
-                throw Panic("Expecting BWT over the DNA alphabet (including N) with the sentinel $.");
-    }
+    explicit FMDIndex(const FMIndex& fm, const bwt::BWT& b) : fm_(&fm) { check_alphabet(b); }
+    // FMDIndex::from(fmindex) proper: the BWT is the index's own (also for one that came from FMIndex::load)
+    explicit FMDIndex(const FMIndex& fm) : fm_(&fm) { check_alphabet(fm.bwt()); }
     std::vector<Smem> smems(const Text& pattern, size_t i, size_t l) const { return run({pattern}, {(uint32_t)i}, l, false)[0]; }
     std::vector<Smem> all_smems(const Text& pattern, size_t l) const { return run({pattern}, {}, l, true)[0]; }
     std::vector<std::vector<Smem>> smems_batch(const std::vector<Text>& patterns, const std::vector<uint32_t>& positions,
@@ -704,6 +711,11 @@ public:
     }
 
 private:
+    static void check_alphabet(const bwt::BWT& b) {  // fmindex.rs:323-327
+        for (uint8_t c : b)
+            if (!c || !std::char_traits<char>::find("ACGTNacgtn$", 11, (char)c))
+                throw Panic("Expecting BWT over the DNA alphabet (including N) with the sentinel $.");
+    }
     std::vector<std::vector<Smem>> run(const std::vector<Text>& patterns, const std::vector<uint32_t>& positions, size_t l,
                                        bool all) const {
         Text pat;

@@ -95,7 +95,8 @@ SYMBOLS = ["bg_device_count", "bg_init", "bg_free", "bg_strerror", "bg_last_erro
            "bg_pack2_dev", "bg_unpack2_dev", "bg_fm_pattern_codes", "bg_fm_backward_search_packed_dev",
            "bg_fm_backward_search_count_lines_dev", "bg_align_batch_packed_dev", "bg_fm_step2_bytes",
            "bg_shard_range", "bg_shard_balanced", "bg_comm_unique_id", "bg_comm_init", "bg_comm_init_host",
-           "bg_gather_records", "bg_gather_records_cap", "bg_gather_records_host", "bg_comm_free", "bg_fm_save", "bg_fm_load"]
+           "bg_gather_records", "bg_gather_records_cap", "bg_gather_records_host", "bg_comm_free", "bg_fm_save", "bg_fm_load",
+           "bg_fm_len", "bg_fm_less", "bg_fm_bwt", "bg_fm_bwt_dev", "bg_comm_world"]
 
 
 def build(force=False):
@@ -132,6 +133,10 @@ def lib():
         L.bg_fm_free.argtypes = [vp]
         L.bg_fm_save.argtypes = [vp, C.c_char_p]
         L.bg_fm_load.argtypes = [vp, C.c_char_p, C.POINTER(vp)]
+        L.bg_fm_len.argtypes = [vp, C.POINTER(u64)]
+        L.bg_fm_less.argtypes = [vp, vp, C.POINTER(u32)]
+        L.bg_fm_bwt.argtypes = [vp, vp]
+        L.bg_fm_bwt_dev.argtypes = [vp, vp, vp]
         L.bg_fm_build_dev.argtypes = [vp, vp, u64, u32, vp, u32, vp, C.POINTER(vp), vp]
         L.bg_fm_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
         L.bg_fm_device_bytes.restype = u64
@@ -147,6 +152,7 @@ def lib():
         L.bg_gather_records_cap.argtypes = [vp, vp, u64, u32, vp, u64, vp, vp]
         L.bg_gather_records_host.argtypes = [vp, vp, u64, u32, vp, u64, vp]
         L.bg_comm_free.argtypes = [vp]
+        L.bg_comm_world.argtypes = [vp, vp]
         L.bg_fm_backward_search_batch.argtypes = [vp, u64, vp, vp, vp, vp, vp, vp]
         L.bg_fm_backward_search_batch_dev.argtypes = [vp, u64, vp, vp, vp, vp, vp, vp, vp]
         L.bg_fmd_interval_batch.argtypes = [vp, u64, vp, vp, vp, vp]

@@ -71,6 +71,15 @@ class Comm:
                                                      counts.ctypes.data), "bg_gather_records_host")
         return out[:int(counts.sum())], counts
 
+    def world_info(self):
+        """bg_comm_world: what the communicator is, read back from RCCL itself — {"world", "rccl_ranks" (ncclCommCount; 0 for a
+        host-staged communicator), "rccl_rank", "last_path" ("all_gather" | "grouped_broadcast" (ragged) | "host_shm" | None),
+        "gathers"}"""
+        info = np.zeros(5, dtype=np.int64)
+        _lib.check(_lib.lib().bg_comm_world(self.h, info.ctypes.data), "bg_comm_world")
+        return {"world": int(info[0]), "rccl_ranks": int(info[1]), "rccl_rank": int(info[2]),
+                "last_path": [None, "all_gather", "grouped_broadcast", "host_shm"][int(info[3])], "gathers": int(info[4])}
+
     def free(self):
         if self.h:
             _lib.lib().bg_comm_free(self.h)

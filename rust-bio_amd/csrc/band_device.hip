@@ -1223,7 +1223,9 @@ int launch_band_chain(const BandDevArgs& a, hipStream_t st, int part) {
         if (part != 2) chain_kernel<false, 1><<<dim3(a.n_pairs), dim3(64), 4 * (size_t)(kMaxChainMatches + 1), st>>>(c);
         if (part != 1) {
             // rows: four pairs per wavefront (chain_rows_kernel); 0: one pair per wavefront (round 2 .. 4, kept for A/B and tests)
-            if (a.chain_rows)
+            // (chain_rows_kernel addresses the per-pair slices with 32-bit element offsets, pair * (cap_matches + 1): a
+            //  sub-batch a caller's chunk_pairs made larger than that goes through the 64-bit pointers of chain_kernel)
+            if (a.chain_rows && (uint64_t)a.n_pairs * ((uint64_t)a.cap_matches + 1) < (1ull << 32))
                 chain_rows_kernel<<<dim3((a.n_pairs + 3) / 4), dim3(64), 0, st>>>(c);
             else
                 chain_kernel<false, 2><<<dim3(a.n_pairs), dim3(64), 0, st>>>(c);

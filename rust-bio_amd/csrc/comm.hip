@@ -38,6 +38,8 @@ struct Rccl {
     decltype(&ncclGroupStart) group_start = nullptr;
     decltype(&ncclGroupEnd) group_end = nullptr;
     decltype(&ncclCommDestroy) destroy = nullptr;
+    decltype(&ncclCommCount) comm_count = nullptr;      // (optional: bg_comm_world's read-back)
+    decltype(&ncclCommUserRank) comm_rank = nullptr;
     bool ok = false;
 };
 Rccl& rccl() {
@@ -55,6 +57,8 @@ Rccl& rccl() {
         x.group_start = (decltype(x.group_start))dlsym(x.so, "ncclGroupStart");
         x.group_end = (decltype(x.group_end))dlsym(x.so, "ncclGroupEnd");
         x.destroy = (decltype(x.destroy))dlsym(x.so, "ncclCommDestroy");
+        x.comm_count = (decltype(x.comm_count))dlsym(x.so, "ncclCommCount");
+        x.comm_rank = (decltype(x.comm_rank))dlsym(x.so, "ncclCommUserRank");
         x.ok = x.get_id && x.init_rank && x.all_gather && x.broadcast && x.group_start && x.group_end && x.destroy;
         return x;
     }();
@@ -87,6 +91,9 @@ struct bg_comm {
     ShmCtrl* ctrl = nullptr;
     uint32_t my_sense = 0;
     uint64_t seq = 0;
+    // what the last gather did (bg_comm_world): 1 one ncclAllGather, 2 grouped broadcasts (ragged shards), 3 host-staged
+    int last_path = 0;
+    uint64_t n_gathers = 0;
 };
 
 namespace {
@@ -264,6 +271,28 @@ extern "C" int bg_comm_init_host(bg_ctx* ctx, int rank, int world, const char* n
     return BG_OK;
 }
 
+// What the communicator IS, read back from the library that runs it (not from what the caller asked for): info[0] = world
+// as given to bg_comm_init*, info[1] = ncclCommCount of the RCCL communicator (0: host-staged — no RCCL involved),
+// info[2] = ncclCommUserRank (-1: host-staged), info[3] = path of the last gather (0 none yet, 1 one ncclAllGather,
+// 2 grouped ncclBroadcasts for ragged shards, 3 host-staged through shared memory), info[4] = gathers done so far.
+extern "C" int bg_comm_world(bg_comm* c, int64_t* info /* 5 entries */) {
+    if (!c || !info) return BG_ERR_INVALID_ARG;
+    info[0] = c->world;
+    info[1] = 0;
+    info[2] = -1;
+    if (c->nccl) {
+        Rccl& r = rccl();
+        int n = -1, me = -1;
+        if (!r.comm_count || !r.comm_rank) return BG_ERR_UNSUPPORTED;
+        if (r.comm_count(c->nccl, &n) != ncclSuccess || r.comm_rank(c->nccl, &me) != ncclSuccess) return BG_ERR_HIP;
+        info[1] = n;
+        info[2] = me;
+    }
+    info[3] = c->last_path;
+    info[4] = (int64_t)c->n_gathers;
+    return BG_OK;
+}
+
 extern "C" int bg_comm_free(bg_comm* c) {
     if (!c) return BG_OK;
     if (c->nccl) rccl().destroy(c->nccl);
@@ -304,6 +333,8 @@ int rccl_records(bg_comm* c, const void* local, uint32_t rec_bytes, void* all, c
     const int W = c->world;
     bool equal = true;
     for (int k = 1; k < W; k++) equal = equal && counts[k] == counts[0];
+    c->last_path = equal ? 1 : 2;
+    c->n_gathers++;
     if (equal) {  // one all-gather when the shards are equal
         if (counts[0] && r.all_gather(local, all, (size_t)counts[0] * rec_bytes, ncclUint8, c->nccl, st) != ncclSuccess) return BG_ERR_HIP;
         return BG_OK;
@@ -408,6 +439,8 @@ int gather_any(bg_comm* c, const void* local, uint64_t n_local, uint32_t rec_byt
             BG_HIP(hipStreamSynchronize(st));  // the records are results of work queued there
         }
         if ((rc = shm_gather(c, c->ctx, local, n_local, rec_bytes, all, cap, counts))) return rc;
+        c->last_path = 3;
+        c->n_gathers++;
     }
     if (counts_out)
         for (int k = 0; k < W; k++) counts_out[k] = counts[k];
@@ -443,20 +476,48 @@ extern "C" int bg_gather_records_host(bg_comm* c, const void* local, uint64_t n_
     if (!c->nccl) {
         if (!c->ctrl) return BG_ERR_INVALID_ARG;
         rc = shm_gather(c, nullptr, local, n_local, rec_bytes, all, all_cap, counts);  // host pointers: plain copies
+        c->last_path = 3;
+        c->n_gathers++;
     } else {
         BG_HIP(hipSetDevice(c->ctx->device));
         hipStream_t st = c->ctx->stream;
         uint64_t min_cap = kNoCap, total = 0;
-        if ((rc = rccl_counts(c, n_local, all_cap, counts, min_cap, st))) return rc;
-        for (uint64_t k : counts) total += k;
-        if (total > min_cap) return BG_ERR_OPS_CAP;
-        void *d_loc = nullptr, *d_all = nullptr;  // sized from the gathered counts
-        BG_HIP(hipMalloc(&d_loc, std::max<size_t>((size_t)n_local * rec_bytes, 16)));
-        if (hipMalloc(&d_all, std::max<size_t>((size_t)total * rec_bytes, 16)) != hipSuccess) {
-            // (every rank allocates the same amount: they fail or succeed alike on like GPUs; a lone failure leaves the
-            // others in the collective until RCCL's own watchdog ends it)
+        // a rank that fails locally (the staging allocations) must not leave its peers alone in the collective: d_loc is
+        // allocated before the counts travel and its outcome rides with them (a count of ~0 marks a failed rank); d_all,
+        // which is sized from the counts, is agreed on in a second 8-byte exchange before a single record moves
+        void *d_loc = nullptr, *d_all = nullptr;
+        const bool loc_ok = hipMalloc(&d_loc, std::max<size_t>((size_t)n_local * rec_bytes, 16)) == hipSuccess;
+        if ((rc = rccl_counts(c, loc_ok ? n_local : kNoCap, all_cap, counts, min_cap, st))) {
             hipFree(d_loc);
-            return BG_ERR_OOM;
+            return rc;
+        }
+        bool peers_ok = true;
+        for (uint64_t k : counts) peers_ok = peers_ok && k != kNoCap;
+        if (!peers_ok) {
+            hipFree(d_loc);
+            return BG_ERR_OOM;  // on every rank
+        }
+        for (uint64_t k : counts) total += k;
+        if (total > min_cap) {
+            hipFree(d_loc);
+            return BG_ERR_OPS_CAP;
+        }
+        const bool all_ok = hipMalloc(&d_all, std::max<size_t>((size_t)total * rec_bytes, 16)) == hipSuccess;
+        {
+            std::vector<uint64_t> oks((size_t)W, 0);
+            uint64_t dummy = kNoCap;
+            if ((rc = rccl_counts(c, all_ok ? 1 : 0, kNoCap, oks, dummy, st))) {
+                hipFree(d_loc);
+                hipFree(d_all);
+                return rc;
+            }
+            bool every = true;
+            for (uint64_t k : oks) every = every && k == 1;
+            if (!every) {
+                hipFree(d_loc);
+                hipFree(d_all);
+                return BG_ERR_OOM;  // on every rank
+            }
         }
         if (n_local && hipMemcpyAsync(d_loc, local, (size_t)n_local * rec_bytes, hipMemcpyHostToDevice, st) != hipSuccess) rc = BG_ERR_HIP;
         const int rc2 = rccl_records(c, d_loc, rec_bytes, d_all, counts, st);  // entered even after a failed upload: the peers are in it

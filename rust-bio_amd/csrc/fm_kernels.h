@@ -208,7 +208,7 @@ struct bg_fm {
     bgfm::Fm2Dev dev2 = {};      // 2-step rank blocks (fm_kernels.h), built behind the index by fm_build_step2
     void* d_blocks2 = nullptr;
     bool no_step2 = false;       // option "no_step2": searches take single steps only (tests, A/B)
-    int ilp = 2;                 // option "ilp": queries per quad of the 2-step search (1: fm_search_fast_kernel; 2-4: fm_search_fast2x_kernel)
+    int ilp = 2;                 // option "ilp": queries per quad of the search (1: fm_search_fast_kernel / fmw_search_kernel; 2: the 2x kernels)
     void* d_blocks = nullptr;
     void* d_exc_pos = nullptr;
     void* d_exc_sym_pos = nullptr;
@@ -251,6 +251,7 @@ struct bg_fm {
     std::vector<uint64_t> h_less;
     uint32_t occ_k = 0;
 };
+int fm_decode_bwt_dev(const bg_fm* fm, uint8_t* d_out, hipStream_t st);  // fm_persist.hip: the handle's BWT bytes
 void fm_remember_inputs(bg_fm* fm, const uint8_t* alphabet, uint32_t n_sym, uint32_t occ_k, const uint64_t* less, uint32_t less_len);
 
 // fm_wide.hip: the index with 64-bit positions (built from a BWT in HBM; `less` null: the BWT's own cumulative counts)

@@ -19,6 +19,7 @@
 // xorshift-multiply mix): a truncated or altered file is refused with BG_ERR_IO.
 #include <cstdio>
 #include <cstring>
+#include <new>
 #include <vector>
 
 #include "fm_kernels.h"
@@ -127,6 +128,29 @@ int put_positions(Writer& w, const void* d_arr, uint64_t n, bool is64, void* pin
 
 }  // namespace
 
+// The BWT of a handle, read back out of its rank blocks into n bytes of device memory: the 2-bit codes turned into their
+// bytes, the listed exceptions (sentinels, stray N) put back over them; an index with dense symbols keeps the raw bytes.
+int fm_decode_bwt_dev(const bg_fm* fm, uint8_t* d_out, hipStream_t st) {
+    const uint64_t n = fm->wide ? fm->wdev.n : (uint64_t)fm->dev.n;
+    if (!fm->wide && fm->d_bwt_raw) {
+        BG_HIP(hipMemcpyAsync(d_out, fm->d_bwt_raw, n, hipMemcpyDeviceToDevice, st));
+        return BG_OK;
+    }
+    const uint32_t code_bytes = (uint32_t)fm->code_byte[0] | (uint32_t)fm->code_byte[1] << 8 | (uint32_t)fm->code_byte[2] << 16 |
+                                (uint32_t)fm->code_byte[3] << 24;
+    const uint32_t grid = (uint32_t)std::min<uint64_t>((n + 255) / 256, 1u << 20);
+    fmp_codes_to_bytes_kernel<<<dim3(grid), dim3(256), 0, st>>>((const uint32_t*)fm->d_blocks, n, code_bytes, d_out);
+    const uint32_t n_exc = fm->wide ? fm->wdev.n_exc : fm->dev.n_exc;
+    if (n_exc) {
+        if (fm->wide)
+            fmp_exceptions_kernel<uint64_t><<<dim3((n_exc + 255) / 256), dim3(256), 0, st>>>((const uint64_t*)fm->d_exc_pos, (const uint8_t*)fm->d_exc_byte, n_exc, d_out);
+        else
+            fmp_exceptions_kernel<uint32_t><<<dim3((n_exc + 255) / 256), dim3(256), 0, st>>>((const uint32_t*)fm->d_exc_pos, (const uint8_t*)fm->d_exc_byte, n_exc, d_out);
+    }
+    BG_HIP(hipGetLastError());
+    return BG_OK;
+}
+
 // what a handle has to remember for bg_fm_save (set by bg_fm_build / bg_fm_build_dev, fm_index.hip)
 void fm_remember_inputs(bg_fm* fm, const uint8_t* alphabet, uint32_t n_sym, uint32_t occ_k, const uint64_t* less, uint32_t less_len) {
     fm->alphabet.assign(alphabet, alphabet + n_sym);
@@ -157,20 +181,10 @@ extern "C" int bg_fm_save(const bg_fm* fm, const char* path) {
     const uint8_t* bwt_src = fm->wide ? nullptr : (const uint8_t*)fm->d_bwt_raw;
     if (!bwt_src) {
         BG_HIP(hipMalloc((void**)&d_bwt, std::max<uint64_t>(n, 16)));
-        const uint32_t code_bytes = (uint32_t)fm->code_byte[0] | (uint32_t)fm->code_byte[1] << 8 | (uint32_t)fm->code_byte[2] << 16 |
-                                    (uint32_t)fm->code_byte[3] << 24;
-        const uint32_t grid = (uint32_t)std::min<uint64_t>((n + 255) / 256, 1u << 20);
-        fmp_codes_to_bytes_kernel<<<dim3(grid), dim3(256)>>>((const uint32_t*)fm->d_blocks, n, code_bytes, d_bwt);
-        const uint32_t n_exc = fm->wide ? fm->wdev.n_exc : fm->dev.n_exc;
-        if (n_exc) {
-            if (fm->wide)
-                fmp_exceptions_kernel<uint64_t><<<dim3((n_exc + 255) / 256), dim3(256)>>>((const uint64_t*)fm->d_exc_pos, (const uint8_t*)fm->d_exc_byte, n_exc, d_bwt);
-            else
-                fmp_exceptions_kernel<uint32_t><<<dim3((n_exc + 255) / 256), dim3(256)>>>((const uint32_t*)fm->d_exc_pos, (const uint8_t*)fm->d_exc_byte, n_exc, d_bwt);
-        }
-        if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+        const int rcd = fm_decode_bwt_dev(fm, d_bwt, nullptr);
+        if (rcd || hipDeviceSynchronize() != hipSuccess) {
             hipFree(d_bwt);
-            return BG_ERR_HIP;
+            return rcd ? rcd : BG_ERR_HIP;
         }
         bwt_src = d_bwt;
     }
@@ -214,19 +228,25 @@ extern "C" int bg_fm_save(const bg_fm* fm, const char* path) {
     return rc;
 }
 
-extern "C" int bg_fm_load(bg_ctx* ctx, const char* path, bg_fm** out) {
-    if (!ctx || !path || !out) return BG_ERR_INVALID_ARG;
-    *out = nullptr;
+namespace {
+struct LoadState {  // what an exception on the way must release
+    FILE* f = nullptr;
+    bg_fm* fm = nullptr;
+};
+int fm_load_impl(bg_ctx* ctx, const char* path, bg_fm** out, LoadState& ls) {
     Reader r;
     r.f = fopen(path, "rb");
     if (!r.f) return BG_ERR_IO;
+    ls.f = r.f;
     char magic[8];
     Header h = {};
     r.get(magic, 8);
     r.get(&h, sizeof(h));
     auto fail = [&](int rc, bg_fm* fm) {
         fclose(r.f);
+        ls.f = nullptr;
         if (fm) bg_fm_free(fm);
+        ls.fm = nullptr;
         return rc;
     };
     if (!r.ok || memcmp(magic, kMagic, 8) != 0 || h.n == 0 || h.n > (1ull << 40) || h.n_sym == 0 || h.n_sym > 256 || h.less_len == 0 ||
@@ -260,6 +280,7 @@ extern "C" int bg_fm_load(bg_ctx* ctx, const char* path, bg_fm** out) {
     // the caller's less travels with the index (an index built over another less than the BWT's own answers with it)
     int rc = bg_fm_build(ctx, bwt.data(), h.n, less.data(), (uint32_t)less.size(), (uint32_t)h.occ_k, alphabet.data(), (uint32_t)alphabet.size(), &fm);
     if (rc) return fail(rc, nullptr);
+    ls.fm = fm;
     std::vector<uint8_t>().swap(bwt);
     // (h.wide is informational: a small index saved under a lowered fm_wide_from — the tests — loads into the layout THIS
     //  context chooses for its size)
@@ -287,6 +308,59 @@ extern "C" int bg_fm_load(bg_ctx* ctx, const char* path, bg_fm** out) {
     const uint64_t want = r.mix.h;
     if (fread(&sum, 1, 8, r.f) != 8 || sum != want) return fail(BG_ERR_IO, fm);
     fclose(r.f);
+    ls.f = nullptr;
+    ls.fm = nullptr;
     *out = fm;
     return BG_OK;
+}
+}  // namespace
+
+extern "C" int bg_fm_load(bg_ctx* ctx, const char* path, bg_fm** out) {
+    if (!ctx || !path || !out) return BG_ERR_INVALID_ARG;
+    *out = nullptr;
+    LoadState ls;
+    try {  // the host arrays of a large index (a raw suffix array: 8 bytes per symbol) may not fit: nothing throws across the ABI
+        return fm_load_impl(ctx, path, out, ls);
+    } catch (const std::bad_alloc&) {
+        if (ls.f) fclose(ls.f);
+        if (ls.fm) bg_fm_free(ls.fm);
+        *out = nullptr;
+        return BG_ERR_OOM;
+    } catch (...) {
+        if (ls.f) fclose(ls.f);
+        if (ls.fm) bg_fm_free(ls.fm);
+        *out = nullptr;
+        return BG_ERR_HIP;
+    }
+}
+
+// ---- what a handle can say about itself (a loaded handle has no caller-side arrays: FMDIndex::from(FMIndex) on a
+// deserialized index, fmindex.rs:311-329, reads the BWT; the C++ mirror's len() the text length)
+extern "C" int bg_fm_len(const bg_fm* fm, uint64_t* n) {
+    if (!fm || !n) return BG_ERR_INVALID_ARG;
+    *n = fm->wide ? fm->wdev.n : (uint64_t)fm->dev.n;
+    return BG_OK;
+}
+extern "C" int bg_fm_less(const bg_fm* fm, uint64_t* less_out, uint32_t* less_len) {
+    if (!fm || !less_len) return BG_ERR_INVALID_ARG;
+    if (fm->h_less.empty()) return BG_ERR_UNSUPPORTED;
+    *less_len = (uint32_t)fm->h_less.size();
+    if (less_out) memcpy(less_out, fm->h_less.data(), fm->h_less.size() * 8);
+    return BG_OK;
+}
+extern "C" int bg_fm_bwt_dev(const bg_fm* fm, uint8_t* d_bwt, void* stream) {
+    if (!fm || !d_bwt) return BG_ERR_INVALID_ARG;
+    BG_HIP(hipSetDevice(fm->ctx->device));
+    return fm_decode_bwt_dev(fm, d_bwt, (hipStream_t)stream);
+}
+extern "C" int bg_fm_bwt(const bg_fm* fm, uint8_t* bwt) {
+    if (!fm || !bwt) return BG_ERR_INVALID_ARG;
+    BG_HIP(hipSetDevice(fm->ctx->device));
+    const uint64_t n = fm->wide ? fm->wdev.n : (uint64_t)fm->dev.n;
+    uint8_t* d = nullptr;
+    BG_HIP(hipMalloc((void**)&d, std::max<uint64_t>(n, 16)));
+    int rc = fm_decode_bwt_dev(fm, d, nullptr);
+    if (!rc && hipMemcpy(bwt, d, n, hipMemcpyDeviceToHost) != hipSuccess) rc = BG_ERR_HIP;
+    hipFree(d);
+    return rc;
 }

@@ -70,10 +70,30 @@ class FMIndex:
                                               self._less.ctypes.data, C.byref(self.h), stream), "FMIndex::new (device)")
         return self
 
+    def __len__(self):
+        """the text length n (bwt.len() of the reference's FMIndex)"""
+        n = C.c_uint64(0)
+        _lib.check(_lib.lib().bg_fm_len(self.h, C.byref(n)), "bg_fm_len")
+        return int(n.value)
+
     def bwt(self):
+        """the BWT bytes; a handle that was loaded (or built from a device BWT) reads them back out of its rank
+        blocks (bg_fm_bwt) — what FMDIndex::from needs of a deserialized FMIndex (fmindex.rs:311-329)"""
         if self._bwt is None:
-            self._bwt = self._d_bwt.cpu().numpy()
+            b = np.empty(len(self), dtype=np.uint8)
+            _lib.check(_lib.lib().bg_fm_bwt(self.h, b.ctypes.data), "bg_fm_bwt")
+            self._bwt = b
         return self._bwt
+
+    def less(self):
+        """the `less` array the index answers with (bwt.rs:186-199)"""
+        if self._less is None:
+            ln = C.c_uint32(0)
+            _lib.check(_lib.lib().bg_fm_less(self.h, None, C.byref(ln)), "bg_fm_less")
+            ls = np.zeros(ln.value, dtype=np.uint64)
+            _lib.check(_lib.lib().bg_fm_less(self.h, ls.ctypes.data, C.byref(ln)), "bg_fm_less")
+            self._less = ls
+        return self._less
 
     def set_option(self, key, value):
         _lib.check(_lib.lib().bg_fm_set_option(self.h, key.encode(), int(value)), "bg_fm_set_option")
@@ -170,6 +190,7 @@ class FMIndex:
         self._d_bwt = None
         self.h = C.c_void_p()
         _lib.check(_lib.lib().bg_fm_load(self.ctx.h, os.fsencode(path), C.byref(self.h)), "FMIndex::deserialize")
+        self.less()  # (bwt() stays lazy: n bytes)
         return self
 
     def close(self):

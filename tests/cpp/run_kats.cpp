@@ -330,6 +330,12 @@ static void kat_fmindex_save_and_load() {
     CHECK(h2[0].alignment && h1[0].alignment && h2[0].alignment->score == h1[0].alignment->score);
     CHECK_EQ(h2[0].ref_start, (size_t)2000);
     CHECK(panics([] { fmindex::FMIndex::load("/tmp/biogpu_kat_index.missing"); }));
+    // the loaded handle knows its length and its BWT (bg_fm_len / bg_fm_bwt): FMDIndex::from works on it when the text is
+    // DNA + '$' (fmindex.rs:311-329)
+    CHECK_EQ(fm2->len(), fm.len());
+    CHECK(fm2->bwt() == b);
+    fmindex::FMDIndex fmd(*fm2);
+    (void)fmd.all_smems(Text(g.begin() + 100, g.begin() + 160), 10);  // (not T$R$: only that the call goes through)
     std::remove(path.c_str());
 }
 

@@ -444,6 +444,24 @@ def test_index_survives_save_and_load(kind, tmp_path):
     assert (o1 == o2).all() and (p1 == p2).all()
     want = np.concatenate([np.asarray(sa[int(l):int(h)], dtype=np.uint64) for l, h in zip(lo[keep], hi[keep])])
     assert (p2 == want).all()
+    # what the loaded handle says about itself: the text length, less, and the BWT read back out of the rank blocks
+    # (bg_fm_len / bg_fm_less / bg_fm_bwt) — FMDIndex::from works on a deserialized FMIndex (fmindex.rs:311-329)
+    assert len(fm2) == len(fm) == len(b)
+    assert (fm2.less() == ls).all() and (fm2.bwt() == b).all()
+    import torch as _t
+    d_b = _t.empty(len(b), dtype=_t.uint8, device="cuda:0")
+    _lib.check(_lib.lib().bg_fm_bwt_dev(fm2.h, d_b.data_ptr(), 0))
+    _t.cuda.synchronize()
+    assert (d_b.cpu().numpy() == b).all()
+    if kind == "two_sentinels":  # T$R$: the loaded index is an FMD index like the saved one
+        from rust_bio_amd.fmindex import FMDIndex
+        fmd1, fmd2 = FMDIndex(fm), FMDIndex(fm2)
+        reads = [bytes(g[s:s + 60]) for s in rng.integers(0, 19_000, size=50)]
+        got1, got2 = fmd1.all_smems_batch(reads, 5), fmd2.all_smems_batch(reads, 5)
+        assert got1 == got2
+        ofmd = orc.FMDIndex(b, ls, orc.Occ(b, 32, alpha))
+        for q, rb in enumerate(reads):
+            assert [((iv.lower, iv.lower_rev, iv.size, iv.match_size), p_, ln) for iv, p_, ln in got2[q]] == ofmd.all_smems(rb, 5), q
     if with_text:  # the owned text travelled too: seed-and-extend on the loaded handle
         reads = [bytes(g[s:s + 100]) for s in rng.integers(0, len(g) - 200, size=200)]
         rd, ro = _lib.concat(reads)
