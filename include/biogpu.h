@@ -37,13 +37,15 @@
  * Text positions are 64-bit at the boundary, like the reference's usize (fmindex.rs:70-71, bwt.rs:94, suffix_array.rs:
  * 264).  Inside, an index below 2^32 - 1 symbols keeps the uint32 layout of rounds 1-4 (and its speed); from 2^32 - 1
  * symbols on — T$R$ of a human genome for an FMD index is 6.2 G — bg_fm_build / bg_fm_build_dev lay the SAME rank blocks
- * out with superblock-relative counters and 64-bit bases (csrc/fm_wide.hip) and bg_fm_backward_search_batch[_dev],
- * bg_fm_set_[sampled_]suffix_array, bg_sa_get_batch[_dev] and bg_interval_occ_batch[_dev] work on them unchanged;
+ * out with superblock-relative counters and 64-bit bases (csrc/fm_wide.hip) and every entry point that takes a bg_fm works
+ * on them: backward search with byte or 2-bit packed patterns (2-step blocks included), bg_fm_set_[sampled_]suffix_array,
+ * bg_sa_get_batch[_dev], bg_interval_occ_batch[_dev], bg_fm_set_text + bg_seed_extend_batch[_dev], bg_fm_save / bg_fm_load,
+ * and the FMD kernels through their *64 entry points (bg_fmd_smems_batch64[_dev], bg_fmd_interval_batch64: uint64 records;
+ * the uint32-record flavours answer BG_ERR_UNSUPPORTED on such an index, the *64 flavours serve both layouts).
  * bg_suffix_array_dev64 / bg_bwt_dev64 / bg_sa_sample_dev64 build the 64-bit suffix array in HBM.  BG_ERR_TOO_LARGE only
- * beyond 2^40 symbols.  What a 64-bit index does NOT offer (BG_ERR_UNSUPPORTED): the 2-bit packed pattern entry points
- * and bg_fm_pattern_codes (the byte entry points answer the same queries), bg_fm_set_text / seed-and-extend, the FMD
- * kernels (their interval records are uint32 in this ABI), and BWTs with more than 1024 positions outside their four most
- * frequent bytes (protein texts: they would need rank bit vectors with 64-bit bases).
+ * beyond 2^40 symbols.  The one thing a 64-bit index does NOT offer (BG_ERR_UNSUPPORTED at build time): BWTs with more
+ * than 1024 positions outside their four most frequent bytes (protein texts, genomes with long N runs: they would need
+ * rank bit vectors with 64-bit bases); bg_fm_backward_search_count_lines_dev is a measurement aid of the 32-bit kernels.
  * A sequence of an aligner call may have up to 2^24 symbols.
  */
 #ifndef BIOGPU_H
@@ -205,7 +207,8 @@ enum { BG_FM_COMPLETE = 0, BG_FM_PARTIAL = 1, BG_FM_ABSENT = 2,
  * after a pattern's last 12 symbols; < 0 disables it.  OFF by default: it buys 2.5 % on an index that sits in
  * the Infinity Cache and nothing on one that does not.  Results do not depend on it.
  * "ilp" — queries a quad of lanes walks at once in backward search: 2 (default: fm_search_fast2x_kernel on the 2-step blocks
- * of a DNA-like index, fmw_search2x_kernel on a 64-bit index) or 1 (the round-4 kernels; A/B, tests).  "no_step2" = 1 —
+ * of a DNA-like index — on either position width — fmw_search2x_kernel on a 64-bit index without such blocks) or 1 (the
+ * round-4 kernels; A/B, tests).  "no_step2" = 1 —
  * single LF steps even where the index has 2-step blocks; "no_fast" = 1 — every search through the generic kernel (tests).
  * None of them changes a result. */
 int bg_fm_set_option(bg_fm* fm, const char* key, int64_t value);
@@ -244,7 +247,7 @@ int bg_unpack2_dev(bg_ctx* ctx, const uint32_t* d_packed, uint64_t n, const uint
 int bg_pack2_host(const uint8_t* bytes, uint64_t n, const uint8_t* codes, uint32_t* packed);
 /* The byte values of the index's four 2-bit codes — the `codes` to pack its patterns with.  BG_ERR_UNSUPPORTED when
  * the text has fewer than four frequent letters or symbols ranked by bit vectors: such an
- * index takes byte patterns only. */
+ * index takes byte patterns only.  (Both position widths.) */
 int bg_fm_pattern_codes(const bg_fm* fm, uint8_t* codes);
 /* bg_fm_backward_search_batch_dev on patterns packed with bg_fm_pattern_codes' codes; d_sym_off[q] is the SYMBOL
  * offset of pattern q in the stream (n_q + 1 entries).  Same outputs.  (A dword load per 16 steps instead of a byte
@@ -314,6 +317,18 @@ int bg_fmd_smems_batch_dev(bg_fm* fm, int all, uint64_t n_p, const uint8_t* d_pa
                            const uint64_t* d_pat_off, const uint32_t* d_i_pos, uint32_t min_len,
                            uint32_t max_pattern_len, uint32_t cap, uint32_t* d_count, uint32_t* d_out,
                            void* stream);
+/* The same three with uint64 records — the reference's BiInterval is usize throughout (fmindex.rs:254-259) — for any
+ * index, and the only flavour an index with 64-bit positions answers (T$R$ of a human genome: 6.2 G symbols): six uint64
+ * per match {lower, lower_rev, size, match_size, position, length}, four per interval. */
+int bg_fmd_smems_batch64(bg_fm* fm, int all, uint64_t n_p, const uint8_t* pat, const uint64_t* pat_off,
+                         const uint32_t* i_pos, uint32_t min_len, uint32_t cap, uint32_t* count,
+                         uint64_t* out);
+int bg_fmd_interval_batch64(bg_fm* fm, uint64_t n_req, const uint8_t* op, const uint64_t* iv_in,
+                            const uint8_t* sym, uint64_t* iv_out);
+int bg_fmd_smems_batch64_dev(bg_fm* fm, int all, uint64_t n_p, const uint8_t* d_pat,
+                             const uint64_t* d_pat_off, const uint32_t* d_i_pos, uint32_t min_len,
+                             uint32_t max_pattern_len, uint32_t cap, uint32_t* d_count, uint64_t* d_out,
+                             void* stream);
 
 /* ------------------------------------------------------------------ pairwise alignment */
 

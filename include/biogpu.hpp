@@ -727,16 +727,17 @@ private:
             cap = std::max(cap, p.size() + 1);
         }
         const size_t n = patterns.size();
-        std::vector<uint32_t> count(n), out(n * cap * 6);
-        const int rc = bg_fmd_smems_batch(fm_->raw(), all ? 1 : 0, n, pat.data(), off.data(), all ? nullptr : positions.data(),
-                                          (uint32_t)l, (uint32_t)cap, count.data(), out.data());
+        std::vector<uint32_t> count(n);
+        std::vector<uint64_t> out(n * cap * 6);  // (usize records, fmindex.rs:254-259: the flavour both index layouts answer)
+        const int rc = bg_fmd_smems_batch64(fm_->raw(), all ? 1 : 0, n, pat.data(), off.data(), all ? nullptr : positions.data(),
+                                            (uint32_t)l, (uint32_t)cap, count.data(), out.data());
         if (rc == BG_ERR_OUT_OF_ALPHABET) throw Panic("index out of bounds");
         check(rc, "FMDIndex::smems");
         std::vector<std::vector<Smem>> res(n);
         for (size_t q = 0; q < n; q++)
             for (uint32_t t = 0; t < count[q]; t++) {
-                const uint32_t* r = &out[(q * cap + t) * 6];
-                res[q].push_back({{r[0], r[1], r[2], r[3]}, r[4], r[5]});
+                const uint64_t* r = &out[(q * cap + t) * 6];
+                res[q].push_back({{(size_t)r[0], (size_t)r[1], (size_t)r[2], (size_t)r[3]}, (size_t)r[4], (size_t)r[5]});
             }
         return res;
     }

@@ -535,26 +535,96 @@ extern "C" void orc_intervals_by_scan(const uint8_t* text, uint64_t n, uint64_t 
                                       uint64_t* lower, uint64_t* upper, uint64_t* pos_out, uint64_t pos_cap, uint64_t* n_pos,
                                       int threads) {
     if (threads < 1) threads = 1;
+    // Thousands of patterns per pass (round 6: the stratified sample of the 64-bit index needs >= 2 000 intervals beyond 2^32):
+    // comparing every suffix with every pattern of its first byte is out of reach, so the comparison is cut in two by the
+    // first kK bytes.  key(i) = text[i .. i + kK) as a big-endian integer, bytes past the end as 0 (a suffix that ends is
+    // smaller than anything longer; patterns hold no 0 byte — one that does, or is shorter than kK, takes the slow path
+    // below).  For a pattern P with key kp:  text[i..] < P  iff  key(i) < kp, or key(i) == kp and the rest compares smaller —
+    // the first part is a histogram over the sorted distinct pattern keys (one binary search per suffix, entered through a
+    // table over the first two bytes), the second a byte comparison for the few suffixes that share P's first kK bytes.
+    constexpr uint64_t kK = 8;
+    std::vector<uint32_t> fast, slow;
+    for (uint64_t p = 0; p < n_pat; p++) {
+        const uint64_t m = pat_off[p + 1] - pat_off[p];
+        bool zero = false;
+        for (uint64_t k = 0; k < m; k++) zero = zero || pat[pat_off[p] + k] == 0;
+        if (m >= kK && !zero)
+            fast.push_back((uint32_t)p);
+        else if (m)
+            slow.push_back((uint32_t)p);
+    }
+    auto key_of = [&](uint32_t p) {
+        uint64_t k = 0;
+        for (uint64_t u = 0; u < kK; u++) k = (k << 8) | pat[pat_off[p] + u];
+        return k;
+    };
+    std::vector<uint64_t> keys;  // sorted, distinct
+    for (uint32_t p : fast) keys.push_back(key_of(p));
+    std::sort(keys.begin(), keys.end());
+    keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+    const size_t nk = keys.size();
+    std::vector<std::vector<uint32_t>> with_key(nk);  // the patterns of each key
+    for (uint32_t p : fast) with_key[(size_t)(std::lower_bound(keys.begin(), keys.end(), key_of(p)) - keys.begin())].push_back(p);
+    std::vector<uint32_t> entry(65537, 0);  // entry[h] = first key whose top two bytes are >= h
+    {
+        size_t j = 0;
+        for (uint32_t h = 0; h <= 65536; h++) {
+            while (j < nk && (keys[j] >> 48) < h) j++;
+            entry[h] = (uint32_t)j;
+        }
+    }
+    std::vector<std::vector<uint32_t>> bucket(256);  // slow patterns by first byte
+    for (uint32_t p : slow) bucket[pat[pat_off[p]]].push_back(p);
     struct Part {
-        std::vector<uint64_t> less, pref;
+        std::vector<uint64_t> less, pref, gap, eq;  // gap[j]: suffixes with keys[j-1] < key < keys[j]; eq[j]: key == keys[j]
         std::vector<std::vector<uint64_t>> pos;
         uint64_t hist[256];
     };
     std::vector<Part> parts(threads);
-    std::vector<std::vector<uint32_t>> bucket(256);  // patterns by first byte
-    for (uint64_t p = 0; p < n_pat; p++)
-        if (pat_off[p + 1] > pat_off[p]) bucket[pat[pat_off[p]]].push_back((uint32_t)p);
     auto work = [&](int t) {
         Part& P = parts[t];
         P.less.assign(n_pat, 0);
         P.pref.assign(n_pat, 0);
         P.pos.assign(n_pat, {});
+        P.gap.assign(nk + 1, 0);
+        P.eq.assign(nk + 1, 0);
         std::fill(P.hist, P.hist + 256, 0);
         const uint64_t lo = n * (uint64_t)t / (uint64_t)threads, hi = n * (uint64_t)(t + 1) / (uint64_t)threads;
+        uint64_t key = 0;
+        for (uint64_t u = 0; u + 1 < kK; u++) key = (key << 8) | (lo + u < n ? text[lo + u] : 0);
         for (uint64_t i = lo; i < hi; i++) {
+            key = (key << 8) | (i + kK - 1 < n ? text[i + kK - 1] : 0);
             const uint8_t c = text[i];
             P.hist[c]++;
-            for (uint32_t p : bucket[c]) {  // first bytes agree: compare on
+            if (nk) {
+                const uint32_t h = (uint32_t)(key >> 48);
+                size_t a = entry[h], b = entry[h + 1];  // first key >= `key` lies in [a, b]
+                while (a < b) {
+                    const size_t mid = (a + b) >> 1;
+                    if (keys[mid] < key)
+                        a = mid + 1;
+                    else
+                        b = mid;
+                }
+                if (a < nk && keys[a] == key) {
+                    P.eq[a]++;
+                    for (uint32_t p : with_key[a]) {  // the first kK bytes agree: compare on
+                        const uint8_t* q = pat + pat_off[p];
+                        const uint64_t m = pat_off[p + 1] - pat_off[p];
+                        uint64_t k = kK;
+                        while (k < m && i + k < n && text[i + k] == q[k]) k++;
+                        if (k == m) {
+                            P.pref[p]++;
+                            if (P.pos[p].size() < pos_cap) P.pos[p].push_back(i);
+                        } else if (i + k >= n || text[i + k] < q[k]) {
+                            P.less[p]++;
+                        }
+                    }
+                } else {
+                    P.gap[a]++;
+                }
+            }
+            for (uint32_t p : bucket[c]) {  // slow path (the definition, byte by byte): first bytes agree
                 const uint8_t* q = pat + pat_off[p];
                 const uint64_t m = pat_off[p + 1] - pat_off[p];
                 uint64_t k = 1;
@@ -575,17 +645,30 @@ extern "C" void orc_intervals_by_scan(const uint8_t* text, uint64_t n, uint64_t 
         for (int t = 0; t < threads; t++) th.emplace_back(work, t);
         for (auto& x : th) x.join();
     }
+    // suffixes whose key is below keys[j]
+    std::vector<uint64_t> below(nk + 1, 0);
+    {
+        uint64_t acc = 0;
+        for (size_t j = 0; j < nk; j++) {
+            for (int t = 0; t < threads; t++) acc += parts[t].gap[j];
+            below[j] = acc;
+            for (int t = 0; t < threads; t++) acc += parts[t].eq[j];
+        }
+    }
+    std::vector<uint8_t> is_fast(n_pat, 0);
+    for (uint32_t p : fast) is_fast[p] = 1;
     for (uint64_t p = 0; p < n_pat; p++) {
         const uint64_t m = pat_off[p + 1] - pat_off[p];
         uint64_t less = 0, pref = 0, np = 0;
         for (int t = 0; t < threads; t++) {
             less += parts[t].less[p];
             pref += parts[t].pref[p];
-            if (m)
+            if (m && !is_fast[p])
                 for (int c = 0; c < pat[pat_off[p]]; c++) less += parts[t].hist[c];  // suffixes with a smaller first byte
             for (uint64_t v : parts[t].pos[p])
                 if (np < pos_cap) pos_out[p * pos_cap + np++] = v;
         }
+        if (is_fast[p]) less += below[(size_t)(std::lower_bound(keys.begin(), keys.end(), key_of((uint32_t)p)) - keys.begin())];
         if (m == 0) pref = n;  // every suffix starts with the empty pattern
         lower[p] = less;
         upper[p] = less + pref;

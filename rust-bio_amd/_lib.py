@@ -96,7 +96,8 @@ SYMBOLS = ["bg_device_count", "bg_init", "bg_free", "bg_strerror", "bg_last_erro
            "bg_fm_backward_search_count_lines_dev", "bg_align_batch_packed_dev", "bg_fm_step2_bytes",
            "bg_shard_range", "bg_shard_balanced", "bg_comm_unique_id", "bg_comm_init", "bg_comm_init_host",
            "bg_gather_records", "bg_gather_records_cap", "bg_gather_records_host", "bg_comm_free", "bg_fm_save", "bg_fm_load",
-           "bg_fm_len", "bg_fm_less", "bg_fm_bwt", "bg_fm_bwt_dev", "bg_comm_world"]
+           "bg_fm_len", "bg_fm_less", "bg_fm_bwt", "bg_fm_bwt_dev", "bg_comm_world",
+           "bg_fmd_smems_batch64", "bg_fmd_smems_batch64_dev", "bg_fmd_interval_batch64"]
 
 
 def build(force=False):
@@ -158,6 +159,9 @@ def lib():
         L.bg_fmd_interval_batch.argtypes = [vp, u64, vp, vp, vp, vp]
         L.bg_fmd_smems_batch.argtypes = [vp, i32, u64, vp, vp, vp, u32, u32, vp, vp]
         L.bg_fmd_smems_batch_dev.argtypes = [vp, i32, u64, vp, vp, vp, u32, u32, u32, vp, vp, vp]
+        L.bg_fmd_interval_batch64.argtypes = [vp, u64, vp, vp, vp, vp]
+        L.bg_fmd_smems_batch64.argtypes = [vp, i32, u64, vp, vp, vp, u32, u32, vp, vp]
+        L.bg_fmd_smems_batch64_dev.argtypes = [vp, i32, u64, vp, vp, vp, u32, u32, u32, vp, vp, vp]
         L.bg_fm_set_suffix_array.argtypes = [vp, vp, u64]
         L.bg_fm_set_sampled_suffix_array.argtypes = [vp, vp, u64, u32, C.c_uint8, vp, vp, u64]
         L.bg_sa_get_batch.argtypes = [vp, u64, vp, vp]

@@ -56,19 +56,12 @@ namespace {
 // SEEDS: the patterns are the seed windows of a batch of reads (seed-and-extend, seed_extend.hip) — query q is
 // seed q % S of read q / S: pat[pat_off[r] + k * stride ..+ seed_len) while it fits in the read (else an empty
 // pattern: Absent), so overlapping windows need no copy of the reads.
-struct SeedSrc {
-    uint32_t S, stride, seed_len;
-    uint32_t code_bytes;            // PACKED: the byte value of each 2-bit code (code c in bits 8c..8c+7)
-    unsigned long long* lines;      // COUNT: receives the number of 64-byte block loads the launch issued
-};
 // PACKED: `pat` is a 2-bit stream (16 symbols per little-endian dword, symbol s in bits 2 (s % 16) of dword s / 16, the
 // codes being the index's own: bg_fm_pattern_codes / bg_pack2_dev) and `pat_off` counts SYMBOLS: a pattern costs a dword
 // load every 16 steps instead of a byte load per step, its symbols are codes already (no class lookup, none of the
 // sparse / dense / panic arms).  Only for indexes whose four codes are all symbols (DNA-like BWTs).
 // COUNT: the block loads of the launch are counted (bench.py: requested lines against the gather ceiling of
 // tools/microbench/ub_gather64.hip); the results are the same.
-constexpr uint8_t kTagDeferred = 0xFF;  // fm_search_fast_kernel leaves such a query to the generic kernel
-static_assert(kTagDeferred > BG_FM_PANIC, "the deferral mark must not collide with a BG_FM_* tag");
 // (the DEFER launch reads every tag once — n_q bytes, ~10 us per 10 M queries — and the fast kernel writes every tag it
 //  owns, deferred or answered, so a caller's stale tag buffer cannot fake a deferral)
 // DEFER: only the queries whose tag is kTagDeferred are searched (second launch behind fm_search_fast_kernel)
@@ -289,7 +282,6 @@ __global__ __launch_bounds__(256) void fm_backward_search_kernel(
 // (tests/test_gpu_fm.py, test_gpu_pack2.py); 466 -> ~560 M queries/s on the 100 Mbp index.
 // PACKED: `pat` is a 2-bit stream already (pack2.hip, the index's codes; offsets in symbols): taking a query is a funnel
 // shift of up to 16 dwords into the slot, nothing can be "bad".
-constexpr uint32_t kFastSyms = 256;
 // STEP2: the LF loop takes two pattern symbols per block access from the index's 2-step rank blocks (fm_kernels.h:
 // Fm2Dev; f2.blocks2 != null), single steps — the last symbol of an odd-length pattern, and the two steps of a double
 // step that found nothing — from the same blocks: half the requests of a query against a request-rate limit.
@@ -559,16 +551,22 @@ __global__ __launch_bounds__(256) void fm_search_fast_kernel(FmDev fm, uint64_t 
 // against eight.  More is not better: three queries per quad (116 VGPRs, four wavefronts: twelve) reach 988 / 752, four
 // (147: three wavefronts) 838 / 673, and the same two queries compiled for six wavefronts (80 VGPRs, three values in
 // scratch) 1006 / 715 — the optimum is where this kernel sits.
-template <bool SEEDS, bool COUNT, bool PACKED, int U>
-__global__ __launch_bounds__(256) void fm_search_fast2x_kernel(FmDev fm, uint64_t n_q, const uint8_t* __restrict__ pat,
+// WIDE (round 6): the same kernel on 64-bit positions (FmLayout<true>: l, r, less, C2 and the exception positions are
+// uint64; the blocks' counters are relative to a superblock whose absolute base — sixteen pair codes + four single-step sums —
+// is one more load per rank, issued in phase A next to the block's).  The narrow instantiation compiles to the code it was.
+template <bool SEEDS, bool COUNT, bool PACKED, int U, bool WIDE = false>
+__global__ __launch_bounds__(256) void fm_search_fast2x_kernel(typename FmLayout<WIDE>::Dev fm, uint64_t n_q, const uint8_t* __restrict__ pat,
                                                                const uint64_t* __restrict__ pat_off, uint8_t* __restrict__ tag,
                                                                uint64_t* __restrict__ lower, uint64_t* __restrict__ upper,
-                                                               uint32_t* __restrict__ matched_len, const SeedSrc seeds, const Fm2Dev f2) {
+                                                               uint32_t* __restrict__ matched_len, const SeedSrc seeds,
+                                                               const typename FmLayout<WIDE>::Dev2 f2) {
+    using P = typename FmLayout<WIDE>::Pos;
     constexpr uint32_t SLOT = kFastSyms / 16;  // dwords per pattern slot
     __shared__ uint16_t s_class[256];
-    __shared__ uint32_t s_less4[4];
+    __shared__ P s_less4[4];
     __shared__ uint32_t s_pk[64 * U * SLOT + 1];  // (+1: the 2-step funnel reads one dword past a slot's last)
-    __shared__ uint32_t s_c2[16], s_e2pos[kMaxExc2], s_e2nib[kMaxExc2];
+    __shared__ P s_c2[16], s_e2pos[kMaxExc2];
+    __shared__ uint32_t s_e2nib[kMaxExc2];
     for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) s_class[i] = fm.sym_class[i];
     if (threadIdx.x < 4) s_less4[threadIdx.x] = fm.less[(seeds.code_bytes >> (8 * threadIdx.x)) & 0xFFu];
     if (threadIdx.x == 0) s_pk[64 * U * SLOT] = 0;
@@ -584,7 +582,8 @@ __global__ __launch_bounds__(256) void fm_search_fast2x_kernel(FmDev fm, uint64_
     const uint64_t n_streams = (uint64_t)gridDim.x * (blockDim.x >> 2) * U;
     struct St {
         uint64_t q;
-        uint32_t pos, l, r, matched;
+        P l, r;
+        uint32_t pos, matched;
         bool active, need, force1;
     };
     St S[U];
@@ -680,7 +679,7 @@ __global__ __launch_bounds__(256) void fm_search_fast2x_kernel(FmDev fm, uint64_
             waiting &= waiting - 1;
         }
     };
-    auto emit = [&](uint64_t q, uint32_t tg, uint32_t lo, uint32_t hi, uint32_t ml) {
+    auto emit = [&](uint64_t q, uint32_t tg, P lo, P hi, uint32_t ml) {
         if (t == 0) {
             tag[q] = (uint8_t)tg;
             lower[q] = lo;
@@ -698,7 +697,9 @@ __global__ __launch_bounds__(256) void fm_search_fast2x_kernel(FmDev fm, uint64_
         if (!__any(any_active)) break;
         // ---- phase A: the symbols and the block loads of both streams (a stream without a query reads block 0)
         uint4 rc[U], rs[U], lc[U], ls[U];
-        uint32_t c[U], p2[U], orr[U], ol[U], lm1[U];
+        uint32_t c[U], p2[U], orr[U], ol[U];
+        P lm1[U];
+        uint64_t sbr[U], sbl[U];  // WIDE: the superblock's absolute count of this step's code (or single-step sum)
         bool single[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
@@ -710,14 +711,21 @@ __global__ __launch_bounds__(256) void fm_search_fast2x_kernel(FmDev fm, uint64_
             const uint32_t cc = __builtin_amdgcn_alignbit(slot[ix + 1], slot[ix], 2 * (p2[u] & 15u));
             c[u] = single[u] ? (cc & 3u) << 2 : (cc & 15u);
             lm1[u] = s.l ? s.l - 1 : 0u;
-            const uint32_t r_ = s.active ? s.r : 0u, l_ = s.active ? lm1[u] : 0u;
-            const uint32_t br = r_ / kSym2PerBlock, bl = l_ / kSym2PerBlock;
-            orr[u] = r_ % kSym2PerBlock;
-            ol[u] = l_ % kSym2PerBlock;
+            const P r_ = s.active ? s.r : 0u, l_ = s.active ? lm1[u] : 0u;
+            const P br = r_ / kSym2PerBlock, bl = l_ / kSym2PerBlock;
+            orr[u] = (uint32_t)(r_ % kSym2PerBlock);
+            ol[u] = (uint32_t)(l_ % kSym2PerBlock);
             rc[u] = f2.blocks2[(uint64_t)br * 8 + t];
             rs[u] = f2.blocks2[(uint64_t)br * 8 + 4 + t];
             lc[u] = f2.blocks2[(uint64_t)bl * 8 + t];
             ls[u] = f2.blocks2[(uint64_t)bl * 8 + 4 + t];
+            if constexpr (WIDE) {
+                const uint32_t bi = single[u] ? 16u + (c[u] >> 2) : c[u];
+                sbr[u] = f2.sb2[(br >> f2.sb_shift) * 20 + bi];
+                sbl[u] = f2.sb2[(bl >> f2.sb_shift) * 20 + bi];
+            } else {
+                sbr[u] = sbl[u] = 0;
+            }
             if (COUNT && s.active) n_lines += bl != br ? 2u : 1u;
         }
         // ---- phase B: fmindex.rs:160-182, twice per block access (see fm_search_fast_kernel<STEP2>)
@@ -726,20 +734,27 @@ __global__ __launch_bounds__(256) void fm_search_fast2x_kernel(FmDev fm, uint64_
             St& s = S[u];
             if (!s.active) continue;
             const uint32_t k = single[u] ? 1u : 2u;
-            const uint32_t base = single[u] ? s_less4[c[u] >> 2] : s_c2[c[u]];
+            const P base = single[u] ? s_less4[c[u] >> 2] : s_c2[c[u]];
             const Pair2Key key2 = pair2_key(c[u], single[u]);
-            uint32_t occ_r = quad_sum(block2_part(rc[u], rs[u], t, orr[u], c[u], single[u], key2));
-            uint32_t occ_l = quad_sum(block2_part(lc[u], ls[u], t, ol[u], c[u], single[u], key2));
+            P occ_r = quad_sum(block2_part(rc[u], rs[u], t, orr[u], c[u], single[u], key2));
+            P occ_l = quad_sum(block2_part(lc[u], ls[u], t, ol[u], c[u], single[u], key2));
+            if constexpr (WIDE) {
+                occ_r += sbr[u];
+                occ_l += sbl[u];
+            }
             {
                 const uint32_t key = single[u] ? 16u : c[u];
-                const uint32_t e0 = f2.exc_pos[0], n0 = single[u] ? (f2.exc_nib[0] & 16u) | (c[u] ? 32u : 0u) : (f2.exc_nib[0] & 15u);
-                const uint32_t e1 = f2.exc_pos[1], n1 = single[u] ? (f2.exc_nib[1] & 16u) | (c[u] ? 32u : 0u) : (f2.exc_nib[1] & 15u);
+                const P e0 = f2.exc_pos[0];
+                const uint32_t n0 = single[u] ? (f2.exc_nib[0] & 16u) | (c[u] ? 32u : 0u) : (f2.exc_nib[0] & 15u);
+                const P e1 = f2.exc_pos[1];
+                const uint32_t n1 = single[u] ? (f2.exc_nib[1] & 16u) | (c[u] ? 32u : 0u) : (f2.exc_nib[1] & 15u);
                 occ_r -= (n0 == key && e0 <= s.r) ? 1u : 0u;
                 occ_l -= (n0 == key && e0 <= lm1[u]) ? 1u : 0u;
                 occ_r -= (n1 == key && e1 <= s.r) ? 1u : 0u;
                 occ_l -= (n1 == key && e1 <= lm1[u]) ? 1u : 0u;
                 for (uint32_t e = 2; e < f2.n_exc; e++) {  // (uniform)
-                    const uint32_t pe = s_e2pos[e], ne = s_e2nib[e];
+                    const P pe = s_e2pos[e];
+                    const uint32_t ne = s_e2nib[e];
                     const uint32_t nk = single[u] ? (ne & 16u) | (c[u] ? 32u : 0u) : (ne & 15u);
                     occ_r -= (nk == key && pe <= s.r) ? 1u : 0u;
                     occ_l -= (nk == key && pe <= lm1[u]) ? 1u : 0u;
@@ -1316,6 +1331,7 @@ extern "C" int bg_fm_free(bg_fm* fm) {
     if (!fm) return BG_OK;
     hipFree(fm->d_blocks);
     hipFree(fm->d_sb);
+    hipFree(fm->d_sb2);
     hipFree(fm->d_blocks2);
     hipFree(fm->d_exc_pos);
     hipFree(fm->d_exc_sym_pos);
@@ -1336,7 +1352,8 @@ extern "C" int bg_fm_free(bg_fm* fm) {
 
 extern "C" uint64_t bg_fm_device_bytes(const bg_fm* fm) { return fm ? fm->bytes : 0; }
 extern "C" uint64_t bg_fm_step2_bytes(const bg_fm* fm) {
-    return fm && !fm->wide && fm->dev2.blocks2 && !fm->no_step2 ? ((uint64_t)fm->dev.n + kSym2PerBlock - 1) / kSym2PerBlock * 128 : 0;
+    if (fm && fm->wide) return fm->wdev2.blocks2 && !fm->no_step2 ? (fm->wdev.n + kSym2PerBlock - 1) / kSym2PerBlock * 128 : 0;
+    return fm && fm->dev2.blocks2 && !fm->no_step2 ? ((uint64_t)fm->dev.n + kSym2PerBlock - 1) / kSym2PerBlock * 128 : 0;
 }
 
 // the four 2-bit codes all stand for symbols and no symbol is ranked by a bit vector: the packed / fast kernels apply
@@ -1353,11 +1370,29 @@ static uint64_t fm_2x_blocks(K kernel, uint64_t n_q, int u) {
 #define FM_LAUNCH_2X(SEEDS, COUNT, PACKED, ...)                                                                                  \
     fm_search_fast2x_kernel<SEEDS, COUNT, PACKED, 2><<<dim3((unsigned)fm_2x_blocks(fm_search_fast2x_kernel<SEEDS, COUNT, PACKED, 2>, n_q, 2)), \
                                                        dim3(256), 0, st>>>(__VA_ARGS__)
+#define FM_LAUNCH_2XW(SEEDS, PACKED, ...)                                                                                                    \
+    fm_search_fast2x_kernel<SEEDS, false, PACKED, 2, true><<<dim3((unsigned)fm_2x_blocks(fm_search_fast2x_kernel<SEEDS, false, PACKED, 2, true>, n_q, 2)), \
+                                                            dim3(256), 0, st>>>(__VA_ARGS__)
 static SeedSrc fm_codes(const bg_fm* fm) {
     SeedSrc ex{};
     ex.code_bytes = (uint32_t)fm->code_byte[0] | (uint32_t)fm->code_byte[1] << 8 | (uint32_t)fm->code_byte[2] << 16 |
                     (uint32_t)fm->code_byte[3] << 24;
     return ex;
+}
+
+// the 2x fast kernel on 64-bit positions (fm_wide.hip decides when; queries it cannot hold are left tagged kTagDeferred)
+int fm_wide_fast2x_launch(bg_fm* fm, uint64_t n_q, const uint8_t* d_pat, const uint64_t* d_pat_off, uint8_t* d_tag, uint64_t* d_lower,
+                          uint64_t* d_upper, uint32_t* d_matched_len, hipStream_t st, const SeedSrc* seeds, bool packed) {
+    SeedSrc src = fm_codes(fm);
+    if (seeds) src.S = seeds->S, src.stride = seeds->stride, src.seed_len = seeds->seed_len;
+    if (seeds)
+        FM_LAUNCH_2XW(true, false, fm->wdev, n_q, d_pat, d_pat_off, d_tag, d_lower, d_upper, d_matched_len, src, fm->wdev2);
+    else if (packed)
+        FM_LAUNCH_2XW(false, true, fm->wdev, n_q, d_pat, d_pat_off, d_tag, d_lower, d_upper, d_matched_len, src, fm->wdev2);
+    else
+        FM_LAUNCH_2XW(false, false, fm->wdev, n_q, d_pat, d_pat_off, d_tag, d_lower, d_upper, d_matched_len, src, fm->wdev2);
+    BG_HIP(hipGetLastError());
+    return BG_OK;
 }
 
 extern "C" int bg_fm_set_option(bg_fm* fm, const char* key, int64_t value) {
@@ -1496,8 +1531,24 @@ int bg_fm_search_seeds_dev(bg_fm* fm, uint64_t n_reads, const uint8_t* d_reads, 
                            uint32_t stride, uint32_t seed_len, uint8_t* d_tag, uint64_t* d_lower, uint64_t* d_upper,
                            uint32_t* d_matched_len, hipStream_t st) {
     const uint64_t n_q = n_reads * S;
-    if (fm->wide) return BG_ERR_UNSUPPORTED;  // (seed-and-extend runs on 32-bit positions: biogpu.h)
     if (n_q == 0) return BG_OK;
+    if (fm->wide) {  // 64-bit positions: fm_wide.hip
+        SeedSrc src{};
+        src.S = S, src.stride = stride, src.seed_len = seed_len;
+        bg_ctx* cx = fm->ctx;
+        if (cx && cx->timing) BG_HIP(hipEventRecord(cx->ev[0], st));
+        const int rcw = fm_wide_search_dev(fm, n_q, d_reads, d_read_off, d_tag, d_lower, d_upper, d_matched_len, st, &src, false);
+        if (rcw) return rcw;
+        if (cx && cx->timing) {
+            BG_HIP(hipEventRecord(cx->ev[1], st));
+            BG_HIP(hipEventSynchronize(cx->ev[1]));
+            float ms = 0;
+            BG_HIP(hipEventElapsedTime(&ms, cx->ev[0], cx->ev[1]));
+            cx->last.fm_ms += ms;
+            cx->last.fm_launches += 1;
+        }
+        return BG_OK;
+    }
     const uint64_t blocks = std::min<uint64_t>((n_q + 63) / 64, 256 * 8);
     SeedSrc src = fm_codes(fm);
     src.S = S, src.stride = stride, src.seed_len = seed_len;
@@ -1535,7 +1586,7 @@ extern "C" int bg_fm_pattern_codes(const bg_fm* fm, uint8_t codes[4]) {
     if (!fm || !codes) return BG_ERR_INVALID_ARG;
     // the four 2-bit codes must all stand for symbols of the text (a DNA-like BWT): with dense symbols code 0 means
     // "something else", and an index over fewer than four letters has codes no pattern symbol may use
-    if (fm->wide || fm->dev.n_dense || fm->n_codes != 4) return BG_ERR_UNSUPPORTED;  // (wide: byte patterns only)
+    if ((!fm->wide && fm->dev.n_dense) || fm->n_codes != 4) return BG_ERR_UNSUPPORTED;
     for (int c = 0; c < 4; c++) codes[c] = fm->code_byte[c];
     return BG_OK;
 }
@@ -1544,14 +1595,17 @@ extern "C" int bg_fm_backward_search_packed_dev(bg_fm* fm, uint64_t n_q, const u
                                                 uint8_t* d_tag, uint64_t* d_lower, uint64_t* d_upper, uint32_t* d_matched_len,
                                                 void* stream) {
     if (!fm || (n_q && (!d_packed || !d_sym_off || !d_tag || !d_lower || !d_upper || !d_matched_len))) return BG_ERR_INVALID_ARG;
-    if (fm->wide || fm->dev.n_dense || fm->n_codes != 4) return BG_ERR_UNSUPPORTED;
+    if ((!fm->wide && fm->dev.n_dense) || fm->n_codes != 4) return BG_ERR_UNSUPPORTED;
     if (n_q == 0) return BG_OK;
     bg_ctx* ctx = fm->ctx;
     hipStream_t st = (hipStream_t)stream;
     const uint64_t blocks = std::min<uint64_t>((n_q + 63) / 64, 256 * 8);
     const SeedSrc ex = fm_codes(fm);
     if (ctx->timing) BG_HIP(hipEventRecord(ctx->ev[0], st));
-    if (!fm->no_fast) {  // the LDS-slot kernel; patterns beyond its 256 symbols are left to the generic packed kernel
+    if (fm->wide) {  // 64-bit positions: fm_wide.hip
+        const int rcw = fm_wide_search_dev(fm, n_q, (const uint8_t*)d_packed, d_sym_off, d_tag, d_lower, d_upper, d_matched_len, st, nullptr, true);
+        if (rcw) return rcw;
+    } else if (!fm->no_fast) {  // the LDS-slot kernel; patterns beyond its 256 symbols are left to the generic packed kernel
         if (fm_step2_ok(fm) && fm->ilp >= 2)
             FM_LAUNCH_2X(false, false, true, fm->dev, n_q, (const uint8_t*)d_packed, d_sym_off, d_tag, d_lower, d_upper, d_matched_len, ex, fm->dev2);
         else if (fm_step2_ok(fm))

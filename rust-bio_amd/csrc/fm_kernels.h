@@ -189,6 +189,47 @@ struct FmWideDev {
     uint32_t n_exc;
     uint32_t sb_shift;             // blocks per superblock = 1 << sb_shift
 };
+// 2-step rank blocks on 64-bit positions (round 6): the 128-byte blocks of Fm2Dev with their sixteen counters RELATIVE to a
+// superblock of 2^sb_shift blocks, and per superblock twenty absolute 64-bit bases — sixteen pair codes, then the four
+// "first component == a" sums a single step adds up (one extra load per rank, from an array that stays in cache: 160 bytes
+// per 2^sb_shift * 128 positions).  C2 and the exception positions are 64-bit.
+struct Fm2WideDev {
+    const uint4* blocks2;        // null: no 2-step blocks
+    const uint64_t* sb2;         // [n_superblocks][20]
+    uint64_t c2[16];
+    uint64_t exc_pos[kMaxExc2];  // sorted; unused entries ~0
+    uint8_t exc_nib[kMaxExc2];
+    uint32_t n_exc;
+    uint32_t sb_shift;
+};
+// what the kernels that exist for both position widths are instantiated over
+template <bool WIDE>
+struct FmLayout;
+template <>
+struct FmLayout<false> {
+    using Pos = uint32_t;
+    using Dev = FmDev;
+    using Dev2 = Fm2Dev;
+};
+template <>
+struct FmLayout<true> {
+    using Pos = uint64_t;
+    using Dev = FmWideDev;
+    using Dev2 = Fm2WideDev;
+};
+
+// SEEDS: the patterns are the seed windows of a batch of reads (seed-and-extend, seed_extend.hip) — query q is
+// seed q % S of read q / S: pat[pat_off[r] + k * stride ..+ seed_len) while it fits in the read (else an empty
+// pattern: Absent), so overlapping windows need no copy of the reads.
+struct SeedSrc {
+    uint32_t S, stride, seed_len;
+    uint32_t code_bytes;            // PACKED: the byte value of each 2-bit code (code c in bits 8c..8c+7)
+    unsigned long long* lines;      // COUNT: receives the number of 64-byte block loads the launch issued
+};
+constexpr uint8_t kTagDeferred = 0xFF;  // the fast kernels leave such a query to the generic kernel launched behind them
+static_assert(kTagDeferred > BG_FM_PANIC, "the deferral mark must not collide with a BG_FM_* tag");
+constexpr uint32_t kFastSyms = 256;     // symbols of a pattern slot of the fast kernels (LDS)
+
 __device__ __forceinline__ uint32_t count_le64(const uint64_t* arr, uint32_t lo, uint32_t hi, uint64_t r) {
     while (lo < hi) {
         const uint32_t mid = (lo + hi) >> 1;
@@ -246,6 +287,8 @@ struct bg_fm {
     bool wide = false;
     bgfm::FmWideDev wdev = {};
     void* d_sb = nullptr;
+    bgfm::Fm2WideDev wdev2 = {};  // 2-step blocks on 64-bit positions (d_blocks2 holds the blocks)
+    void* d_sb2 = nullptr;
     // what the handle was built from, for bg_fm_save (fm_persist.hip): the reference's FMIndex holds the same
     std::vector<uint8_t> alphabet;
     std::vector<uint64_t> h_less;
@@ -257,8 +300,14 @@ void fm_remember_inputs(bg_fm* fm, const uint8_t* alphabet, uint32_t n_sym, uint
 // fm_wide.hip: the index with 64-bit positions (built from a BWT in HBM; `less` null: the BWT's own cumulative counts)
 int fm_wide_build_dev(bg_ctx* ctx, const uint8_t* d_bwt, uint64_t n, const uint8_t* alphabet, uint32_t n_sym, const uint64_t* less,
                       uint32_t less_len, uint64_t* less_out, bg_fm** out, hipStream_t st);
+// `seeds` non-null: the SEEDS flavour (n_q = reads * S; S, stride, seed_len set); `packed`: pat is a 2-bit stream, offsets in symbols
 int fm_wide_search_dev(bg_fm* fm, uint64_t n_q, const uint8_t* d_pat, const uint64_t* d_pat_off, uint8_t* d_tag, uint64_t* d_lower,
-                       uint64_t* d_upper, uint32_t* d_matched_len, hipStream_t st);
+                       uint64_t* d_upper, uint32_t* d_matched_len, hipStream_t st, const bgfm::SeedSrc* seeds = nullptr, bool packed = false);
+// fm_index.hip: the 2x fast kernel instantiated for 64-bit positions (needs fm->wdev2.blocks2); deferred queries are left tagged
+int fm_wide_fast2x_launch(bg_fm* fm, uint64_t n_q, const uint8_t* d_pat, const uint64_t* d_pat_off, uint8_t* d_tag, uint64_t* d_lower,
+                          uint64_t* d_upper, uint32_t* d_matched_len, hipStream_t st, const bgfm::SeedSrc* seeds, bool packed);
+// fm_step2.hip: the 2-step blocks behind a finished 64-bit index (best effort; synchronises the stream)
+void fm_build_step2_wide(bg_fm* fm, hipStream_t st);
 int fm_wide_sa_get(bg_fm* fm, uint64_t n, const uint64_t* d_index, uint64_t* d_pos, hipStream_t st);
 // texts from this many symbols on take the 64-bit layout (tests lower it through the ctx option "fm_wide_from")
 uint64_t fm_wide_threshold(const bg_ctx* ctx);

@@ -20,6 +20,7 @@
 #include <algorithm>
 #include <cstring>
 #include <numeric>
+#include <string.h>
 #include <vector>
 
 #include <rocprim/device/device_scan.hpp>
@@ -228,20 +229,26 @@ __global__ __launch_bounds__(256) void fmw_search_kernel(FmWideDev fm, uint64_t 
 // block 0; the line of l - 1 is requested even where it is the line of r) — phase B ranks and updates both.  Stream
 // (quad, u) takes queries (2 quad + u) + k * 2 quads.  bg_fm_set_option("ilp", 1): the kernel above.  On the 4.4 G-symbol
 // index: 302 -> 404 M queries/s (profiles/r05_fm_wide_4g4.json), same arrays.
+// Round 6: the flavours the narrow generic kernel has — SEEDS (the seed windows of a batch of reads: query q is seed q % S of
+// read q / S, fm_kernels.h SeedSrc), PACKED (`pat` is a 2-bit stream in the index's codes, offsets in symbols: the class of a
+// symbol is its code) and DEFER (only the queries the 2x fast kernel in front left tagged kTagDeferred).
+template <bool SEEDS, bool PACKED, bool DEFER>
 __global__ __launch_bounds__(256) void fmw_search2x_kernel(FmWideDev fm, uint64_t n_q, const uint8_t* __restrict__ pat,
                                                            const uint64_t* __restrict__ pat_off, uint8_t* __restrict__ tag,
                                                            uint64_t* __restrict__ lower, uint64_t* __restrict__ upper,
-                                                           uint32_t* __restrict__ matched_len) {
+                                                           uint32_t* __restrict__ matched_len, const SeedSrc seeds) {
     constexpr int U = 2;
     __shared__ uint16_t s_class[256];
     __shared__ uint64_t s_less[256];
     __shared__ uint64_t s_exc[kWideMaxExc];
     for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) {
         s_class[i] = fm.sym_class[i];
-        s_less[i] = fm.less[i];
+        // PACKED: entry c (< 4) is less[] of the byte that code c stands for
+        s_less[i] = (PACKED && i < 4) ? fm.less[(seeds.code_bytes >> (8 * i)) & 0xFFu] : fm.less[i];
     }
     for (uint32_t i = threadIdx.x; i < fm.n_exc; i += blockDim.x) s_exc[i] = fm.exc_pos[i];
     __syncthreads();
+    const uint32_t* __restrict__ pk = (const uint32_t*)pat;
     const uint32_t t = threadIdx.x & 3;
     const uint64_t n_streams = (uint64_t)gridDim.x * (blockDim.x >> 2) * U;
     struct St {
@@ -258,17 +265,34 @@ __global__ __launch_bounds__(256) void fmw_search2x_kernel(FmWideDev fm, uint64_
             matched_len[q] = ml;
         }
     };
+    auto symbol = [&](uint64_t at) -> uint32_t {  // the pattern symbol at stream position `at`: a byte, or a 2-bit code
+        if (PACKED) return (pk[at >> 4] >> (2 * ((uint32_t)at & 15u))) & 3u;
+        return pat[at];
+    };
     auto fetch = [&](St& s) {  // the stream's next non-empty query; empty patterns are Absent at once (fmindex.rs:185-207)
         s.active = false;
         while (s.q < n_q) {
-            s.off = pat_off[s.q];
-            const uint32_t len = (uint32_t)(pat_off[s.q + 1] - s.off);
+            if (DEFER && tag[s.q] != kTagDeferred) {
+                s.q += n_streams;
+                continue;
+            }
+            uint32_t len;
+            if (SEEDS) {
+                const uint64_t rd = s.q / seeds.S;
+                const uint32_t k = (uint32_t)(s.q - rd * seeds.S);
+                const uint64_t o = pat_off[rd];
+                s.off = o + (uint64_t)k * seeds.stride;
+                len = (uint64_t)k * seeds.stride + seeds.seed_len <= pat_off[rd + 1] - o ? seeds.seed_len : 0u;
+            } else {
+                s.off = pat_off[s.q];
+                len = (uint32_t)(pat_off[s.q + 1] - s.off);
+            }
             if (len) {
                 s.pos = len;
                 s.l = 0;
                 s.r = fm.n - 1;  // fmindex.rs:148
                 s.matched = 0;
-                s.a_next = pat[s.off + len - 1];
+                s.a_next = symbol(s.off + len - 1);
                 s.active = true;
                 return;
             }
@@ -297,8 +321,8 @@ __global__ __launch_bounds__(256) void fmw_search2x_kernel(FmWideDev fm, uint64_
             St& s = S[u];
             a[u] = s.a_next;
             const uint32_t p1 = s.active ? s.pos - 1u : 0u;
-            if (s.active && p1) s.a_next = pat[s.off + p1 - 1];  // (address independent of the ranks)
-            cls[u] = s_class[a[u]];
+            if (s.active && p1) s.a_next = symbol(s.off + p1 - 1);  // (address independent of the ranks)
+            cls[u] = PACKED ? a[u] : (uint32_t)s_class[a[u]];
             const bool coded = s.active && cls[u] < 4;
             const uint64_t r_ = coded ? s.r : 0, l_ = coded && s.l ? s.l - 1 : 0;
             br[u] = r_ / kSymPerBlock;
@@ -321,10 +345,10 @@ __global__ __launch_bounds__(256) void fmw_search2x_kernel(FmWideDev fm, uint64_
             uint64_t occ_r = 0, occ_l = 0;
             bool stop = false;
             uint32_t stop_tag = BG_FM_PARTIAL;
-            if (cls[u] == kClsPanic) {
+            if (!PACKED && cls[u] == kClsPanic) {
                 stop = true;
                 stop_tag = BG_FM_PANIC;
-            } else if (cls[u] < 4) {
+            } else if (PACKED || cls[u] < 4) {
                 occ_r = base_r[u] + (uint64_t)quad_sum(block_part(vr[u], t, orr[u], cls[u]));
                 if (s.l > 0) occ_l = base_l[u] + (uint64_t)quad_sum(block_part(vl[u], t, ol[u], cls[u]));
                 if (cls[u] == 0 && fm.n_exc) {  // sparse exceptions sit in the stream as code 0
@@ -548,9 +572,9 @@ int fm_wide_build_dev(bg_ctx* ctx, const uint8_t* d_bwt, uint64_t n, const uint8
         fm->ctx = ctx;
         fm->wide = true;
         fm->less_len = less_len;
-        fm->fmd_ok = false;   // (the FMD kernels' interval records are 32-bit)
-        fm->no_fast = true;
-        fm->no_step2 = true;
+        fm->fmd_ok = true;  // the BWT is a word over dna::n_alphabet() + '$' (FMDIndex::from, fmindex.rs:323-327)
+        for (int c = 0; c < 256; c++)
+            if (hist[c] && (c == 0 || !strchr("ACGTNacgtn$", c))) fm->fmd_ok = false;
         for (int c = 0; c < 256; c++)
             if (code_of[c] >= 0) fm->code_byte[code_of[c]] = (uint8_t)c;
         fm->n_codes = n_codes;
@@ -637,6 +661,17 @@ int fm_wide_build_dev(bg_ctx* ctx, const uint8_t* d_bwt, uint64_t n, const uint8
         fm->wdev.n_exc = ns;
         fm->wdev.sb_shift = sb_shift;
         fm->n_text = 0;
+        {
+            // 2-step rank blocks (fm_step2.hip) lean on less[] being the BWT's own cumulative counts; a caller's less that
+            // says otherwise keeps single steps (as on the 32-bit layout, fm_index.hip)
+            bool consistent = true;
+            uint64_t run = 0;
+            for (uint32_t c = 0; c < m && c < 256 && consistent; c++) {
+                if (hist[c] && less[c] != run) consistent = false;
+                run += hist[c];
+            }
+            if (consistent) fm_build_step2_wide(fm, st);
+        }
         return BG_OK;
     };
     const int rc = body();
@@ -649,17 +684,43 @@ int fm_wide_build_dev(bg_ctx* ctx, const uint8_t* d_bwt, uint64_t n, const uint8
     return BG_OK;
 }
 
+namespace {
+template <bool SEEDS, bool PACKED, bool DEFER>
+int launch_2x(bg_fm* fm, uint64_t n_q, const uint8_t* d_pat, const uint64_t* d_pat_off, uint8_t* d_tag, uint64_t* d_lower, uint64_t* d_upper,
+              uint32_t* d_matched_len, const SeedSrc& src, hipStream_t st) {
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fmw_search2x_kernel<SEEDS, PACKED, DEFER>, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+    const uint64_t blocks = std::min<uint64_t>((n_q + 127) / 128, 256ull * (uint64_t)per_cu);
+    fmw_search2x_kernel<SEEDS, PACKED, DEFER><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(fm->wdev, n_q, d_pat, d_pat_off, d_tag, d_lower, d_upper,
+                                                                                          d_matched_len, src);
+    BG_HIP(hipGetLastError());
+    return BG_OK;
+}
+}  // namespace
+
+// Which kernel answers a search on 64-bit positions:
+//   * the index has 2-step blocks (a DNA-like text with at most a handful of positions outside its four letters — T$R$ of a
+//     genome without N) and neither "no_step2", "no_fast" nor "ilp" = 1 is set: fm_search_fast2x_kernel<WIDE> (fm_index.hip),
+//     then this file's generic kernel for the queries it deferred (a byte outside the codes, more than 256 symbols);
+//   * otherwise the generic kernels here: two queries per quad (every flavour), or one ("ilp" = 1, byte patterns).
 int fm_wide_search_dev(bg_fm* fm, uint64_t n_q, const uint8_t* d_pat, const uint64_t* d_pat_off, uint8_t* d_tag, uint64_t* d_lower,
-                       uint64_t* d_upper, uint32_t* d_matched_len, hipStream_t st) {
-    if (fm->ilp >= 2) {  // two queries per quad (the default)
-        int per_cu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fmw_search2x_kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
-        const uint64_t blocks = std::min<uint64_t>((n_q + 127) / 128, 256ull * (uint64_t)per_cu);
-        fmw_search2x_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(fm->wdev, n_q, d_pat, d_pat_off, d_tag, d_lower, d_upper, d_matched_len);
-    } else {
-        const uint64_t blocks = std::min<uint64_t>((n_q + 63) / 64, 256 * 8);
-        fmw_search_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(fm->wdev, n_q, d_pat, d_pat_off, d_tag, d_lower, d_upper, d_matched_len);
+                       uint64_t* d_upper, uint32_t* d_matched_len, hipStream_t st, const SeedSrc* seeds, bool packed) {
+    SeedSrc src{};
+    if (seeds) src = *seeds;
+    src.code_bytes = (uint32_t)fm->code_byte[0] | (uint32_t)fm->code_byte[1] << 8 | (uint32_t)fm->code_byte[2] << 16 | (uint32_t)fm->code_byte[3] << 24;
+    const bool fast = fm->wdev2.blocks2 && !fm->no_step2 && !fm->no_fast && fm->ilp >= 2 && fm->n_codes == 4 && (!seeds || seeds->seed_len <= kFastSyms);
+    int rc;
+    if (fast) {
+        if ((rc = fm_wide_fast2x_launch(fm, n_q, d_pat, d_pat_off, d_tag, d_lower, d_upper, d_matched_len, st, seeds, packed))) return rc;
+        if (seeds) return launch_2x<true, false, true>(fm, n_q, d_pat, d_pat_off, d_tag, d_lower, d_upper, d_matched_len, src, st);
+        if (packed) return launch_2x<false, true, true>(fm, n_q, d_pat, d_pat_off, d_tag, d_lower, d_upper, d_matched_len, src, st);
+        return launch_2x<false, false, true>(fm, n_q, d_pat, d_pat_off, d_tag, d_lower, d_upper, d_matched_len, src, st);
     }
+    if (seeds) return launch_2x<true, false, false>(fm, n_q, d_pat, d_pat_off, d_tag, d_lower, d_upper, d_matched_len, src, st);
+    if (packed) return launch_2x<false, true, false>(fm, n_q, d_pat, d_pat_off, d_tag, d_lower, d_upper, d_matched_len, src, st);
+    if (fm->ilp >= 2) return launch_2x<false, false, false>(fm, n_q, d_pat, d_pat_off, d_tag, d_lower, d_upper, d_matched_len, src, st);
+    const uint64_t blocks = std::min<uint64_t>((n_q + 63) / 64, 256 * 8);
+    fmw_search_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(fm->wdev, n_q, d_pat, d_pat_off, d_tag, d_lower, d_upper, d_matched_len);
     BG_HIP(hipGetLastError());
     return BG_OK;
 }

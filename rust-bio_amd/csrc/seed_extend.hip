@@ -38,11 +38,11 @@ void bg_seed_scratch_free(bg_seed_scratch* s) {
 namespace {
 
 constexpr uint32_t kMaxProposals = 1024;  // seed slots x max_occ per read (sorted in LDS by one wavefront)
-constexpr uint32_t kNoStart = 0xFFFFFFFFu;
-
+// proposals are sorted as uint32 on an index with 32-bit positions and as uint64 on one with 64-bit positions (round 6:
+// the kernels below are templates over that type; ~P(0) marks a dropped proposal)
 struct SeedPrm {
     uint32_t S, stride, seed_len, max_occ, pad;
-    uint32_t n_text;  // text length without the final sentinel
+    uint64_t n_text;  // text length without the final sentinel
 };
 
 // S2: votes of every seed slot
@@ -63,11 +63,13 @@ __global__ __launch_bounds__(256) void se_votes_kernel(uint64_t n_q, const uint8
 // S4: one wavefront per read.  The read's hits are pos[hoff[r * S] .. hoff[(r + 1) * S)), grouped by seed slot.  Every
 // hit proposes s = p - k * stride (dropped if negative or >= n_text); the proposals are sorted, merged, and written
 // back over the read's own slice of `pos` (as the sorted unique starts); per read: candidates, hits, y bytes, x bytes.
+template <typename T>
 __global__ __launch_bounds__(64) void se_propose_kernel(SeedPrm prm, uint64_t n_reads, const uint64_t* __restrict__ read_off,
                                                         const uint64_t* __restrict__ hoff, uint64_t* __restrict__ pos,
                                                         uint32_t* __restrict__ n_cand, uint32_t* __restrict__ n_hits,
                                                         uint32_t* __restrict__ x_bytes, uint32_t* __restrict__ y_bytes) {
-    __shared__ uint32_t s_val[kMaxProposals];
+    constexpr T kNoStart = ~(T)0;
+    __shared__ T s_val[kMaxProposals];
     __shared__ uint64_t s_off[65];
     const uint64_t r = blockIdx.x;
     const uint32_t lane = threadIdx.x;
@@ -82,13 +84,13 @@ __global__ __launch_bounds__(64) void se_propose_kernel(SeedPrm prm, uint64_t n_
         uint32_t P = 64;
         while (P < nh) P <<= 1;
         for (uint32_t i = lane; i < P; i += 64) {
-            uint32_t v = kNoStart;
+            T v = kNoStart;
             if (i < nh) {
                 uint32_t k = 0;  // the seed slot of hit i: last k with s_off[k] - h0 <= i
                 while (k + 1 < prm.S && s_off[k + 1] - h0 <= i) k++;
                 const uint64_t p = pos[h0 + i];
                 const uint64_t o = (uint64_t)k * prm.stride;
-                if (p >= o && p - o < prm.n_text) v = (uint32_t)(p - o);  // also drops BG_SA_NONE / BG_SA_PANIC
+                if (p >= o && p - o < prm.n_text) v = (T)(p - o);  // also drops BG_SA_NONE / BG_SA_PANIC
             }
             s_val[i] = v;
         }
@@ -99,7 +101,7 @@ __global__ __launch_bounds__(64) void se_propose_kernel(SeedPrm prm, uint64_t n_
                 for (uint32_t i = lane; i < P; i += 64) {
                     const uint32_t ixj = i ^ j;
                     if (ixj > i) {
-                        const uint32_t a = s_val[i], b = s_val[ixj];
+                        const T a = s_val[i], b = s_val[ixj];
                         const bool up = (i & k2) == 0;
                         if ((a > b) == up) {
                             s_val[i] = b;
@@ -114,7 +116,7 @@ __global__ __launch_bounds__(64) void se_propose_kernel(SeedPrm prm, uint64_t n_
         uint32_t base = 0;
         for (uint32_t b0 = 0; b0 < P; b0 += 64) {
             const uint32_t i = b0 + lane;
-            const uint32_t v = s_val[i];
+            const T v = s_val[i];
             const bool keep = v != kNoStart && (i == 0 || s_val[i - 1] != v);
             const uint64_t m = __ballot(keep);
             if (keep) pos[h0 + base + (uint32_t)__popcll(m & ((1ull << lane) - 1))] = v;
@@ -126,9 +128,9 @@ __global__ __launch_bounds__(64) void se_propose_kernel(SeedPrm prm, uint64_t n_
     __syncthreads();
     uint32_t yl = 0;
     for (uint32_t c = lane; c < n_unique; c += 64) {
-        const uint32_t v = (uint32_t)pos[h0 + c];
-        const uint32_t lo = v > prm.pad ? v - prm.pad : 0u;
-        const uint64_t hi = min((uint64_t)prm.n_text, (uint64_t)v + L + prm.pad);
+        const uint64_t v = pos[h0 + c];
+        const uint64_t lo = v > prm.pad ? v - prm.pad : 0u;
+        const uint64_t hi = min(prm.n_text, v + L + prm.pad);
         yl += (uint32_t)(hi - lo);
     }
 #pragma unroll
@@ -148,7 +150,7 @@ __global__ __launch_bounds__(64) void se_gather_kernel(SeedPrm prm, uint64_t n_r
                                                        const uint64_t* __restrict__ coff, const uint64_t* __restrict__ xoff,
                                                        const uint64_t* __restrict__ yoff, uint8_t* __restrict__ x,
                                                        uint64_t* __restrict__ x_off, uint8_t* __restrict__ y, uint64_t* __restrict__ y_off,
-                                                       uint32_t* __restrict__ w_lo) {
+                                                       uint64_t* __restrict__ w_lo) {
     const uint64_t r = blockIdx.x;
     const uint32_t lane = threadIdx.x;
     if (r >= n_reads) return;
@@ -164,9 +166,9 @@ __global__ __launch_bounds__(64) void se_gather_kernel(SeedPrm prm, uint64_t n_r
     const uint64_t h0 = hoff[r * prm.S];
     uint64_t yo = yoff[r];
     for (uint32_t c = 0; c < nc; c++) {
-        const uint32_t v = (uint32_t)pos[h0 + c];
-        const uint32_t lo = v > prm.pad ? v - prm.pad : 0u;
-        const uint32_t hi = (uint32_t)min((uint64_t)prm.n_text, (uint64_t)v + L + prm.pad);
+        const uint64_t v = pos[h0 + c];
+        const uint64_t lo = v > prm.pad ? v - prm.pad : 0u;
+        const uint64_t hi = min(prm.n_text, v + L + prm.pad);
         const uint64_t xo = xoff[r] + (uint64_t)c * L;
         if (lane == 0) {
             x_off[c0 + c] = xo;
@@ -174,7 +176,7 @@ __global__ __launch_bounds__(64) void se_gather_kernel(SeedPrm prm, uint64_t n_r
             w_lo[c0 + c] = lo;
         }
         for (uint32_t i = lane; i < L; i += 64) x[xo + i] = reads[ro + i];
-        for (uint32_t i = lane; i < hi - lo; i += 64) y[yo + i] = text[(uint64_t)lo + i];
+        for (uint32_t i = lane; i < (uint32_t)(hi - lo); i += 64) y[yo + i] = text[lo + i];
         yo += hi - lo;
     }
 }
@@ -185,7 +187,7 @@ __global__ __launch_bounds__(64) void se_gather_kernel(SeedPrm prm, uint64_t n_r
 __global__ __launch_bounds__(256) void se_best_kernel(uint64_t n_reads, uint64_t r0, const uint64_t* __restrict__ coff,
                                                       const uint32_t* __restrict__ n_hits,
                                                       const bg_alignment_t* __restrict__ aln, const uint8_t* __restrict__ c_ops,
-                                                      const uint32_t* __restrict__ w_lo, bg_seed_hit_t* __restrict__ hits,
+                                                      const uint64_t* __restrict__ w_lo, bg_seed_hit_t* __restrict__ hits,
                                                       uint8_t* __restrict__ ops, uint64_t ops_stride) {
     const uint64_t r = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     const uint32_t l16 = threadIdx.x & 15;
@@ -217,8 +219,8 @@ __global__ __launch_bounds__(256) void se_best_kernel(uint64_t n_reads, uint64_t
         h.aln = a;
         h.aln.ops_off = (r0 + r + 1) * ops_stride - a.n_ops;
         h.window_start = w_lo[c0 + c];
-        h.ref_start = (uint64_t)w_lo[c0 + c] + a.ystart;
-        h.ref_end = (uint64_t)w_lo[c0 + c] + a.yend;
+        h.ref_start = w_lo[c0 + c] + a.ystart;
+        h.ref_end = w_lo[c0 + c] + a.yend;
         if (ops && c_ops)
             for (uint32_t i = l16; i < a.n_ops; i += 16) ops[h.aln.ops_off + i] = c_ops[a.ops_off + i];
     }
@@ -228,23 +230,22 @@ __global__ __launch_bounds__(256) void se_best_kernel(uint64_t n_reads, uint64_t
 }  // namespace
 
 extern "C" int bg_fm_set_text(bg_fm* fm, const uint8_t* text, uint64_t n) {
-    if (fm && fm->wide) return BG_ERR_UNSUPPORTED;  // seed-and-extend runs on 32-bit positions (biogpu.h)
-    if (!fm || !text || n != fm->dev.n) return BG_ERR_INVALID_ARG;
+    if (!fm || !text || n != (fm->wide ? fm->wdev.n : (uint64_t)fm->dev.n)) return BG_ERR_INVALID_ARG;
     BG_HIP(hipSetDevice(fm->ctx->device));
     if (fm->text_owned) hipFree(fm->d_text);
     fm->d_text = nullptr;
     fm->text_owned = false;
     BG_HIP(hipMalloc(&fm->d_text, n));
     fm->text_owned = true;
-    BG_HIP(hipMemcpy(fm->d_text, text, n, hipMemcpyHostToDevice));
+    if (bg_copy_pieces(fm->d_text, text, n, hipMemcpyHostToDevice, fm->ctx->stream) != hipSuccess || hipStreamSynchronize(fm->ctx->stream) != hipSuccess)
+        return BG_ERR_HIP;
     fm->n_text = n - 1;
     fm->bytes += n;
     return BG_OK;
 }
 
 extern "C" int bg_fm_set_text_dev(bg_fm* fm, const uint8_t* d_text, uint64_t n) {
-    if (fm && fm->wide) return BG_ERR_UNSUPPORTED;
-    if (!fm || !d_text || n != fm->dev.n) return BG_ERR_INVALID_ARG;
+    if (!fm || !d_text || n != (fm->wide ? fm->wdev.n : (uint64_t)fm->dev.n)) return BG_ERR_INVALID_ARG;
     if (fm->text_owned) hipFree(fm->d_text);
     fm->d_text = (void*)d_text;
     fm->text_owned = false;
@@ -257,7 +258,6 @@ extern "C" int bg_seed_extend_batch_dev(bg_fm* fm, const bg_scoring_t* sc, const
                                         bg_seed_hit_t* d_hits, uint8_t* d_ops, uint64_t ops_stride, uint64_t* totals,
                                         void* stream) {
     if (!fm || !sc || !prm_in || (n_reads && (!d_read_off || !d_hits))) return BG_ERR_INVALID_ARG;
-    if (fm->wide) return BG_ERR_UNSUPPORTED;
     if (!fm->d_text || fm->sa_kind == 0) return BG_ERR_INVALID_ARG;  // needs bg_fm_set_text + a suffix array
     if (prm_in->seed_len == 0 || prm_in->stride == 0 || prm_in->max_occ == 0) return BG_ERR_INVALID_ARG;
     if (max_read_len > 65535 || prm_in->pad > 65535) return BG_ERR_TOO_LARGE;
@@ -275,7 +275,7 @@ extern "C" int bg_seed_extend_batch_dev(bg_fm* fm, const bg_scoring_t* sc, const
     prm.seed_len = prm_in->seed_len;
     prm.max_occ = prm_in->max_occ;
     prm.pad = prm_in->pad;
-    prm.n_text = (uint32_t)fm->n_text;
+    prm.n_text = fm->n_text;
     if (prm.S > 64 || (uint64_t)prm.S * prm.max_occ > kMaxProposals) return BG_ERR_UNSUPPORTED;
     if (!ctx->seed) ctx->seed = new bg_seed_scratch();
     bg_seed_scratch& W = *ctx->seed;
@@ -326,7 +326,10 @@ extern "C" int bg_seed_extend_batch_dev(bg_fm* fm, const bg_scoring_t* sc, const
         uint32_t *d_nh = d_nc + nr, *d_xb = d_nh + nr, *d_yb = d_xb + nr;
         uint64_t* d_coff = (uint64_t*)W.p[8];
         uint64_t *d_xoff = d_coff + (nr + 1), *d_yoff = d_xoff + (nr + 1);
-        se_propose_kernel<<<dim3((unsigned)nr), dim3(64), 0, st>>>(prm, nr, roff, d_hoff, d_pos, d_nc, d_nh, d_xb, d_yb);
+        if (fm->wide)
+            se_propose_kernel<uint64_t><<<dim3((unsigned)nr), dim3(64), 0, st>>>(prm, nr, roff, d_hoff, d_pos, d_nc, d_nh, d_xb, d_yb);
+        else
+            se_propose_kernel<uint32_t><<<dim3((unsigned)nr), dim3(64), 0, st>>>(prm, nr, roff, d_hoff, d_pos, d_nc, d_nh, d_xb, d_yb);
         BG_HIP(hipGetLastError());
         if ((rc = bg_scan_u32(d_nc, nr, d_coff, d_sums, st))) return rc;
         if ((rc = bg_scan_u32(d_xb, nr, d_xoff, d_sums, st))) return rc;
@@ -341,13 +344,13 @@ extern "C" int bg_seed_extend_batch_dev(bg_fm* fm, const bg_scoring_t* sc, const
         if ((rc = need(9, X))) return rc;
         if ((rc = need(10, Y))) return rc;
         if ((rc = need(11, 2 * (C + 1) * 8))) return rc;
-        if ((rc = need(12, C * 4))) return rc;
+        if ((rc = need(12, C * 8))) return rc;
         if ((rc = need(13, C * sizeof(bg_alignment_t)))) return rc;
         if ((rc = need(14, C * cstride))) return rc;
         uint8_t *d_x = (uint8_t*)W.p[9], *d_y = (uint8_t*)W.p[10], *d_cops = d_ops ? (uint8_t*)W.p[14] : nullptr;
         uint64_t* d_cxoff = (uint64_t*)W.p[11];
         uint64_t* d_cyoff = d_cxoff + (C + 1);
-        uint32_t* d_wlo = (uint32_t*)W.p[12];
+        uint64_t* d_wlo = (uint64_t*)W.p[12];
         bg_alignment_t* d_aln = (bg_alignment_t*)W.p[13];
         se_gather_kernel<<<dim3((unsigned)nr), dim3(64), 0, st>>>(prm, nr, d_reads, roff, (const uint8_t*)fm->d_text, d_hoff, d_pos, d_coff,
                                                                   d_xoff, d_yoff, d_x, d_cxoff, d_y, d_cyoff, d_wlo);

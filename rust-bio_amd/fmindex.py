@@ -223,11 +223,13 @@ class FMDIndex:
     """FMDIndex::from(fmindex) (fmindex.rs:311-329): bi-directional search over an FM index of T$R$...
     `smems` / `all_smems` (363-501) run on the device; results are (BiInterval, position, length)."""
 
-    def __init__(self, fmindex):
-        b = fmindex.bwt()
-        ok = np.isin(b, np.frombuffer(b"ACGTNacgtn$", dtype=np.uint8)).all()
-        assert ok, "Expecting BWT over the DNA alphabet (including N) with the sentinel $."
+    def __init__(self, fmindex, records32=False, check=True):
+        if check:  # (check=False: a caller that knows — the engine refuses a BWT outside the alphabet anyway, BG_ERR_UNSUPPORTED)
+            b = fmindex.bwt()
+            ok = np.isin(b, np.frombuffer(b"ACGTNacgtn$", dtype=np.uint8)).all()
+            assert ok, "Expecting BWT over the DNA alphabet (including N) with the sentinel $."
         self.fm = fmindex
+        self.records32 = records32
 
     def smems_arrays(self, pat, pat_off, i_pos, l, all_=False, cap=None):
         p = _lib.as_u8(pat)
@@ -237,10 +239,16 @@ class FMDIndex:
             cap = int(np.diff(off).max()) + 1 if n else 1
         ip = np.ascontiguousarray(i_pos, dtype=np.uint32) if i_pos is not None else None
         cnt = np.zeros(n, dtype=np.uint32)
-        out = np.zeros((n, cap, 6), dtype=np.uint32)
-        rc = _lib.lib().bg_fmd_smems_batch(self.fm.h, 1 if all_ else 0, n, p.ctypes.data, off.ctypes.data,
-                                           ip.ctypes.data if ip is not None else None, l, cap, cnt.ctypes.data,
-                                           out.ctypes.data)
+        # (BiInterval is usize in the reference, fmindex.rs:254-259: the uint64-record entry point serves both index layouts;
+        #  records32=True keeps the uint32 flavour of rounds 2-5 reachable for the tests)
+        if self.records32:
+            out = np.zeros((n, cap, 6), dtype=np.uint32)
+            fn = _lib.lib().bg_fmd_smems_batch
+        else:
+            out = np.zeros((n, cap, 6), dtype=np.uint64)
+            fn = _lib.lib().bg_fmd_smems_batch64
+        rc = fn(self.fm.h, 1 if all_ else 0, n, p.ctypes.data, off.ctypes.data,
+                ip.ctypes.data if ip is not None else None, l, cap, cnt.ctypes.data, out.ctypes.data)
         _lib.check(rc, "FMDIndex::smems")
         return cnt, out
 
@@ -259,17 +267,18 @@ class FMDIndex:
         return [self._decode(cnt, out, q) for q in range(len(patterns))]
 
     def _interval(self, op, iv=None, a=0):
+        dt = np.uint32 if self.records32 else np.uint64
         if iv is None:
-            ivn = np.zeros((1, 4), dtype=np.uint32)
+            ivn = np.zeros((1, 4), dtype=dt)
         elif isinstance(iv, BiInterval):
-            ivn = np.array([[iv.lower, iv.lower_rev, iv.size, iv.match_size]], dtype=np.uint32)
+            ivn = np.array([[iv.lower, iv.lower_rev, iv.size, iv.match_size]], dtype=dt)
         else:
-            ivn = np.array([list(iv)], dtype=np.uint32)
-        out = np.zeros((1, 4), dtype=np.uint32)
+            ivn = np.array([list(iv)], dtype=dt)
+        out = np.zeros((1, 4), dtype=dt)
         ops = np.array([op], dtype=np.uint8)
         sym = np.array([a], dtype=np.uint8)
-        _lib.check(_lib.lib().bg_fmd_interval_batch(self.fm.h, 1, ops.ctypes.data, ivn.ctypes.data, sym.ctypes.data,
-                                                    out.ctypes.data), "FMDIndex interval")
+        fn = _lib.lib().bg_fmd_interval_batch if self.records32 else _lib.lib().bg_fmd_interval_batch64
+        _lib.check(fn(self.fm.h, 1, ops.ctypes.data, ivn.ctypes.data, sym.ctypes.data, out.ctypes.data), "FMDIndex interval")
         return BiInterval(*(int(v) for v in out[0]))
 
     def init_interval(self): return self._interval(0)                    # fmindex.rs:517

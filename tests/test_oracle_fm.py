@@ -166,17 +166,27 @@ def test_intervals_by_scan_equal_backward_search_and_the_suffix_array():
     acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
     text = np.append(acgt[rng.integers(0, 4, size=20_000)], np.uint8(ord("$")))
     text[rng.integers(0, 20_000, size=30)] = ord("N")
-    sa = np.asarray(orc.suffix_array(text), dtype=np.uint64)
-    b = np.frombuffer(bytes(orc.bwt(text, sa)), dtype=np.uint8)
     alpha = b"ACGTN$"
-    ls = orc.less(b, alpha)
-    occ = orc.Occ(b, 3, alpha)
     pats = [text[s:s + L].tobytes() for s, L in zip(rng.integers(0, 19_000, size=300), rng.integers(1, 14, size=300))]
     pats += [acgt[rng.integers(0, 4, size=int(L))].tobytes() for L in rng.integers(6, 16, size=200)] + [b"A", b"T", b"N", b"TTTTTTTTTTTTTTTTTTTT"]
+    # round 6: the scan takes thousands of patterns per pass through an 8-byte key table — long patterns (many of them sharing
+    # their first 8 bytes, some cut one symbol short or changed at the end, some running into the sentinel and past the end
+    # of the text), duplicates, and a copied segment so that intervals hold several rows
+    text[15_000:15_400] = text[3_000:3_400]
+    for s0 in rng.integers(0, 19_900, size=400):
+        L = int(rng.integers(8, 60))
+        q = text[int(s0):int(s0) + L].tobytes()
+        pats += [q, q[:-1] + b"A", q + b"T"]
+    pats += [text[-12:].tobytes(), text[-9:].tobytes() + b"A", text[-8:].tobytes(), text[-30:-1].tobytes(), pats[-5], pats[-5]]
+    sa = np.asarray(orc.suffix_array(text), dtype=np.uint64)
+    b = np.frombuffer(bytes(orc.bwt(text, sa)), dtype=np.uint8)
+    ls = orc.less(b, alpha)
+    occ = orc.Occ(b, 3, alpha)
     buf = np.frombuffer(b"".join(pats), dtype=np.uint8)
     off = np.zeros(len(pats) + 1, dtype=np.uint64)
     off[1:] = np.cumsum([len(p) for p in pats])
     tag, lo, hi, ml = orc.backward_search_batch(b, ls, occ, buf, off)
+    assert (tag == 0).sum() > 500 and (tag != 0).sum() > 500 and ((hi - lo)[tag == 0] > 1).sum() > 20
     for threads in (1, 3):
         slo, shi, spos = orc.intervals_by_scan(text, buf, off, pos_cap=100_000, threads=threads)
         for k, p in enumerate(pats):
