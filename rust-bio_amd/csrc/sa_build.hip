@@ -31,6 +31,9 @@
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 #include <rocprim/device/device_select.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
+#include <rocprim/iterator/discard_iterator.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
 
 #include <algorithm>
 #include <vector>
@@ -55,6 +58,54 @@ __global__ __launch_bounds__(256) void sab_presence_kernel(const uint8_t* __rest
 // key of suffix i: its first K symbols, b bits each, most significant first, up to and including its first sentinel
 // (code 0): what follows a sentinel counts as 0 — a comparison never goes past one (transform_text makes every
 // sentinel a symbol of its own) — and so do symbols past the end
+// (the body of the key: shared by the kernels below)
+__device__ __forceinline__ uint64_t sab_key_of(const uint8_t* __restrict__ t, uint64_t n, const CodeMap& cm, uint32_t b, uint32_t K, uint64_t i) {
+    uint64_t k = 0;
+    bool open = true;
+    for (uint32_t u = 0; u < K; u++) {
+        const uint64_t p = i + u;
+        const uint64_t c = (open && p < n) ? (uint64_t)cm.code[t[p]] : 0ull;
+        open = open && c != 0;
+        k = (k << b) | c;
+    }
+    return k;
+}
+// Round 0 in several passes (round 6): a text whose (key, suffix) pairs do not fit the device twice over — 6.2 G symbols of
+// T$R$ of a human genome: 32 bytes per symbol for the sort alone — is sorted bucket range by bucket range.  A bucket is the
+// top `sbits` bits of the key (the suffix's first few symbols); the buckets' sizes say which rows each owns, contiguous
+// bucket ranges of at most `cap` suffixes are collected (in position order: the sort stays stable), sorted and written to
+// their rows.  Groups never span buckets, so ranks and the active flags come out as from one sort.
+template <typename P>
+__global__ __launch_bounds__(256) void sab_bucket_hist_kernel(const uint8_t* __restrict__ t, uint64_t n, CodeMap cm, uint32_t b, uint32_t S,
+                                                              unsigned long long* __restrict__ hist) {
+    __shared__ uint32_t s_h[4096];  // (at most 12 bits of bucket; a block's share of the text stays far below 2^32)
+    const uint32_t nb = 1u << (b * S);
+    for (uint32_t k = threadIdx.x; k < nb; k += blockDim.x) s_h[k] = 0;
+    __syncthreads();
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        atomicAdd(&s_h[sab_key_of(t, n, cm, b, S, i)], 1u);
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < nb; k += blockDim.x)
+        if (s_h[k]) atomicAdd(&hist[k], (unsigned long long)s_h[k]);
+}
+__global__ __launch_bounds__(256) void sab_bucket_flags_kernel(const uint8_t* __restrict__ t, uint64_t n, CodeMap cm, uint32_t b, uint32_t S,
+                                                               uint32_t lo, uint32_t hi, uint8_t* __restrict__ flag) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t k = (uint32_t)sab_key_of(t, n, cm, b, S, i);
+        flag[i] = k >= lo && k < hi;
+    }
+}
+template <typename P>
+__global__ __launch_bounds__(256) void sab_list_keys_kernel(const uint8_t* __restrict__ t, uint64_t n, CodeMap cm, uint32_t b, uint32_t K,
+                                                            const P* __restrict__ val, uint64_t m, uint64_t* __restrict__ key) {
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += (uint64_t)gridDim.x * blockDim.x)
+        key[j] = sab_key_of(t, n, cm, b, K, (uint64_t)val[j]);
+}
+template <typename P>
+struct CountFrom {  // positions 0, 1, 2, ... as the input of a stream compaction
+    __host__ __device__ P operator()(uint64_t i) const { return (P)i; }
+};
+
 template <typename P>
 __global__ __launch_bounds__(256) void sab_init_keys_kernel(const uint8_t* __restrict__ t, uint64_t n, CodeMap cm, uint32_t b, uint32_t K,
                                                             uint64_t* __restrict__ key, P* __restrict__ val) {
@@ -100,25 +151,26 @@ __global__ __launch_bounds__(256) void sab_sentinel_rows_kernel(const P* __restr
 }
 
 // hp[j] = j where a new group starts (else 0): an inclusive max-scan turns it into "start of my group"
+// (row0: the row of the sorted list's first entry — a pass of round 0 owns rows [row0, row0 + n))
 template <typename P>
-__global__ __launch_bounds__(256) void sab_heads_kernel(const uint64_t* __restrict__ key, uint64_t n, P* __restrict__ hp) {
+__global__ __launch_bounds__(256) void sab_heads_kernel(const uint64_t* __restrict__ key, uint64_t n, uint64_t row0, P* __restrict__ hp) {
     // (grid-stride: a launch may not exceed 2^32 threads, and texts here do)
     for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (uint64_t)gridDim.x * blockDim.x) {
-        hp[j] = (j == 0 || key[j] != key[j - 1]) ? (P)j : (P)0;
+        hp[j] = (j == 0 || key[j] != key[j - 1]) ? (P)(row0 + j) : (P)0;
     }
 }
 
 // round 0: rank of every suffix, the array itself, and which suffixes are still in a group of several
 template <typename P>
-__global__ __launch_bounds__(256) void sab_round0_kernel(const P* __restrict__ suf, const P* __restrict__ grp, uint64_t n,
+__global__ __launch_bounds__(256) void sab_round0_kernel(const P* __restrict__ suf, const P* __restrict__ grp, uint64_t n, uint64_t row0,
                                                          P* __restrict__ rank, P* __restrict__ sa, uint8_t* __restrict__ active) {
     // (grid-stride: a launch may not exceed 2^32 threads, and texts here do)
     for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (uint64_t)gridDim.x * blockDim.x) {
         const P i = suf[j], g = grp[j];
         rank[i] = g;
-        sa[j] = i;
-        const bool head = g == (P)j, next_head = j + 1 == n || grp[j + 1] == (P)(j + 1);
-        active[j] = !(head && next_head);
+        sa[row0 + j] = i;
+        const bool head = g == (P)(row0 + j), next_head = j + 1 == n || grp[j + 1] == (P)(row0 + j + 1);
+        active[row0 + j] = !(head && next_head);
     }
 }
 
@@ -292,49 +344,127 @@ int sa_build_impl(bg_ctx* ctx, const uint8_t* d_text, uint64_t n, P* d_sa, hipSt
 
     uint64_t *keyA = nullptr, *keyB = nullptr;
     P *valA = nullptr, *valB = nullptr, *rank = nullptr;
-    uint8_t* active = nullptr;
+    uint8_t *active = nullptr, *flag = nullptr;
     void* tmp = nullptr;
     uint64_t* d_count = nullptr;
+    unsigned long long* d_hist = nullptr;
     P* d_sent = nullptr;
     auto run = [&]() -> int {
         BG_HIP(hipMalloc((void**)&d_sent, n_sent * sizeof(P)));
-        BG_HIP(hipMalloc((void**)&keyA, n * 8));
-        BG_HIP(hipMalloc((void**)&keyB, n * 8));
-        BG_HIP(hipMalloc((void**)&valA, n * sizeof(P)));
-        BG_HIP(hipMalloc((void**)&valB, n * sizeof(P)));
         BG_HIP(hipMalloc((void**)&rank, n * sizeof(P)));
         BG_HIP(hipMalloc((void**)&active, n));
         BG_HIP(hipMalloc((void**)&d_count, 8));
+        // ---- round 0, in passes of at most `cap` suffixes (one pass when everything fits: the round-2 .. 5 path)
+        constexpr size_t kPairBytes = 16 + 2 * sizeof(P);  // (key, suffix), double-buffered
+        uint64_t cap = n;
+        if (ctx->sa_chunk_symbols > 0) {
+            cap = (uint64_t)ctx->sa_chunk_symbols;
+        } else {
+            size_t free_b = 0, total_b = 0;
+            BG_HIP(hipMemGetInfo(&free_b, &total_b));
+            // the doubling rounds of a repetitive text want memory of their own later; a pass needs its pairs + the flags
+            const uint64_t fit = (uint64_t)((double)free_b * 0.7) / kPairBytes;
+            if (fit < n + (n >> 4)) cap = std::max<uint64_t>(fit > n / 64 ? fit - n / 64 : fit, 1u << 20);
+        }
+        uint32_t S = 1;  // symbols of a bucket: at most 12 bits of key
+        while (S < K && b * (S + 1) <= 12) S++;
+        const uint32_t n_bucket = 1u << (b * S);
+        struct Pass {
+            uint32_t lo, hi;       // buckets [lo, hi)
+            uint64_t row0, m;      // rows [row0, row0 + m)
+        };
+        std::vector<Pass> passes;
+        if (cap >= n) {
+            passes.push_back({0, n_bucket, 0, n});
+        } else {
+            BG_HIP(hipMalloc((void**)&d_hist, (size_t)n_bucket * 8));
+            BG_HIP(hipMemsetAsync(d_hist, 0, (size_t)n_bucket * 8, st));
+            sab_bucket_hist_kernel<P><<<dim3(std::min<unsigned>(nblk(n), 8192)), dim3(256), 0, st>>>(d_text, n, cm, b, S, d_hist);
+            BG_HIP(hipGetLastError());
+            std::vector<unsigned long long> hist(n_bucket);
+            BG_HIP(hipMemcpyAsync(hist.data(), d_hist, (size_t)n_bucket * 8, hipMemcpyDeviceToHost, st));
+            BG_HIP(hipStreamSynchronize(st));
+            uint64_t row = 0;
+            for (uint32_t k = 0; k < n_bucket;) {
+                Pass ps{k, k, row, 0};
+                while (ps.hi < n_bucket && (ps.m == 0 || ps.m + hist[ps.hi] <= cap)) ps.m += hist[ps.hi++];
+                passes.push_back(ps);
+                row += ps.m;
+                k = ps.hi;
+            }
+            BG_HIP(hipMalloc((void**)&flag, n));
+        }
+        uint64_t C = 0;  // the largest pass (one bucket may exceed cap: a text of few distinct words)
+        for (const Pass& ps : passes) C = std::max(C, ps.m);
+        C = std::max<uint64_t>(C, n_sent);
+        BG_HIP(hipMalloc((void**)&keyA, C * 8));
+        BG_HIP(hipMalloc((void**)&keyB, C * 8));
+        BG_HIP(hipMalloc((void**)&valA, C * sizeof(P)));
+        BG_HIP(hipMalloc((void**)&valB, C * sizeof(P)));
         rocprim::double_buffer<uint64_t> keys(keyA, keyB);
         rocprim::double_buffer<P> vals(valA, valB);
-        size_t t_sort = 0, t_scan = 0, t_sel = 0;
-        BG_HIP(rocprim::radix_sort_pairs(nullptr, t_sort, keys, vals, n, 0, 64, st));
-        BG_HIP(rocprim::inclusive_scan(nullptr, t_scan, (P*)nullptr, (P*)nullptr, n, MaxOf<P>(), st));
+        size_t t_sort = 0, t_scan = 0, t_sel = 0, t_sel2 = 0;
+        BG_HIP(rocprim::radix_sort_pairs(nullptr, t_sort, keys, vals, C, 0, 64, st));
+        BG_HIP(rocprim::inclusive_scan(nullptr, t_scan, (P*)nullptr, (P*)nullptr, C, MaxOf<P>(), st));
         BG_HIP(rocprim::select(nullptr, t_sel, (P*)nullptr, (uint8_t*)nullptr, (P*)nullptr, d_count, n, st));
-        size_t tmp_bytes = std::max(std::max(t_sort, t_scan), t_sel);
+        auto positions = rocprim::make_transform_iterator(rocprim::counting_iterator<uint64_t>(0), CountFrom<P>());
+        BG_HIP(rocprim::select(nullptr, t_sel2, positions, (uint8_t*)nullptr, (P*)nullptr, d_count, n, st));
+        size_t tmp_bytes = std::max(std::max(t_sort, t_scan), std::max(t_sel, t_sel2));
         BG_HIP(hipMalloc(&tmp, std::max<size_t>(tmp_bytes, 256)));
 
-        // ---- round 0
-        sab_init_keys_kernel<P><<<dim3(nblk(n)), dim3(256), 0, st>>>(d_text, n, cm, b, K, keys.current(), vals.current());
-        BG_HIP(hipGetLastError());
-        BG_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, vals, n, 0, (unsigned)(b * K), st));
-        // group heads and their scan: 32-bit positions — two arrays in the sort's other key buffer; 64-bit positions — one
-        // there and one in the other value buffer (free until the active list is selected into it)
-        P* hp = (P*)keys.alternate();
-        P* grp = WIDE ? vals.alternate() : hp + n;
-        sab_heads_kernel<P><<<dim3(nblk(n)), dim3(256), 0, st>>>(keys.current(), n, hp);
-        BG_HIP(rocprim::inclusive_scan(tmp, tmp_bytes, hp, grp, n, MaxOf<P>(), st));
-        sab_round0_kernel<P><<<dim3(nblk(n)), dim3(256), 0, st>>>(vals.current(), grp, n, rank, d_sa, active);
-        // rows 0 .. n_sent - 1 (key 0): the sentinel suffixes, final from here on
-        sab_sentinel_rows_kernel<P><<<dim3(nblk(n_sent)), dim3(256), 0, st>>>(vals.current(), n_sent, d_sent, rank, d_sa, active);
-        BG_HIP(hipGetLastError());
-        // active suffixes, in array order
-        P* act = vals.alternate();
-        BG_HIP(rocprim::select(tmp, tmp_bytes, vals.current(), active, act, d_count, n, st));
+        for (size_t pi = 0; pi < passes.size(); pi++) {
+            const Pass& ps = passes[pi];
+            if (ps.m == 0) continue;
+            if (passes.size() == 1) {
+                sab_init_keys_kernel<P><<<dim3(nblk(n)), dim3(256), 0, st>>>(d_text, n, cm, b, K, keys.current(), vals.current());
+            } else {
+                sab_bucket_flags_kernel<<<dim3(nblk(n)), dim3(256), 0, st>>>(d_text, n, cm, b, S, ps.lo, ps.hi, flag);
+                BG_HIP(rocprim::select(tmp, tmp_bytes, positions, flag, vals.current(), d_count, n, st));
+                sab_list_keys_kernel<P><<<dim3(nblk(ps.m)), dim3(256), 0, st>>>(d_text, n, cm, b, K, vals.current(), ps.m, keys.current());
+            }
+            BG_HIP(hipGetLastError());
+            BG_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, vals, ps.m, 0, (unsigned)(b * K), st));
+            // group heads and their scan: 32-bit positions — two arrays in the sort's other key buffer; 64-bit positions — one
+            // there and one in the other value buffer
+            P* hp = (P*)keys.alternate();
+            P* grp = WIDE ? vals.alternate() : hp + ps.m;
+            sab_heads_kernel<P><<<dim3(nblk(ps.m)), dim3(256), 0, st>>>(keys.current(), ps.m, ps.row0, hp);
+            BG_HIP(rocprim::inclusive_scan(tmp, tmp_bytes, hp, grp, ps.m, MaxOf<P>(), st));
+            sab_round0_kernel<P><<<dim3(nblk(ps.m)), dim3(256), 0, st>>>(vals.current(), grp, ps.m, ps.row0, rank, d_sa, active);
+            // rows 0 .. n_sent - 1 (key 0, the first bucket of the first pass): the sentinel suffixes, final from here on
+            if (ps.row0 == 0) sab_sentinel_rows_kernel<P><<<dim3(nblk(n_sent)), dim3(256), 0, st>>>(vals.current(), n_sent, d_sent, rank, d_sa, active);
+            BG_HIP(hipGetLastError());
+        }
+        // active suffixes, in array order: counted first, so that the doubling rounds get buffers of THEIR size (a random
+        // genome leaves a thousandth of its suffixes tied after 21-32 symbols; the pass buffers go back first)
+        BG_HIP(rocprim::select(tmp, tmp_bytes, d_sa, active, rocprim::discard_iterator(), d_count, n, st));
         uint64_t A = 0;
         BG_HIP(hipMemcpyAsync(&A, d_count, 8, hipMemcpyDeviceToHost, st));
         BG_HIP(hipStreamSynchronize(st));
-        vals.swap();  // the active list is the current value buffer from here on
+        if (A > C) {
+            hipFree(keyA), hipFree(keyB), hipFree(valA), hipFree(valB);
+            keyA = keyB = nullptr;
+            valA = valB = nullptr;
+            BG_HIP(hipMalloc((void**)&keyA, A * 8));
+            BG_HIP(hipMalloc((void**)&keyB, A * 8));
+            BG_HIP(hipMalloc((void**)&valA, A * sizeof(P)));
+            BG_HIP(hipMalloc((void**)&valB, A * sizeof(P)));
+            keys = rocprim::double_buffer<uint64_t>(keyA, keyB);
+            vals = rocprim::double_buffer<P>(valA, valB);
+            size_t t2 = 0;
+            BG_HIP(rocprim::radix_sort_pairs(nullptr, t2, keys, vals, A, 0, 64, st));
+            if (t2 > tmp_bytes) {
+                hipFree(tmp);
+                tmp = nullptr;
+                tmp_bytes = t2;
+                BG_HIP(hipMalloc(&tmp, tmp_bytes));
+            }
+        }
+        if (flag) {
+            hipFree(flag);
+            flag = nullptr;
+        }
+        if (A) BG_HIP(rocprim::select(tmp, tmp_bytes, d_sa, active, vals.current(), d_count, n, st));
 
         // ---- doubling rounds over the active suffixes only
         for (uint64_t h = K; A > 0; h *= 2) {
@@ -390,6 +520,8 @@ int sa_build_impl(bg_ctx* ctx, const uint8_t* d_text, uint64_t n, P* d_sa, hipSt
     hipFree(valB);
     hipFree(rank);
     hipFree(active);
+    hipFree(flag);
+    hipFree(d_hist);
     hipFree(d_count);
     hipFree(d_sent);
     hipFree(tmp);

@@ -261,3 +261,78 @@ def test_wide_seed_and_extend_equals_the_pipeline_oracle(with_n):
     mapped = compare(hits, ops, ohits, oops, ostride)
     assert mapped[:-50].mean() > 0.9
     fm.close()
+
+
+def test_wide_index_over_several_sentinels_and_fewer_than_four_letters():
+    rng = np.random.default_rng(3)
+    ac = np.frombuffer(b"AC", dtype=np.uint8)
+    t = np.concatenate([ac[rng.integers(0, 2, size=4000)], np.frombuffer(b"$", np.uint8), ac[rng.integers(0, 2, size=3000)], np.frombuffer(b"$", np.uint8)])
+    sa = suffix_array(t)
+    b = bwt(t, sa)
+    alpha = b"AC$"
+    ls = less(b, alpha)
+    fm = FMIndex(b, ls, Occ(b, 3, alpha), ctx=wide_ctx(1))
+    pats = [ac[rng.integers(0, 2, size=int(rng.integers(1, 30)))].tobytes() for _ in range(500)] + [b"$", b"A$", b"$A", b"G"]
+    check_search(fm, b, ls, alpha, pats)
+
+
+def test_wide_refuses_what_needs_rank_bit_vectors():
+    rng = np.random.default_rng(9)
+    prot = np.append(np.frombuffer(b"ARNDCQEGHILKMFPSTWYV", dtype=np.uint8)[rng.integers(0, 20, size=50_000)], np.uint8(ord("$")))
+    sa = suffix_array(prot)
+    b = bwt(prot, sa)
+    alpha = b"ARNDCQEGHILKMFPSTWYV$"
+    with pytest.raises(Exception) as e:
+        FMIndex(b, less(b, alpha), Occ(b, 3, alpha), ctx=wide_ctx())
+    assert "UNSUPPORTED" in str(e.value).upper() or "-11" in str(e.value)
+
+
+def sa_texts():
+    from test_gpu_sa_build import texts
+    return [(n, t) for n, t in texts() if n not in ("random_1m",)] + [("random_300k", synth.genome(300_000, 3))]
+
+
+@pytest.mark.parametrize("name,text", sa_texts(), ids=[t[0] for t in sa_texts()])
+def test_device_suffix_array_64_equals_the_oracle(name, text):
+    """bg_suffix_array_dev64 / bg_bwt_dev64: uint64 positions, a doubling round as two stable radix passes"""
+    d_text = torch.from_numpy(np.ascontiguousarray(text)).to(DEV)
+    d_sa = suffix_array_dev(d_text, wide=True)
+    torch.cuda.synchronize()
+    assert d_sa.dtype == torch.int64
+    got = d_sa.cpu().numpy().astype(np.uint64)
+    osa = np.asarray(orc.suffix_array(text), dtype=np.uint64)
+    assert (got == osa).all(), name
+    d_b = bwt_dev(d_text, d_sa)
+    assert bytes(d_b.cpu().numpy()) == bytes(orc.bwt(text, osa)), name
+
+
+def test_text_to_searchable_wide_index_entirely_on_the_device():
+    """text in HBM -> 64-bit suffix array -> BWT -> samples -> wide index -> search + locate, against the oracle"""
+    rng = np.random.default_rng(23)
+    g = synth.genome(200_000, 11)
+    d_text = torch.from_numpy(g).to(DEV)
+    ctx = wide_ctx(3)
+    d_sa = suffix_array_dev(d_text, ctx=ctx, wide=True)
+    d_b = bwt_dev(d_text, d_sa, ctx=ctx)
+    fm = FMIndex.from_device(d_b, 3, N_ALPHABET, ctx=ctx)
+    sa = np.asarray(orc.suffix_array(g), dtype=np.uint64)
+    b = np.frombuffer(bytes(orc.bwt(g, sa)), dtype=np.uint8)
+    assert (fm._less == less(b, N_ALPHABET)).all()
+    pats = patterns(g, rng, 4000, lo=8, hi=40)
+    tag, lo, hi = check_search(fm, b, fm._less, N_ALPHABET, pats)
+    s = sample_dev(d_sa, d_b, int(g[-1]), 16, ctx=ctx)
+    want_s = SampledSuffixArray(sa, g, b, 16)
+    assert (s.sample == want_s.sample).all() and (s.extra_rows == want_s.extra_rows).all() and (s.extra_pos == want_s.extra_pos).all()
+    s.attach(fm)
+    hit = (tag == 0) & (hi - lo < 30)
+    _, pos = fm.interval_occ_arrays(lo[hit], hi[hit])
+    assert (pos == np.concatenate([sa[int(a):int(e)] for a, e in zip(lo[hit], hi[hit])])).all()
+
+
+def test_narrow_indexes_are_untouched_by_the_threshold_default():
+    """without the test options an index below 2^32 - 1 symbols keeps the uint32 layout (2-step blocks and all)"""
+    g = synth.genome(50_000, 3)
+    sa = suffix_array(g)
+    b = bwt(g, sa)
+    fm = FMIndex(b, less(b, N_ALPHABET), Occ(b, 3, N_ALPHABET), ctx=_lib.Context(0))
+    assert fm.step2_bytes() > 0

@@ -82,3 +82,23 @@ def test_sample_dev_equals_raw_suffix_array_sample():
 def test_refusals():
     with pytest.raises(_lib.SentinelError):
         dev_sa(np.frombuffer(b"AC#T$", dtype=np.uint8))  # '#' < '$': suffix_array.rs:431-437
+
+
+@pytest.mark.parametrize("wide", [False, True])
+@pytest.mark.parametrize("chunk", [1 << 20, 30_000, 1000])
+def test_round_zero_in_several_passes_gives_the_same_array(chunk, wide):
+    """Round 6: round 0 of the builder sorts bucket range by bucket range when its (key, suffix) pairs would not fit the
+    device (6.2 G symbols of T$R$: sa_build.hip) — forced here through the ctx option sa_chunk_symbols, on both position
+    widths and every text of the list (a single bucket larger than the chunk, several sentinels, one letter): the array is
+    the oracle's, entry for entry."""
+    ctx = _lib.Context(0)
+    ctx.set_option("sa_chunk_symbols", chunk)
+    for name, text in texts():
+        if name == "random_1m" and chunk < 30_000:
+            continue
+        d_text = torch.from_numpy(np.ascontiguousarray(text)).to(DEV)
+        d_sa = suffix_array_dev(d_text, ctx=ctx, wide=wide)
+        torch.cuda.synchronize()
+        got = d_sa.cpu().numpy().astype(np.uint64) if wide else d_sa.cpu().numpy().view(np.uint32).astype(np.uint64)
+        assert (got == np.asarray(orc.suffix_array(text), dtype=np.uint64)).all(), (name, chunk, wide)
+    ctx.close()
