@@ -2,13 +2,16 @@
 the 288 GB part, a seeded sample of intervals and positions equals the oracle's"):
     python tools/exp/fm_wide_big.py [symbols=4400000000] [queries=10000000] > gpurun_out/r05_fm_wide_4g4.json
   1. the text in HBM: random ACGT (SplitMix64, synth_gpu.genome) with a 2 Mbp segment copied three times further on (real work
-     for the prefix doubling: groups that stay tied for 2 M symbols) and a hundred N, '$' at the end;
+     for the prefix doubling: groups that stay tied for 2 M symbols) and `n_N` N (argv[3], default 2: the 2-step rank blocks
+     take a text with at most four positions outside its four letters; 100 reproduces round 5's single-step text), '$' at the end;
   2. bg_suffix_array_dev64 -> bg_bwt_dev64 -> bg_sa_sample_dev64 (rate 32) -> bg_fm_build_dev (the 64-bit layout, fm_wide.hip)
      -> bg_fm_set_sampled_suffix_array: nothing text-sized leaves the device except the samples;
   3. `queries` 100 bp patterns (half cut from the text — some from the copied segment: several occurrences — half random)
      through bg_fm_backward_search_batch_dev: the rate of the 64-bit kernel;
   4. parity, three ways:
-     a. ORACLE BY DEFINITION on a seeded sample (oracle/fm.cpp: orc_intervals_by_scan — lower = #suffixes < P, upper = lower +
+     a. ORACLE BY DEFINITION on a STRATIFIED seeded sample — round 6: >= 1 000 Complete and >= 1 000 Partial results whose
+        interval starts at or beyond row 2^32 (patterns that begin with T), 500 of each from anywhere, the copied segment's
+        multi-row intervals, and every Complete pattern's position list — (oracle/fm.cpp: orc_intervals_by_scan — lower = #suffixes < P, upper = lower +
         #suffixes with prefix P, and the occurrence positions, by one pass over the 4.4 GB text on the host threads; no suffix
         array on the host): Complete intervals equal, Partial results equal the interval of the matched suffix and the suffix one
         symbol longer does not occur, located positions (K6 on 64-bit samples) equal the scan's;
@@ -34,9 +37,14 @@ from rust_bio_amd.suffix_array import bwt_dev, sample_dev, suffix_array_dev  # n
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 4_400_000_000
 NQ = int(sys.argv[2]) if len(sys.argv) > 2 else 10_000_000
+N_N = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 P = 100
 dev = torch.device("cuda:0")
 ctx = _lib.Context(0)
+if os.environ.get("BG_FORCE_WIDE"):  # dry run on a small text: the same code paths (64-bit layout, several passes of round 0)
+    ctx.set_option("fm_wide_from", 1)
+    ctx.set_option("fm_wide_sb_shift", 6)
+    ctx.set_option("sa_chunk_symbols", max(1 << 16, N // 3))
 threads = len(os.sched_getaffinity(0))
 try:  # cgroup CPU quota: threads beyond it are only throttled (run A: 256 "cores" on a 16-CPU quota made the oracle 2.5 x slower)
     quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
@@ -59,7 +67,7 @@ SEG = min(2_000_000, N // 16)
 for k in range(1, 4):  # the same segment four times in all
     dst = (N // 5) * k + 12345
     g[dst:dst + SEG] = g[777:777 + SEG]
-npos = torch.arange(100, dtype=torch.int64, device=dev) * (N // 101) + 31
+npos = torch.arange(N_N, dtype=torch.int64, device=dev) * (N // (N_N + 1)) + 31
 g[npos] = ord("N")
 res["text_s"] = round(sync() - t0, 2)
 torch.cuda.empty_cache()
@@ -79,6 +87,7 @@ fm = FMIndex.from_device(d_b, 128, b"ACGTNacgtn", ctx=ctx)
 samples.attach(fm)
 res["index_s"] = round(sync() - t0, 2)
 res["index_bytes"] = fm.device_bytes()
+res["step2_bytes"] = fm.step2_bytes()
 res["less"] = {chr(c): int(fm._less[c]) for c in b"$ACGNT"}
 # the suffix array itself is not needed any more (35 GB): K6 locates through the samples
 sa_probe = d_sa[torch.tensor([0, 1, N // 2, N], device=dev)].cpu().tolist()
@@ -117,27 +126,61 @@ def search():
     fm.backward_search_dev(NQ, pat.data_ptr(), off.data_ptr(), d_tag.data_ptr(), d_lo.data_ptr(), d_hi.data_ptr(), d_ml.data_ptr())
 
 
-# the one-query-per-quad kernel first (fm option ilp = 1), then the default (two queries per quad): same arrays
+def timed(reps=3):
+    search()
+    t0 = sync()
+    for _ in range(reps):
+        search()
+    return (sync() - t0) / reps
+
+
+def snapshot():
+    return d_tag.clone(), d_lo.clone(), d_hi.clone(), d_ml.clone()
+
+
+def same_as(ref):
+    ok = d_tag < 2
+    return bool(torch.equal(ref[0], d_tag) and torch.equal(ref[3], d_ml) and torch.equal(ref[1][ok], d_lo[ok]) and torch.equal(ref[2][ok], d_hi[ok]))
+
+
+# every kernel of the 64-bit search on the same arrays: one query per quad on single steps (round 5's first kernel), two per
+# quad on single steps (round 5's default), and — where the text has 2-step blocks — the 2x fast kernel on them (round 6),
+# with byte patterns and with the patterns packed to 2 bits
+rates = {}
 fm.set_option("ilp", 1)
-search()
-t0 = sync()
-for _ in range(3):
-    search()
-dt1 = (sync() - t0) / 3
-one = (d_tag.clone(), d_lo.clone(), d_hi.clone(), d_ml.clone())
+rates["single_steps_one_query_per_quad"] = timed()
+ref = snapshot()
 fm.set_option("ilp", 2)
+fm.set_option("no_step2", 1)
+rates["single_steps_two_queries_per_quad"] = timed()
+equal = {"single_steps_two_queries_per_quad": same_as(ref)}
+fm.set_option("no_step2", 0)
+kernel = "fmw_search2x_kernel (64-bit positions, 1-step blocks, byte patterns, two queries per quad)"
+if fm.step2_bytes():
+    rates["two_step_blocks_byte_patterns"] = timed()
+    equal["two_step_blocks_byte_patterns"] = same_as(ref)
+    kernel = "fm_search_fast2x_kernel<WIDE> (64-bit positions, 2-step blocks, byte patterns, two queries per quad) + the generic kernel for deferred queries"
+    from rust_bio_amd import pack2
+    pk, bad = pack2.pack_dev(pat, codes=fm.pattern_codes(), ctx=ctx)
+    if bad == 0:
+        byte_search = search
+
+        def search():  # noqa: F811
+            fm.backward_search_packed_dev(NQ, pk.data_ptr(), off.data_ptr(), d_tag.data_ptr(), d_lo.data_ptr(), d_hi.data_ptr(), d_ml.data_ptr())
+
+        rates["two_step_blocks_packed_patterns"] = timed()
+        equal["two_step_blocks_packed_patterns"] = same_as(ref)
+        search = byte_search
+    del pk
 search()
-t0 = sync()
-for _ in range(3):
-    search()
-dt = (sync() - t0) / 3
-same = bool(torch.equal(one[0], d_tag) and torch.equal(one[3], d_ml) and torch.equal(one[1][d_tag < 2], d_lo[d_tag < 2]) and
-            torch.equal(one[2][d_tag < 2], d_hi[d_tag < 2]))
-del one
+torch.cuda.synchronize()
+del ref
+dt = rates.get("two_step_blocks_byte_patterns", rates["single_steps_two_queries_per_quad"])
 res["search"] = {"queries": NQ, "pattern_len": P, "ms": round(dt * 1e3, 2), "queries_per_s": round(NQ / dt, 1),
                  "complete": int((d_tag == 0).sum()), "partial": int((d_tag == 1).sum()), "absent": int((d_tag == 2).sum()),
-                 "kernel": "fmw_search2x_kernel (64-bit positions, 1-step blocks, byte patterns, two queries per quad)",
-                 "one_query_per_quad": {"ms": round(dt1 * 1e3, 2), "queries_per_s": round(NQ / dt1, 1), "results_equal": same}}
+                 "kernel": kernel,
+                 "all_kernels_M_queries_per_s": {k: round(NQ / v / 1e6, 1) for k, v in rates.items()},
+                 "results_equal_to_the_one_query_kernel": equal}
 res["intervals_with_a_bound_beyond_2_32"] = int(((d_hi > (1 << 32)) & (d_tag < 2)).sum())
 
 # ---- 4b. located positions are occurrences; a query cut from p finds p
@@ -166,10 +209,19 @@ res["locate"]["every_position_is_an_occurrence"] = ok_occ
 res["locate"]["every_query_finds_where_it_was_cut"] = bool(found_self[(hi_s - lo_s) <= 64].all())
 res["locate"]["positions_beyond_2_32"] = int((d_pos >= (1 << 32)).sum())
 
-# ---- 4a. the oracle by definition on a seeded sample
-NS = 96
-pick = torch.cat([torch.nonzero((d_tag == 0) & ~is_rand)[:40].view(-1), torch.nonzero((d_tag == 0) & in_seg & ~is_rand)[:8].view(-1),
-                  torch.nonzero(d_tag == 1)[:NS - 48].view(-1)])
+# ---- 4a. the oracle by definition on a stratified seeded sample
+BEY = 1 << 32
+NS_BEY, NS_ANY = 1000, 500
+
+
+def first(mask, k):
+    return torch.nonzero(mask)[:k].view(-1)
+
+
+pick = torch.cat([first((d_tag == 0) & ~is_rand & (d_lo >= BEY), NS_BEY), first((d_tag == 0) & ~is_rand & (d_lo < BEY), NS_ANY),
+                  first((d_tag == 0) & in_seg & ~is_rand, 64),
+                  first((d_tag == 1) & (d_lo >= BEY), NS_BEY), first((d_tag == 1) & (d_lo < BEY), NS_ANY)])
+pick = torch.unique(pick)
 h_pat = pat.view(NQ, P)[pick].cpu().numpy()
 h_tag, h_lo, h_hi, h_ml = d_tag[pick].cpu().numpy(), d_lo[pick].cpu().numpy().astype(np.uint64), d_hi[pick].cpu().numpy().astype(np.uint64), d_ml[pick].cpu().numpy()
 scan_pats, kinds = [], []
@@ -212,7 +264,12 @@ for lo_, hi_, want in zip(loc_lo, loc_hi, loc_want):
 res["oracle_sample"] = {"patterns": len(pick), "complete": n_c, "partial": n_p, "scans": len(scan_pats), "oracle_threads": threads,
                         "interval_mismatches": int(bad), "position_list_mismatches": int(bad_pos),
                         "max_interval_size": int(max(h - l for l, h in zip(loc_lo, loc_hi))),
-                        "intervals_beyond_2_32": int(sum(1 for l in loc_lo if l >= (1 << 32)))}
+                        "intervals_beyond_2_32": int(sum(1 for l in loc_lo if l >= (1 << 32))),
+                        "complete_intervals_beyond_2_32": int(sum(1 for j, (kind, k) in enumerate(kinds) if kind == "complete" and int(h_lo[k]) >= BEY)),
+                        "partial_intervals_beyond_2_32": int(sum(1 for j, (kind, k) in enumerate(kinds) if kind == "partial" and int(h_lo[k]) >= BEY)),
+                        "position_lists_compared": len(loc_lo),
+                        "position_lists_of_intervals_beyond_2_32": int(sum(1 for l in loc_lo if l >= BEY)),
+                        "positions_beyond_2_32_in_those_lists": int(sum(1 for w in loc_want for v in w if v >= BEY))}
 res["bit_exact"] = bool(bad == 0 and bad_pos == 0 and ok_occ and res["locate"]["every_query_finds_where_it_was_cut"])
 res["hbm_free_before_the_suffix_array_gb"] = round(free0 / 1e9, 1)
 print(json.dumps(res))
