@@ -1,7 +1,7 @@
 """An FMD index over T$R$ of a human-genome-sized text — 6.2 G symbols, the case the 64-bit layout exists for (VERDICT r5 item 1:
 "a 6.2 G-symbol T$R$ index built in HBM, SMEMs of >= 10 k sampled reads equal to an oracle"):
     python tools/exp/fmd_wide_big.py [genome_bp=3100000000] [reads=12000] > gpurun_out/<tag>/fmd_wide_big.json
-  1. the text in HBM: T = random ACGT (SplitMix64) with a 1 Mbp segment copied twice further on and two N, then '$',
+  1. the text in HBM: T = random ACGT (SplitMix64) with a 1 Mbp segment copied twice further on and one N (argv[3]), then '$',
      revcomp(T), '$' (FMDIndex::from's input, /root/reference/src/data_structures/fmindex.rs:311-340): 2 |T| + 2 symbols;
   2. bg_suffix_array_dev64 (round 0 in bucket-range passes: sa_build.hip) -> bg_bwt_dev64 -> bg_sa_sample_dev64 ->
      bg_fm_build_dev (64-bit layout + 2-step blocks) — everything stays on the device;
@@ -71,8 +71,9 @@ SEG = min(1_000_000, G // 16)
 for k in (1, 2):
     dst = (G // 3) * k + 4321
     g[dst:dst + SEG] = g[999:999 + SEG]
-g[G // 7] = ord("N")
-g[G // 2 + 5] = ord("N")
+N_N = int(sys.argv[3]) if len(sys.argv) > 3 else 1  # (every N of T is one of R too; with the two sentinels at most four listed
+for k in range(N_N):                                  #  positions keep the 2-step rank blocks: one N by default, more = single steps)
+    g[(G // (N_N + 1)) * (k + 1) + 5] = ord("N")
 g[G] = ord("$")
 comp = torch.zeros(256, dtype=torch.uint8, device=dev)
 for a, b in zip(b"ACGTN", b"TGCAN"):
