@@ -113,6 +113,8 @@ const char* bg_last_error(void); /* text of the last HIP failure on this thread 
  *                      that small texts exercise csrc/fm_wide.hip); 0 restores the default
  *   fm_wide_sb_shift   log2 of the rank blocks per superblock of the 64-bit layout (default 17; 0 .. 24; tests use small
  *                      values so that short texts span many superblocks)
+ *   fq_no_fused = 1    bg_fastq_parse[_dev] through its general multi-pass kernels only, without the one-pass kernel that serves
+ *                      four-line ASCII records in front (tests, A/B)
  *   sa_chunk_symbols   suffixes sorted per pass of round 0 of bg_suffix_array_dev[64] (0 = derived from free device memory;
  *                      tests use small values so that short texts take several passes)
  *   band_budget_gb     traceback + aux bytes per scratch set of the banded pipeline, in GB (0 = default: 40, and never more

@@ -74,6 +74,7 @@ struct bg_ctx {
     bool no_couples = false;  // tests: K1p without the (m, n) slot order on ragged batches
     int band_chain_global = -1;  // chain_kernel tree placement: -1 by batch size, 0 LDS, 1 global scratch
     bool band_host_sync = false;  // A/B: issue() waits on the host for K4 of two sub-batches ago before launching the chaining (rounds 2-4)
+    bool fq_no_fused = false;  // tests, A/B: bg_fastq_parse_dev through F1 .. F6 only (no one-pass kernel in front)
     int64_t sa_chunk_symbols = 0;  // tests: suffixes per pass of round 0 of the device suffix-array builder (0: by free memory)
     bool band_chain_rows = true;  // global-tree chaining: four pairs per wavefront (chain_rows_kernel); false: one (A/B, tests)
     bool band_join_global = false;  // tests: k-mer join with its table in global memory even where the LDS flavour applies

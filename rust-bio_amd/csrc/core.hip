@@ -209,6 +209,10 @@ extern "C" int bg_set_option(bg_ctx* ctx, const char* key, int64_t value) {
         ctx->fm_wide_sb_shift = (uint32_t)value;
         return BG_OK;
     }
+    if (!strcmp(key, "fq_no_fused")) {
+        ctx->fq_no_fused = value != 0;
+        return BG_OK;
+    }
     if (!strcmp(key, "sa_chunk_symbols")) {
         if (value < 0) return BG_ERR_INVALID_ARG;
         ctx->sa_chunk_symbols = value;

@@ -495,6 +495,372 @@ __global__ __launch_bounds__(256) void fq_gather_kernel(const uint8_t* __restric
     }
 }
 
+// ---- FF: the whole reader in ONE pass over the text (round 6) ---------------------------------------------------------
+// F1 .. F6 above read the text five times (newline count, line starts, line info, header split, gather: 2.46 GB of HBM
+// traffic for 0.70 GB of algorithmic bytes, profiles/r05_pmc_traffic.json) through seven kernels and three host round
+// trips.  Nearly every FASTQ is four lines per record in plain ASCII; for such a text ONE kernel does everything, each
+// byte read from HBM once:
+//   * a tile of 16 KB per block (its number from a ticket, so that a tile only ever waits for tiles that are running);
+//     every thread takes four 16-byte pieces (coalesced), finds the newlines (SWAR) and their ordinals (block scan of the
+//     packed piece counts); the tile's newline count goes through a decoupled look-back (Merrill & Garland: a 64-bit word
+//     per tile holding flag + value, a wavefront reading 64 predecessors per step) -> the global line index of its first
+//     line, while another wavefront finds the four newlines in front of the tile (the lines a record of this tile may
+//     begin with) in a 1 KB window of the previous tile;
+//   * a record belongs to the tile its fourth line ends in: the thread that owns it checks the four-line hypothesis of F3
+//     (line 4k starts with '@', 4k+1 not with '+', 4k+2 with '+', the quality trims to something), trims the lines
+//     (ASCII white space: str::trim_end when every byte is ASCII), splits the header at its first space (fastq.rs:275-277);
+//   * the records' sequence / quality lengths are scanned in the block, the tile totals go through two more look-backs
+//     (two wavefronts, concurrently) -> seq_off / qual_off of every record, the fixed fields of bg_fastq_record_t;
+//   * 16 lanes per record copy the two lines (from L2: this very block just read them) and evaluate Record::check.
+// Whatever the fast path cannot promise — a byte >= 0x80, a line count that is not a multiple of four, a record that fails
+// the hypothesis, a tile with more than 4096 newlines or 512 records — raises one flag; the host reads {lines, flag} back
+// (the call's ONE synchronisation) and, if it is up, runs F1 .. F6, which are exact for any input and overwrite whatever
+// the fused kernel wrote.  Every write of the fused kernel stays inside the caller's buffers whatever the text holds.
+constexpr uint32_t kTile = 16384, kNlCap = 4096, kRecCap = 512;
+constexpr int kHalo = 4;
+constexpr uint64_t kFlagAgg = 1ull << 62, kFlagPre = 2ull << 62, kValMask = (1ull << 62) - 1;
+
+struct FusedArgs {
+    const uint8_t* t;
+    uint64_t len;
+    uint64_t* tiles;     // [3][n_tiles]: flag | value words of the three look-backs (newlines, sequence bytes, quality bytes)
+    uint32_t* ticket;
+    uint64_t* out;       // [0] lines, [1] irregular, [2] sequence bytes, [3] quality bytes
+    bg_fastq_record_t* recs;
+    uint64_t rec_cap;
+    uint8_t *seq, *qual;
+    uint64_t *seq_off, *qual_off;
+    uint32_t n_tiles;
+};
+
+// exclusive prefix of this tile's aggregate over all tiles before it; called by one whole wavefront
+__device__ uint64_t fq_lookback(uint64_t* tiles, uint32_t id, uint64_t agg) {
+    const int lane = threadIdx.x & 63;
+    if (id == 0) {
+        if (lane == 0) __hip_atomic_store(&tiles[0], kFlagPre | agg, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        return 0;
+    }
+    if (lane == 0) __hip_atomic_store(&tiles[id], kFlagAgg | agg, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    uint64_t excl = 0;
+    int64_t j = (int64_t)id - 1;
+    for (;;) {
+        const int64_t idx = j - lane;
+        uint64_t v = kFlagPre;  // in front of tile 0: an inclusive prefix of 0
+        if (idx >= 0) {
+            do {
+                v = __hip_atomic_load(&tiles[idx], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+            } while ((v >> 62) == 0);
+        }
+        const uint64_t pm = __ballot((v >> 62) == 2);
+        uint64_t val = v & kValMask;
+        if (pm) {  // the closest inclusive prefix ends the walk: lanes beyond it do not count
+            const int first = __ffsll((long long)pm) - 1;
+            if (lane > first) val = 0;
+        }
+#pragma unroll
+        for (int o = 32; o; o >>= 1) {
+            const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)val, o), hi = (uint32_t)__shfl_xor((int)(uint32_t)(val >> 32), o);
+            val += (uint64_t)hi << 32 | lo;
+        }
+        excl += val;
+        if (pm) break;
+        j -= 64;
+    }
+    if (lane == 0) __hip_atomic_store(&tiles[id], kFlagPre | ((excl + agg) & kValMask), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    return excl;
+}
+
+__device__ __forceinline__ uint32_t newline_mask16(const uint4 v) {  // bit i: byte i of the piece is '\n'
+    uint32_t m = 0;
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const uint32_t b = newline_bits(w[q]);  // bit 7 of every matching byte
+        m |= (((b >> 7) & 1u) | ((b >> 14) & 2u) | ((b >> 21) & 4u) | ((b >> 28) & 8u)) << (4 * q);
+    }
+    return m;
+}
+
+struct FusedRec {  // what the copy phase needs of a record (LDS)
+    int32_t seq_rel, qual_rel;  // line starts relative to the tile (may be negative: a line that begins in the previous tile)
+    uint32_t seq_n, qual_n;
+    uint64_t seq_dst, qual_dst;
+    uint32_t flags;             // 1: the id is empty
+    uint32_t pad;
+};
+
+__global__ __launch_bounds__(256) void fq_fused_kernel(const FusedArgs a) {
+    __shared__ int32_t s_nl[kHalo + kNlCap + 1];
+    __shared__ FusedRec s_rec[kRecCap];
+    __shared__ uint64_t s_w[8];
+    __shared__ uint64_t s_bc[8];  // [0] tile id, [1] lines before the tile, [2] sequence bytes before it, [3] quality bytes, [4] irregular
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) {
+        s_bc[0] = atomicAdd(a.ticket, 1u);
+        s_bc[4] = 0;
+    }
+    __syncthreads();
+    const uint32_t tile = (uint32_t)s_bc[0];
+    const uint64_t t0 = (uint64_t)tile * kTile;
+    const bool last_tile = tile + 1 == a.n_tiles;
+    const bool aligned = ((uintptr_t)a.t & 15) == 0;
+    // ---- newlines of the tile
+    uint32_t m[4];
+    uint64_t packed = 0;
+    bool hi = false;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint64_t base = t0 + ((uint64_t)j * 256 + tid) * 16;
+        const uint4 v = base < a.len ? load16(a.t, a.len, base, aligned) : make_uint4(0, 0, 0, 0);
+        m[j] = newline_mask16(v);
+        hi |= ((v.x | v.y | v.z | v.w) & 0x80808080u) != 0;
+        packed |= (uint64_t)__popc(m[j]) << (16 * j);
+    }
+    // a text that does not end in '\n': its last line ends at the end of the text (one more "newline", behind all others)
+    const uint32_t extra = (last_tile && a.t[a.len - 1] != '\n') ? 1u : 0u;
+    // inclusive scan of the packed counts over the block (row j = pieces j * 256 ..: four scans in one)
+    uint64_t inc = packed;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)inc, o), hh = (uint32_t)__shfl_up((int)(uint32_t)(inc >> 32), o);
+        if ((int)lane >= o) inc += (uint64_t)hh << 32 | lo;
+    }
+    if (lane == 63) s_w[wave] = inc;
+    if (__any(hi) && lane == 0) s_bc[4] = 1;
+    __syncthreads();
+    uint64_t wbase = 0, rows = 0;
+    for (uint32_t w = 0; w < 4; w++) {
+        if (w < wave) wbase += s_w[w];
+        rows += s_w[w];
+    }
+    const uint64_t excl = wbase + inc - packed;  // per row: newlines of the row's pieces before this thread's
+    uint32_t row_total[4], row_base[4];
+    uint32_t T = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        row_total[j] = (uint32_t)(rows >> (16 * j)) & 0xFFFFu;
+        row_base[j] = T;
+        T += row_total[j];
+    }
+    const uint32_t T_all = T + extra;
+    bool irregular = T_all > kNlCap;
+    // ---- wavefront 0: lines before the tile; wavefront 1: the four newlines in front of it
+    if (wave == 0) {
+        const uint64_t before = fq_lookback(a.tiles, tile, T_all);
+        if (lane == 0) s_bc[1] = before;
+    } else if (wave == 1) {
+        int need = kHalo;
+        uint64_t end = t0;  // window [end - 1024, end)
+        int windows = 0;
+        while (need > 0 && end > 0 && windows < 64) {
+            const uint64_t wstart = end >= 1024 ? end - 1024 : 0;
+            const uint64_t base = wstart + (uint64_t)lane * 16;
+            uint32_t mm = 0;
+            if (base < end) {
+                const uint4 v = load16(a.t, end, base, aligned && (wstart & 15) == 0);  // (bytes from `end` on read as 0)
+                mm = newline_mask16(v);
+            }
+            const uint32_t c = __popc(mm);
+            uint32_t pre = c;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t u = (uint32_t)__shfl_up((int)pre, o);
+                if ((int)lane >= o) pre += u;
+            }
+            const uint32_t total = (uint32_t)__shfl((int)pre, 63);
+            uint32_t k = pre - c;  // ordinal of this lane's first newline inside the window
+            const int take = min(need, (int)total);
+            uint32_t bits = mm;
+            while (bits) {
+                const int b = __ffs((int)bits) - 1;
+                bits &= bits - 1;
+                const int from_end = (int)total - 1 - (int)k;  // 0: the window's last newline
+                if (from_end < take) s_nl[need - 1 - from_end] = (int32_t)((int64_t)(base + b) - (int64_t)t0);
+                k++;
+            }
+            need -= take;
+            end = wstart;
+            windows++;
+        }
+        if (need > 0 && end > 0 && lane == 0) s_bc[4] = 1;  // a line longer than 64 KB in front of the tile: not for this path
+        if ((int)lane < need) s_nl[lane] = -1 - (int32_t)(int64_t)t0;  // in front of the text: "newline" at position -1
+    }
+    // ---- every thread: its newlines into the list
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        uint32_t k = row_base[j] + ((uint32_t)(excl >> (16 * j)) & 0xFFFFu);
+        uint32_t bits = m[j];
+        const uint32_t rel = (j * 256 + tid) * 16;
+        while (bits && !irregular) {
+            const int b = __ffs((int)bits) - 1;
+            bits &= bits - 1;
+            s_nl[kHalo + k++] = (int32_t)(rel + b);
+        }
+    }
+    if (extra && tid == 0 && !irregular) s_nl[kHalo + T] = (int32_t)(a.len - t0);
+    __syncthreads();
+    const uint64_t lines_before = s_bc[1];
+    // ---- the records whose fourth line ends in this tile
+    const uint32_t j0 = (3u - (uint32_t)(lines_before & 3)) & 3u;
+    uint32_t nr = (!irregular && j0 < T_all) ? (T_all - j0 + 3) / 4 : 0;
+    if (nr > kRecCap) {
+        irregular = true;
+        nr = 0;
+    }
+    const uint8_t* tb = a.t + t0;  // (relative positions are added to this; a line of the previous tile: negative)
+    auto is_ws_ascii = [](uint8_t c) { return c == ' ' || (c >= 9 && c <= 13); };
+    uint64_t lens[2] = {0, 0};  // seq | qual << 32 of this thread's records
+    bg_fastq_record_t rr[2];
+    bool bad_rec = false;
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const uint32_t i = tid + 256u * u;
+        if (i >= nr) continue;
+        const uint32_t j = kHalo + j0 + 4 * i;  // list index of the record's last newline
+        const int32_t e_h = s_nl[j - 3], e_s = s_nl[j - 2], e_p = s_nl[j - 1], e_q = s_nl[j];
+        const int32_t b_h = s_nl[j - 4] + 1, b_s = e_h + 1, b_p = e_s + 1, b_q = e_p + 1;
+        // trimmed ends (the '\n' itself is white space; a virtual newline at the end of the text is not a byte)
+        int32_t x_h = e_h, x_s = e_s, x_q = e_q;
+        while (x_h > b_h && is_ws_ascii(tb[x_h - 1])) x_h--;
+        while (x_s > b_s && is_ws_ascii(tb[x_s - 1])) x_s--;
+        while (x_q > b_q && is_ws_ascii(tb[x_q - 1])) x_q--;
+        const uint8_t f_h = tb[b_h], f_s = b_s <= e_s && (uint64_t)(t0 + b_s) < a.len ? tb[b_s] : 0, f_p = (uint64_t)(t0 + b_p) < a.len ? tb[b_p] : 0;
+        // F3's hypothesis (fastq.rs:266-300 on four-line records)
+        if (!(f_h == '@' && f_s != '+' && f_p == '+' && x_q > b_q)) bad_rec = true;
+        bg_fastq_record_t o = {};
+        const uint32_t hn = (uint32_t)(x_h - b_h);  // trimmed header, '@' included ('@' is not white space: >= 1 when f_h == '@')
+        const uint32_t n = hn ? hn - 1 : 0;
+        {  // fastq.rs:275-277: line[1..].trim_end().splitn(2, ' ')
+            const uint8_t* p = tb + b_h + 1;
+            uint32_t sp = 0;
+            while (sp < n && ((uintptr_t)(p + sp) & 7)) {
+                if (p[sp] == ' ') goto found;
+                sp++;
+            }
+            while (sp + 8 <= n) {
+                const uint64_t w = *(const uint64_t*)(p + sp) ^ 0x2020202020202020ull;
+                const uint64_t z = (w - 0x0101010101010101ull) & ~w & 0x8080808080808080ull;
+                if (z) {
+                    sp += (uint32_t)(__ffsll((long long)z) - 1) >> 3;
+                    goto found;
+                }
+                sp += 8;
+            }
+            while (sp < n && p[sp] != ' ') sp++;
+        found:
+            o.id_off = t0 + b_h + 1;
+            o.id_len = sp;
+            if (sp < n) {
+                o.desc_off = o.id_off + sp + 1;
+                o.desc_len = n - sp - 1;
+                o.has_desc = 1;
+            }
+        }
+        o.seq_len = (uint32_t)(x_s - b_s);
+        o.qual_len = (uint32_t)(x_q - b_q);
+        rr[u] = o;
+        lens[u] = (uint64_t)o.seq_len | (uint64_t)o.qual_len << 32;
+        FusedRec d;
+        d.seq_rel = b_s;
+        d.qual_rel = b_q;
+        d.seq_n = o.seq_len;
+        d.qual_n = o.qual_len;
+        d.seq_dst = d.qual_dst = 0;
+        d.flags = o.id_len == 0 ? 1u : 0u;
+        d.pad = 0;
+        s_rec[i] = d;
+    }
+    // ---- offsets: block scan of the lengths in record order (row u = records u * 256 ..), then the tile totals' look-backs
+    uint64_t ex[2], row_sum[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        uint64_t v = lens[u];
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)v, o), hh = (uint32_t)__shfl_up((int)(uint32_t)(v >> 32), o);
+            if ((int)lane >= o) v += (uint64_t)hh << 32 | lo;
+        }
+        __syncthreads();
+        if (lane == 63) s_w[wave] = v;
+        __syncthreads();
+        uint64_t wb = 0, all = 0;
+        for (uint32_t w = 0; w < 4; w++) {
+            if (w < wave) wb += s_w[w];
+            all += s_w[w];
+        }
+        ex[u] = wb + v - lens[u];
+        row_sum[u] = all;
+    }
+    if (__any(bad_rec) && lane == 0) s_bc[4] = 1;
+    const uint64_t tile_sum = row_sum[0] + row_sum[1];  // (32-bit halves: a tile's lines hold far fewer than 2^32 bytes)
+    if (wave == 0) {
+        const uint64_t b = fq_lookback(a.tiles + a.n_tiles, tile, tile_sum & 0xFFFFFFFFull);
+        if (lane == 0) s_bc[2] = b;
+    } else if (wave == 1) {
+        const uint64_t b = fq_lookback(a.tiles + 2ull * a.n_tiles, tile, tile_sum >> 32);
+        if (lane == 0) s_bc[3] = b;
+    }
+    __syncthreads();
+    const uint64_t seq_before = s_bc[2], qual_before = s_bc[3];
+    const uint64_t rec0 = (lines_before + j0) / 4;  // global index of the tile's first record
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const uint32_t i = tid + 256u * u;
+        if (i >= nr) continue;
+        const uint64_t e = ex[u] + (u ? row_sum[0] : 0);
+        const uint64_t so = seq_before + (e & 0xFFFFFFFFull), qo = qual_before + (e >> 32);
+        const uint64_t r = rec0 + i;
+        s_rec[i].seq_dst = so;
+        s_rec[i].qual_dst = qo;
+        if (r < a.rec_cap) {
+            rr[u].seq_off = so;
+            rr[u].qual_off = qo;
+            a.recs[r] = rr[u];  // (check: written by the copy phase)
+            a.seq_off[r] = so;
+            a.qual_off[r] = qo;
+        }
+    }
+    if (last_tile && tid == 0) {  // closing offsets and the totals the host reads
+        const uint64_t lines = lines_before + T_all, n_rec = lines / 4;
+        const uint64_t st = seq_before + (tile_sum & 0xFFFFFFFFull), qt = qual_before + (tile_sum >> 32);
+        if (n_rec <= a.rec_cap) {
+            a.seq_off[n_rec] = st;
+            a.qual_off[n_rec] = qt;
+        }
+        a.out[0] = lines;
+        a.out[2] = st;
+        a.out[3] = qt;
+    }
+    if (irregular && tid == 0) s_bc[4] = 1;
+    __syncthreads();
+    if (s_bc[4] && tid == 0) atomicOr((unsigned long long*)&a.out[1], 1ull);
+    // ---- copy + Record::check, 16 lanes per record (the bytes are in L2: this block, or the one before it, just read them)
+    {
+        const int g = tid >> 4, gl = tid & 15;
+        const uint8_t* t_end = a.t + a.len;
+        for (uint32_t i = g; i < nr; i += 16) {
+            const FusedRec d = s_rec[i];
+            bool seq_hi = false, seq_bad = false, qual_hi = false, unused = false;
+            // (destinations are prefix sums of line lengths: inside the caller's `len` bytes whatever the text holds)
+            copy_line<true, 16>(a.seq + d.seq_dst, tb + d.seq_rel, d.seq_n, gl, t_end, seq_hi, seq_bad);
+            copy_line<false, 16>(a.qual + d.qual_dst, tb + d.qual_rel, d.qual_n, gl, t_end, qual_hi, unused);
+            const int sh = (tid & 63) / 16 * 16;
+            const uint64_t gm = 0xFFFFull << sh;
+            seq_hi = (__ballot(seq_hi) & gm) != 0;
+            seq_bad = (__ballot(seq_bad) & gm) != 0;
+            qual_hi = (__ballot(qual_hi) & gm) != 0;
+            const uint64_t r = rec0 + i;
+            if (gl == 0 && r < a.rec_cap)
+                a.recs[r].check = (d.flags & 1u) ? BG_FQCHECK_EMPTY_ID
+                                  : seq_hi         ? BG_FQCHECK_NONASCII_SEQ
+                                  : seq_bad        ? BG_FQCHECK_INVALID_SEQ
+                                  : qual_hi        ? BG_FQCHECK_NONASCII_QUAL
+                                  : d.seq_n != d.qual_n ? BG_FQCHECK_UNEQUAL
+                                                        : BG_FQCHECK_OK;
+        }
+    }
+}
+
 int scan_lengths(const uint32_t* d_len, uint64_t n, uint64_t* d_off, uint64_t* d_sums, hipStream_t st) {
     const uint32_t nb = (uint32_t)(n / 2048 + 1);  // one more block than items need: it writes the closing offset
     fq_block_sums_kernel<<<dim3(nb), dim3(256), 0, st>>>(d_len, n, d_sums);
@@ -679,6 +1045,37 @@ extern "C" int bg_fastq_parse_dev(bg_ctx* ctx, const uint8_t* d_text, uint64_t l
     }
     if (!d_text || !d_recs || !d_seq || !d_seq_off || !d_qual || !d_qual_off) return BG_ERR_INVALID_ARG;
     int rc;
+    // FF: the one-pass reader (four-line ASCII records: nearly every FASTQ); anything else raises its flag and takes F1 .. F6
+    if (!ctx->fq_no_fused) {
+        const uint64_t n_tiles = (len + kTile - 1) / kTile;
+        if (n_tiles < (1ull << 31)) {
+            const size_t words = 3 * n_tiles + 8;
+            if ((rc = bg_reserve(&ctx->aux, &ctx->aux_bytes, words * 8))) return rc;
+            BG_HIP(hipMemsetAsync(ctx->aux, 0, words * 8, st));
+            FusedArgs fa = {};
+            fa.t = d_text;
+            fa.len = len;
+            fa.tiles = (uint64_t*)ctx->aux;
+            fa.out = fa.tiles + 3 * n_tiles;
+            fa.ticket = (uint32_t*)(fa.out + 4);
+            fa.recs = d_recs;
+            fa.rec_cap = rec_cap;
+            fa.seq = d_seq;
+            fa.qual = d_qual;
+            fa.seq_off = d_seq_off;
+            fa.qual_off = d_qual_off;
+            fa.n_tiles = (uint32_t)n_tiles;
+            fq_fused_kernel<<<dim3((uint32_t)n_tiles), dim3(256), 0, st>>>(fa);
+            BG_HIP(hipGetLastError());
+            uint64_t res[4] = {0, 1, 0, 0};
+            BG_HIP(hipMemcpyAsync(res, fa.out, sizeof(res), hipMemcpyDeviceToHost, st));
+            BG_HIP(hipStreamSynchronize(st));  // the call's one host round trip
+            if (res[1] == 0 && (res[0] & 3) == 0) {
+                *n_records = res[0] / 4;
+                return *n_records > rec_cap ? BG_ERR_TOO_LARGE : BG_OK;
+            }
+        }
+    }
     // F1: newline counts per chunk, their scan (+ total), line starts
     const uint64_t nchunks = (len + kChunk - 1) / kChunk;
     const size_t n_part = 2 * (nchunks / 2048 + 2);  // partial sums of the two-level scan

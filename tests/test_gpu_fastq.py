@@ -172,3 +172,76 @@ def test_long_reads_and_header_spaces_at_every_offset():
         t = b"".join(out)
         for cut in (0, 1, 2, 3, 5):  # shift every alignment by dropping leading records' bytes... a prefix record of odd length
             same_as_oracle((b"@p\n" + b"A" * cut + b"\n+\n" + b"I" * cut + b"\n" if cut else b"") + t)
+
+
+def both_paths_like_the_oracle(text):
+    """the one-pass kernel (or, where it raises its flag, the general kernels behind it) and the general kernels alone"""
+    p = same_as_oracle(text)
+    ctx = _lib.Context(0)
+    ctx.set_option("fq_no_fused", 1)
+    q = fastq.parse_arrays(text, ctx=ctx)
+    assert (p.status, p.err_pos, len(p)) == (q.status, q.err_pos, len(q))
+    assert (p.recs == q.recs).all() and (p.seq == q.seq).all() and (p.qual == q.qual).all()
+    assert (p.seq_off == q.seq_off).all() and (p.qual_off == q.qual_off).all()
+    ctx.close()
+    return p
+
+
+def test_one_pass_reader_on_tiles_halos_and_what_it_leaves_to_the_general_kernels():
+    """Round 6, fq_fused_kernel: records that straddle its 16 KB tiles (every phase of the line index at a tile boundary),
+    lines longer than a tile (the window search in front of a tile runs over several windows), CRLF, a text without a final
+    newline ending exactly on / next to a tile boundary, empty ids, invalid and unequal records (Record::check), and the
+    inputs it must hand over: a non-ASCII byte, a wrapped record in the middle, a line count that is no multiple of four,
+    more than 512 records in a tile (reads of a few bases), more than 4096 newlines in a tile."""
+    rng = np.random.default_rng(21)
+    alpha = np.frombuffer(b"ACGTN", dtype=np.uint8)
+
+    def rec(k, ln, nl=b"\n", idl=None, desc=True):
+        seq = alpha[rng.integers(0, 5, size=ln)].tobytes()
+        qual = rng.integers(33, 75, size=ln).astype(np.uint8).tobytes()
+        hdr = b"@" + (b"r%d" % k if idl is None else b"x" * idl) + (b" d %d" % k if desc else b"")
+        return hdr + nl + seq + nl + b"+" + nl + qual + nl
+
+    # 150 bp reads, 3000 records (~1 MB: 60 tiles), shifted byte by byte so that tile boundaries fall everywhere in a record
+    body = b"".join(rec(k, 150, desc=k % 2 == 0) for k in range(3000))
+    for shift in (0, 1, 7, 33, 150, 151, 152, 153, 154, 160, 300, 305):
+        pre = (b"@s\n" + b"A" * shift + b"\n+\n" + b"I" * shift + b"\n") if shift else b""
+        p = both_paths_like_the_oracle(pre + body)
+        assert p.status == "ok" and len(p) == 3000 + (1 if shift else 0)
+    # the text ends without a newline, exactly at a tile boundary and one byte either side of it
+    for total in (16384, 16383, 16385, 32768, 32769):
+        t = b"".join(rec(k, 100) for k in range(total // 100))[:0]
+        parts, size, k = [], 0, 0
+        while True:
+            r = rec(k, int(rng.integers(20, 200)))
+            if size + len(r) > total - 300:
+                break
+            parts.append(r)
+            size += len(r)
+            k += 1
+        tail_len = (total - size - len(b"@t\n\n+\n")) // 2
+        odd = total - size - len(b"@t\n\n+\n") - 2 * tail_len
+        last = b"@t" + b"y" * odd + b"\n" + b"A" * tail_len + b"\n+\n" + b"I" * tail_len  # no newline at the end
+        t = b"".join(parts) + last
+        assert len(t) == total
+        p = both_paths_like_the_oracle(t)
+        assert p.status == "ok" and len(p) == len(parts) + 1
+        both_paths_like_the_oracle(t + b"\n")
+    # long reads: lines of 20 - 70 kb (several tiles per line; the four newlines in front of a tile are far away)
+    both_paths_like_the_oracle(b"".join(rec(k, int(rng.integers(20_000, 70_000))) for k in range(12)))
+    both_paths_like_the_oracle(b"".join(rec(k, int(rng.integers(2_000, 9_000)), nl=b"\r\n") for k in range(60)))
+    # Record::check on the one-pass path: empty id, invalid sequence byte, unequal lengths
+    t = rec(0, 50) + b"@\nACGT\n+\nIIII\n" + b"@bad\nAC#T\n+\nIIII\n" + b"@uneq\nACGT\n+\nIII\n" + b"@ lead space\nAC\n+\nII\n" + b"@ok  two\nA\n+\nI\n"
+    p = both_paths_like_the_oracle(t * 300)
+    assert len(p) == 1800
+    # handed over to the general kernels: the result must still be the reference's
+    base = b"".join(rec(k, 80) for k in range(800))
+    both_paths_like_the_oracle(base + "@é\nAC\n+\nII\n".encode() + base)                      # a non-ASCII byte
+    both_paths_like_the_oracle(base + b"@w\nAC\nGT\n+\nII\nII\n" + base)                       # a wrapped record: six lines
+    both_paths_like_the_oracle(base + b"@trunc\nACGT\n")                                       # lines % 4 != 0
+    both_paths_like_the_oracle(base[:-1] + b"\n\n")                                            # an empty line at the end
+    both_paths_like_the_oracle(b"".join(rec(k, 3, idl=1, desc=False) for k in range(5000)))    # ~1300 records per tile
+    both_paths_like_the_oracle(base + b"@n\n" + b"\n" * 9000 + base)                           # > 4096 newlines in a tile
+    both_paths_like_the_oracle(b"@a\nAC\n+\nII\n" * 3 + b"garbage\nAC\n+\nII\n" + b"@a\nAC\n+\nII\n" * 3)  # MissingAt in the middle
+    both_paths_like_the_oracle(b"@a\nAC\n+\n\n" + b"@a\nAC\n+\nII\n" * 3)                      # an empty quality line: IncompleteRecord
+    both_paths_like_the_oracle(b"@a\n+C\n+\nII\n" * 5)                                         # a sequence line that starts with '+'
