@@ -16,6 +16,7 @@
 //   F6  one wavefront per record gathers the trimmed lines and evaluates Record::check on the way.
 // Everything is byte/integer work bound by HBM reads of the text (about three passes).
 #include <algorithm>
+#include <type_traits>
 #include <vector>
 
 #include "bg_common.h"
@@ -516,8 +517,18 @@ __global__ __launch_bounds__(256) void fq_gather_kernel(const uint8_t* __restric
 // the hypothesis, a tile with more than 4096 newlines or 512 records — raises one flag; the host reads {lines, flag} back
 // (the call's ONE synchronisation) and, if it is up, runs F1 .. F6, which are exact for any input and overwrite whatever
 // the fused kernel wrote.  Every write of the fused kernel stays inside the caller's buffers whatever the text holds.
-constexpr uint32_t kTile = 16384, kNlCap = 4096, kRecCap = 512;
+constexpr uint32_t kTile = 16384, kNlCap = 2048, kRecCap = 256;  // (LDS: 33 KB per block — tile, newline list, records — four blocks per CU)
 constexpr int kHalo = 4;
+#ifndef FQ_LDS_TILE  // 1: the tile's bytes are staged in LDS (the text is read from memory once); 0: owners and the copy phase re-read them (L2)
+#define FQ_LDS_TILE 0
+#endif
+constexpr bool kLdsTile = FQ_LDS_TILE != 0;
+#ifndef FQ_LB1_WAVES  // wavefronts that poll in the two look-backs (64 tiles each per round trip): tools/exp/ko_build.sh variants
+#define FQ_LB1_WAVES 1
+#endif
+#ifndef FQ_LB2_WAVES
+#define FQ_LB2_WAVES 2
+#endif
 constexpr uint64_t kFlagAgg = 1ull << 62, kFlagPre = 2ull << 62, kValMask = (1ull << 62) - 1;
 
 struct FusedArgs {
@@ -533,41 +544,84 @@ struct FusedArgs {
     uint32_t n_tiles;
 };
 
-// exclusive prefix of this tile's aggregate over all tiles before it; called by one whole wavefront
-__device__ uint64_t fq_lookback(uint64_t* tiles, uint32_t id, uint64_t agg) {
-    const int lane = threadIdx.x & 63;
+// Exclusive prefixes of this tile's aggregates over all tiles before it — NV values at once (their words sit n_tiles
+// apart), by the WHOLE block: thread i polls tile id - 1 - i (- 256 per further step), the values up to the nearest
+// inclusive prefix are summed.  Flag and value share one 64-bit word, so the word is all that travels between blocks:
+// RELAXED agent-scope atomics (coherent across the XCDs' L2s by themselves; acquire / release here would flush and
+// invalidate whole caches around every word — the first build did, and ran 5 ms instead of 0.4).  Why the whole block:
+// inclusive prefixes advance one window of tiles per polling round trip (~2 us across XCDs), i.e. 64 tiles per round trip
+// with one wavefront — 20 000 tiles then cost 0.6 ms in the look-back alone, whatever the occupancy; 256 lanes: 0.15 ms.
+template <int NV, int WAVES>
+__device__ void fq_lookback(uint64_t* tiles, uint64_t stride, uint32_t id, const uint64_t (&agg)[NV], uint64_t (&excl)[NV], uint64_t* s_tmp /* 8 * NV words */) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int k = 0; k < NV; k++) excl[k] = 0;
+#ifdef FQ_KO_LOOKBACK  // (knock-out builds, tools/exp/ko_build.sh: wrong results, timing only)
+    return;
+#endif
     if (id == 0) {
-        if (lane == 0) __hip_atomic_store(&tiles[0], kFlagPre | agg, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        return 0;
+        if (tid == 0)
+#pragma unroll
+            for (int k = 0; k < NV; k++) __hip_atomic_store(&tiles[k * stride], kFlagPre | agg[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
     }
-    if (lane == 0) __hip_atomic_store(&tiles[id], kFlagAgg | agg, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    uint64_t excl = 0;
+    if (tid == 0)
+#pragma unroll
+        for (int k = 0; k < NV; k++) __hip_atomic_store(&tiles[k * stride + id], kFlagAgg | agg[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bool found[NV];
+#pragma unroll
+    for (int k = 0; k < NV; k++) found[k] = false;
     int64_t j = (int64_t)id - 1;
     for (;;) {
-        const int64_t idx = j - lane;
-        uint64_t v = kFlagPre;  // in front of tile 0: an inclusive prefix of 0
-        if (idx >= 0) {
-            do {
-                v = __hip_atomic_load(&tiles[idx], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-            } while ((v >> 62) == 0);
-        }
-        const uint64_t pm = __ballot((v >> 62) == 2);
-        uint64_t val = v & kValMask;
-        if (pm) {  // the closest inclusive prefix ends the walk: lanes beyond it do not count
-            const int first = __ffsll((long long)pm) - 1;
-            if (lane > first) val = 0;
-        }
+        const int64_t idx = j - (int64_t)tid;
+        bool all_found = true;
 #pragma unroll
-        for (int o = 32; o; o >>= 1) {
-            const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)val, o), hi = (uint32_t)__shfl_xor((int)(uint32_t)(val >> 32), o);
-            val += (uint64_t)hi << 32 | lo;
+        for (int k = 0; k < NV; k++) {
+            if ((int)wave >= WAVES) {  // (a narrower window: these wavefronts only keep the barriers company)
+                if (lane == 0) s_tmp[k * 8 + wave] = 0, s_tmp[k * 8 + 4 + wave] = 0;
+                continue;
+            }
+            uint64_t v = kFlagPre;  // in front of tile 0: an inclusive prefix of 0
+            if (idx >= 0 && !found[k]) {
+                do {
+                    v = __hip_atomic_load(&tiles[k * stride + idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } while ((v >> 62) == 0);
+            }
+            const uint64_t pm = __ballot((v >> 62) == 2);
+            uint64_t val = v & kValMask;
+            if (pm) {  // the nearest inclusive prefix of this wavefront's window ends the walk: lanes beyond it do not count
+                const int first = __ffsll((long long)pm) - 1;
+                if ((int)lane > first) val = 0;
+            }
+#pragma unroll
+            for (int o = 32; o; o >>= 1) {
+                const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)val, o), hi = (uint32_t)__shfl_xor((int)(uint32_t)(val >> 32), o);
+                val += (uint64_t)hi << 32 | lo;
+            }
+            if (lane == 0) {
+                s_tmp[k * 8 + wave] = val;
+                s_tmp[k * 8 + 4 + wave] = pm ? 1 : 0;
+            }
         }
-        excl += val;
-        if (pm) break;
-        j -= 64;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NV; k++) {
+            if (!found[k]) {
+                for (uint32_t w = 0; w < 4 && !found[k]; w++) {  // wavefront 0 holds the nearest tiles
+                    excl[k] += s_tmp[k * 8 + w];
+                    found[k] = s_tmp[k * 8 + 4 + w] != 0;
+                }
+            }
+            all_found = all_found && found[k];
+        }
+        __syncthreads();
+        if (all_found) break;
+        j -= 64 * WAVES;
     }
-    if (lane == 0) __hip_atomic_store(&tiles[id], kFlagPre | ((excl + agg) & kValMask), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    return excl;
+    if (tid == 0)
+#pragma unroll
+        for (int k = 0; k < NV; k++)
+            __hip_atomic_store(&tiles[k * stride + id], kFlagPre | ((excl[k] + agg[k]) & kValMask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 __device__ __forceinline__ uint32_t newline_mask16(const uint4 v) {  // bit i: byte i of the piece is '\n'
@@ -584,7 +638,7 @@ __device__ __forceinline__ uint32_t newline_mask16(const uint4 v) {  // bit i: b
 struct FusedRec {  // what the copy phase needs of a record (LDS)
     int32_t seq_rel, qual_rel;  // line starts relative to the tile (may be negative: a line that begins in the previous tile)
     uint32_t seq_n, qual_n;
-    uint64_t seq_dst, qual_dst;
+    uint32_t seq_dst, qual_dst; // destinations relative to the tile's first sequence / quality byte
     uint32_t flags;             // 1: the id is empty
     uint32_t pad;
 };
@@ -592,7 +646,16 @@ struct FusedRec {  // what the copy phase needs of a record (LDS)
 __global__ __launch_bounds__(256) void fq_fused_kernel(const FusedArgs a) {
     __shared__ int32_t s_nl[kHalo + kNlCap + 1];
     __shared__ FusedRec s_rec[kRecCap];
+    // the tile's bytes: what the records' owners look at (first bytes, line ends, headers) and what the copy phase reads comes
+    // from here — the text is read from memory ONCE (a second read of it, 16 KB per block with 2 000 blocks in flight, does not
+    // stay in a 4 MB L2); only lines that begin in the previous tile are read from there
+    __shared__ uint4 s_tile4[kLdsTile ? kTile / 16 + 2 : 1];
+#ifdef FQ_PAD_LDS
+    __shared__ uint32_t s_padlds[FQ_PAD_LDS / 4];
+    if (threadIdx.x == 9999) s_padlds[0] = 1;
+#endif
     __shared__ uint64_t s_w[8];
+    __shared__ uint64_t s_lb[16];
     __shared__ uint64_t s_bc[8];  // [0] tile id, [1] lines before the tile, [2] sequence bytes before it, [3] quality bytes, [4] irregular
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) {
@@ -612,6 +675,7 @@ __global__ __launch_bounds__(256) void fq_fused_kernel(const FusedArgs a) {
     for (int j = 0; j < 4; j++) {
         const uint64_t base = t0 + ((uint64_t)j * 256 + tid) * 16;
         const uint4 v = base < a.len ? load16(a.t, a.len, base, aligned) : make_uint4(0, 0, 0, 0);
+        if (kLdsTile) s_tile4[j * 256 + tid] = v;
         m[j] = newline_mask16(v);
         hi |= ((v.x | v.y | v.z | v.w) & 0x80808080u) != 0;
         packed |= (uint64_t)__popc(m[j]) << (16 * j);
@@ -644,11 +708,12 @@ __global__ __launch_bounds__(256) void fq_fused_kernel(const FusedArgs a) {
     }
     const uint32_t T_all = T + extra;
     bool irregular = T_all > kNlCap;
-    // ---- wavefront 0: lines before the tile; wavefront 1: the four newlines in front of it
-    if (wave == 0) {
-        const uint64_t before = fq_lookback(a.tiles, tile, T_all);
-        if (lane == 0) s_bc[1] = before;
-    } else if (wave == 1) {
+    // ---- wavefront 3: the four newlines in front of the tile; then the whole block: lines before the tile
+#ifdef FQ_KO_HALO
+    if (false) {
+#else
+    if (wave == 3) {
+#endif
         int need = kHalo;
         uint64_t end = t0;  // window [end - 1024, end)
         int windows = 0;
@@ -698,8 +763,14 @@ __global__ __launch_bounds__(256) void fq_fused_kernel(const FusedArgs a) {
         }
     }
     if (extra && tid == 0 && !irregular) s_nl[kHalo + T] = (int32_t)(a.len - t0);
+    uint64_t lines_before;
+    {
+        const uint64_t agg[1] = {T_all};
+        uint64_t ex1[1];
+        fq_lookback<1, FQ_LB1_WAVES>(a.tiles, a.n_tiles, tile, agg, ex1, s_lb);  // (its barriers also publish the list to the block)
+        lines_before = ex1[0];
+    }
     __syncthreads();
-    const uint64_t lines_before = s_bc[1];
     // ---- the records whose fourth line ends in this tile
     const uint32_t j0 = (3u - (uint32_t)(lines_before & 3)) & 3u;
     uint32_t nr = (!irregular && j0 < T_all) ? (T_all - j0 + 3) / 4 : 0;
@@ -707,47 +778,83 @@ __global__ __launch_bounds__(256) void fq_fused_kernel(const FusedArgs a) {
         irregular = true;
         nr = 0;
     }
+#ifdef FQ_KO_RECORDS
+    nr = 0;
+#endif
     const uint8_t* tb = a.t + t0;  // (relative positions are added to this; a line of the previous tile: negative)
+    const uint8_t* s_tile = (const uint8_t*)s_tile4;
+    if (kLdsTile && tid < 2) s_tile4[kTile / 16 + tid] = make_uint4(0, 0, 0, 0);  // (pad: 16-byte reads may run past the tile's last byte)
+    auto gb = [&](int32_t rel) -> uint8_t { return kLdsTile && rel >= 0 ? s_tile[rel] : tb[rel]; };  // a byte of the text by tile-relative position
     auto is_ws_ascii = [](uint8_t c) { return c == ' ' || (c >= 9 && c <= 13); };
-    uint64_t lens[2] = {0, 0};  // seq | qual << 32 of this thread's records
-    bg_fastq_record_t rr[2];
+    uint64_t lens = 0;  // seq | qual << 32 of this thread's record
+    bg_fastq_record_t rr = {};
     bool bad_rec = false;
-#pragma unroll
-    for (int u = 0; u < 2; u++) {
-        const uint32_t i = tid + 256u * u;
-        if (i >= nr) continue;
-        const uint32_t j = kHalo + j0 + 4 * i;  // list index of the record's last newline
+    if (tid < nr) {
+        const uint32_t j = kHalo + j0 + 4 * tid;  // list index of the record's last newline
         const int32_t e_h = s_nl[j - 3], e_s = s_nl[j - 2], e_p = s_nl[j - 1], e_q = s_nl[j];
         const int32_t b_h = s_nl[j - 4] + 1, b_s = e_h + 1, b_p = e_s + 1, b_q = e_p + 1;
+        // the bytes this needs — the three first bytes, the byte in front of each of the three trimmed line ends, the head of
+        // the header — are loaded together before any of them is looked at (a chain of dependent L2 reads otherwise)
+        const uint8_t f_h = gb(b_h), f_s = gb(b_s), f_p = gb(b_p);  // (b_s <= e_s < len, b_p <= e_p < len: bytes of the text)
+        const uint8_t l_h = e_h > b_h ? gb(e_h - 1) : (uint8_t)'x', l_s = e_s > b_s ? gb(e_s - 1) : (uint8_t)'x', l_q = e_q > b_q ? gb(e_q - 1) : (uint8_t)'x';
+        // header: 8 bytes at a time from the 8-byte boundary at or below its second byte (bytes in front of it masked off)
+        const int32_t hrel = b_h + 1;
+        const uint32_t mis = (uint32_t)hrel & 7u;  // (tile starts are multiples of 16 KB: LDS and text share the alignment when the text is 8-byte aligned)
+        const int32_t hrel0 = hrel - (int32_t)mis;
+        const bool h_lds = kLdsTile && hrel0 >= 0;  // the two words lie in the tile (+ its pad)
+        const uint64_t* hw = (const uint64_t*)(tb + hrel0);
+        const bool h2 = h_lds || (((uintptr_t)hw & 7) == 0 && (const uint8_t*)hw >= a.t && (const uint8_t*)(hw + 2) <= a.t + a.len);
+        uint64_t w0 = 0, w1 = 0;  // (two words: most headers' ids end inside them)
+        if (h_lds) {
+            w0 = *(const uint64_t*)(s_tile + hrel0);
+            w1 = *(const uint64_t*)(s_tile + hrel0 + 8);
+        } else if (h2) {
+            w0 = hw[0];
+            w1 = hw[1];
+        }
+        auto hp_at = [&](uint32_t at) -> uint8_t { return gb(hrel + (int32_t)at); };
         // trimmed ends (the '\n' itself is white space; a virtual newline at the end of the text is not a byte)
         int32_t x_h = e_h, x_s = e_s, x_q = e_q;
-        while (x_h > b_h && is_ws_ascii(tb[x_h - 1])) x_h--;
-        while (x_s > b_s && is_ws_ascii(tb[x_s - 1])) x_s--;
-        while (x_q > b_q && is_ws_ascii(tb[x_q - 1])) x_q--;
-        const uint8_t f_h = tb[b_h], f_s = b_s <= e_s && (uint64_t)(t0 + b_s) < a.len ? tb[b_s] : 0, f_p = (uint64_t)(t0 + b_p) < a.len ? tb[b_p] : 0;
+        if (is_ws_ascii(l_h)) {
+            x_h--;
+            while (x_h > b_h && is_ws_ascii(gb(x_h - 1))) x_h--;
+        }
+        if (is_ws_ascii(l_s)) {
+            x_s--;
+            while (x_s > b_s && is_ws_ascii(gb(x_s - 1))) x_s--;
+        }
+        if (is_ws_ascii(l_q)) {
+            x_q--;
+            while (x_q > b_q && is_ws_ascii(gb(x_q - 1))) x_q--;
+        }
         // F3's hypothesis (fastq.rs:266-300 on four-line records)
         if (!(f_h == '@' && f_s != '+' && f_p == '+' && x_q > b_q)) bad_rec = true;
         bg_fastq_record_t o = {};
         const uint32_t hn = (uint32_t)(x_h - b_h);  // trimmed header, '@' included ('@' is not white space: >= 1 when f_h == '@')
         const uint32_t n = hn ? hn - 1 : 0;
         {  // fastq.rs:275-277: line[1..].trim_end().splitn(2, ' ')
-            const uint8_t* p = tb + b_h + 1;
-            uint32_t sp = 0;
-            while (sp < n && ((uintptr_t)(p + sp) & 7)) {
-                if (p[sp] == ' ') goto found;
-                sp++;
-            }
-            while (sp + 8 <= n) {
-                const uint64_t w = *(const uint64_t*)(p + sp) ^ 0x2020202020202020ull;
-                const uint64_t z = (w - 0x0101010101010101ull) & ~w & 0x8080808080808080ull;
+            uint32_t sp = n;  // (no space: the whole trimmed line is the id)
+            auto spaces = [](uint64_t w) {  // bit 7 of every byte that is ' '
+                const uint64_t x = w ^ 0x2020202020202020ull;
+                return (x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull;
+            };
+            bool done = false;
+            if (h2) {
+                uint64_t z = spaces(w0) & (~0ull << (8 * mis));  // bytes in front of the header's second byte do not count
                 if (z) {
-                    sp += (uint32_t)(__ffsll((long long)z) - 1) >> 3;
-                    goto found;
+                    sp = ((uint32_t)(__ffsll((long long)z) - 1) >> 3) - mis;
+                    done = true;
+                } else if ((z = spaces(w1))) {
+                    sp = 8 - mis + ((uint32_t)(__ffsll((long long)z) - 1) >> 3);
+                    done = true;
                 }
-                sp += 8;
             }
-            while (sp < n && p[sp] != ' ') sp++;
-        found:
+            if (!done) {
+                uint32_t at = h2 ? 16 - mis : 0;
+                while (at < n && hp_at(at) != ' ') at++;
+                sp = at;
+            }
+            if (sp > n) sp = n;  // a space behind the trimmed end is not part of the line
             o.id_off = t0 + b_h + 1;
             o.id_len = sp;
             if (sp < n) {
@@ -758,8 +865,8 @@ __global__ __launch_bounds__(256) void fq_fused_kernel(const FusedArgs a) {
         }
         o.seq_len = (uint32_t)(x_s - b_s);
         o.qual_len = (uint32_t)(x_q - b_q);
-        rr[u] = o;
-        lens[u] = (uint64_t)o.seq_len | (uint64_t)o.qual_len << 32;
+        rr = o;
+        lens = (uint64_t)o.seq_len | (uint64_t)o.qual_len << 32;
         FusedRec d;
         d.seq_rel = b_s;
         d.qual_rel = b_q;
@@ -768,13 +875,12 @@ __global__ __launch_bounds__(256) void fq_fused_kernel(const FusedArgs a) {
         d.seq_dst = d.qual_dst = 0;
         d.flags = o.id_len == 0 ? 1u : 0u;
         d.pad = 0;
-        s_rec[i] = d;
+        s_rec[tid] = d;
     }
-    // ---- offsets: block scan of the lengths in record order (row u = records u * 256 ..), then the tile totals' look-backs
-    uint64_t ex[2], row_sum[2];
-#pragma unroll
-    for (int u = 0; u < 2; u++) {
-        uint64_t v = lens[u];
+    // ---- offsets: block scan of the lengths in record order, then the tile totals' look-backs
+    uint64_t ex, tile_sum;
+    {
+        uint64_t v = lens;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)v, o), hh = (uint32_t)__shfl_up((int)(uint32_t)(v >> 32), o);
@@ -788,34 +894,30 @@ __global__ __launch_bounds__(256) void fq_fused_kernel(const FusedArgs a) {
             if (w < wave) wb += s_w[w];
             all += s_w[w];
         }
-        ex[u] = wb + v - lens[u];
-        row_sum[u] = all;
+        ex = wb + v - lens;
+        tile_sum = all;  // (32-bit halves: a tile's lines hold far fewer than 2^32 bytes)
     }
     if (__any(bad_rec) && lane == 0) s_bc[4] = 1;
-    const uint64_t tile_sum = row_sum[0] + row_sum[1];  // (32-bit halves: a tile's lines hold far fewer than 2^32 bytes)
-    if (wave == 0) {
-        const uint64_t b = fq_lookback(a.tiles + a.n_tiles, tile, tile_sum & 0xFFFFFFFFull);
-        if (lane == 0) s_bc[2] = b;
-    } else if (wave == 1) {
-        const uint64_t b = fq_lookback(a.tiles + 2ull * a.n_tiles, tile, tile_sum >> 32);
-        if (lane == 0) s_bc[3] = b;
+    if (tid < nr) {
+        s_rec[tid].seq_dst = (uint32_t)ex;
+        s_rec[tid].qual_dst = (uint32_t)(ex >> 32);
+    }
+    uint64_t seq_before, qual_before;
+    {
+        const uint64_t agg[2] = {tile_sum & 0xFFFFFFFFull, tile_sum >> 32};
+        uint64_t ex2[2];
+        fq_lookback<2, FQ_LB2_WAVES>(a.tiles + a.n_tiles, a.n_tiles, tile, agg, ex2, s_lb);
+        seq_before = ex2[0];
+        qual_before = ex2[1];
     }
     __syncthreads();
-    const uint64_t seq_before = s_bc[2], qual_before = s_bc[3];
     const uint64_t rec0 = (lines_before + j0) / 4;  // global index of the tile's first record
-#pragma unroll
-    for (int u = 0; u < 2; u++) {
-        const uint32_t i = tid + 256u * u;
-        if (i >= nr) continue;
-        const uint64_t e = ex[u] + (u ? row_sum[0] : 0);
-        const uint64_t so = seq_before + (e & 0xFFFFFFFFull), qo = qual_before + (e >> 32);
-        const uint64_t r = rec0 + i;
-        s_rec[i].seq_dst = so;
-        s_rec[i].qual_dst = qo;
-        if (r < a.rec_cap) {
-            rr[u].seq_off = so;
-            rr[u].qual_off = qo;
-            a.recs[r] = rr[u];  // (check: written by the copy phase)
+    if (tid < nr) {
+        const uint64_t so = seq_before + (ex & 0xFFFFFFFFull), qo = qual_before + (ex >> 32);
+        const uint64_t r = rec0 + tid;
+        rr.seq_off = so;
+        rr.qual_off = qo;
+        if (r < a.rec_cap) {  // (the record itself: after the copy phase, with its check)
             a.seq_off[r] = so;
             a.qual_off[r] = qo;
         }
@@ -834,29 +936,175 @@ __global__ __launch_bounds__(256) void fq_fused_kernel(const FusedArgs a) {
     if (irregular && tid == 0) s_bc[4] = 1;
     __syncthreads();
     if (s_bc[4] && tid == 0) atomicOr((unsigned long long*)&a.out[1], 1ull);
-    // ---- copy + Record::check, 16 lanes per record (the bytes are in L2: this block, or the one before it, just read them)
+    // ---- copy + Record::check.  The tile's sequence bytes go to ONE contiguous range of `seq` (its records follow each other
+    // there), likewise the qualities: every thread takes 16-byte pieces of that range on the DESTINATION's alignment, finds the
+    // record a piece belongs to (binary search over the records' ends, LDS) and reads its 16 source bytes as five aligned
+    // dwords funnel-shifted into four — one load phase and one 16-byte store per piece, all 256 lanes busy (16 lanes per
+    // record, head / body / tail one after the other, was 37 % of the kernel).  A piece that straddles two records or the
+    // ends of the range goes byte by byte.  The bytes come from L2: this block, or the one before it, just read them.
     {
-        const int g = tid >> 4, gl = tid & 15;
         const uint8_t* t_end = a.t + a.len;
-        for (uint32_t i = g; i < nr; i += 16) {
-            const FusedRec d = s_rec[i];
-            bool seq_hi = false, seq_bad = false, qual_hi = false, unused = false;
-            // (destinations are prefix sums of line lengths: inside the caller's `len` bytes whatever the text holds)
-            copy_line<true, 16>(a.seq + d.seq_dst, tb + d.seq_rel, d.seq_n, gl, t_end, seq_hi, seq_bad);
-            copy_line<false, 16>(a.qual + d.qual_dst, tb + d.qual_rel, d.qual_n, gl, t_end, qual_hi, unused);
-            const int sh = (tid & 63) / 16 * 16;
-            const uint64_t gm = 0xFFFFull << sh;
-            seq_hi = (__ballot(seq_hi) & gm) != 0;
-            seq_bad = (__ballot(seq_bad) & gm) != 0;
-            qual_hi = (__ballot(qual_hi) & gm) != 0;
-            const uint64_t r = rec0 + i;
-            if (gl == 0 && r < a.rec_cap)
-                a.recs[r].check = (d.flags & 1u) ? BG_FQCHECK_EMPTY_ID
-                                  : seq_hi         ? BG_FQCHECK_NONASCII_SEQ
-                                  : seq_bad        ? BG_FQCHECK_INVALID_SEQ
-                                  : qual_hi        ? BG_FQCHECK_NONASCII_QUAL
-                                  : d.seq_n != d.qual_n ? BG_FQCHECK_UNEQUAL
-                                                        : BG_FQCHECK_OK;
+#ifdef FQ_KO_COPY
+        nr = 0;
+#endif
+        auto tile_copy = [&](auto SEQ_T, uint8_t* dst_base, uint32_t total) {
+            constexpr bool SEQ = decltype(SEQ_T)::value;
+            auto rel_of = [&](uint32_t i) { return SEQ ? s_rec[i].seq_rel : s_rec[i].qual_rel; };
+            auto dst_of = [&](uint32_t i) { return SEQ ? s_rec[i].seq_dst : s_rec[i].qual_dst; };
+            auto end_of = [&](uint32_t i) { return SEQ ? s_rec[i].seq_dst + s_rec[i].seq_n : s_rec[i].qual_dst + s_rec[i].qual_n; };
+            auto flag = [&](uint32_t i, bool hi, bool bad) {
+                const uint32_t f = (hi ? (SEQ ? 2u : 8u) : 0u) | (bad ? 4u : 0u);
+                if (f) atomicOr(&s_rec[i].flags, f);
+            };
+            auto classify = [&](uint32_t c, bool& hi, bool& bad) {
+                hi |= c >= 0x80;
+                if (SEQ) bad |= !((c >= 'A' && c <= 'Z') || (c >= 'a' && c <= 'z') || c == '-' || c == '.' || c == '*');
+            };
+            const uint32_t d0 = (uint32_t)((uintptr_t)dst_base & 15);
+            const uint32_t n_pieces = (d0 + total + 15) >> 4;
+            for (uint32_t c = tid; c < n_pieces && nr; c += 256) {
+                const uint32_t o_lo = 16 * c > d0 ? 16 * c - d0 : 0, o_hi = min(total, 16 * c + 16 - d0);
+                uint32_t lo = 0, hi_i = nr - 1;  // the record whose bytes hold offset o_lo: the first one that ends beyond it
+                while (lo < hi_i) {
+                    const uint32_t mid = (lo + hi_i) >> 1;
+                    if (end_of(mid) > o_lo)
+                        hi_i = mid;
+                    else
+                        lo = mid + 1;
+                }
+                uint32_t i = lo;
+                // 16 source bytes for output offsets o_lo .. o_lo + 15 as record i has them (five aligned dwords funnel-shifted
+                // into four); false if that would read outside the text
+                auto load16u = [&](uint32_t rec, uint32_t (&w)[4]) -> bool {
+                    const int32_t rel = rel_of(rec) + (int32_t)(16 * c - d0 - dst_of(rec));
+                    uint32_t r5[5], sh;
+                    if (kLdsTile && rel >= 0 && rel + 20 <= (int32_t)(kTile + 32)) {  // inside the tile (+ pad): from LDS
+                        sh = (uint32_t)rel & 3u;
+                        const uint32_t* q4 = (const uint32_t*)(s_tile + (rel - (int32_t)sh));
+#pragma unroll
+                        for (int q = 0; q < 5; q++) r5[q] = q4[q];
+                    } else {
+                        // two ALIGNED 16-byte loads (a wavefront's pieces are consecutive: each load instruction covers whole
+                        // cache lines; five dword loads at a 16-byte stride used a quarter of every line they touched and were
+                        // what the copy phase spent its time on), the five dwords that hold the piece picked by its dword offset
+                        const uint8_t* p = tb + rel;
+                        const uint32_t sh16 = (uint32_t)((uintptr_t)p & 15);
+                        const uint8_t* pa = p - sh16;
+                        if (pa < a.t || pa + 32 > t_end) {
+                            sh = (uint32_t)((uintptr_t)p & 3);
+                            const uint8_t* pd = p - sh;
+                            if (pd < a.t || pd + 20 > t_end) return false;
+#pragma unroll
+                            for (int q = 0; q < 5; q++) r5[q] = *(const uint32_t*)(pd + 4 * q);
+                        } else {
+                            const uint4 lo4 = *(const uint4*)pa, hi4 = *(const uint4*)(pa + 16);
+                            const uint32_t r8[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+                            const uint32_t d = sh16 >> 2;
+                            sh = sh16 & 3u;
+#pragma unroll
+                            for (int q = 0; q < 5; q++) r5[q] = d == 0 ? r8[q] : d == 1 ? r8[q + 1] : d == 2 ? r8[q + 2] : r8[q + 3];
+                        }
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; q++) w[q] = __builtin_amdgcn_alignbyte(r5[q + 1], r5[q], sh);
+                    return true;
+                };
+                uint32_t w[4];
+                bool fast = load16u(i, w);
+                const uint32_t p0 = 16 * c - d0;              // output offset of the piece's byte 0 (may lie in front of the range: as int)
+                const uint32_t e1 = end_of(i);
+                uint32_t i2 = i, split = 16;                  // bytes [split, 16) of the piece belong to record i2
+                if (fast && o_hi > e1) {                      // the piece runs into the next record (skipping empty ones)
+                    i2 = i + 1;
+                    while (i2 + 1 < nr && end_of(i2) <= e1) i2++;
+                    if (o_hi > end_of(i2)) {
+                        fast = false;                         // three records in one piece (reads of a few bases): byte by byte
+                    } else {
+                        uint32_t w2[4];
+                        fast = load16u(i2, w2);
+                        split = e1 - p0;                      // (1 .. 15)
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const int k = (int)split - 4 * q;  // bytes of word q that still belong to record i
+                            const uint32_t keep = k >= 4 ? 0xFFFFFFFFu : k <= 0 ? 0u : (1u << (8 * k)) - 1u;
+                            w[q] = (w[q] & keep) | (w2[q] & ~keep);
+                        }
+                    }
+                }
+                if (fast) {
+                    const uint32_t first = o_lo - p0, last = o_hi - p0;  // valid bytes of the piece: [first, last)
+                    if (first == 0 && last == 16) {
+#ifdef FQ_KO_STORE
+                        asm volatile("" ::"v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]));
+#elif defined(FQ_NT_STORE)
+                        __builtin_nontemporal_store(make_uint4(w[0], w[1], w[2], w[3]), (uint4*)(dst_base + o_lo));
+#else
+                        *(uint4*)(dst_base + o_lo) = make_uint4(w[0], w[1], w[2], w[3]);
+#endif
+                    } else {  // the first / last piece of the tile's range: its other bytes are another tile's
+#pragma unroll
+                        for (int k = 0; k < 16; k++)
+                            if ((uint32_t)k >= first && (uint32_t)k < last) dst_base[(int32_t)(p0 + k)] = (uint8_t)(w[k >> 2] >> (8 * (k & 3)));
+                    }
+                    bool hiA = false, badA = false, hiB = false, badB = false;
+#ifdef FQ_KO_CLASSIFY
+                    if (true) {
+#else
+                    if (first == 0 && last == 16 && split == 16) {  // the common piece: sixteen bytes of one record, four at a time
+#endif
+                        hiA = ((w[0] | w[1] | w[2] | w[3]) & 0x80808080u) != 0;
+                        if (SEQ && !hiA) {  // fastq.rs:392-401: alphabetic, or one of - . *   (bytes below 0x80 here)
+                            auto zero = [](uint32_t x) { return ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u; };  // bit 7 of every zero byte
+                            uint32_t ok = 0x80808080u;
+#pragma unroll
+                            for (int q = 0; q < 4; q++) {
+                                const uint32_t t = w[q] | 0x20202020u;  // letters fold to lower case ('-' '.' '*' stay what they are: bit 5 is set in them)
+                                const uint32_t letter = (t + 0x1F1F1F1Fu) & ~(t + 0x05050505u) & 0x80808080u;  // 'a' <= t <= 'z'
+                                ok &= letter | zero(w[q] ^ 0x2D2D2D2Du) | zero(w[q] ^ 0x2E2E2E2Eu) | zero(w[q] ^ 0x2A2A2A2Au);
+                            }
+                            badA = ok != 0x80808080u;
+                        } else if (SEQ) {
+                            badA = true;  // (a byte >= 0x80 is no letter either)
+                        }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 16; k++) {
+                            const uint32_t ch = (w[k >> 2] >> (8 * (k & 3))) & 0xffu;
+                            if ((uint32_t)k >= first && (uint32_t)k < last) {
+                                if ((uint32_t)k < split)
+                                    classify(ch, hiA, badA);
+                                else
+                                    classify(ch, hiB, badB);
+                            }
+                        }
+                    }
+                    flag(i, hiA, badA);
+                    flag(i2, hiB, badB);
+                } else {
+                    for (uint32_t o = o_lo; o < o_hi; o++) {
+                        while (o >= end_of(i)) i++;  // (o < total = the last record's end: i stays below nr)
+                        const uint8_t ch = gb(rel_of(i) + (int32_t)(o - dst_of(i)));
+                        dst_base[o] = ch;
+                        bool hi = false, bad = false;
+                        classify(ch, hi, bad);
+                        flag(i, hi, bad);
+                    }
+                }
+            }
+        };
+        tile_copy(std::true_type{}, a.seq + seq_before, (uint32_t)(tile_sum & 0xFFFFFFFFull));
+        tile_copy(std::false_type{}, a.qual + qual_before, (uint32_t)(tile_sum >> 32));
+        __syncthreads();
+        if (tid < nr) {
+            const uint64_t r = rec0 + tid;
+            const uint32_t f = s_rec[tid].flags;
+            rr.check = (f & 1u)   ? BG_FQCHECK_EMPTY_ID
+                       : (f & 2u) ? BG_FQCHECK_NONASCII_SEQ
+                       : (f & 4u) ? BG_FQCHECK_INVALID_SEQ
+                       : (f & 8u) ? BG_FQCHECK_NONASCII_QUAL
+                       : rr.seq_len != rr.qual_len ? BG_FQCHECK_UNEQUAL
+                                                   : BG_FQCHECK_OK;
+            if (r < a.rec_cap) a.recs[r] = rr;
         }
     }
 }
