@@ -74,6 +74,12 @@ def parse_args():
                     help="seed_extend.strong: reads in total, split over the GPUs (configs[4]: 10 M); 0: skip")
     ap.add_argument("--skip-ingest", action="store_true")
     ap.add_argument("--ingest-reads", type=int, default=1_000_000, help="FASTQ ingest leg: four-line records per GPU")
+    ap.add_argument("--skip-fmd", action="store_true", help="no FMD-index SMEM leg")
+    ap.add_argument("--fmd-genome", type=int, default=100_000_000, help="SMEM leg: genome length T (the index is over T$R$: 2 T + 2 symbols)")
+    ap.add_argument("--fmd-reads", type=int, default=500_000, help="SMEM leg: 150 bp reads per GPU")
+    ap.add_argument("--quick", action="store_true",
+                    help="A/B work: no CPU legs (parity, cpu_baseline), no 3 Gbp index, no packed / strong / host-API side legs, one "
+                         "sub-batch of the banded workload — every kernel still runs on its full-size shape; NOT the measured configuration")
     ap.add_argument("--skip-cpu", action="store_true", help="no oracle parity / cpu_baseline legs")
     ap.add_argument("--parity-frac", type=float, default=1.0, help="fraction of every leg's output compared with the oracle")
     ap.add_argument("--cpu-threads", type=int, default=0)
@@ -93,6 +99,12 @@ def relaunch_under_torchrun(args):
 
 
 ARGS = parse_args()
+if ARGS.quick:
+    ARGS.skip_cpu = ARGS.skip_packed = True
+    ARGS.fm_big_genome = 0
+    ARGS.pipeline_reads_total = 0
+    ARGS.banded_pairs = min(ARGS.banded_pairs, 16384)
+    ARGS.banded_parity_pairs = 0
 relaunch_under_torchrun(ARGS)
 
 import numpy as np  # noqa: E402
@@ -617,6 +629,10 @@ def main():
     if args.fm_big_genome:
         fm_big_leg(args, ctx, dev, stream, rank, world, do_cpu, orc, threads, parity, result)
 
+    # ------------------------------------------------------------------ FMD-index SMEM leg
+    if not args.skip_fmd:
+        result["fmd_smems"] = fmd_leg(args, ctx, dev, stream, rank, world, do_cpu, orc, parity)
+
     # ------------------------------------------------------------------ banded leg (configs[3] shape)
     if not args.skip_banded:
         result["banded"] = banded_leg(args, ctx, dev, rank, world, do_cpu, orc, threads, parity)
@@ -633,6 +649,85 @@ def main():
         print(json.dumps(result), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
+
+
+def fmd_leg(args, ctx, dev, stream, rank, world, do_cpu, orc, parity):
+    """FMDIndex::all_smems (fmindex.rs:479-501; smems 363-434, backward_ext / forward_ext 527-564) for a batch of reads on an
+    FMD index over T$R$ (fmindex.rs:311-340), K7 (csrc/fmd_smems.hip) through bg_fmd_smems_batch64_dev: text, suffix array,
+    BWT and index built on the device; a sample of the reads against the oracle's restatement, which is also the CPU baseline
+    (one core: the reference's FMDIndex is a single-threaded API)."""
+    from rust_bio_amd.suffix_array import bwt_dev, suffix_array_dev
+    G, NR, L, MINLEN, CAP = args.fmd_genome, args.fmd_reads, 150, 20, 24
+    N = 2 * G + 2
+    comp = torch.zeros(256, dtype=torch.uint8, device=dev)
+    for a_, b_ in zip(b"ACGTN", b"TGCAN"):
+        comp[a_] = b_
+    t0 = time.perf_counter()
+    g = torch.empty(N, dtype=torch.uint8, device=dev)
+    g[:G] = synth_gpu.genome(G, seed=51, device=dev)[:G]
+    g[G] = ord("$")
+    g[G + 1:N - 1] = comp[g[:G].flip(0).to(torch.int64)]
+    g[N - 1] = ord("$")
+    d_sa = suffix_array_dev(g, ctx=ctx)
+    d_b = bwt_dev(g, d_sa, ctx=ctx)
+    del d_sa
+    fm = FMIndex.from_device(d_b, 128, N_ALPHABET, ctx=ctx)
+    torch.cuda.synchronize()
+    build_s = time.perf_counter() - t0
+    z = synth_gpu.splitmix64(4321 + 100003 * rank, NR, dev)
+    start = torch.remainder(z & ((1 << 62) - 1), G - L)
+    ar = torch.arange(L, dtype=torch.int64, device=dev)
+    reads = g[start.view(-1, 1) + ar.view(1, -1)].clone()
+    u = synth_gpu.splitmix64(99, NR * L, dev).view(NR, L)
+    acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    reads = torch.where((u & 0xFFFF) < int(0.03 * 65536), acgt[(u >> 20) & 3], reads)
+    rc = torch.arange(NR, device=dev) % 2 == 1
+    reads[rc] = comp[reads[rc].flip(1).to(torch.int64)]
+    reads = reads.contiguous()
+    r_off = torch.arange(NR + 1, dtype=torch.int64, device=dev) * L
+    d_cnt = torch.zeros(NR, dtype=torch.int32, device=dev)
+    d_out = torch.zeros((NR, CAP, 6), dtype=torch.int64, device=dev)
+
+    def step():
+        _lib.check(_lib.lib().bg_fmd_smems_batch64_dev(fm.h, 1, NR, reads.data_ptr(), r_off.data_ptr(), None, MINLEN, L, CAP,
+                                                       d_cnt.data_ptr(), d_out.data_ptr(), stream), "bg_fmd_smems_batch64_dev")
+        if world > 1:  # the single collective: the SMEM count of every read
+            GATHER.gather(d_cnt.view(-1, 1), [NR] * world)
+
+    t = timed_steps(step, args.steps, args.warmup, dev)
+    cnt = d_cnt.cpu().numpy().astype(np.int64)
+    n_smem = int(cnt.sum())
+    # every extension (backward_ext, fmindex.rs:527-558) ranks two rows = two 64-byte lines; a read takes at least L - 1
+    # forward extensions and as many backward ones as its SMEM lists hold: 2 (L - 1) is a LOWER bound of the extensions per read
+    alg = NR * (L + 2.0 * (L - 1) * 128 + 4) + n_smem * 48.0
+    leg = {"value": round(world * NR * args.steps / t, 1), "unit": "reads/s", "ms_per_step": round(t / args.steps * 1e3, 3), "scaling": "weak",
+           "config": {"workload": f"FMDIndex over T$R$ of a {G} bp synthetic genome ({N} symbols), all_smems(min length {MINLEN}) of {NR} x {L} bp "
+                                  "reads per GPU (3 % substitutions, half reverse-complemented)", "index_bytes": fm.device_bytes(),
+                      "text_to_index_s": round(build_s, 2)},
+           "smems": n_smem, "reads_over_cap": int((cnt > CAP).sum()),
+           "roofline": {"bound": "hbm", "kernel": "fmd_smems_kernel<false, true>", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "achieved": round(alg / (t / args.steps) / 1e9, 1), "traffic": None, "achieved_is_a_lower_bound": True,
+                        "note": "two random 64-byte rank lines per bi-interval extension, at least 2 (L - 1) extensions per read; the walk is "
+                                "latency-bound (one dependent block access per extension, a quad of lanes per read)"}}
+    leg["roofline"]["frac"] = round(leg["roofline"]["achieved"] / HBM_PEAK_GBS, 4)
+    if do_cpu:
+        ns = min(NR, 3000)
+        h_b = d_b.cpu().numpy()
+        ls = np.asarray(fm._less, dtype=np.uint64)
+        ofmd = orc.FMDIndex(h_b, ls, orc.Occ(h_b, 128, N_ALPHABET))
+        h_reads = reads[:ns].cpu().numpy()
+        out = d_out[:ns].cpu().numpy().astype(np.uint64)
+        t0 = time.perf_counter()
+        want = [ofmd.all_smems(h_reads[q].tobytes(), MINLEN) for q in range(ns)]
+        ct = time.perf_counter() - t0
+        ok = all([((int(r[0]), int(r[1]), int(r[2]), int(r[3])), int(r[4]), int(r[5])) for r in out[q, :cnt[q]]] == want[q] for q in range(ns))
+        parity["fmd_reads_checked"] = ns
+        parity["fmd_bit_exact"] = bool(ok)
+        leg["cpu_baseline"] = {"value": round(ns / ct, 1), "unit": "reads/s", "cores": 1, "kind": "port",
+                               "sample": f"{ns} of the reads, oracle FMDIndex::all_smems (fmindex.rs:363-564 restated), one call per read"}
+    del g, d_b, fm, reads, d_out
+    torch.cuda.empty_cache()
+    return leg
 
 
 def k1_legs(args, ctx, dev, stream, rank, world, do_cpu, orc, threads, parity):
@@ -1286,8 +1381,9 @@ def ingest_leg(args, ctx, dev, stream, rank, world, do_cpu, orc, parity):
               "roofline": {"bound": "hbm", "achieved": round((len(text) + 2 * seq_bytes + 56 * k + 16 * k) / it / 1e9, 2),
                            "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "traffic": ingest_traffic(len(text)),
-                           "note": "algorithmic bytes: text once + sequences, qualities, records and offsets written; "
-                                   "several short kernels + host syncs per call (launch/sync bound)"}}
+                           "kernel": "fq_fused_kernel",
+                           "note": "algorithmic bytes: text once + sequences, qualities, records and offsets written; one kernel "
+                                   "(decoupled look-back over 16 KB tiles) and one host synchronisation per call"}}
     ingest["roofline"]["frac"] = round(ingest["roofline"]["achieved"] / HBM_PEAK_GBS, 5)
     if do_cpu:
         ns = min(n_fq, 200_000)

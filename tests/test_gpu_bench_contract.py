@@ -19,7 +19,8 @@ def test_bench_line_has_the_contract_fields_and_green_parity():
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--pairs", "20000",
            "--k1-pairs", "4096", "--genome", "300000", "--fm-big-genome", "400000", "--queries", "20000", "--banded-pairs", "70",
-           "--banded-parity-pairs", "70", "--pipeline-reads", "3000", "--pipeline-reads-total", "4001", "--ingest-reads", "3000"]
+           "--banded-parity-pairs", "70", "--pipeline-reads", "3000", "--pipeline-reads-total", "4001", "--ingest-reads", "3000",
+           "--fmd-genome", "200000", "--fmd-reads", "2000"]
     out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1200)
     assert out.returncode == 0, out.stderr.decode()[-3000:]
     lines = [ln for ln in out.stdout.decode().splitlines() if ln.startswith("{")]
@@ -36,7 +37,7 @@ def test_bench_line_has_the_contract_fields_and_green_parity():
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
     # the other BASELINE configs, each with roofline + cpu_baseline + its strong variant
-    for leg in ("fm", "fm_big", "seed_extend", "banded"):
+    for leg in ("fm", "fm_big", "seed_extend", "banded", "fmd_smems"):
         assert d[leg]["value"] > 0 and "roofline" in d[leg] and "cpu_baseline" in d[leg], leg
     assert d["fm"]["strong"]["queries_total"] == 20000 and d["banded"]["strong"]["pairs_total"] == 70
     assert d["seed_extend"]["strong"]["reads_total"] == 4001 and d["seed_extend"]["strong"]["gathered_records"] == 4001

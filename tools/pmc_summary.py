@@ -99,6 +99,7 @@ KERNEL_SHAPES = [
     ("band_rows_kernel", "k_load4", "k_store4"),
     ("sw_fill_pk16_kernel", "k_load4", "k_store8"), ("sw_fill_kernel", "k_load4", "k_store8"),
     ("sw_traceback_kernel", "k_quadload", "k_store8"),
+    ("fq_fused_kernel", "k_load16", "k_store16"),  # the one-pass reader (round 6): uint4 tile loads, uint4 sequence / quality stores
     ("fq_gather_kernel", "k_load16", "k_store16"), ("fq_count_newlines", "k_load16", "k_store4"),
     ("fq_line_starts", "k_load16", "k_store8"), ("fq_line_info", "k_load8", "k_store8"), ("fq_measure", "k_load16", "k_store4"),
 ]
