@@ -717,9 +717,18 @@ def fmd_leg(args, ctx, dev, stream, rank, world, do_cpu, orc, parity):
         ofmd = orc.FMDIndex(h_b, ls, orc.Occ(h_b, 128, N_ALPHABET))
         h_reads = reads[:ns].cpu().numpy()
         out = d_out[:ns].cpu().numpy().astype(np.uint64)
+        ofmd.ext_calls(reset=True)
         t0 = time.perf_counter()
         want = [ofmd.all_smems(h_reads[q].tobytes(), MINLEN) for q in range(ns)]
         ct = time.perf_counter() - t0
+        # the extensions the ALGORITHM makes (counted in the oracle's restatement on the sample): the roofline's numerator
+        ext_per_read = ofmd.ext_calls() / ns
+        alg = NR * (L + ext_per_read * 128 + 4) + n_smem * 48.0
+        leg["roofline"].update({"achieved": round(alg / (t / args.steps) / 1e9, 1), "achieved_is_a_lower_bound": False,
+                                "extensions_per_read": round(ext_per_read, 1),
+                                "note": "two random 64-byte rank lines per bi-interval extension; extensions per read counted in the oracle's "
+                                        "restatement on the parity sample; the walk is latency-bound (dependent block accesses, a quad of lanes per read)"})
+        leg["roofline"]["frac"] = round(leg["roofline"]["achieved"] / HBM_PEAK_GBS, 4)
         ok = all([((int(r[0]), int(r[1]), int(r[2]), int(r[3])), int(r[4]), int(r[5])) for r in out[q, :cnt[q]]] == want[q] for q in range(ns))
         parity["fmd_reads_checked"] = ns
         parity["fmd_bit_exact"] = bool(ok)

@@ -16,6 +16,13 @@
 
 #include "oracle.h"
 
+static uint64_t g_fmd_ext_calls = 0;  // backward_ext calls (forward_ext goes through it) since the last reset
+extern "C" uint64_t orc_fmd_ext_calls(int reset) {
+    const uint64_t v = g_fmd_ext_calls;
+    if (reset) g_fmd_ext_calls = 0;
+    return v;
+}
+
 namespace {
 
 // alphabets/mod.rs:37-116 — a set of bytes
@@ -388,6 +395,7 @@ struct Fmd {
     BiInterval init_interval() const { return BiInterval{0, 0, n, 0}; }
     // fmindex.rs:527-558
     BiInterval backward_ext(const BiInterval& interval, uint8_t a) const {
+        g_fmd_ext_calls++;  // (measurement aid of bench.py's SMEM leg: extensions the algorithm makes per read)
         uint64_t s = 0, o = 0, l = interval.lower_rev;
         for (const char* p = "$TGCNAtgcna"; *p; p++) {
             const uint8_t b = (uint8_t)*p;

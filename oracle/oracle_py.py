@@ -118,6 +118,7 @@ def lib():
               C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.POINTER(AlignmentRec),
               C.c_void_p, C.c_uint64, u64p, C.c_void_p, C.c_void_p]),
             ("orc_fmd_check", C.c_int, [C.c_void_p, C.c_uint64]),
+            ("orc_fmd_ext_calls", C.c_uint64, [C.c_int]),
             ("orc_fmd_smems", C.c_int64,
              [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64,
               C.c_uint64, C.c_int, C.c_void_p, C.c_uint64]),
@@ -545,6 +546,11 @@ class FMDIndex:
         assert n <= cap
         r = out[:6 * n].reshape(n, 6)
         return [((int(v[0]), int(v[1]), int(v[2]), int(v[3])), int(v[4]), int(v[5])) for v in r]
+
+    @staticmethod
+    def ext_calls(reset=False):
+        """backward_ext calls the restatement has made since the last reset (forward_ext is one of them): bench.py's SMEM leg"""
+        return int(lib().orc_fmd_ext_calls(1 if reset else 0))
 
     def smems(self, pattern, i, l): return self._smems(pattern, i, l, 0)
     def all_smems(self, pattern, l): return self._smems(pattern, 0, l, 1)

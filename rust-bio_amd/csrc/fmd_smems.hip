@@ -365,7 +365,13 @@ int smems_dev(bg_fm* fm, bool out64, int all, uint64_t n_p, const uint8_t* d_pat
     if (n_p == 0) return BG_OK;
     bg_ctx* ctx = fm->ctx;
     bg_scratch_guard guard(ctx, st);  // the interval lists live in the ctx's scratch
-    uint64_t blocks = std::min<uint64_t>((n_p + 63) / 64, 256 * 4);
+    // persistent quads, as many as are resident (the kernel's registers decide: six blocks per CU on the 32-bit layout, five
+    // on the 64-bit one; round 2 .. 5 launched four): the walk is a chain of dependent block accesses per read, and reads in
+    // flight are all the parallelism it has
+    int per_cu = 0;
+    const void* kfn = fm->wide ? (const void*)fmd_smems_kernel<true, true> : out64 ? (const void*)fmd_smems_kernel<false, true> : (const void*)fmd_smems_kernel<false, false>;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+    uint64_t blocks = std::min<uint64_t>((n_p + 63) / 64, 256ull * (uint64_t)per_cu);
     const uint32_t list_cap = max_pattern_len + 2;
     int rc = bg_reserve(&ctx->bnd, &ctx->bnd_bytes, blocks * 64 * 2 * (size_t)list_cap * sizeof(uint4) * (fm->wide ? 2 : 1));
     if (rc) return rc;

@@ -16,11 +16,11 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $R/bench.py --skip-cpu"
 # the counter passes keep one launch shape per kernel: the seed-and-extend leg reuses K2 / K5 on other batch sizes
-PMCBENCH="$BENCH --skip-pipeline --skip-packed --fm-big-genome 0 --banded-pairs 98304 --pipeline-reads-total 0 --steps 2 --warmup 0"
+PMCBENCH="$BENCH --skip-fmd --skip-pipeline --skip-packed --fm-big-genome 0 --banded-pairs 98304 --pipeline-reads-total 0 --steps 2 --warmup 0"
 # ... and the FM kernel on the 3 Gbp index gets passes of its own (same kernel name as the 100 Mbp leg)
 # ... together with the seed-and-extend leg on the same index (its kernels have names of their own: the SEEDS flavour of K5,
 # K6, the se_* stages, the semiglobal flavour of K1p; K2 is shared with the 65 536-pair headline leg of this command)
-BIGBENCH="$BENCH --skip-fm --skip-k1 --skip-banded --skip-ingest --skip-packed --skip-semiglobal --pairs 65536 --pipeline-reads-total 0 --steps 2 --warmup 0"
+BIGBENCH="$BENCH --skip-fmd --skip-fm --skip-k1 --skip-banded --skip-ingest --skip-packed --skip-semiglobal --pairs 65536 --pipeline-reads-total 0 --steps 2 --warmup 0"
 
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o bench -- $BENCH > "$OUT/${TAG}_bench.log" 2>&1
 cp "$OUT"/kt/bench_kernel_stats.csv "$OUT/${TAG}_bench_kernel_stats.csv" 2>/dev/null
