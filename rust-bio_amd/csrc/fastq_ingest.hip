@@ -519,8 +519,10 @@ __global__ __launch_bounds__(256) void fq_gather_kernel(const uint8_t* __restric
 // the fused kernel wrote.  Every write of the fused kernel stays inside the caller's buffers whatever the text holds.
 constexpr uint32_t kTile = 16384, kNlCap = 2048, kRecCap = 256;  // (LDS: 33 KB per block — tile, newline list, records — four blocks per CU)
 constexpr int kHalo = 4;
-#ifndef FQ_LDS_TILE  // 1: the tile's bytes are staged in LDS (the text is read from memory once); 0: owners and the copy phase re-read them (L2)
-#define FQ_LDS_TILE 0
+#ifndef FQ_LDS_TILE  // 1: the tile's bytes are staged in LDS — the text is read from memory once (FETCH_SIZE + WRITE_SIZE 1.07 x the
+                     // algorithmic bytes); 0: owners and the copy phase re-read them through L2, which does not hold them: 5 - 8 %
+                     // faster per call, 1.77 x the algorithmic bytes (profiles/r06_ingest_experiments.txt)
+#define FQ_LDS_TILE 1
 #endif
 constexpr bool kLdsTile = FQ_LDS_TILE != 0;
 #ifndef FQ_LB1_WAVES  // wavefronts that poll in the two look-backs (64 tiles each per round trip): tools/exp/ko_build.sh variants
@@ -658,6 +660,9 @@ __global__ __launch_bounds__(256) void fq_fused_kernel(const FusedArgs a) {
     __shared__ uint64_t s_lb[16];
     __shared__ uint64_t s_bc[8];  // [0] tile id, [1] lines before the tile, [2] sequence bytes before it, [3] quality bytes, [4] irregular
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // (one tile per block.  Persistent blocks that take tile after tile were measured, profiles/r06_ingest_experiments.txt:
+    //  0.74 ms per call against 0.65 — and 1.86 / 1.15 / 0.81 / 0.74 ms with 1 / 2 / 4 / 8 blocks per CU: a tile's own chain of
+    //  round trips is ~24 us, beyond four blocks per CU the copy phase's throughput bounds the kernel)
     if (tid == 0) {
         s_bc[0] = atomicAdd(a.ticket, 1u);
         s_bc[4] = 0;
