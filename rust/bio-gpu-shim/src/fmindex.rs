@@ -105,3 +105,55 @@ impl Drop for GpuFMIndex<'_> {
         unsafe { sys::bg_fm_free(self.h) };
     }
 }
+
+/// `FMDIndex::from(fmindex)` (fmindex.rs:311-329) over a `GpuFMIndex` built on `T$R$`: the reference asserts that the BWT is
+/// a word over `dna::n_alphabet()` + `$`; here the BWT is the handle's own, read back out of its rank blocks
+/// (`bg_fm_bwt`) — so an index that came from `GpuFMIndex::load` works like a deserialized one does in the reference.
+/// `BiInterval` is `usize` throughout (fmindex.rs:254-259): the `*64` entry points carry uint64 records on any index
+/// size — `T$R$` of a human genome is 6.2 G symbols, beyond `u32`.
+pub struct GpuFMDIndex<'a, 'ctx> {
+    fm: &'a GpuFMIndex<'ctx>,
+}
+
+impl<'a, 'ctx> GpuFMDIndex<'a, 'ctx> {
+    pub fn from(fm: &'a GpuFMIndex<'ctx>) -> Self {
+        let mut n = 0u64;
+        assert!(unsafe { sys::bg_fm_len(fm.h, &mut n) } == 0);
+        let mut bwt = vec![0u8; n as usize];
+        let rc = unsafe { sys::bg_fm_bwt(fm.h, bwt.as_mut_ptr()) };
+        assert!(rc == 0, "{}", strerror(rc));
+        let alphabet = bio::alphabets::dna::n_alphabet();
+        assert!(bwt.iter().all(|&c| c == b'$' || alphabet.is_word(&[c])),
+                "Expecting BWT over the DNA alphabet (including N) with the sentinel $.");
+        GpuFMDIndex { fm }
+    }
+
+    /// `all_smems(pattern, l)` (fmindex.rs:479-501) for many patterns: (interval, position on the pattern, length) triples
+    /// in the order the reference pushes them.
+    pub fn all_smems_batch(&self, patterns: &[&[u8]], min_len: usize) -> Vec<Vec<(bio::data_structures::fmindex::BiInterval, usize, usize)>> {
+        self.run(patterns, None, min_len)
+    }
+
+    /// `smems(pattern, i, l)` (fmindex.rs:363-434) for many (pattern, i) pairs.
+    pub fn smems_batch(&self, patterns: &[&[u8]], positions: &[u32], min_len: usize) -> Vec<Vec<(bio::data_structures::fmindex::BiInterval, usize, usize)>> {
+        self.run(patterns, Some(positions), min_len)
+    }
+
+    fn run(&self, patterns: &[&[u8]], positions: Option<&[u32]>, min_len: usize) -> Vec<Vec<(bio::data_structures::fmindex::BiInterval, usize, usize)>> {
+        let (pat, off) = concat(patterns);
+        let n = patterns.len();
+        let cap = patterns.iter().map(|p| p.len()).max().unwrap_or(0) + 1;
+        let (mut count, mut out) = (vec![0u32; n], vec![0u64; n * cap * 6]);
+        let rc = unsafe {
+            sys::bg_fmd_smems_batch64(self.fm.h, positions.is_none() as i32, n as u64, pat.as_ptr(), off.as_ptr(),
+                                      positions.map_or(std::ptr::null(), |p| p.as_ptr()), min_len as u32, cap as u32,
+                                      count.as_mut_ptr(), out.as_mut_ptr())
+        };
+        assert!(rc == 0, "{}", strerror(rc)); // BG_ERR_OUT_OF_ALPHABET: the reference's index panic (fmindex.rs:229)
+        (0..n).map(|q| (0..count[q] as usize).map(|t| {
+            let r = &out[(q * cap + t) * 6..];
+            (bio::data_structures::fmindex::BiInterval { lower: r[0] as usize, lower_rev: r[1] as usize, size: r[2] as usize, match_size: r[3] as usize },
+             r[4] as usize, r[5] as usize)
+        }).collect()).collect()
+    }
+}
