@@ -43,7 +43,6 @@ struct FmdArgsT {
     uint32_t list_cap;
 };
 
-__constant__ uint8_t kExtOrder[11] = {'$', 'T', 'G', 'C', 'N', 'A', 't', 'g', 'c', 'n', 'a'};  // fmindex.rs:536
 
 __device__ __forceinline__ uint64_t k7_base(const FmDev&, uint64_t, uint32_t) { return 0; }
 __device__ __forceinline__ uint64_t k7_base(const FmWideDev& fm, uint64_t blk, uint32_t c) { return fm.sb[(blk >> fm.sb_shift) * 4 + c]; }
@@ -65,18 +64,18 @@ struct Ctx {
     const P* s_less;
     const uint8_t* s_comp;
     const P* s_exc;
-    uint32_t t;
+    const P* s_exc_sym;          // the sparse symbols' own position lists (LDS copies of fm.exc_sym_pos / fm.sparse_off: every
+    const uint32_t* s_sparse_off;  // extension ranks '$' first, fmindex.rs:536 — from global memory that was a chain of four to
+    uint32_t t;                  // six dependent round trips per extension, round 6)
     bool panic;
 
     __device__ uint32_t exc_le(P r) const { return k7_count_le(s_exc, 0u, a.fm.n_exc, r); }
-    // counts of the four codes in bwt[0..=r]
-    __device__ void counts(P r, P c[4]) const {
-        const uint64_t b = (uint64_t)(r / kSymPerBlock);
-        const uint32_t o = (uint32_t)(r - (P)b * kSymPerBlock);
-        const uint4 v = a.fm.blocks[b * 4 + t];
-#pragma unroll
-        for (uint32_t k = 0; k < 4; k++) c[k] = (P)k7_base(a.fm, b, k) + quad_sum(block_part(v, t, o, k));
-        if (a.fm.n_exc) c[0] -= exc_le(r);  // exceptions sit in the stream as code 0
+    __device__ P less_of(uint32_t s) {
+        if (s >= a.less_len) {  // index out of bounds in the reference
+            panic = true;
+            return 0;
+        }
+        return s_less[s];
     }
     __device__ P occ_cls(uint32_t cls, P r, const P c[4]) {
         if (cls < 4) return c[cls];
@@ -87,17 +86,10 @@ struct Ctx {
         if (cls >= kClsDense) return k7_dense(a.fm, cls - kClsDense, r, t);  // a genome with many N: ranked in bit vectors
         if (cls >= kClsSparse) {
             const uint32_t e = cls - kClsSparse;
-            const uint32_t lo = a.fm.sparse_off[e], hi = a.fm.sparse_off[e + 1];
-            return k7_count_le(a.fm.exc_sym_pos, lo, hi, r) - lo;
+            const uint32_t lo = s_sparse_off[e], hi = s_sparse_off[e + 1];
+            return k7_count_le(s_exc_sym, lo, hi, r) - lo;
         }
         return 0;  // in the alphabet, never in the BWT
-    }
-    __device__ P less_of(uint32_t s) {
-        if (s >= a.less_len) {  // index out of bounds in the reference
-            panic = true;
-            return 0;
-        }
-        return s_less[s];
     }
     // fmindex.rs:527-558
     __device__ BiIv backward_ext(const BiIv& iv, uint32_t sym) {
@@ -106,16 +98,34 @@ struct Ctx {
             panic = true;
             return r;
         }
-        P cR[4], cL[4] = {0, 0, 0, 0};
-        const P posR = iv.lower + iv.size - 1;
-        counts(posR, cR);
-        if (iv.lower > 0) counts(iv.lower - 1, cL);
+        // both rows' blocks are requested before either is looked at (one round trip, not two: the second load used to sit
+        // behind `if (iv.lower > 0)` and the first one's reductions); lower == 0 reads row 0's block and drops the counts
+        const P posR = iv.lower + iv.size - 1, posL = iv.lower > 0 ? iv.lower - 1 : 0;
+        const uint64_t bR = (uint64_t)(posR / kSymPerBlock), bL = (uint64_t)(posL / kSymPerBlock);
+        const uint4 vR = a.fm.blocks[bR * 4 + t], vL = a.fm.blocks[bL * 4 + t];
+        const uint32_t oR = (uint32_t)(posR - (P)bR * kSymPerBlock), oL = (uint32_t)(posL - (P)bL * kSymPerBlock);
+        P cR[4], cL[4];
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) {
+            cR[k] = (P)k7_base(a.fm, bR, k) + quad_sum(block_part(vR, t, oR, k));
+            cL[k] = (P)k7_base(a.fm, bL, k) + quad_sum(block_part(vL, t, oL, k));
+        }
+        if (a.fm.n_exc) {  // exceptions sit in the stream as code 0
+            cR[0] -= exc_le(posR);
+            cL[0] -= exc_le(posL);
+        }
+        const bool has_l = iv.lower > 0;
         P s = 0, o = 0, l = iv.lower_rev;
+        // (A variant with the eleven classes as wavefront-uniform scalars and a per-lane select by the symbol's position in the
+        //  order was built and measured, round 6: 131 - 139 VGPRs, three wavefronts per SIMD instead of six, 2.0 M reads/s
+        //  against 2.4 M for this form.)
+        constexpr uint8_t kOrder[11] = {'$', 'T', 'G', 'C', 'N', 'A', 't', 'g', 'c', 'n', 'a'};  // fmindex.rs:536
+#pragma unroll
         for (int idx = 0; idx < 11; idx++) {
-            const uint32_t b = kExtOrder[idx];
+            const uint32_t b = kOrder[idx];
             const uint32_t cls = s_class[b];
             l += s;
-            o = iv.lower == 0 ? 0 : occ_cls(cls, iv.lower - 1, cL);
+            o = has_l ? occ_cls(cls, posL, cL) : (P)0;
             s = occ_cls(cls, posR, cR) - o;
             if (b == sym) break;
         }
@@ -167,7 +177,25 @@ __device__ __forceinline__ void list_get(const uint4* list, uint32_t i, BiIvT<ui
 
 template <bool WIDE>
 __device__ __forceinline__ void k7_tables(const FmdArgsT<WIDE>& a, uint16_t* s_class, typename FmLayout<WIDE>::Pos* s_less, uint8_t* s_comp,
-                                          typename FmLayout<WIDE>::Pos* s_exc) {
+                                          typename FmLayout<WIDE>::Pos* s_exc, typename FmLayout<WIDE>::Pos* s_exc_sym, uint32_t* s_sparse_off) {
+    // (sparse symbols: at most 256 of them, their positions together are the n_exc <= kMaxExcLds exception positions; an index
+    //  with dense symbols lists only the sparse ones here)
+    for (uint32_t i = threadIdx.x; i < 257; i += blockDim.x) s_sparse_off[i] = 0;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) {
+        const uint32_t c = a.fm.sym_class[i];
+        if (c >= kClsSparse && c < kClsDense) {
+            const uint32_t e = c - kClsSparse;
+            s_sparse_off[e] = a.fm.sparse_off[e];
+            s_sparse_off[e + 1] = a.fm.sparse_off[e + 1];  // (neighbours write the same value)
+        }
+    }
+    __syncthreads();
+    {
+        uint32_t n_sym_pos = 0;
+        for (uint32_t i = 0; i < 257; i++) n_sym_pos = max(n_sym_pos, s_sparse_off[i]);
+        for (uint32_t i = threadIdx.x; i < n_sym_pos && i < kMaxExcLds; i += blockDim.x) s_exc_sym[i] = a.fm.exc_sym_pos[i];
+    }
     for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) {
         s_class[i] = a.fm.sym_class[i];
         s_less[i] = a.fm.less[i];
@@ -184,8 +212,26 @@ __device__ __forceinline__ void k7_tables(const FmdArgsT<WIDE>& a, uint16_t* s_c
     __syncthreads();
 }
 
+// Round 6: the walk as a STATE MACHINE with ONE extension site.  smems (fmindex.rs:363-434) is a forward pass of forward_ext
+// calls, then for every position to the left a pass of backward_ext calls over a list of intervals; all_smems (479-501) calls
+// it again and again.  Written as nested loops, the sixteen quads of a wavefront — each somewhere else in its own read — ran
+// the forward loop's extension and the backward loop's one after the other, every quad waiting through both round trips per
+// step.  Here a quad's position in those loops is a phase + a few counters, every trip of the wavefront's loop takes each
+// quad to its next extension (transitions that need none are chained in front), all quads then make their extension at the
+// same instruction — forward_ext is backward_ext on the swapped interval with the complement (560-564) — and finish their
+// step.  The read's bytes sit in LDS (reads up to kPatLds symbols), the next list entry is fetched beside the extension.
+constexpr uint32_t kPatLds = 248;  // symbols of a read kept in LDS (64 quads x 248 B = 15.5 KB); longer reads are read in place
+
+#ifndef K7_WAVES  // wavefronts per SIMD the kernel is compiled for (0: the compiler's choice; tools/exp/ko_build.sh variants)
+#define K7_WAVES 0
+#endif
+#if K7_WAVES
+#define K7_OCC __attribute__((amdgpu_waves_per_eu(K7_WAVES, K7_WAVES)))
+#else
+#define K7_OCC
+#endif
 template <bool WIDE, bool OUT64>
-__global__ __launch_bounds__(256) void fmd_smems_kernel(const FmdArgsT<WIDE> a) {
+__global__ __launch_bounds__(256) K7_OCC void fmd_smems_kernel(const FmdArgsT<WIDE> a) {
     using P = typename FmLayout<WIDE>::Pos;
     using BiIv = BiIvT<P>;
     using O = std::conditional_t<OUT64, uint64_t, uint32_t>;
@@ -195,110 +241,208 @@ __global__ __launch_bounds__(256) void fmd_smems_kernel(const FmdArgsT<WIDE> a) 
     __shared__ P s_less[256];
     __shared__ uint8_t s_comp[256];
     __shared__ P s_exc[kMaxExcLds];
-    k7_tables<WIDE>(a, s_class, s_less, s_comp, s_exc);
+    __shared__ P s_exc_sym[kMaxExcLds];
+    __shared__ uint32_t s_sparse_off[257];
+    __shared__ uint8_t s_pat[64 * kPatLds];
+    k7_tables<WIDE>(a, s_class, s_less, s_comp, s_exc, s_exc_sym, s_sparse_off);
 
     const uint32_t t = threadIdx.x & 3;
     const uint64_t slot = (uint64_t)blockIdx.x * (blockDim.x >> 2) + (threadIdx.x >> 2);
     const uint64_t n_slots = (uint64_t)gridDim.x * (blockDim.x >> 2);
-    uint4* list0 = a.lists + slot * 2 * a.list_cap * LW;
-    uint4* list1 = list0 + (uint64_t)a.list_cap * LW;
+    uint4* const list0 = a.lists + slot * 2 * a.list_cap * LW;
+    uint4* const list1 = list0 + (uint64_t)a.list_cap * LW;
+    uint8_t* const my_pat = s_pat + (threadIdx.x >> 2) * kPatLds;
+    Ctx<WIDE> cx{a, s_class, s_less, s_comp, s_exc, s_exc_sym, s_sparse_off, t, false};
 
-    for (uint64_t q = slot; q < a.n_p; q += n_slots) {
-        const uint64_t off = a.pat_off[q];
-        const uint32_t plen = (uint32_t)(a.pat_off[q + 1] - off);
-        const uint8_t* pattern = a.pat + off;
-        Ctx<WIDE> cx{a, s_class, s_less, s_comp, s_exc, t, false};
-        uint32_t n_out = 0;
-        O* out = (O*)a.out + q * (uint64_t)a.cap * 6;
-        auto emit = [&](const BiIv& iv, uint32_t pos, uint32_t len) {
-            if (t == 0 && n_out < a.cap) {
-                O* o = out + (uint64_t)n_out * 6;
-                o[0] = (O)iv.lower;
-                o[1] = (O)iv.lower_rev;
-                o[2] = (O)iv.size;
-                o[3] = iv.msz;
-                o[4] = pos;
-                o[5] = len;
-            }
-            n_out++;
-        };
-        // one smems(pattern, i, l) call (fmindex.rs:363-434); returns the largest pos + len it found
-        auto smems = [&](uint32_t i, uint32_t& reach) {
-            uint4* curr = list0;
-            uint4* prev = list1;
-            uint32_t n_curr = 0, n_prev = 0;
-            uint32_t match_len = 0;
-            BiIv interval = cx.init_interval_with(pattern[i]);
-            if (interval.size != 0) match_len += 1;
-            for (uint32_t p = i + 1; p < plen && !cx.panic; p++) {
-                const BiIv fwd = cx.forward_ext(interval, pattern[p]);
-                if (interval.size != fwd.size) {
-                    interval.mlen = match_len;
-                    if (t == 0) list_put(curr, n_curr, interval);
-                    n_curr++;
+    enum : uint32_t { PH_LOAD, PH_START, PH_FWD, PH_K, PH_BWD, PH_AFTER, PH_FINISH, PH_DONE };
+    uint32_t phase = PH_LOAD;
+    uint64_t q = slot;
+    const uint8_t* pattern = nullptr;
+    bool pat_lds = false;
+    uint32_t plen = 0, i0 = 0, reach = 0, n_out = 0;
+    O* out = nullptr;
+    // forward pass
+    BiIv interval{};
+    uint32_t match_len = 0, p = 0;
+    // lists
+    bool flip = false;  // false: curr = list0, prev = list1
+    uint32_t n_curr = 0, n_prev = 0;
+    // backward passes
+    int32_t k = 0, j = 0;
+    uint32_t e = 0, sym_k = 0;
+    bool have_last = false, prev_reversed = false, have_next = false;
+    P last_size = 0;
+    BiIv pv_next{};
+
+    auto sym_at = [&](uint32_t pos) -> uint32_t { return pat_lds ? (uint32_t)my_pat[pos] : (uint32_t)pattern[pos]; };
+    auto curr_list = [&]() { return flip ? list1 : list0; };
+    auto prev_list = [&]() { return flip ? list0 : list1; };
+    auto emit = [&](const BiIv& iv, uint32_t pos, uint32_t len) {
+        if (t == 0 && n_out < a.cap) {
+            O* o = out + (uint64_t)n_out * 6;
+            o[0] = (O)iv.lower;
+            o[1] = (O)iv.lower_rev;
+            o[2] = (O)iv.size;
+            o[3] = iv.msz;
+            o[4] = pos;
+            o[5] = len;
+        }
+        n_out++;
+    };
+    auto end_forward = [&]() {  // the loop at fmindex.rs:381-394 is over: its last interval, then the lists change roles
+        interval.mlen = match_len;
+        if (t == 0) list_put(curr_list(), n_curr, interval);
+        n_curr++;
+        flip = !flip;  // "reverse intervals such that longest comes first": prev is read back to front instead
+        n_prev = n_curr;
+        prev_reversed = true;
+        j = (int32_t)plen;
+        k = (int32_t)i0 - 1;
+        phase = PH_K;
+    };
+
+    for (;;) {
+        // ---- transitions that need no extension, until the quad stands in front of one (or is done)
+        for (;;) {
+            if (phase == PH_FWD && !cx.panic && p < plen) break;
+            if (phase == PH_BWD && !cx.panic && e < n_prev) break;
+            if (phase == PH_DONE) break;
+            if (phase == PH_LOAD) {
+                if (q >= a.n_p) {
+                    phase = PH_DONE;
+                    continue;
                 }
-                if (fwd.size == 0) break;
+                const uint64_t off = a.pat_off[q];
+                plen = (uint32_t)(a.pat_off[q + 1] - off);
+                pattern = a.pat + off;
+                pat_lds = plen <= kPatLds;
+                if (pat_lds)
+                    for (uint32_t c = t; c < plen; c += 4) my_pat[c] = pattern[c];  // (the quad's lanes: same wavefront, LDS in order)
+                cx.panic = false;
+                n_out = 0;
+                out = (O*)a.out + q * (uint64_t)a.cap * 6;
+                phase = PH_START;
+                if (plen == 0) {
+                    if (!a.all) cx.panic = true;  // pattern[i] on an empty pattern
+                    phase = PH_FINISH;
+                } else if (a.all) {  // fmindex.rs:479-501
+                    i0 = 0;
+                    reach = 1;
+                } else {
+                    i0 = a.i_pos[q];
+                    reach = 0;
+                    if (i0 >= plen) {
+                        cx.panic = true;
+                        phase = PH_FINISH;
+                    }
+                }
+            } else if (phase == PH_START) {  // one smems(pattern, i0, l) call (fmindex.rs:363-434)
+                flip = false;
+                n_curr = 0;
+                match_len = 0;
+                interval = cx.init_interval_with(sym_at(i0));
+                if (interval.size != 0) match_len += 1;
+                p = i0 + 1;
+                phase = PH_FWD;
+            } else if (phase == PH_FWD) {  // (p == plen, or the reference panicked)
+                if (cx.panic)
+                    phase = PH_FINISH;
+                else
+                    end_forward();
+            } else if (phase == PH_K) {  // the head of the loop at fmindex.rs:401
+                if (k < -1 || cx.panic) {
+                    phase = PH_AFTER;
+                } else {
+                    sym_k = k == -1 ? (uint32_t)'$' : sym_at((uint32_t)k);
+                    n_curr = 0;
+                    have_last = false;
+                    e = 0;
+                    have_next = false;
+                    phase = PH_BWD;
+                }
+            } else if (phase == PH_BWD) {  // (e == n_prev: the end of the inner loop, fmindex.rs:425-431)
+                if (cx.panic || n_curr == 0) {
+                    phase = PH_AFTER;
+                } else {
+                    flip = !flip;
+                    n_prev = n_curr;
+                    prev_reversed = false;
+                    k--;
+                    phase = PH_K;
+                }
+            } else if (phase == PH_AFTER) {  // smems returned
+                if (a.all && !cx.panic && reach < plen) {
+                    i0 = reach;
+                    reach = i0 + 1;
+                    phase = PH_START;
+                } else {
+                    phase = PH_FINISH;
+                }
+            } else {  // PH_FINISH
+                if (t == 0) a.out_count[q] = cx.panic ? 0xFFFFFFFFu : n_out;
+                q += n_slots;
+                phase = PH_LOAD;
+            }
+        }
+        if (!__any(phase != PH_DONE)) break;
+        if (phase == PH_DONE) continue;
+        // ---- the operands of this quad's extension
+        const bool fwd_step = phase == PH_FWD;
+        BiIv in, pv{};
+        uint32_t sym;
+        if (fwd_step) {  // forward_ext(interval, a) = backward_ext(swapped, complement(a)).swapped (fmindex.rs:560-564)
+            in = interval;
+            in.lower = interval.lower_rev;
+            in.lower_rev = interval.lower;
+            sym = s_comp[sym_at(p)];
+        } else {
+            const uint4* pl = prev_list();
+            if (have_next)
+                pv = pv_next;
+            else
+                list_get(pl, prev_reversed ? n_prev - 1 - e : e, pv);
+            have_next = e + 1 < n_prev;
+            if (have_next) list_get(pl, prev_reversed ? n_prev - 2 - e : e + 1, pv_next);  // (in flight beside the extension's blocks)
+            in = pv;
+            sym = sym_k;
+        }
+        // ---- the one extension site
+        BiIv r = cx.backward_ext(in, sym);
+        // ---- the rest of the step
+        if (fwd_step) {
+            BiIv fwd = r;
+            fwd.lower = r.lower_rev;
+            fwd.lower_rev = r.lower;
+            if (interval.size != fwd.size) {
+                interval.mlen = match_len;
+                if (t == 0) list_put(curr_list(), n_curr, interval);
+                n_curr++;
+            }
+            if (fwd.size == 0) {
+                if (cx.panic)
+                    phase = PH_FINISH;
+                else
+                    end_forward();
+            } else {
                 interval = fwd;
                 match_len += 1;
-            }
-            interval.mlen = match_len;
-            if (t == 0) list_put(curr, n_curr, interval);
-            n_curr++;
-            // "reverse intervals such that longest comes first": prev is read back to front instead
-            uint4* tmp = curr;
-            curr = prev;
-            prev = tmp;
-            n_prev = n_curr;
-            bool prev_reversed = true;
-            int32_t j = (int32_t)plen;
-            for (int32_t k = (int32_t)i - 1; k >= -1 && !cx.panic; k--) {
-                const uint32_t sym = k == -1 ? (uint32_t)'$' : (uint32_t)pattern[k];
-                n_curr = 0;
-                bool have_last = false;
-                P last_size = 0;
-                for (uint32_t e = 0; e < n_prev && !cx.panic; e++) {
-                    BiIv pv;
-                    list_get(prev, prev_reversed ? n_prev - 1 - e : e, pv);
-                    BiIv fwd = cx.backward_ext(pv, sym);
-                    if ((fwd.size == 0 || k == -1) && n_curr == 0 && k < j && pv.mlen >= a.min_len) {
-                        j = k;
-                        emit(pv, (uint32_t)(k + 1), pv.mlen);
-                        reach = max(reach, (uint32_t)(k + 1) + pv.mlen);
-                    }
-                    if (fwd.size != 0 && !(have_last && fwd.size == last_size)) {
-                        have_last = true;
-                        last_size = fwd.size;
-                        fwd.mlen = pv.mlen + 1;
-                        if (t == 0) list_put(curr, n_curr, fwd);
-                        n_curr++;
-                    }
-                }
-                if (n_curr == 0) break;
-                tmp = curr;
-                curr = prev;
-                prev = tmp;
-                n_prev = n_curr;
-                prev_reversed = false;
-            }
-        };
-        if (plen == 0) {
-            if (!a.all) cx.panic = true;  // pattern[i] on an empty pattern
-        } else if (a.all) {  // fmindex.rs:479-501
-            uint32_t i0 = 0;
-            while (i0 < plen && !cx.panic) {
-                uint32_t reach = i0 + 1;
-                smems(i0, reach);
-                i0 = reach;
+                p++;
             }
         } else {
-            const uint32_t i = a.i_pos[q];
-            uint32_t reach = 0;
-            if (i >= plen)
-                cx.panic = true;
-            else
-                smems(i, reach);
+            if ((r.size == 0 || k == -1) && n_curr == 0 && k < j && pv.mlen >= a.min_len) {
+                j = k;
+                emit(pv, (uint32_t)(k + 1), pv.mlen);
+                reach = max(reach, (uint32_t)(k + 1) + pv.mlen);
+            }
+            if (r.size != 0 && !(have_last && r.size == last_size)) {
+                have_last = true;
+                last_size = r.size;
+                r.mlen = pv.mlen + 1;
+                if (t == 0) list_put(curr_list(), n_curr, r);
+                n_curr++;
+            }
+            e++;
         }
-        if (t == 0) a.out_count[q] = cx.panic ? 0xFFFFFFFFu : n_out;
     }
 }
 
@@ -314,13 +458,15 @@ __global__ __launch_bounds__(256) void fmd_interval_kernel(FmdArgsT<WIDE> a, uin
     __shared__ P s_less[256];
     __shared__ uint8_t s_comp[256];
     __shared__ P s_exc[kMaxExcLds];
-    k7_tables<WIDE>(a, s_class, s_less, s_comp, s_exc);
+    __shared__ P s_exc_sym[kMaxExcLds];
+    __shared__ uint32_t s_sparse_off[257];
+    k7_tables<WIDE>(a, s_class, s_less, s_comp, s_exc, s_exc_sym, s_sparse_off);
     const O* iv_in = (const O*)iv_in_;
     O* iv_out = (O*)iv_out_;
     const uint32_t t = threadIdx.x & 3;
     const uint64_t q = (uint64_t)blockIdx.x * (blockDim.x >> 2) + (threadIdx.x >> 2);
     if (q >= n_req) return;  // quad-uniform
-    Ctx<WIDE> cx{a, s_class, s_less, s_comp, s_exc, t, false};
+    Ctx<WIDE> cx{a, s_class, s_less, s_comp, s_exc, s_exc_sym, s_sparse_off, t, false};
     BiIv in{(P)iv_in[4 * q], (P)iv_in[4 * q + 1], (P)iv_in[4 * q + 2], (uint32_t)iv_in[4 * q + 3], 0};
     BiIv r = in;
     switch (op[q]) {
