@@ -209,6 +209,43 @@ res["locate"]["every_position_is_an_occurrence"] = ok_occ
 res["locate"]["every_query_finds_where_it_was_cut"] = bool(found_self[(hi_s - lo_s) <= 64].all())
 res["locate"]["positions_beyond_2_32"] = int((d_pos >= (1 << 32)).sum())
 
+# ---- 4d. seed -> locate -> extend on 64-bit positions (round 6): reads cut from the text — half of them beyond position 2^32 — with
+# 2 % substitutions must come home (bg_seed_extend_batch_dev: SEEDS flavour of the 64-bit search, K6 on 64-bit samples, proposals
+# sorted as uint64, windows cut at 64-bit offsets); small-scale parity of the same call against oracle/pipeline.cpp is
+# tests/test_gpu_fm_wide.py::test_wide_seed_and_extend_equals_the_pipeline_oracle
+from rust_bio_amd.pairwise import Scoring  # noqa: E402
+from rust_bio_amd.pipeline import attach_text, seed_extend_dev  # noqa: E402
+attach_text(fm, d_text=g)
+RN, RL = 200_000, 150
+zr = synth_gpu.splitmix64(555, RN, dev)
+lo_half = torch.remainder(zr & ((1 << 62) - 1), min(N - RL - 1, (1 << 32) - RL - 1))
+hi_half = (1 << 32) + torch.remainder(zr & ((1 << 62) - 1), max(1, N - RL - 1 - (1 << 32))) if N > (1 << 32) + RL + 1 else lo_half
+r_start = torch.where(torch.arange(RN, device=dev) % 2 == 0, lo_half, hi_half)
+arr = torch.arange(RL, dtype=torch.int64, device=dev)
+rd = g[r_start.view(-1, 1) + arr.view(1, -1)].clone()
+ur = synth_gpu.splitmix64(556, RN * RL, dev).view(RN, RL)
+acgt_t = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+rd = torch.where((ur & 0xFFFF) < int(0.02 * 65536), acgt_t[(ur >> 20) & 3], rd).contiguous()
+clean = ((rd != ord("N")) & (rd != ord("$"))).all(dim=1)
+r_off = torch.arange(RN + 1, dtype=torch.int64, device=dev) * RL
+d_hits = torch.zeros(RN * 96, dtype=torch.uint8, device=dev)
+sc = Scoring.from_scores(-5, -1, 1, -1)
+seed_extend_dev(fm, sc, RN, rd.data_ptr(), r_off.data_ptr(), RL, d_hits.data_ptr())
+t0 = sync()
+seed_extend_dev(fm, sc, RN, rd.data_ptr(), r_off.data_ptr(), RL, d_hits.data_ptr())
+dt_se = sync() - t0
+h64 = d_hits.view(torch.int64).view(RN, 12)
+score = (h64[:, 0] << 32) >> 32  # (sign-extended int32 score in the low word)
+ref_start = h64[:, 9]
+mapped = score > -858993459
+home = mapped & ((ref_start - r_start).abs() <= 8)
+res["seed_extend"] = {"reads": RN, "read_len": RL, "ms": round(dt_se * 1e3, 2), "reads_per_s": round(RN / dt_se, 1),
+                      "mapped": int(mapped.sum()), "mapped_within_8_of_where_they_were_cut": int(home.sum()),
+                      "reads_cut_beyond_2_32": int((r_start >= (1 << 32)).sum()),
+                      "of_them_home": int((home & (r_start >= (1 << 32))).sum()),
+                      "clean_reads_not_home": int((clean & ~home).sum())}
+del rd, d_hits, ur
+
 # ---- 4a. the oracle by definition on a stratified seeded sample
 BEY = 1 << 32
 NS_BEY, NS_ANY = 1000, 500
@@ -271,5 +308,6 @@ res["oracle_sample"] = {"patterns": len(pick), "complete": n_c, "partial": n_p, 
                         "position_lists_of_intervals_beyond_2_32": int(sum(1 for l in loc_lo if l >= BEY)),
                         "positions_beyond_2_32_in_those_lists": int(sum(1 for w in loc_want for v in w if v >= BEY))}
 res["bit_exact"] = bool(bad == 0 and bad_pos == 0 and ok_occ and res["locate"]["every_query_finds_where_it_was_cut"])
+res["seed_extend"]["ok"] = bool(res["seed_extend"]["mapped_within_8_of_where_they_were_cut"] >= 0.97 * RN)
 res["hbm_free_before_the_suffix_array_gb"] = round(free0 / 1e9, 1)
 print(json.dumps(res))
