@@ -238,7 +238,14 @@ h64 = d_hits.view(torch.int64).view(RN, 12)
 score = (h64[:, 0] << 32) >> 32  # (sign-extended int32 score in the low word)
 ref_start = h64[:, 9]
 mapped = score > -858993459
-home = mapped & ((ref_start - r_start).abs() <= 8)
+near = (ref_start - r_start).abs() <= 8
+# (a read from the copied segment comes home to the smallest of its identical occurrences: the text there must read the same)
+rs = torch.where(mapped, ref_start, r_start).clamp(0, N - RL - 1)
+same_text = torch.zeros(RN, dtype=torch.bool, device=dev)
+for s0 in range(0, RN, 1 << 16):
+    e0 = min(RN, s0 + (1 << 16))
+    same_text[s0:e0] = (g[rs[s0:e0].view(-1, 1) + arr.view(1, -1)] == g[r_start[s0:e0].view(-1, 1) + arr.view(1, -1)]).all(dim=1)
+home = mapped & (near | same_text)
 res["seed_extend"] = {"reads": RN, "read_len": RL, "ms": round(dt_se * 1e3, 2), "reads_per_s": round(RN / dt_se, 1),
                       "mapped": int(mapped.sum()), "mapped_within_8_of_where_they_were_cut": int(home.sum()),
                       "reads_cut_beyond_2_32": int((r_start >= (1 << 32)).sum()),
