@@ -1013,6 +1013,7 @@ static int fm_build_host_impl(bg_ctx* ctx, const uint8_t* bwt, uint64_t n, const
     if ((rc = upload(&fm->d_sparse_off, sparse_off.data(), sparse_off.size() * 4))) return fail(rc);
     if ((rc = upload(&fm->d_exc_byte, exc_byte.data(), exc_byte.size()))) return fail(rc);
     if ((rc = upload(&fm->d_class, cls, 256 * sizeof(uint16_t)))) return fail(rc);
+    memcpy(fm->h_class, cls, sizeof(fm->h_class));
     if ((rc = upload(&fm->d_less, less32, sizeof(less32)))) return fail(rc);
     if (gen && (rc = upload(&fm->d_bwt_raw, bwt, n))) return fail(rc);
     fm->dev.blocks = (const uint4*)fm->d_blocks;
@@ -1276,6 +1277,7 @@ static int fm_build_dev_impl(bg_ctx* ctx, const uint8_t* d_bwt, uint64_t n, uint
         if ((rc = upload(&fm->d_sparse_off, sparse_off.data(), sparse_off.size() * 4))) return rc;
         if ((rc = upload(&fm->d_exc_byte, exc_byte.data(), exc_byte.size()))) return rc;
         if ((rc = upload(&fm->d_class, K.cls, 256 * sizeof(uint16_t)))) return rc;
+        memcpy(fm->h_class, K.cls, sizeof(fm->h_class));
         if ((rc = upload(&fm->d_less, less32, sizeof(less32)))) return rc;
         if (K.gen) {
             if ((rc = keep(&fm->d_bwt_raw, n))) return rc;

@@ -283,6 +283,7 @@ struct bg_fm {
     int n_codes = 0;         // distinct bytes with a 2-bit code (<= 4)
     uint32_t less_len = 0;
     bool fmd_ok = false;  // the BWT is a word over dna::n_alphabet() + '$' (FMDIndex::from, fmindex.rs:323-327)
+    uint16_t h_class[256] = {};  // host copy of the symbol classes (K7 picks its plain-DNA instantiation from them)
     // 64-bit positions (fm_wide.hip): `wdev` instead of `dev` / `dev2`; the suffix array attached to it is uint64
     bool wide = false;
     bgfm::FmWideDev wdev = {};

@@ -648,6 +648,7 @@ int fm_wide_build_dev(bg_ctx* ctx, const uint8_t* d_bwt, uint64_t n, const uint8
         if ((rc = upload(&fm->d_sparse_off, sparse_off.data(), sparse_off.size() * 4))) return rc;
         if ((rc = upload(&fm->d_exc_byte, exc_byte.data(), exc_byte.size()))) return rc;
         if ((rc = upload(&fm->d_class, cls, 256 * sizeof(uint16_t)))) return rc;
+        memcpy(fm->h_class, cls, sizeof(fm->h_class));
         if ((rc = upload(&fm->d_less, less, sizeof(less)))) return rc;
         BG_HIP(hipStreamSynchronize(st));
         fm->wdev.blocks = (const uint4*)fm->d_blocks;

@@ -55,7 +55,7 @@ __device__ __forceinline__ uint32_t k7_dense(const FmDev& fm, uint32_t d, uint32
 }
 __device__ __forceinline__ uint32_t k7_dense(const FmWideDev&, uint32_t, uint64_t, uint32_t) { return 0; }  // (no dense symbols there)
 
-template <bool WIDE>
+template <bool WIDE, bool PLAIN = false>
 struct Ctx {
     using P = typename FmLayout<WIDE>::Pos;
     using BiIv = BiIvT<P>;
@@ -68,6 +68,11 @@ struct Ctx {
     const uint32_t* s_sparse_off;  // extension ranks '$' first, fmindex.rs:536 — from global memory that was a chain of four to
     uint32_t t;                  // six dependent round trips per extension, round 6)
     bool panic;
+    // "plain DNA" (wavefront-uniform, found once per kernel): T, G, C, A have 2-bit codes, '$' is a listed symbol (or absent),
+    // N and the lower-case letters never occur in the BWT — every index over an ACGT text.  plain_codes: the codes of T, G, C, A
+    // in bits 0-1, 2-3, 4-5, 6-7; plain_dollar: '$' 's list index, 0xFFFF if it never occurs; 0xFFFFFFFF in plain_codes: not plain
+    uint32_t plain_codes, plain_dollar;
+    const uint8_t* s_pos;        // position of a byte in the order "$TGCNAtgcna" (fmindex.rs:536); 10 for 'a' and any other byte
 
     __device__ uint32_t exc_le(P r) const { return k7_count_le(s_exc, 0u, a.fm.n_exc, r); }
     __device__ P less_of(uint32_t s) {
@@ -115,6 +120,44 @@ struct Ctx {
             cL[0] -= exc_le(posL);
         }
         const bool has_l = iv.lower > 0;
+        if constexpr (PLAIN) {
+            // Plain DNA, straight line: the sizes of '$', T, G, C, (N: 0,) A in the order of fmindex.rs:536, a prefix sum up to
+            // the lane's symbol.  The general loop below spends ~800 vector + scalar instructions per extension on eleven
+            // per-lane class dispatches (SQ counters, profiles/r06_sq_fmd.txt); this is ~100.
+            auto pick = [&](const P (&c)[4], uint32_t code) -> P { return code == 0 ? c[0] : code == 1 ? c[1] : code == 2 ? c[2] : c[3]; };
+            P occR[6], occL[6];
+            occR[0] = occL[0] = 0;
+            if (plain_dollar != 0xFFFFu) {
+                const uint32_t lo = s_sparse_off[plain_dollar], hi = s_sparse_off[plain_dollar + 1];
+                occR[0] = k7_count_le(s_exc_sym, lo, hi, posR) - lo;
+                occL[0] = k7_count_le(s_exc_sym, lo, hi, posL) - lo;
+            }
+#pragma unroll
+            for (int k = 0; k < 3; k++) {  // T, G, C
+                occR[1 + k] = pick(cR, (plain_codes >> (2 * k)) & 3u);
+                occL[1 + k] = pick(cL, (plain_codes >> (2 * k)) & 3u);
+            }
+            occR[4] = occL[4] = 0;  // N
+            occR[5] = pick(cR, (plain_codes >> 6) & 3u);  // A
+            occL[5] = pick(cL, (plain_codes >> 6) & 3u);
+            const uint32_t pos = s_pos[sym & 0xFFu];
+            P l2 = iv.lower_rev, o2 = 0, s2 = 0;
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                const P lk = has_l ? occL[k] : (P)0;
+                const P sz = occR[k] - lk;
+                if ((uint32_t)k < pos) l2 += sz;
+                if ((uint32_t)k == pos) {
+                    o2 = lk;
+                    s2 = sz;
+                }
+            }
+            r.lower = less_of(sym) + o2;
+            r.lower_rev = l2;
+            r.size = s2;
+            r.msz = iv.msz + 1;
+            return r;
+        }
         P s = 0, o = 0, l = iv.lower_rev;
         // (A variant with the eleven classes as wavefront-uniform scalars and a per-lane select by the symbol's position in the
         //  order was built and measured, round 6: 131 - 139 VGPRs, three wavefronts per SIMD instead of six, 2.0 M reads/s
@@ -157,6 +200,25 @@ struct Ctx {
         return r;
     }
 };
+
+// what backward_ext's straight-line form needs to know about the index (see Ctx::plain_codes), and the order table
+__device__ __forceinline__ void k7_plain(const uint16_t* s_class, uint8_t* s_pos, uint32_t& plain_codes, uint32_t& plain_dollar) {
+    const char* order = "$TGCNAtgcna";  // fmindex.rs:536
+    for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) {
+        uint8_t at = 10;
+        for (int k = 0; k < 11; k++)
+            if (i == (uint32_t)(uint8_t)order[k]) at = (uint8_t)k;
+        s_pos[i] = at;
+    }
+    const uint32_t cT = s_class['T'], cG = s_class['G'], cC = s_class['C'], cA = s_class['A'], cD = s_class['$'];
+    bool plain = cT < 4 && cG < 4 && cC < 4 && cA < 4 && (cD == kClsZero || (cD >= kClsSparse && cD < kClsDense));
+    for (const char* z = "Ntgcna"; *z; z++) plain = plain && s_class[(uint8_t)*z] == kClsZero;
+    uint32_t codes = plain ? (cT | cG << 2 | cC << 4 | cA << 6) : 0xFFFFFFFFu;
+    uint32_t dollar = cD == kClsZero ? 0xFFFFu : cD - kClsSparse;
+    plain_codes = (uint32_t)__builtin_amdgcn_readfirstlane((int)codes);
+    plain_dollar = (uint32_t)__builtin_amdgcn_readfirstlane((int)dollar);
+    __syncthreads();
+}
 
 // list entries: one uint4 per interval on 32-bit positions, two on 64-bit
 __device__ __forceinline__ void list_put(uint4* list, uint32_t i, const BiIvT<uint32_t>& v) {
@@ -230,7 +292,7 @@ constexpr uint32_t kPatLds = 248;  // symbols of a read kept in LDS (64 quads x 
 #else
 #define K7_OCC
 #endif
-template <bool WIDE, bool OUT64>
+template <bool WIDE, bool OUT64, bool PLAIN>
 __global__ __launch_bounds__(256) K7_OCC void fmd_smems_kernel(const FmdArgsT<WIDE> a) {
     using P = typename FmLayout<WIDE>::Pos;
     using BiIv = BiIvT<P>;
@@ -244,6 +306,7 @@ __global__ __launch_bounds__(256) K7_OCC void fmd_smems_kernel(const FmdArgsT<WI
     __shared__ P s_exc_sym[kMaxExcLds];
     __shared__ uint32_t s_sparse_off[257];
     __shared__ uint8_t s_pat[64 * kPatLds];
+    __shared__ uint8_t s_pos[256];
     k7_tables<WIDE>(a, s_class, s_less, s_comp, s_exc, s_exc_sym, s_sparse_off);
 
     const uint32_t t = threadIdx.x & 3;
@@ -252,7 +315,8 @@ __global__ __launch_bounds__(256) K7_OCC void fmd_smems_kernel(const FmdArgsT<WI
     uint4* const list0 = a.lists + slot * 2 * a.list_cap * LW;
     uint4* const list1 = list0 + (uint64_t)a.list_cap * LW;
     uint8_t* const my_pat = s_pat + (threadIdx.x >> 2) * kPatLds;
-    Ctx<WIDE> cx{a, s_class, s_less, s_comp, s_exc, s_exc_sym, s_sparse_off, t, false};
+    Ctx<WIDE, PLAIN> cx{a, s_class, s_less, s_comp, s_exc, s_exc_sym, s_sparse_off, t, false, 0xFFFFFFFFu, 0xFFFFu, s_pos};
+    k7_plain(s_class, s_pos, cx.plain_codes, cx.plain_dollar);  // (PLAIN: the host looked at the same classes, bg_fm::h_class)
 
     enum : uint32_t { PH_LOAD, PH_START, PH_FWD, PH_K, PH_BWD, PH_AFTER, PH_FINISH, PH_DONE };
     uint32_t phase = PH_LOAD;
@@ -460,13 +524,16 @@ __global__ __launch_bounds__(256) void fmd_interval_kernel(FmdArgsT<WIDE> a, uin
     __shared__ P s_exc[kMaxExcLds];
     __shared__ P s_exc_sym[kMaxExcLds];
     __shared__ uint32_t s_sparse_off[257];
+    __shared__ uint8_t s_pos[256];
     k7_tables<WIDE>(a, s_class, s_less, s_comp, s_exc, s_exc_sym, s_sparse_off);
+    uint32_t pc = 0xFFFFFFFFu, pd = 0xFFFFu;
+    k7_plain(s_class, s_pos, pc, pd);
     const O* iv_in = (const O*)iv_in_;
     O* iv_out = (O*)iv_out_;
     const uint32_t t = threadIdx.x & 3;
     const uint64_t q = (uint64_t)blockIdx.x * (blockDim.x >> 2) + (threadIdx.x >> 2);
     if (q >= n_req) return;  // quad-uniform
-    Ctx<WIDE> cx{a, s_class, s_less, s_comp, s_exc, s_exc_sym, s_sparse_off, t, false};
+    Ctx<WIDE, false> cx{a, s_class, s_less, s_comp, s_exc, s_exc_sym, s_sparse_off, t, false, pc, pd, s_pos};
     BiIv in{(P)iv_in[4 * q], (P)iv_in[4 * q + 1], (P)iv_in[4 * q + 2], (uint32_t)iv_in[4 * q + 3], 0};
     BiIv r = in;
     switch (op[q]) {
@@ -514,13 +581,16 @@ int smems_dev(bg_fm* fm, bool out64, int all, uint64_t n_p, const uint8_t* d_pat
     // persistent quads, as many as are resident (the kernel's registers decide: six blocks per CU on the 32-bit layout, five
     // on the 64-bit one; round 2 .. 5 launched four): the walk is a chain of dependent block accesses per read, and reads in
     // flight are all the parallelism it has
-    int per_cu = 0;
-    const void* kfn = fm->wide ? (const void*)fmd_smems_kernel<true, true> : out64 ? (const void*)fmd_smems_kernel<false, true> : (const void*)fmd_smems_kernel<false, false>;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
-    uint64_t blocks = std::min<uint64_t>((n_p + 63) / 64, 256ull * (uint64_t)per_cu);
-    const uint32_t list_cap = max_pattern_len + 2;
-    int rc = bg_reserve(&ctx->bnd, &ctx->bnd_bytes, blocks * 64 * 2 * (size_t)list_cap * sizeof(uint4) * (fm->wide ? 2 : 1));
-    if (rc) return rc;
+    // plain DNA (every index over an ACGT text, with or without '$' in the BWT): the straight-line extension (Ctx::backward_ext)
+    bool plain = true;
+    {
+        const uint16_t* hc = fm->h_class;
+        for (const char* z = "TGCA"; *z; z++) plain = plain && hc[(uint8_t)*z] < 4;
+        for (const char* z = "Ntgcna"; *z; z++) plain = plain && hc[(uint8_t)*z] == kClsZero;
+        const uint16_t cd = hc[(uint8_t)'$'];
+        plain = plain && (cd == kClsZero || (cd >= kClsSparse && cd < kClsDense));
+        if (getenv("BG_K7_GENERAL")) plain = false;  // (tests, A/B)
+    }
     auto fill = [&](auto& a) {
         a.n_p = n_p;
         a.pat = d_pat;
@@ -531,21 +601,34 @@ int smems_dev(bg_fm* fm, bool out64, int all, uint64_t n_p, const uint8_t* d_pat
         a.cap = cap;
         a.out_count = d_count;
         a.out = d_out;
-        a.lists = (uint4*)ctx->bnd;
-        a.list_cap = list_cap;
+        a.list_cap = max_pattern_len + 2;
     };
+    // persistent quads, as many as are resident (the kernel's registers decide): the walk is a chain of dependent block
+    // accesses per read, and reads in flight are all the parallelism it has
+    auto launch = [&](auto kernel, auto args) -> int {
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+        const uint64_t blocks = std::min<uint64_t>((n_p + 63) / 64, 256ull * (uint64_t)per_cu);
+        int rc = bg_reserve(&ctx->bnd, &ctx->bnd_bytes, blocks * 64 * 2 * (size_t)args.list_cap * sizeof(uint4) * (fm->wide ? 2 : 1));
+        if (rc) return rc;
+        args.lists = (uint4*)ctx->bnd;
+        kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(args);
+        return BG_OK;
+    };
+    int rc;
     if (fm->wide) {
         auto a = k7_args<true>(fm);
         fill(a);
-        fmd_smems_kernel<true, true><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(a);
+        rc = plain ? launch(fmd_smems_kernel<true, true, true>, a) : launch(fmd_smems_kernel<true, true, false>, a);
     } else {
         auto a = k7_args<false>(fm);
         fill(a);
         if (out64)
-            fmd_smems_kernel<false, true><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(a);
+            rc = plain ? launch(fmd_smems_kernel<false, true, true>, a) : launch(fmd_smems_kernel<false, true, false>, a);
         else
-            fmd_smems_kernel<false, false><<<dim3((unsigned)blocks), dim3(256), 0, st>>>(a);
+            rc = plain ? launch(fmd_smems_kernel<false, false, true>, a) : launch(fmd_smems_kernel<false, false, false>, a);
     }
+    if (rc) return rc;
     BG_HIP(hipGetLastError());
     return BG_OK;
 }

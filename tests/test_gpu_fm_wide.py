@@ -180,13 +180,16 @@ def test_wide_two_step_blocks_packed_patterns_and_seeds(sb_shift):
     fm.close()
 
 
-def test_wide_fmd_smems_equal_the_oracle():
-    """K7 on 64-bit positions (fmd_smems.hip: fmd_smems_kernel<true, true>, uint64 records through bg_fmd_smems_batch64):
-    FMDIndex::smems / all_smems (fmindex.rs:363-501) and the single interval steps (504-564) on T$R$ with a few N"""
+@pytest.mark.parametrize("with_n", [True, False])
+def test_wide_fmd_smems_equal_the_oracle(with_n):
+    """K7 on 64-bit positions (fmd_smems.hip: fmd_smems_kernel<true, true, PLAIN>, uint64 records through bg_fmd_smems_batch64):
+    FMDIndex::smems / all_smems (fmindex.rs:363-501) and the single interval steps (504-564) on T$R$ — with a few N (the
+    general extension: eleven per-lane class dispatches) and without (the straight-line extension of plain ACGT indexes)"""
     from rust_bio_amd.fmindex import FMDIndex
     rng = np.random.default_rng(77)
     g = synth.random_dna(30_000, seed=5).copy()
-    g[rng.integers(0, len(g), size=6)] = ord("N")
+    if with_n:
+        g[rng.integers(0, len(g), size=6)] = ord("N")
     fwd = g.tobytes()
     text = np.frombuffer(fwd + b"$" + revcomp(fwd) + b"$", dtype=np.uint8)
     sa = suffix_array(text)

@@ -60,10 +60,13 @@ def test_all_smems_doctest_and_issue39():
         assert [p for iv, _, _ in r for p in iv.forward().occ(sa)] == [c["read_pos"]], i
 
 
-def test_random_reads_vs_oracle():
+@pytest.mark.parametrize("with_n", [True, False])
+def test_random_reads_vs_oracle(with_n):
+    """(with N: the general extension; without: K7's plain-DNA instantiation — bg_fm::h_class decides at launch)"""
     rng = np.random.default_rng(13)
     g = synth.random_dna(20_000, seed=8).copy()
-    g[rng.integers(0, len(g), size=10)] = ord("N")
+    if with_n:
+        g[rng.integers(0, len(g), size=10)] = ord("N")
     fwd = g.tobytes()
     text = fwd + b"$" + revcomp(fwd) + b"$"
     sa, b, ls, fmd = build(text, k=16)
