@@ -501,43 +501,44 @@ __global__ __launch_bounds__(256) void fq_gather_kernel(const uint8_t* __restric
 // traffic for 0.70 GB of algorithmic bytes, profiles/r05_pmc_traffic.json) through seven kernels and three host round
 // trips.  Nearly every FASTQ is four lines per record in plain ASCII; for such a text ONE kernel does everything, each
 // byte read from HBM once:
-//   * a tile of 16 KB per block (its number from a ticket, so that a tile only ever waits for tiles that are running);
-//     every thread takes four 16-byte pieces (coalesced), finds the newlines (SWAR) and their ordinals (block scan of the
-//     packed piece counts); the tile's newline count goes through a decoupled look-back (Merrill & Garland: a 64-bit word
-//     per tile holding flag + value, a wavefront reading 64 predecessors per step) -> the global line index of its first
-//     line, while another wavefront finds the four newlines in front of the tile (the lines a record of this tile may
-//     begin with) in a 1 KB window of the previous tile;
-//   * a record belongs to the tile its fourth line ends in: the thread that owns it checks the four-line hypothesis of F3
-//     (line 4k starts with '@', 4k+1 not with '+', 4k+2 with '+', the quality trims to something), trims the lines
-//     (ASCII white space: str::trim_end when every byte is ASCII), splits the header at its first space (fastq.rs:275-277);
-//   * the records' sequence / quality lengths are scanned in the block, the tile totals go through two more look-backs
-//     (two wavefronts, concurrently) -> seq_off / qual_off of every record, the fixed fields of bg_fastq_record_t;
-//   * 16 lanes per record copy the two lines (from L2: this very block just read them) and evaluate Record::check.
+//   * a tile of 16 KB per block, in block order (fq_lookback: why no ticket, and why nothing can hang), staged in LDS with the
+//     1 KB in front of it; every thread takes four 16-byte pieces (coalesced), finds the newlines (SWAR) and their ordinals
+//     (block scan of the packed piece counts) -> the tile's newline list, while one wavefront finds the four newlines in
+//     front of the tile (the lines a record of this tile may begin with);
+//   * which lines are headers is GUESSED from the text (a header begins with '@', the line two further on with '+': every
+//     line start the block holds votes) and confirmed by the look-back below; a record belongs to the tile its fourth line
+//     ends in: the thread that owns it checks the four-line hypothesis of F3 (line 4k starts with '@', 4k+1 not with '+',
+//     4k+2 with '+', the quality trims to something), trims the lines (ASCII white space: str::trim_end when every byte is
+//     ASCII), splits the header at its first space (fastq.rs:275-277);
+//   * the records' sequence / quality lengths are scanned in the block; the tile's three totals — lines, sequence bytes,
+//     quality bytes — go through ONE decoupled look-back (Merrill & Garland: a 64-bit word per tile and value holding flag +
+//     value; two levels, a wavefront per value) -> the global index of its first record, seq_off / qual_off of every
+//     record, the fixed fields of bg_fastq_record_t;
+//   * every thread copies 16-byte pieces of the tile's sequence / quality output from LDS and evaluates Record::check on them
+//     (SWAR), a table saying which record a piece begins in.
 // Whatever the fast path cannot promise — a byte >= 0x80, a line count that is not a multiple of four, a record that fails
-// the hypothesis, a tile with more than 4096 newlines or 512 records — raises one flag; the host reads {lines, flag} back
-// (the call's ONE synchronisation) and, if it is up, runs F1 .. F6, which are exact for any input and overwrite whatever
-// the fused kernel wrote.  Every write of the fused kernel stays inside the caller's buffers whatever the text holds.
-constexpr uint32_t kTile = 16384, kNlCap = 2048, kRecCap = 256;  // (LDS: 33 KB per block — tile, newline list, records — four blocks per CU)
+// the hypothesis, a wrong guess, a tile with more than 2048 newlines or 256 records, a line that begins more than 31 KB in
+// front of the tile its record ends in — raises one flag; the host reads {lines, flag} back (the call's ONE
+// synchronisation) and, if it is up, runs F1 .. F6, which are exact for any input and overwrite whatever the fused kernel
+// wrote.  Every write of the fused kernel stays inside the caller's buffers whatever the text holds (a line is some tile's
+// sequence line at most once, whatever the tiles guess).
+// Round 6, 1 M records of 150 bp (323 MB): 0.436 ms per call, 741 GB/s of text (round 5's seven kernels: 1.5 ms); the
+// steps from the first one-pass build (0.70 ms) are in profiles/r06_ingest_experiments.txt.
+constexpr uint32_t kTile = 16384, kNlCap = 2048, kRecCap = 256;  // (LDS: 26 KB per block — tile + halo 17.4, newline list 4, records 4 — six blocks per CU)
 constexpr int kHalo = 4;
+constexpr int32_t kHaloBytes = 1024;  // bytes in front of the tile kept in LDS too (lines of the tile's first record begin there)
 #ifndef FQ_LDS_TILE  // 1: the tile's bytes are staged in LDS — the text is read from memory once (FETCH_SIZE + WRITE_SIZE 1.07 x the
                      // algorithmic bytes); 0: owners and the copy phase re-read them through L2, which does not hold them: 5 - 8 %
                      // faster per call, 1.77 x the algorithmic bytes (profiles/r06_ingest_experiments.txt)
 #define FQ_LDS_TILE 1
 #endif
 constexpr bool kLdsTile = FQ_LDS_TILE != 0;
-#ifndef FQ_LB1_WAVES  // wavefronts that poll in the two look-backs (64 tiles each per round trip): tools/exp/ko_build.sh variants
-#define FQ_LB1_WAVES 1
-#endif
-#ifndef FQ_LB2_WAVES
-#define FQ_LB2_WAVES 2
-#endif
 constexpr uint64_t kFlagAgg = 1ull << 62, kFlagPre = 2ull << 62, kValMask = (1ull << 62) - 1;
 
 struct FusedArgs {
     const uint8_t* t;
     uint64_t len;
-    uint64_t* tiles;     // [3][n_tiles]: flag | value words of the three look-backs (newlines, sequence bytes, quality bytes)
-    uint32_t* ticket;
+    uint64_t* tiles;     // [2][3][n_tiles]: flag | value words of the look-back's two levels x (newlines, sequence bytes, quality bytes)
     uint64_t* out;       // [0] lines, [1] irregular, [2] sequence bytes, [3] quality bytes
     bg_fastq_record_t* recs;
     uint64_t rec_cap;
@@ -546,84 +547,101 @@ struct FusedArgs {
     uint32_t n_tiles;
 };
 
-// Exclusive prefixes of this tile's aggregates over all tiles before it — NV values at once (their words sit n_tiles
-// apart), by the WHOLE block: thread i polls tile id - 1 - i (- 256 per further step), the values up to the nearest
-// inclusive prefix are summed.  Flag and value share one 64-bit word, so the word is all that travels between blocks:
-// RELAXED agent-scope atomics (coherent across the XCDs' L2s by themselves; acquire / release here would flush and
-// invalidate whole caches around every word — the first build did, and ran 5 ms instead of 0.4).  Why the whole block:
-// inclusive prefixes advance one window of tiles per polling round trip (~2 us across XCDs), i.e. 64 tiles per round trip
-// with one wavefront — 20 000 tiles then cost 0.6 ms in the look-back alone, whatever the occupancy; 256 lanes: 0.15 ms.
-template <int NV, int WAVES>
-__device__ void fq_lookback(uint64_t* tiles, uint64_t stride, uint32_t id, const uint64_t (&agg)[NV], uint64_t (&excl)[NV], uint64_t* s_tmp /* 8 * NV words */) {
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// Exclusive prefixes of this tile's aggregates (NV values, their words sit `stride` apart) over all tiles before it: a
+// decoupled look-back (Merrill & Garland) on TWO levels.  Flag and value share one 64-bit word, so the word is all that
+// travels between blocks: RELAXED agent-scope atomics (coherent across the XCDs' L2s by themselves; acquire / release here
+// would flush and invalidate whole caches around every word — the first build did, and ran 5 ms instead of 0.4).
+//   level 1, l1[tile]: the tile's own aggregate, later its inclusive prefix;
+//   level 2, l2[tile]: the sum of the 65 tiles ending with it (its level-1 window + itself), later its inclusive prefix.
+// Wavefront k works on value k: lane i reads l1[id - 1 - i] and, at the same time, lanes 0 .. 15 read l2[id - 65 (i + 1)].  If
+// the level-1 window holds an inclusive prefix the walk ends there; otherwise its sum (64 tiles) goes out as this tile's level-2
+// word and the level-2 words carry on from tile id - 65, sixty-five tiles a lane.  Why two levels (round 6, tools/exp/
+// timeline_ingest.py): a word written by one block is seen by another ~2.5 us later, and with ~1500 blocks resident, started
+// 21 ns apart, the ~600 tiles in front of a tile are themselves still looking back — one level of 64- or 128-tile windows walked
+// five windows deep, 13 of a block's 30 us (and the longer the look-backs take, the more tiles are in one: the walk feeds itself).
+// The level-2 word of a tile is there one round trip after its aggregate, whatever the tiles in front of it are doing.
+// A tile's number is its block's index (no ticket: 19 715 blocks taking one atomicAdd each on ONE address cost 225 us by
+// themselves — tools/microbench/ub_ticket.hip): blocks are dispatched in index order, so the tiles a block waits for are
+// running or done.  Should that ever not hold, the wait is BOUNDED: a lane that polled kMaxPolls times raises `*gave_up` (the
+// kernel's "irregular" flag: the host then takes the general kernels) and goes on as if it had seen a prefix — nothing can hang.
+constexpr uint32_t kMaxPolls = 1u << 20;  // (~1 s of polling; a tile normally waits a few polls)
+constexpr int kL2Lanes = 16, kL2Span = 65;
+template <int NV>
+__device__ void fq_lookback(uint64_t* l1, uint64_t* l2, uint64_t stride, uint32_t id, const uint64_t (&agg)[NV], uint64_t (&excl)[NV], uint64_t* s_tmp /* NV words */,
+                            uint64_t* gave_up, uint32_t wave /* the caller's (virtual) wavefront number */) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    static_assert(NV <= 4, "a wavefront per value");
 #pragma unroll
     for (int k = 0; k < NV; k++) excl[k] = 0;
 #ifdef FQ_KO_LOOKBACK  // (knock-out builds, tools/exp/ko_build.sh: wrong results, timing only)
     return;
 #endif
+    auto st = [](uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    auto ld = [](const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
     if (id == 0) {
         if (tid == 0)
 #pragma unroll
-            for (int k = 0; k < NV; k++) __hip_atomic_store(&tiles[k * stride], kFlagPre | agg[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int k = 0; k < NV; k++) st(&l1[k * stride], kFlagPre | agg[k]), st(&l2[k * stride], kFlagPre | agg[k]);
         return;
     }
-    if (tid == 0)
+    if ((int)wave < NV) {
+        uint64_t my = 0;
 #pragma unroll
-        for (int k = 0; k < NV; k++) __hip_atomic_store(&tiles[k * stride + id], kFlagAgg | agg[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    bool found[NV];
-#pragma unroll
-    for (int k = 0; k < NV; k++) found[k] = false;
-    int64_t j = (int64_t)id - 1;
-    for (;;) {
-        const int64_t idx = j - (int64_t)tid;
-        bool all_found = true;
-#pragma unroll
-        for (int k = 0; k < NV; k++) {
-            if ((int)wave >= WAVES) {  // (a narrower window: these wavefronts only keep the barriers company)
-                if (lane == 0) s_tmp[k * 8 + wave] = 0, s_tmp[k * 8 + 4 + wave] = 0;
-                continue;
-            }
-            uint64_t v = kFlagPre;  // in front of tile 0: an inclusive prefix of 0
-            if (idx >= 0 && !found[k]) {
-                do {
-                    v = __hip_atomic_load(&tiles[k * stride + idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                } while ((v >> 62) == 0);
-            }
-            const uint64_t pm = __ballot((v >> 62) == 2);
-            uint64_t val = v & kValMask;
-            if (pm) {  // the nearest inclusive prefix of this wavefront's window ends the walk: lanes beyond it do not count
-                const int first = __ffsll((long long)pm) - 1;
-                if ((int)lane > first) val = 0;
-            }
+        for (int k = 0; k < NV; k++)
+            if ((int)wave == k) my = agg[k];
+        uint64_t* const p1 = l1 + wave * stride;
+        uint64_t* const p2 = l2 + wave * stride;
+        if (lane == 0) st(&p1[id], kFlagAgg | my);
+        auto wave_sum = [](uint64_t val) {
 #pragma unroll
             for (int o = 32; o; o >>= 1) {
                 const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)val, o), hi = (uint32_t)__shfl_xor((int)(uint32_t)(val >> 32), o);
                 val += (uint64_t)hi << 32 | lo;
             }
-            if (lane == 0) {
-                s_tmp[k * 8 + wave] = val;
-                s_tmp[k * 8 + 4 + wave] = pm ? 1 : 0;
+            return val;
+        };
+        auto spin = [&](const uint64_t* p, uint64_t v) {  // until the word is written
+            uint32_t polls = 0;
+            while ((v >> 62) == 0 && ++polls < kMaxPolls) v = ld(p);
+            if ((v >> 62) == 0) {  // never seen: give up (see above)
+                atomicOr((unsigned long long*)gave_up, 1ull);
+                v = kFlagPre;
+            }
+            return v;
+        };
+        const int64_t i1 = (int64_t)id - 1 - (int64_t)lane;
+        int64_t i2 = (int64_t)id - kL2Span * ((int64_t)lane + 1);
+        // both levels' first reads together (in front of tile 0: an inclusive prefix of 0)
+        uint64_t v1 = i1 >= 0 ? ld(&p1[i1]) : kFlagPre;
+        uint64_t v2 = (int)lane >= kL2Lanes ? kFlagAgg : i2 >= 0 ? ld(&p2[i2]) : kFlagPre;
+        if (i1 >= 0) v1 = spin(&p1[i1], v1);
+        const uint64_t pm1 = __ballot((v1 >> 62) == 2);
+        uint64_t val = v1 & kValMask;
+        if (pm1 && (int)lane > __ffsll((long long)pm1) - 1) val = 0;  // lanes beyond the nearest inclusive prefix do not count
+        uint64_t e = wave_sum(val);
+        if (!pm1) {
+            if (lane == 0) st(&p2[id], kFlagAgg | ((e + my) & kValMask));
+            for (;;) {
+                if ((int)lane < kL2Lanes && i2 >= 0) v2 = spin(&p2[i2], v2);
+                const uint64_t pm2 = __ballot((int)lane < kL2Lanes && (v2 >> 62) == 2);
+                uint64_t val2 = (int)lane < kL2Lanes ? v2 & kValMask : 0;
+                if (pm2 && (int)lane > __ffsll((long long)pm2) - 1) val2 = 0;
+                e += wave_sum(val2);
+                if (pm2) break;
+                i2 -= (int64_t)kL2Span * kL2Lanes;
+                v2 = (int)lane >= kL2Lanes ? kFlagAgg : i2 >= 0 ? ld(&p2[i2]) : kFlagPre;
             }
         }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < NV; k++) {
-            if (!found[k]) {
-                for (uint32_t w = 0; w < 4 && !found[k]; w++) {  // wavefront 0 holds the nearest tiles
-                    excl[k] += s_tmp[k * 8 + w];
-                    found[k] = s_tmp[k * 8 + 4 + w] != 0;
-                }
-            }
-            all_found = all_found && found[k];
+        if (lane == 0) {
+            st(&p1[id], kFlagPre | ((e + my) & kValMask));
+            st(&p2[id], kFlagPre | ((e + my) & kValMask));
+            s_tmp[wave] = e;
         }
-        __syncthreads();
-        if (all_found) break;
-        j -= 64 * WAVES;
     }
-    if (tid == 0)
+    __syncthreads();
 #pragma unroll
-        for (int k = 0; k < NV; k++)
-            __hip_atomic_store(&tiles[k * stride + id], kFlagPre | ((excl[k] + agg[k]) & kValMask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int k = 0; k < NV; k++) excl[k] = s_tmp[k];
+    __syncthreads();
 }
 
 __device__ __forceinline__ uint32_t newline_mask16(const uint4 v) {  // bit i: byte i of the piece is '\n'
@@ -637,41 +655,68 @@ __device__ __forceinline__ uint32_t newline_mask16(const uint4 v) {  // bit i: b
     return m;
 }
 
-struct FusedRec {  // what the copy phase needs of a record (LDS)
-    int32_t seq_rel, qual_rel;  // line starts relative to the tile (may be negative: a line that begins in the previous tile)
-    uint32_t seq_n, qual_n;
-    uint32_t seq_dst, qual_dst; // destinations relative to the tile's first sequence / quality byte
+typedef int16_t fq_rel_t;   // positions relative to the tile, lengths and the newline list: 16 bits (see FusedRec)
+typedef uint16_t fq_len_t;
+typedef int16_t fq_nl_t;
+struct FusedRec {  // what the copy phase needs of a record (LDS; 16 bytes: with the newline list in 16 bits too the block's
+                   // LDS is 26 KB, six blocks per CU — at 38 KB it was four, and the kernel waits on memory most of its life)
+    fq_rel_t seq_rel, qual_rel;  // line starts relative to the tile (may be negative: a line that begins in front of the tile;
+                                // the halo search stops 31 KB in front of it)
+    fq_len_t seq_n, qual_n;     // (a record's lines lie between 31 KB in front of the tile and its end: < 48 KB)
+    fq_len_t seq_dst, qual_dst; // destinations relative to the tile's first sequence / quality byte (likewise)
     uint32_t flags;             // 1: the id is empty
-    uint32_t pad;
 };
+static_assert(sizeof(FusedRec) == 16, "");
+constexpr int kHaloWindows = 31;  // 1 KB windows the search for the four newlines in front of a tile may take
 
+#ifdef FQ_TIMELINE  // (variant builds only, tools/exp/timeline_ingest.py: wall-clock stamps of thread 0 at the phase boundaries)
+__device__ uint64_t g_fq_tl[16 * 32768];
+#define FQ_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 32768) g_fq_tl[16 * blockIdx.x + (k)] = wall_clock64(); } while (0)
+extern "C" int bg_debug_fq_timeline(uint64_t* out, size_t n) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fq_tl), n * 8); }
+#else
+#define FQ_STAMP(k)
+#endif
 __global__ __launch_bounds__(256) void fq_fused_kernel(const FusedArgs a) {
-    __shared__ int32_t s_nl[kHalo + kNlCap + 1];
+    FQ_STAMP(0);
+    __shared__ fq_nl_t s_nl[kHalo + kNlCap + 4];  // newline positions relative to the tile; the copy phase's piece tables later
     __shared__ FusedRec s_rec[kRecCap];
     // the tile's bytes: what the records' owners look at (first bytes, line ends, headers) and what the copy phase reads comes
     // from here — the text is read from memory ONCE (a second read of it, 16 KB per block with 2 000 blocks in flight, does not
     // stay in a 4 MB L2); only lines that begin in the previous tile are read from there
-    __shared__ uint4 s_tile4[kLdsTile ? kTile / 16 + 2 : 1];
+    __shared__ uint4 s_tile4[kLdsTile ? (kHaloBytes + kTile) / 16 + 2 : 1];  // [halo: the 1 KB in front of the tile][tile][pad]
+    static_assert(sizeof(s_nl) >= 2 * (kTile / 16 + 4) && kRecCap <= 256, "");
+    uint8_t (*s_prec)[kTile / 16 + 4] = (uint8_t (*)[kTile / 16 + 4])s_nl;  // the record a 16-byte piece of the tile's sequence / quality output begins in
 #ifdef FQ_PAD_LDS
     __shared__ uint32_t s_padlds[FQ_PAD_LDS / 4];
     if (threadIdx.x == 9999) s_padlds[0] = 1;
 #endif
     __shared__ uint64_t s_w[8];
-    __shared__ uint64_t s_lb[16];
-    __shared__ uint64_t s_bc[8];  // [0] tile id, [1] lines before the tile, [2] sequence bytes before it, [3] quality bytes, [4] irregular
+    __shared__ uint64_t s_lb[24];
+    __shared__ uint64_t s_bc[8];  // [4] irregular: seen before the records are looked at, [5] irregular: seen later, [6] phases of the line index the tile's lines rule out
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // (one tile per block.  Persistent blocks that take tile after tile were measured, profiles/r06_ingest_experiments.txt:
     //  0.74 ms per call against 0.65 — and 1.86 / 1.15 / 0.81 / 0.74 ms with 1 / 2 / 4 / 8 blocks per CU: a tile's own chain of
     //  round trips is ~24 us, beyond four blocks per CU the copy phase's throughput bounds the kernel)
-    if (tid == 0) {
-        s_bc[0] = atomicAdd(a.ticket, 1u);
-        s_bc[4] = 0;
-    }
+    if (tid == 0) s_bc[4] = s_bc[5] = s_bc[6] = 0;
     __syncthreads();
-    const uint32_t tile = (uint32_t)s_bc[0];
+    const uint32_t tile = blockIdx.x;
+    // The phases only one wavefront works in (the records' owners are the first threads, the look-back takes a wavefront per
+    // value, the search in front of the tile one) go by a VIRTUAL wavefront number.  -DFQ_ROTATE lets it rotate with the tile,
+    // in case every block's wavefront 0 lands on the same SIMD of its CU and that SIMD carries all of that work: measured in
+    // round 6, no difference (0.438 against 0.439 ms per call) — it is the physical number.
+#ifdef FQ_ROTATE
+    const uint32_t vw = (wave - tile) & 3u;
+#else
+    const uint32_t vw = wave;
+#endif
+    const uint32_t vtid = vw * 64 + lane;
     const uint64_t t0 = (uint64_t)tile * kTile;
     const bool last_tile = tile + 1 == a.n_tiles;
     const bool aligned = ((uintptr_t)a.t & 15) == 0;
+    // (the 1 KB in front of the tile — where the search for the four newlines in front of it begins — is asked for now, with
+    //  the tile: one memory latency, not two in a row)
+    uint4 hv = make_uint4(0, 0, 0, 0);
+    if (vw == 3 && t0 >= (uint64_t)kHaloBytes) hv = load16(a.t, t0, t0 - kHaloBytes + (uint64_t)lane * 16, aligned);
     // ---- newlines of the tile
     uint32_t m[4];
     uint64_t packed = 0;
@@ -680,11 +725,12 @@ __global__ __launch_bounds__(256) void fq_fused_kernel(const FusedArgs a) {
     for (int j = 0; j < 4; j++) {
         const uint64_t base = t0 + ((uint64_t)j * 256 + tid) * 16;
         const uint4 v = base < a.len ? load16(a.t, a.len, base, aligned) : make_uint4(0, 0, 0, 0);
-        if (kLdsTile) s_tile4[j * 256 + tid] = v;
+        if (kLdsTile) s_tile4[kHaloBytes / 16 + j * 256 + tid] = v;
         m[j] = newline_mask16(v);
         hi |= ((v.x | v.y | v.z | v.w) & 0x80808080u) != 0;
         packed |= (uint64_t)__popc(m[j]) << (16 * j);
     }
+    if (kLdsTile && tid < 2) s_tile4[(kHaloBytes + kTile) / 16 + tid] = make_uint4(0, 0, 0, 0);  // (pad: 16-byte reads may run past the tile's last byte)
     // a text that does not end in '\n': its last line ends at the end of the text (one more "newline", behind all others)
     const uint32_t extra = (last_tile && a.t[a.len - 1] != '\n') ? 1u : 0u;
     // inclusive scan of the packed counts over the block (row j = pieces j * 256 ..: four scans in one)
@@ -697,6 +743,7 @@ __global__ __launch_bounds__(256) void fq_fused_kernel(const FusedArgs a) {
     if (lane == 63) s_w[wave] = inc;
     if (__any(hi) && lane == 0) s_bc[4] = 1;
     __syncthreads();
+    FQ_STAMP(1);  // tile loaded, counted
     uint64_t wbase = 0, rows = 0;
     for (uint32_t w = 0; w < 4; w++) {
         if (w < wave) wbase += s_w[w];
@@ -717,18 +764,20 @@ __global__ __launch_bounds__(256) void fq_fused_kernel(const FusedArgs a) {
 #ifdef FQ_KO_HALO
     if (false) {
 #else
-    if (wave == 3) {
+    if (vw == 3) {
 #endif
         int need = kHalo;
         uint64_t end = t0;  // window [end - 1024, end)
         int windows = 0;
-        while (need > 0 && end > 0 && windows < 64) {
+        while (need > 0 && end > 0 && windows < kHaloWindows) {
             const uint64_t wstart = end >= 1024 ? end - 1024 : 0;
             const uint64_t base = wstart + (uint64_t)lane * 16;
             uint32_t mm = 0;
             if (base < end) {
-                const uint4 v = load16(a.t, end, base, aligned && (wstart & 15) == 0);  // (bytes from `end` on read as 0)
+                const bool first = windows == 0 && wstart + (uint64_t)kHaloBytes == t0;  // the 1 KB in front of the tile: loaded above
+                const uint4 v = first ? hv : load16(a.t, end, base, aligned && (wstart & 15) == 0);  // (bytes from `end` on read as 0)
                 mm = newline_mask16(v);
+                if (kLdsTile && first) s_tile4[lane] = v;
             }
             const uint32_t c = __popc(mm);
             uint32_t pre = c;
@@ -745,15 +794,15 @@ __global__ __launch_bounds__(256) void fq_fused_kernel(const FusedArgs a) {
                 const int b = __ffs((int)bits) - 1;
                 bits &= bits - 1;
                 const int from_end = (int)total - 1 - (int)k;  // 0: the window's last newline
-                if (from_end < take) s_nl[need - 1 - from_end] = (int32_t)((int64_t)(base + b) - (int64_t)t0);
+                if (from_end < take) s_nl[need - 1 - from_end] = (fq_nl_t)((int64_t)(base + b) - (int64_t)t0);
                 k++;
             }
             need -= take;
             end = wstart;
             windows++;
         }
-        if (need > 0 && end > 0 && lane == 0) s_bc[4] = 1;  // a line longer than 64 KB in front of the tile: not for this path
-        if ((int)lane < need) s_nl[lane] = -1 - (int32_t)(int64_t)t0;  // in front of the text: "newline" at position -1
+        if (need > 0 && end > 0 && lane == 0) s_bc[4] = 1;  // a line that begins more than 31 KB in front of the tile: not for this path
+        if ((int)lane < need) s_nl[lane] = (fq_nl_t)(-1 - (int32_t)(int64_t)t0);  // (end == 0 was reached: t0 <= 31 KB)  // in front of the text: "newline" at position -1
     }
     // ---- every thread: its newlines into the list
 #pragma unroll
@@ -764,20 +813,62 @@ __global__ __launch_bounds__(256) void fq_fused_kernel(const FusedArgs a) {
         while (bits && !irregular) {
             const int b = __ffs((int)bits) - 1;
             bits &= bits - 1;
-            s_nl[kHalo + k++] = (int32_t)(rel + b);
+            s_nl[kHalo + k++] = (fq_nl_t)(rel + b);
         }
     }
-    if (extra && tid == 0 && !irregular) s_nl[kHalo + T] = (int32_t)(a.len - t0);
-    uint64_t lines_before;
+    if (extra && tid == 0 && !irregular) s_nl[kHalo + T] = (fq_nl_t)(a.len - t0);
+    FQ_STAMP(2);  // newline list written (thread 0 is not in wavefront 3: the halo search is not in this)
+    // ---- which lines are headers?  The line index of the tile's first line (mod 4) says so, and that is a look-back away; but
+    // the text itself nearly always says it too: a header begins with '@' and the line two further on with '+' (the hypothesis
+    // the records are held to anyway, below).  Every line whose first byte the block holds votes: phases it rules out are OR-ed
+    // into s_bc[6]; if exactly one of the four is left the records are read on that GUESS at once, and the tile's three totals
+    // (lines, sequence bytes, quality bytes) go through ONE look-back instead of two in a row (the timeline of round 6: the two
+    // look-backs were 13 of a block's 35 us).  The look-back's line count then confirms the guess — a wrong one (a tile of
+    // lines that all look like headers) raises the flag: the host takes the general kernels.  No unique guess (a tile inside a
+    // long line): the line count first, as before.
+    typedef const __attribute__((address_space(3))) uint8_t* lds_bytes_t;
+    const lds_bytes_t l_tile = (lds_bytes_t)(const uint8_t*)s_tile4 + kHaloBytes;  // (tile-relative positions index it: -kHaloBytes .. kTile + pad)
+    const int32_t lds_lo = kLdsTile ? (t0 ? -kHaloBytes : 0) : 1 << 30;  // positions from here on are in LDS
+    __syncthreads();  // (the list, wavefront 3's four entries in front of it, the tile's bytes)
     {
-        const uint64_t agg[1] = {T_all};
-        uint64_t ex1[1];
-        fq_lookback<1, FQ_LB1_WAVES>(a.tiles, a.n_tiles, tile, agg, ex1, s_lb);  // (its barriers also publish the list to the block)
-        lines_before = ex1[0];
+        uint32_t imp = 0;
+        const uint32_t n_list = irregular ? 0 : kHalo + T_all;
+        const int32_t lim = (int32_t)min((uint64_t)kTile, a.len - t0);
+        for (uint32_t jj = tid; jj < n_list; jj += 256) {
+            const int32_t nl = s_nl[jj], pos = nl + 1;  // the line behind newline jj
+            const bool dup = jj + 1 < n_list && s_nl[jj + 1] == nl;  // (in front of the text: several entries say "-1", the last one counts)
+            if (kLdsTile && !dup && pos >= lds_lo && pos < lim) {
+                const uint8_t c = l_tile[pos];
+                if (c != '@') imp |= 1u << (jj & 3);        // a header follows newline jj  <=>  j0 == jj mod 4  (kHalo is 4)
+                if (c != '+') imp |= 1u << ((jj + 2) & 3);  // the '+' line follows newline jj  <=>  j0 == jj - 2 mod 4
+            }
+        }
+#pragma unroll
+        for (int o = 32; o; o >>= 1) imp |= (uint32_t)__shfl_xor((int)imp, o);
+        if (lane == 0 && imp) atomicOr((unsigned long long*)&s_bc[6], (unsigned long long)imp);
     }
     __syncthreads();
+    if (s_bc[4]) irregular = true;  // (a byte >= 0x80, or the lines in front of the tile begin too far away: the list's first
+                                    //  entries are not set — no record of this tile is looked at; the host takes the general kernels)
+    const uint32_t cand = ~(uint32_t)s_bc[6] & 15u;
+#ifdef FQ_NO_GUESS
+    const bool spec = false;
+#else
+    const bool spec = !irregular && __popc(cand) == 1;
+#endif
+    uint64_t lines_before = 0;
+    uint32_t j0;
+    if (spec) {
+        j0 = (uint32_t)__ffs((int)cand) - 1;
+    } else {
+        const uint64_t agg[1] = {T_all};
+        uint64_t ex1[1];
+        fq_lookback<1>(a.tiles, a.tiles + 3 * (uint64_t)a.n_tiles, a.n_tiles, tile, agg, ex1, s_lb, &a.out[1], vw);
+        lines_before = ex1[0];
+        j0 = (3u - (uint32_t)(lines_before & 3)) & 3u;
+    }
+    FQ_STAMP(3);  // look-back #1 done (or guessed)
     // ---- the records whose fourth line ends in this tile
-    const uint32_t j0 = (3u - (uint32_t)(lines_before & 3)) & 3u;
     uint32_t nr = (!irregular && j0 < T_all) ? (T_all - j0 + 3) / 4 : 0;
     if (nr > kRecCap) {
         irregular = true;
@@ -787,15 +878,24 @@ __global__ __launch_bounds__(256) void fq_fused_kernel(const FusedArgs a) {
     nr = 0;
 #endif
     const uint8_t* tb = a.t + t0;  // (relative positions are added to this; a line of the previous tile: negative)
-    const uint8_t* s_tile = (const uint8_t*)s_tile4;
-    if (kLdsTile && tid < 2) s_tile4[kTile / 16 + tid] = make_uint4(0, 0, 0, 0);  // (pad: 16-byte reads may run past the tile's last byte)
-    auto gb = [&](int32_t rel) -> uint8_t { return kLdsTile && rel >= 0 ? s_tile[rel] : tb[rel]; };  // a byte of the text by tile-relative position
+    const uint8_t* s_tile = (const uint8_t*)s_tile4 + kHaloBytes;  // (tile-relative positions index it: -kHaloBytes .. kTile + pad)
+    // a byte of the text by tile-relative position: from the LDS copy where that holds it.  (Two loads in two address spaces
+    // under a branch, NOT one load through a selected generic pointer: flat loads faulted — aperture violation — on in-range
+    // LDS addresses once the tile's buffer sat at LDS offset 0; and a DS read is the cheaper instruction.)
+    auto gb = [&](int32_t rel) -> uint8_t {
+        uint8_t v;
+        if (rel >= lds_lo)
+            v = l_tile[rel];
+        else
+            v = tb[rel];
+        return v;
+    };
     auto is_ws_ascii = [](uint8_t c) { return c == ' ' || (c >= 9 && c <= 13); };
     uint64_t lens = 0;  // seq | qual << 32 of this thread's record
     bg_fastq_record_t rr = {};
     bool bad_rec = false;
-    if (tid < nr) {
-        const uint32_t j = kHalo + j0 + 4 * tid;  // list index of the record's last newline
+    if (vtid < nr) {
+        const uint32_t j = kHalo + j0 + 4 * vtid;  // list index of the record's last newline
         const int32_t e_h = s_nl[j - 3], e_s = s_nl[j - 2], e_p = s_nl[j - 1], e_q = s_nl[j];
         const int32_t b_h = s_nl[j - 4] + 1, b_s = e_h + 1, b_p = e_s + 1, b_q = e_p + 1;
         // the bytes this needs — the three first bytes, the byte in front of each of the three trimmed line ends, the head of
@@ -806,7 +906,7 @@ __global__ __launch_bounds__(256) void fq_fused_kernel(const FusedArgs a) {
         const int32_t hrel = b_h + 1;
         const uint32_t mis = (uint32_t)hrel & 7u;  // (tile starts are multiples of 16 KB: LDS and text share the alignment when the text is 8-byte aligned)
         const int32_t hrel0 = hrel - (int32_t)mis;
-        const bool h_lds = kLdsTile && hrel0 >= 0;  // the two words lie in the tile (+ its pad)
+        const bool h_lds = hrel0 >= lds_lo;  // the two words lie in the LDS copy (halo, tile, pad)
         const uint64_t* hw = (const uint64_t*)(tb + hrel0);
         const bool h2 = h_lds || (((uintptr_t)hw & 7) == 0 && (const uint8_t*)hw >= a.t && (const uint8_t*)(hw + 2) <= a.t + a.len);
         uint64_t w0 = 0, w1 = 0;  // (two words: most headers' ids end inside them)
@@ -873,14 +973,13 @@ __global__ __launch_bounds__(256) void fq_fused_kernel(const FusedArgs a) {
         rr = o;
         lens = (uint64_t)o.seq_len | (uint64_t)o.qual_len << 32;
         FusedRec d;
-        d.seq_rel = b_s;
-        d.qual_rel = b_q;
-        d.seq_n = o.seq_len;
-        d.qual_n = o.qual_len;
+        d.seq_rel = (fq_rel_t)b_s;
+        d.qual_rel = (fq_rel_t)b_q;
+        d.seq_n = (fq_len_t)o.seq_len;
+        d.qual_n = (fq_len_t)o.qual_len;
         d.seq_dst = d.qual_dst = 0;
         d.flags = o.id_len == 0 ? 1u : 0u;
-        d.pad = 0;
-        s_rec[tid] = d;
+        s_rec[vtid] = d;
     }
     // ---- offsets: block scan of the lengths in record order, then the tile totals' look-backs
     uint64_t ex, tile_sum;
@@ -892,34 +991,47 @@ __global__ __launch_bounds__(256) void fq_fused_kernel(const FusedArgs a) {
             if ((int)lane >= o) v += (uint64_t)hh << 32 | lo;
         }
         __syncthreads();
-        if (lane == 63) s_w[wave] = v;
+        FQ_STAMP(4);  // records parsed
+        if (lane == 63) s_w[vw] = v;
         __syncthreads();
         uint64_t wb = 0, all = 0;
         for (uint32_t w = 0; w < 4; w++) {
-            if (w < wave) wb += s_w[w];
+            if (w < vw) wb += s_w[w];
             all += s_w[w];
         }
         ex = wb + v - lens;
         tile_sum = all;  // (32-bit halves: a tile's lines hold far fewer than 2^32 bytes)
     }
-    if (__any(bad_rec) && lane == 0) s_bc[4] = 1;
-    if (tid < nr) {
-        s_rec[tid].seq_dst = (uint32_t)ex;
-        s_rec[tid].qual_dst = (uint32_t)(ex >> 32);
+    if (__any(bad_rec) && lane == 0) s_bc[5] = 1;  // (not [4]: a wavefront may still be reading that one above)
+    if (vtid < nr) {
+        s_rec[vtid].seq_dst = (fq_len_t)ex;
+        s_rec[vtid].qual_dst = (fq_len_t)(ex >> 32);
     }
     uint64_t seq_before, qual_before;
-    {
+    if (spec) {  // all three totals at once; the line count confirms the guess
+        const uint64_t agg[3] = {T_all, tile_sum & 0xFFFFFFFFull, tile_sum >> 32};
+        uint64_t ex3[3];
+        fq_lookback<3>(a.tiles, a.tiles + 3 * (uint64_t)a.n_tiles, a.n_tiles, tile, agg, ex3, s_lb, &a.out[1], vw);
+        lines_before = ex3[0];
+        seq_before = ex3[1];
+        qual_before = ex3[2];
+        if (((3u - (uint32_t)(lines_before & 3)) & 3u) != j0) {  // (block-uniform) guessed wrong: what this tile published is wrong too
+            irregular = true;
+            nr = 0;
+        }
+    } else {
         const uint64_t agg[2] = {tile_sum & 0xFFFFFFFFull, tile_sum >> 32};
         uint64_t ex2[2];
-        fq_lookback<2, FQ_LB2_WAVES>(a.tiles + a.n_tiles, a.n_tiles, tile, agg, ex2, s_lb);
+        fq_lookback<2>(a.tiles + a.n_tiles, a.tiles + 4 * (uint64_t)a.n_tiles, a.n_tiles, tile, agg, ex2, s_lb, &a.out[1], vw);
         seq_before = ex2[0];
         qual_before = ex2[1];
     }
     __syncthreads();
+    FQ_STAMP(5);  // look-back #2 done
     const uint64_t rec0 = (lines_before + j0) / 4;  // global index of the tile's first record
-    if (tid < nr) {
+    if (vtid < nr) {
         const uint64_t so = seq_before + (ex & 0xFFFFFFFFull), qo = qual_before + (ex >> 32);
-        const uint64_t r = rec0 + tid;
+        const uint64_t r = rec0 + vtid;
         rr.seq_off = so;
         rr.qual_off = qo;
         if (r < a.rec_cap) {  // (the record itself: after the copy phase, with its check)
@@ -938,22 +1050,47 @@ __global__ __launch_bounds__(256) void fq_fused_kernel(const FusedArgs a) {
         a.out[2] = st;
         a.out[3] = qt;
     }
-    if (irregular && tid == 0) s_bc[4] = 1;
+    if (irregular && tid == 0) s_bc[5] = 1;
     __syncthreads();
-    if (s_bc[4] && tid == 0) atomicOr((unsigned long long*)&a.out[1], 1ull);
+    if ((s_bc[4] | s_bc[5]) && tid == 0) atomicOr((unsigned long long*)&a.out[1], 1ull);
     // ---- copy + Record::check.  The tile's sequence bytes go to ONE contiguous range of `seq` (its records follow each other
-    // there), likewise the qualities: every thread takes 16-byte pieces of that range on the DESTINATION's alignment, finds the
-    // record a piece belongs to (binary search over the records' ends, LDS) and reads its 16 source bytes as five aligned
-    // dwords funnel-shifted into four — one load phase and one 16-byte store per piece, all 256 lanes busy (16 lanes per
-    // record, head / body / tail one after the other, was 37 % of the kernel).  A piece that straddles two records or the
-    // ends of the range goes byte by byte.  The bytes come from L2: this block, or the one before it, just read them.
+    // there), likewise the qualities: every thread takes 16-byte pieces of that range on the DESTINATION's alignment.  Which
+    // record a piece begins in comes from a table the records' owners fill (s_prec); its 16 source bytes are five aligned LDS
+    // dwords funnel-shifted into four, a piece that runs into the next record merges a second such read under a byte mask, the
+    // bytes are classified for Record::check four at a time (SWAR) — straight-line code for all but the first / last piece of the
+    // range, pieces with three records, and lines that begin more than 1 KB in front of the tile (those go byte by byte).
+    // (Round 6, SQ counters of a build without this phase against the complete one: the phase was 108 M vector + 183 M scalar
+    //  instructions of the kernel's 169 + 222 M per call — a binary search and a handful of divergent branches per piece, at
+    //  four wavefronts per SIMD the kernel was bound by instruction issue, not by memory.)
     {
-        const uint8_t* t_end = a.t + a.len;
 #ifdef FQ_KO_COPY
         nr = 0;
 #endif
-        auto tile_copy = [&](auto SEQ_T, uint8_t* dst_base, uint32_t total) {
+        const uint32_t seq_total = (uint32_t)(tile_sum & 0xFFFFFFFFull), qual_total = (uint32_t)(tile_sum >> 32);
+        uint8_t* const seq_base = a.seq + seq_before;
+        uint8_t* const qual_base = a.qual + qual_before;
+        const uint32_t d0s = (uint32_t)((uintptr_t)seq_base & 15), d0q = (uint32_t)((uintptr_t)qual_base & 15);
+        // the owners' tables: piece c (output offsets 16 c - d0 .. + 15, clipped to the range) begins in record i
+        // (a tile whose records bring more than the table holds — long lines from in front of it — searches instead)
+        constexpr uint32_t kPrecCap = kTile / 16 + 4;
+        const bool tab_s = ((d0s + seq_total + 15) >> 4) <= kPrecCap, tab_q = ((d0q + qual_total + 15) >> 4) <= kPrecCap;
+        if (vtid < nr) {
+            const FusedRec d = s_rec[vtid];
+            if (d.seq_n && tab_s) {
+                const uint32_t c_lo = d.seq_dst ? (d.seq_dst + d0s + 15) >> 4 : 0, c_hi = (d.seq_dst + d.seq_n + d0s + 15) >> 4;  // [c_lo, c_hi)
+                for (uint32_t c = c_lo; c < c_hi; c++) s_prec[0][c] = (uint8_t)vtid;
+            }
+            if (d.qual_n && tab_q) {
+                const uint32_t c_lo = d.qual_dst ? (d.qual_dst + d0q + 15) >> 4 : 0, c_hi = (d.qual_dst + d.qual_n + d0q + 15) >> 4;
+                for (uint32_t c = c_lo; c < c_hi; c++) s_prec[1][c] = (uint8_t)vtid;
+            }
+        }
+        __syncthreads();
+        FQ_STAMP(6);  // piece tables filled
+        auto tile_copy = [&](auto SEQ_T, uint8_t* dst_base, uint32_t total, uint32_t d0) {
             constexpr bool SEQ = decltype(SEQ_T)::value;
+            const uint8_t* prec = s_prec[SEQ ? 0 : 1];
+            const bool tab = SEQ ? tab_s : tab_q;
             auto rel_of = [&](uint32_t i) { return SEQ ? s_rec[i].seq_rel : s_rec[i].qual_rel; };
             auto dst_of = [&](uint32_t i) { return SEQ ? s_rec[i].seq_dst : s_rec[i].qual_dst; };
             auto end_of = [&](uint32_t i) { return SEQ ? s_rec[i].seq_dst + s_rec[i].seq_n : s_rec[i].qual_dst + s_rec[i].qual_n; };
@@ -961,148 +1098,105 @@ __global__ __launch_bounds__(256) void fq_fused_kernel(const FusedArgs a) {
                 const uint32_t f = (hi ? (SEQ ? 2u : 8u) : 0u) | (bad ? 4u : 0u);
                 if (f) atomicOr(&s_rec[i].flags, f);
             };
-            auto classify = [&](uint32_t c, bool& hi, bool& bad) {
-                hi |= c >= 0x80;
-                if (SEQ) bad |= !((c >= 'A' && c <= 'Z') || (c >= 'a' && c <= 'z') || c == '-' || c == '.' || c == '*');
+            // bit 7 of every byte of w that is >= 0x80 / (SEQ) that is neither alphabetic nor one of - . *  (fastq.rs:392-401)
+            auto bad_bits = [](uint32_t w) -> uint32_t {
+                auto zero = [](uint32_t x) { return ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u; };
+                const uint32_t t = (w | 0x20202020u) & 0x7F7F7F7Fu;
+                const uint32_t letter = (t + 0x1F1F1F1Fu) & ~(t + 0x05050505u) & 0x80808080u;  // 'a' <= t <= 'z' (7-bit bytes)
+                return ~(letter | zero(w ^ 0x2D2D2D2Du) | zero(w ^ 0x2E2E2E2Eu) | zero(w ^ 0x2A2A2A2Au)) & 0x80808080u;
             };
-            const uint32_t d0 = (uint32_t)((uintptr_t)dst_base & 15);
             const uint32_t n_pieces = (d0 + total + 15) >> 4;
             for (uint32_t c = tid; c < n_pieces && nr; c += 256) {
-                const uint32_t o_lo = 16 * c > d0 ? 16 * c - d0 : 0, o_hi = min(total, 16 * c + 16 - d0);
-                uint32_t lo = 0, hi_i = nr - 1;  // the record whose bytes hold offset o_lo: the first one that ends beyond it
-                while (lo < hi_i) {
-                    const uint32_t mid = (lo + hi_i) >> 1;
-                    if (end_of(mid) > o_lo)
-                        hi_i = mid;
-                    else
-                        lo = mid + 1;
+                const uint32_t p0 = 16 * c - d0;  // output offset of the piece's byte 0 (in front of the range for c == 0: as int)
+                const uint32_t o_lo = 16 * c > d0 ? p0 : 0, o_hi = min(total, p0 + 16);
+                uint32_t i;
+                if (tab) {
+                    i = prec[c];
+                } else {  // the first record whose end lies behind the piece's first byte
+                    uint32_t lo = 0, hi = nr - 1;
+                    while (lo < hi) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if (end_of(mid) > o_lo) hi = mid; else lo = mid + 1;
+                    }
+                    i = lo;
                 }
-                uint32_t i = lo;
-                // 16 source bytes for output offsets o_lo .. o_lo + 15 as record i has them (five aligned dwords funnel-shifted
-                // into four); false if that would read outside the text
-                auto load16u = [&](uint32_t rec, uint32_t (&w)[4]) -> bool {
-                    const int32_t rel = rel_of(rec) + (int32_t)(16 * c - d0 - dst_of(rec));
-                    uint32_t r5[5], sh;
-                    if (kLdsTile && rel >= 0 && rel + 20 <= (int32_t)(kTile + 32)) {  // inside the tile (+ pad): from LDS
-                        sh = (uint32_t)rel & 3u;
+                const uint32_t e1 = end_of(i);
+                const bool two = o_hi > e1;
+                uint32_t i2 = two ? i + 1 : i;
+                const int32_t relA = rel_of(i) + (int32_t)(p0 - dst_of(i)), relB = rel_of(i2) + (int32_t)(p0 - dst_of(i2));
+                const bool whole = o_lo == p0 && o_hi == p0 + 16;
+                // fast: a piece of one or two records whose source bytes are in LDS (the second record not empty).  The first and
+                // the last piece of the range are partial — bytes of another tile's records lie in front / behind: the same
+                // sixteen bytes, classified and stored under a byte mask (they went byte by byte through the general path first:
+                // a chain of dependent LDS reads per byte on the two wavefronts every other one then waited for, 7 of the copy
+                // phase's 9 us in the round-6 timeline)
+                const bool fast = kLdsTile && relA >= lds_lo && relB >= lds_lo && (!two || (i2 < nr && o_hi <= end_of(i2) && end_of(i2) > e1));
+                if (fast) {
+                    auto lds16 = [&](int32_t rel, uint32_t (&w)[4]) {
+                        const uint32_t sh = (uint32_t)rel & 3u;
                         const uint32_t* q4 = (const uint32_t*)(s_tile + (rel - (int32_t)sh));
+                        uint32_t r5[5];
 #pragma unroll
                         for (int q = 0; q < 5; q++) r5[q] = q4[q];
-                    } else {
-                        // two ALIGNED 16-byte loads (a wavefront's pieces are consecutive: each load instruction covers whole
-                        // cache lines; five dword loads at a 16-byte stride used a quarter of every line they touched and were
-                        // what the copy phase spent its time on), the five dwords that hold the piece picked by its dword offset
-                        const uint8_t* p = tb + rel;
-                        const uint32_t sh16 = (uint32_t)((uintptr_t)p & 15);
-                        const uint8_t* pa = p - sh16;
-                        if (pa < a.t || pa + 32 > t_end) {
-                            sh = (uint32_t)((uintptr_t)p & 3);
-                            const uint8_t* pd = p - sh;
-                            if (pd < a.t || pd + 20 > t_end) return false;
 #pragma unroll
-                            for (int q = 0; q < 5; q++) r5[q] = *(const uint32_t*)(pd + 4 * q);
-                        } else {
-                            const uint4 lo4 = *(const uint4*)pa, hi4 = *(const uint4*)(pa + 16);
-                            const uint32_t r8[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
-                            const uint32_t d = sh16 >> 2;
-                            sh = sh16 & 3u;
+                        for (int q = 0; q < 4; q++) w[q] = __builtin_amdgcn_alignbyte(r5[q + 1], r5[q], sh);
+                    };
+                    auto below = [](int k) -> uint32_t { return k >= 4 ? 0xFFFFFFFFu : k <= 0 ? 0u : (1u << (8 * k)) - 1u; };  // bytes 0 .. k - 1 of a word
+                    uint32_t w[4], w2[4];
+                    lds16(relA, w);
+                    lds16(relB, w2);  // (== relA's bytes when the piece has one record: merged under an all-ones mask)
+                    const uint32_t split = two ? e1 - p0 : 16u;  // bytes [split, 16) belong to record i2
+                    const uint32_t first = o_lo - p0, last = o_hi - p0;  // the piece's bytes of this range: [first, last)
+                    uint32_t hiA = 0, hiB = 0, badA = 0, badB = 0;
 #pragma unroll
-                            for (int q = 0; q < 5; q++) r5[q] = d == 0 ? r8[q] : d == 1 ? r8[q + 1] : d == 2 ? r8[q + 2] : r8[q + 3];
+                    for (int q = 0; q < 4; q++) {
+                        const uint32_t keep = below((int)split - 4 * q);  // bytes of word q that belong to record i
+                        w[q] = (w[q] & keep) | (w2[q] & ~keep);
+                        uint32_t hb = w[q] & 0x80808080u, bb = SEQ ? bad_bits(w[q]) : 0u;
+                        if (!whole) {
+                            const uint32_t v = below((int)last - 4 * q) & ~below((int)first - 4 * q);
+                            hb &= v;
+                            bb &= v;
                         }
+                        hiA |= hb & keep;
+                        hiB |= hb & ~keep;
+                        badA |= (bb | hb) & keep;   // (a byte >= 0x80 is no letter either)
+                        badB |= (bb | hb) & ~keep;
                     }
-#pragma unroll
-                    for (int q = 0; q < 4; q++) w[q] = __builtin_amdgcn_alignbyte(r5[q + 1], r5[q], sh);
-                    return true;
-                };
-                uint32_t w[4];
-                bool fast = load16u(i, w);
-                const uint32_t p0 = 16 * c - d0;              // output offset of the piece's byte 0 (may lie in front of the range: as int)
-                const uint32_t e1 = end_of(i);
-                uint32_t i2 = i, split = 16;                  // bytes [split, 16) of the piece belong to record i2
-                if (fast && o_hi > e1) {                      // the piece runs into the next record (skipping empty ones)
-                    i2 = i + 1;
-                    while (i2 + 1 < nr && end_of(i2) <= e1) i2++;
-                    if (o_hi > end_of(i2)) {
-                        fast = false;                         // three records in one piece (reads of a few bases): byte by byte
-                    } else {
-                        uint32_t w2[4];
-                        fast = load16u(i2, w2);
-                        split = e1 - p0;                      // (1 .. 15)
-#pragma unroll
-                        for (int q = 0; q < 4; q++) {
-                            const int k = (int)split - 4 * q;  // bytes of word q that still belong to record i
-                            const uint32_t keep = k >= 4 ? 0xFFFFFFFFu : k <= 0 ? 0u : (1u << (8 * k)) - 1u;
-                            w[q] = (w[q] & keep) | (w2[q] & ~keep);
-                        }
-                    }
-                }
-                if (fast) {
-                    const uint32_t first = o_lo - p0, last = o_hi - p0;  // valid bytes of the piece: [first, last)
-                    if (first == 0 && last == 16) {
-#ifdef FQ_KO_STORE
-                        asm volatile("" ::"v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]));
-#elif defined(FQ_NT_STORE)
-                        __builtin_nontemporal_store(make_uint4(w[0], w[1], w[2], w[3]), (uint4*)(dst_base + o_lo));
+#if defined(FQ_KO_STORE)
+                    asm volatile("" ::"v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]));
 #else
+                    if (whole) {
                         *(uint4*)(dst_base + o_lo) = make_uint4(w[0], w[1], w[2], w[3]);
-#endif
-                    } else {  // the first / last piece of the tile's range: its other bytes are another tile's
-#pragma unroll
-                        for (int k = 0; k < 16; k++)
-                            if ((uint32_t)k >= first && (uint32_t)k < last) dst_base[(int32_t)(p0 + k)] = (uint8_t)(w[k >> 2] >> (8 * (k & 3)));
-                    }
-                    bool hiA = false, badA = false, hiB = false, badB = false;
-#ifdef FQ_KO_CLASSIFY
-                    if (true) {
-#else
-                    if (first == 0 && last == 16 && split == 16) {  // the common piece: sixteen bytes of one record, four at a time
-#endif
-                        hiA = ((w[0] | w[1] | w[2] | w[3]) & 0x80808080u) != 0;
-                        if (SEQ && !hiA) {  // fastq.rs:392-401: alphabetic, or one of - . *   (bytes below 0x80 here)
-                            auto zero = [](uint32_t x) { return ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u; };  // bit 7 of every zero byte
-                            uint32_t ok = 0x80808080u;
-#pragma unroll
-                            for (int q = 0; q < 4; q++) {
-                                const uint32_t t = w[q] | 0x20202020u;  // letters fold to lower case ('-' '.' '*' stay what they are: bit 5 is set in them)
-                                const uint32_t letter = (t + 0x1F1F1F1Fu) & ~(t + 0x05050505u) & 0x80808080u;  // 'a' <= t <= 'z'
-                                ok &= letter | zero(w[q] ^ 0x2D2D2D2Du) | zero(w[q] ^ 0x2E2E2E2Eu) | zero(w[q] ^ 0x2A2A2A2Au);
-                            }
-                            badA = ok != 0x80808080u;
-                        } else if (SEQ) {
-                            badA = true;  // (a byte >= 0x80 is no letter either)
-                        }
                     } else {
 #pragma unroll
-                        for (int k = 0; k < 16; k++) {
-                            const uint32_t ch = (w[k >> 2] >> (8 * (k & 3))) & 0xffu;
-                            if ((uint32_t)k >= first && (uint32_t)k < last) {
-                                if ((uint32_t)k < split)
-                                    classify(ch, hiA, badA);
-                                else
-                                    classify(ch, hiB, badB);
-                            }
-                        }
+                        for (uint32_t k = 0; k < 16; k++)
+                            if (k >= first && k < last) dst_base[p0 + k] = (uint8_t)(w[k >> 2] >> (8 * (k & 3)));  // (p0 + k: mod 2^32, >= 0 here)
                     }
-                    flag(i, hiA, badA);
-                    flag(i2, hiB, badB);
-                } else {
+#endif
+                    if (hiA | badA) flag(i, hiA != 0, SEQ && badA != 0);
+                    if (hiB | badB) flag(i2, hiB != 0, SEQ && badB != 0);
+                } else {  // three records in a piece, a line from more than 1 KB in front of the tile
+                    uint32_t ii = i;
                     for (uint32_t o = o_lo; o < o_hi; o++) {
-                        while (o >= end_of(i)) i++;  // (o < total = the last record's end: i stays below nr)
-                        const uint8_t ch = gb(rel_of(i) + (int32_t)(o - dst_of(i)));
+                        while (o >= end_of(ii)) ii++;  // (o < total = the last record's end: ii stays below nr)
+                        const uint8_t ch = gb(rel_of(ii) + (int32_t)(o - dst_of(ii)));
                         dst_base[o] = ch;
-                        bool hi = false, bad = false;
-                        classify(ch, hi, bad);
-                        flag(i, hi, bad);
+                        const bool hi = ch >= 0x80;
+                        const bool bad = SEQ && !((ch >= 'A' && ch <= 'Z') || (ch >= 'a' && ch <= 'z') || ch == '-' || ch == '.' || ch == '*');
+                        flag(ii, hi, bad);
                     }
                 }
             }
         };
-        tile_copy(std::true_type{}, a.seq + seq_before, (uint32_t)(tile_sum & 0xFFFFFFFFull));
-        tile_copy(std::false_type{}, a.qual + qual_before, (uint32_t)(tile_sum >> 32));
+        tile_copy(std::true_type{}, seq_base, seq_total, d0s);
+        tile_copy(std::false_type{}, qual_base, qual_total, d0q);
+        FQ_STAMP(7);  // this wavefront's pieces issued
         __syncthreads();
-        if (tid < nr) {
-            const uint64_t r = rec0 + tid;
-            const uint32_t f = s_rec[tid].flags;
+        FQ_STAMP(8);  // all copied (the barrier waits for the stores)
+        if (vtid < nr) {
+            const uint64_t r = rec0 + vtid;
+            const uint32_t f = s_rec[vtid].flags;
             rr.check = (f & 1u)   ? BG_FQCHECK_EMPTY_ID
                        : (f & 2u) ? BG_FQCHECK_NONASCII_SEQ
                        : (f & 4u) ? BG_FQCHECK_INVALID_SEQ
@@ -1111,6 +1205,7 @@ __global__ __launch_bounds__(256) void fq_fused_kernel(const FusedArgs a) {
                                                    : BG_FQCHECK_OK;
             if (r < a.rec_cap) a.recs[r] = rr;
         }
+        FQ_STAMP(9);
     }
 }
 
@@ -1302,15 +1397,14 @@ extern "C" int bg_fastq_parse_dev(bg_ctx* ctx, const uint8_t* d_text, uint64_t l
     if (!ctx->fq_no_fused) {
         const uint64_t n_tiles = (len + kTile - 1) / kTile;
         if (n_tiles < (1ull << 31)) {
-            const size_t words = 3 * n_tiles + 8;
+            const size_t words = 6 * n_tiles + 8;
             if ((rc = bg_reserve(&ctx->aux, &ctx->aux_bytes, words * 8))) return rc;
             BG_HIP(hipMemsetAsync(ctx->aux, 0, words * 8, st));
             FusedArgs fa = {};
             fa.t = d_text;
             fa.len = len;
             fa.tiles = (uint64_t*)ctx->aux;
-            fa.out = fa.tiles + 3 * n_tiles;
-            fa.ticket = (uint32_t*)(fa.out + 4);
+            fa.out = fa.tiles + 6 * n_tiles;
             fa.recs = d_recs;
             fa.rec_cap = rec_cap;
             fa.seq = d_seq;

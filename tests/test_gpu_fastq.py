@@ -230,6 +230,10 @@ def test_one_pass_reader_on_tiles_halos_and_what_it_leaves_to_the_general_kernel
     # long reads: lines of 20 - 70 kb (several tiles per line; the four newlines in front of a tile are far away)
     both_paths_like_the_oracle(b"".join(rec(k, int(rng.integers(20_000, 70_000))) for k in range(12)))
     both_paths_like_the_oracle(b"".join(rec(k, int(rng.integers(2_000, 9_000)), nl=b"\r\n") for k in range(60)))
+    # records of 20 - 30 KB: they stay on the one-pass path (all four lines begin within 31 KB of the tile their last line ends
+    # in), with more bytes to copy than the tile's piece tables hold; mixed with short reads so that tiles have both
+    both_paths_like_the_oracle(b"".join(rec(k, int(rng.integers(9_000, 14_500)) if k % 3 else int(rng.integers(30, 300))) for k in range(90)))
+    both_paths_like_the_oracle(b"".join(rec(k, 15_000 + k) for k in range(40)))
     # Record::check on the one-pass path: empty id, invalid sequence byte, unequal lengths
     t = rec(0, 50) + b"@\nACGT\n+\nIIII\n" + b"@bad\nAC#T\n+\nIIII\n" + b"@uneq\nACGT\n+\nIII\n" + b"@ lead space\nAC\n+\nII\n" + b"@ok  two\nA\n+\nI\n"
     p = both_paths_like_the_oracle(t * 300)
