@@ -497,7 +497,8 @@ def main():
         hoa = np.arange(n_pairs + 1, dtype=np.uint64) * np.uint64(L)
         hout, hopsb = aligner.align_arrays(3, hxa, hoa, hya, hoa)  # warm-up: sizes the staging sets, touches the result pages
         t_h = median_time(lambda: aligner.align_arrays(3, hxa, hoa, hya, hoa, out=hout, ops=hopsb))
-        host_api = {"value": round(n_pairs * L * L / t_h / 1e9, 2), "unit": "GCUPS", "pairs": n_pairs,
+        host_api = {"value": round(n_pairs * L * L / t_h / 1e9, 2), "unit": "GCUPS", "pairs": n_pairs, "host_threads": threads,
+                    "bytes_over_pcie_GB_per_s": round((2 * n_pairs * L + n_pairs * 64 + float(n_ops_mean) * n_pairs) / t_h / 1e9, 1),
                     "note": "bg_align_batch with pageable host buffers in and out (PCIe-inclusive), median of 3: stages of "
                             "122880 pairs through three pinned staging sets; uploads by copy commands, records and device-compacted "
                             "operations brought back by a small kernel on a high-priority stream, all overlapped with the next stages' kernels"}
@@ -992,8 +993,12 @@ def fm_legs(args, ctx, dev, stream, rank, world, do_cpu, orc, threads, parity, r
         h_out = fm.backward_search_arrays(hp_all, hoff_all)  # warm-up: sizes the staging sets, pages the result arrays in
         t_h = median_time(lambda: fm.backward_search_arrays(hp_all, hoff_all, out=h_out))
         fm_res["host_api"] = {"value": round(n_q / t_h, 1), "unit": "queries/s", "queries": n_q,
+                              "caller_bytes_read_GB_per_s": round(n_q * P / t_h / 1e9, 1), "host_threads": threads,
                               "note": "bg_fm_backward_search_batch: pageable host buffers in and out (PCIe-inclusive), median of 3; "
-                                      "stages of 2^20 queries through three pinned staging sets, the caller's result arrays reused"}
+                                      "stages of 2^20 queries through three pinned staging sets, the caller's result arrays reused. "
+                                      "Bound by the host: its threads read the caller's pattern bytes once to pack them to 2 bits "
+                                      "(BG_TRACE_HOST=1: pack 12.5 of 15.3 ms per 10 M queries of 100 bp on 16 threads = 80 GB/s "
+                                      "of pageable memory) - caller_bytes_read_GB_per_s is what explains box-to-box spread"}
         del h_out
         del hp, hp_all
     result["fm"] = fm_res
