@@ -85,7 +85,7 @@ const char* bg_last_error(void); /* text of the last HIP failure on this thread 
 /* Tunables (0 keeps the default) and the switches the tests use to reach every kernel variant:
  *   chunk_pairs        pairs per sub-batch of bg_align_batch_dev (default 2^20) and of the banded pipeline (16384)
  *   host_chunk_pairs   pairs per stage of bg_align_batch's pipelined host path (122880)
- *   seed_chunk_reads   reads per pass of bg_seed_extend_batch[_dev] (2^20)
+ *   seed_chunk_reads   reads per pass of bg_seed_extend_batch[_dev] (0: equal passes of at most 2^21 reads)
  *   force_wide = 1     scores kept as plain int32 even where they fit the 24-bit keys of the fast kernels
  *   no_pk16 = 1        no packed-int16 fill (K1p): the int32 kernel K1 runs for every batch
  *   no_couples = 1     K1p without the (m, n) slot order on ragged batches

@@ -67,7 +67,7 @@ struct bg_ctx {
     bool fm_host_bytes = false;       // tests, A/B: bg_fm_backward_search_batch stages the pattern bytes (no 2-bit packing on the host)
     int64_t host_chunk_pairs = 0;     // pairs per pipeline stage of bg_align_batch (0 = default)
     int64_t chunk_pairs = 0;  // 0 = default
-    int64_t seed_chunk_reads = 0;  // reads per pass of bg_seed_extend_batch_dev (0 = 2^20)
+    int64_t seed_chunk_reads = 0;  // reads per pass of bg_seed_extend_batch_dev (0 = equal passes of at most 2^21)
     bool force_wide = false;  // tests: disable the NARROW (28-bit key) kernels
     bool no_pk16 = false;     // tests: disable K1p (two pairs per lane in packed int16 halves)
     bool no_local_fast = false;  // tests: Aligner::local on the general K1p (no LF flavour)

@@ -286,7 +286,11 @@ extern "C" int bg_seed_extend_batch_dev(bg_fm* fm, const bg_scoring_t* sc, const
     uint64_t done_hits = 0, done_cand = 0;
     bool any_panic = false;
     // reads per pass: bounds the scratch (seed slots, proposals, candidate pairs); bg_set_option("seed_chunk_reads") for tests
-    const uint64_t chunk = ctx->seed_chunk_reads > 0 ? (uint64_t)ctx->seed_chunk_reads : (1u << 20);
+    // (default: up to 2^21 reads per pass, the passes of a call of equal size — 1.25 M reads went as 2^20 + 0.2 M until round 6:
+    //  two host round trips and a set of under-filled launches for a sixth of the reads)
+    const uint64_t chunk_cap = ctx->seed_chunk_reads > 0 ? (uint64_t)ctx->seed_chunk_reads : (1u << 21);
+    const uint64_t n_pass = (n_reads + chunk_cap - 1) / chunk_cap;
+    const uint64_t chunk = ctx->seed_chunk_reads > 0 ? chunk_cap : (n_reads + n_pass - 1) / n_pass;
     for (uint64_t r0 = 0; r0 < n_reads; r0 += chunk) {
         const uint64_t nr = std::min(chunk, n_reads - r0);
         const uint64_t nq = nr * std::max<uint32_t>(prm.S, 1);
