@@ -72,6 +72,33 @@ __device__ __forceinline__ uint32_t block_part(const uint4 v, uint32_t t, uint32
     return (uint32_t)(__popcll(e0 << (64 - 2 * t0)) + __popcll((e1 << (32 - t1)) << (32 - t1)));
 }
 
+// All four codes' shares at once (K7: a bi-interval extension wants the ranks of every symbol at both ends of the interval —
+// eight block_part calls of ~28 vector instructions each were most of the kernel, round 6): the counts of this lane's symbols
+// inside [0, o] with code 0, 1, 2, 3 in the four bytes of the result (a lane holds 64 symbols, the three lanes of a quad 192:
+// sums over the quad fit a byte too); lane 0 of the quad (the counters) contributes 0.  Per dword of 16 symbols: the symbols
+// beyond the position leave at the top, then three population counts — all bits, the low bits of the 2-bit fields, the
+// fields with both bits — give codes 1, 2, 3; code 0 is what is left of the symbols that count.
+__device__ __forceinline__ uint32_t block_counts4(const uint4 v, uint32_t t, uint32_t o) {
+    const int have = (int)o + 1 - ((int)t - 1) * 64;  // symbols of this lane inside [0, o] (lane 0: irrelevant)
+    const uint32_t x[4] = {v.x, v.y, v.z, v.w};
+    uint32_t n_all = 0, n_low = 0, n_both = 0;
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        const uint32_t sh = 16u - (uint32_t)min(max(have - 16 * d, 0), 16);
+        const uint32_t xt = (x[d] << sh) << sh;  // (two shifts of at most 16: the whole dword may leave)
+        n_all += __popc(xt);
+        n_low += __popc(xt & 0x55555555u);
+        n_both += __popc(xt & (xt >> 1) & 0x55555555u);
+    }
+    const uint32_t kept = (uint32_t)min(max(have, 0), 64);
+    const uint32_t n1 = n_low - n_both, n2 = n_all - n_low - n_both, n0 = kept - (n_all - n_both);
+    return t == 0 ? 0u : n0 | n1 << 8 | n2 << 16 | n_both << 24;
+}
+// the four counters of a block (lane 0 of the quad holds them) in every lane of the quad
+__device__ __forceinline__ uint32_t quad_lane0(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x00 /*quad_perm:[0,0,0,0]*/, 0xf, 0xf, true);
+}
+
 // block_part without branches (K5's fast kernel: the quad's lane 0 / lanes 1-3 split and the "no symbol of mine" early
 // exit cost a divergent region each — exec-mask bookkeeping the straight-line form does not have): every lane computes
 // both the counter select and the bitmap count and keeps the one its position in the quad calls for

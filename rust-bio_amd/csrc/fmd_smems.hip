@@ -55,7 +55,9 @@ __device__ __forceinline__ uint32_t k7_dense(const FmDev& fm, uint32_t d, uint32
 }
 __device__ __forceinline__ uint32_t k7_dense(const FmWideDev&, uint32_t, uint64_t, uint32_t) { return 0; }  // (no dense symbols there)
 
-template <bool WIDE, bool PLAIN = false>
+// PLAIN: 0 the general extension, 1 plain DNA (straight line), 2 plain DNA whose '$' occurs at most twice and is the only listed
+// symbol (T$, T$R$: its rows in registers) — chosen by the host from the index's classes (smems_dev)
+template <bool WIDE, int PLAIN = 0>
 struct Ctx {
     using P = typename FmLayout<WIDE>::Pos;
     using BiIv = BiIvT<P>;
@@ -73,6 +75,10 @@ struct Ctx {
     // in bits 0-1, 2-3, 4-5, 6-7; plain_dollar: '$' 's list index, 0xFFFF if it never occurs; 0xFFFFFFFF in plain_codes: not plain
     uint32_t plain_codes, plain_dollar;
     const uint8_t* s_pos;        // position of a byte in the order "$TGCNAtgcna" (fmindex.rs:536); 10 for 'a' and any other byte
+    // plain DNA whose only listed symbol is '$' with at most two occurrences (T$, T$R$): its rows, "no such row" = the largest P —
+    // the rank of '$' (also the number of exceptions in front of a row) is two comparisons instead of four binary searches over
+    // LDS lists per extension.  small_dollar false: the searches.
+    P dollar_row[2] = {~(P)0, ~(P)0};
 
     __device__ uint32_t exc_le(P r) const { return k7_count_le(s_exc, 0u, a.fm.n_exc, r); }
     __device__ P less_of(uint32_t s) {
@@ -96,6 +102,41 @@ struct Ctx {
         }
         return 0;  // in the alphabet, never in the BWT
     }
+    // the straight-line end of a plain-DNA extension: occ of '$' is in occR[0] / occL[0]; T, G, C, (N: 0,) A from the codes' ranks.
+    __device__ __forceinline__ void plain_tail(const P (&cR)[4], const P (&cL)[4], P (&occR)[6], P (&occL)[6], bool has_l, const BiIv& iv, uint32_t sym, BiIv& r) {
+        auto pick = [&](const P (&c)[4], uint32_t code) -> P { return code == 0 ? c[0] : code == 1 ? c[1] : code == 2 ? c[2] : c[3]; };
+#pragma unroll
+        for (int k = 0; k < 3; k++) {  // T, G, C
+            occR[1 + k] = pick(cR, (plain_codes >> (2 * k)) & 3u);
+            occL[1 + k] = pick(cL, (plain_codes >> (2 * k)) & 3u);
+        }
+        occR[5] = pick(cR, (plain_codes >> 6) & 3u);  // A
+        occL[5] = pick(cL, (plain_codes >> 6) & 3u);
+        occR[4] = occL[4] = 0;  // N
+        // sizes in the order of fmindex.rs:536, their running sum in front of every symbol, and the lane's own symbol's entries
+        const uint32_t pos = s_pos[sym & 0xFFu];
+        P sz[6], before[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            if (!has_l) occL[k] = 0;
+            sz[k] = occR[k] - occL[k];
+        }
+        before[0] = 0;
+#pragma unroll
+        for (int k = 1; k < 6; k++) before[k] = before[k - 1] + sz[k - 1];
+        P o2 = 0, s2 = 0, b2 = before[5] + sz[5];  // (a position behind the order's six: everything is in front, the size is 0)
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            const bool here = (uint32_t)k == pos;
+            o2 = here ? occL[k] : o2;
+            s2 = here ? sz[k] : s2;
+            b2 = here ? before[k] : b2;
+        }
+        r.lower = less_of(sym) + o2;
+        r.lower_rev = iv.lower_rev + b2;
+        r.size = s2;
+        r.msz = iv.msz + 1;
+    }
     // fmindex.rs:527-558
     __device__ BiIv backward_ext(const BiIv& iv, uint32_t sym) {
         BiIv r = iv;
@@ -110,21 +151,35 @@ struct Ctx {
         const uint4 vR = a.fm.blocks[bR * 4 + t], vL = a.fm.blocks[bL * 4 + t];
         const uint32_t oR = (uint32_t)(posR - (P)bR * kSymPerBlock), oL = (uint32_t)(posL - (P)bL * kSymPerBlock);
         P cR[4], cL[4];
+        {  // ranks of the four codes at both positions: block counters + the quad's symbols up to the position (block_counts4)
+            const uint32_t pkR = quad_sum(block_counts4(vR, t, oR)), pkL = quad_sum(block_counts4(vL, t, oL));
+            const uint32_t ctrR[4] = {quad_lane0(vR.x), quad_lane0(vR.y), quad_lane0(vR.z), quad_lane0(vR.w)};
+            const uint32_t ctrL[4] = {quad_lane0(vL.x), quad_lane0(vL.y), quad_lane0(vL.z), quad_lane0(vL.w)};
 #pragma unroll
-        for (uint32_t k = 0; k < 4; k++) {
-            cR[k] = (P)k7_base(a.fm, bR, k) + quad_sum(block_part(vR, t, oR, k));
-            cL[k] = (P)k7_base(a.fm, bL, k) + quad_sum(block_part(vL, t, oL, k));
+            for (uint32_t k = 0; k < 4; k++) {
+                cR[k] = (P)k7_base(a.fm, bR, k) + ctrR[k] + ((pkR >> (8 * k)) & 0xFFu);
+                cL[k] = (P)k7_base(a.fm, bL, k) + ctrL[k] + ((pkL >> (8 * k)) & 0xFFu);
+            }
+        }
+        const bool has_l = iv.lower > 0;
+        if constexpr (PLAIN == 2) {
+            const P dR = (P)(dollar_row[0] <= posR) + (P)(dollar_row[1] <= posR), dL = (P)(dollar_row[0] <= posL) + (P)(dollar_row[1] <= posL);
+            cR[0] -= dR;  // exceptions sit in the stream as code 0
+            cL[0] -= dL;
+            P occR[6], occL[6];
+            occR[0] = dR;
+            occL[0] = dL;
+            plain_tail(cR, cL, occR, occL, has_l, iv, sym, r);
+            return r;
         }
         if (a.fm.n_exc) {  // exceptions sit in the stream as code 0
             cR[0] -= exc_le(posR);
             cL[0] -= exc_le(posL);
         }
-        const bool has_l = iv.lower > 0;
-        if constexpr (PLAIN) {
+        if constexpr (PLAIN == 1) {
             // Plain DNA, straight line: the sizes of '$', T, G, C, (N: 0,) A in the order of fmindex.rs:536, a prefix sum up to
             // the lane's symbol.  The general loop below spends ~800 vector + scalar instructions per extension on eleven
             // per-lane class dispatches (SQ counters, profiles/r06_sq_fmd.txt); this is ~100.
-            auto pick = [&](const P (&c)[4], uint32_t code) -> P { return code == 0 ? c[0] : code == 1 ? c[1] : code == 2 ? c[2] : c[3]; };
             P occR[6], occL[6];
             occR[0] = occL[0] = 0;
             if (plain_dollar != 0xFFFFu) {
@@ -132,30 +187,7 @@ struct Ctx {
                 occR[0] = k7_count_le(s_exc_sym, lo, hi, posR) - lo;
                 occL[0] = k7_count_le(s_exc_sym, lo, hi, posL) - lo;
             }
-#pragma unroll
-            for (int k = 0; k < 3; k++) {  // T, G, C
-                occR[1 + k] = pick(cR, (plain_codes >> (2 * k)) & 3u);
-                occL[1 + k] = pick(cL, (plain_codes >> (2 * k)) & 3u);
-            }
-            occR[4] = occL[4] = 0;  // N
-            occR[5] = pick(cR, (plain_codes >> 6) & 3u);  // A
-            occL[5] = pick(cL, (plain_codes >> 6) & 3u);
-            const uint32_t pos = s_pos[sym & 0xFFu];
-            P l2 = iv.lower_rev, o2 = 0, s2 = 0;
-#pragma unroll
-            for (int k = 0; k < 6; k++) {
-                const P lk = has_l ? occL[k] : (P)0;
-                const P sz = occR[k] - lk;
-                if ((uint32_t)k < pos) l2 += sz;
-                if ((uint32_t)k == pos) {
-                    o2 = lk;
-                    s2 = sz;
-                }
-            }
-            r.lower = less_of(sym) + o2;
-            r.lower_rev = l2;
-            r.size = s2;
-            r.msz = iv.msz + 1;
+            plain_tail(cR, cL, occR, occL, has_l, iv, sym, r);
             return r;
         }
         P s = 0, o = 0, l = iv.lower_rev;
@@ -292,7 +324,7 @@ constexpr uint32_t kPatLds = 248;  // symbols of a read kept in LDS (64 quads x 
 #else
 #define K7_OCC
 #endif
-template <bool WIDE, bool OUT64, bool PLAIN>
+template <bool WIDE, bool OUT64, int PLAIN>
 __global__ __launch_bounds__(256) K7_OCC void fmd_smems_kernel(const FmdArgsT<WIDE> a) {
     using P = typename FmLayout<WIDE>::Pos;
     using BiIv = BiIvT<P>;
@@ -317,6 +349,12 @@ __global__ __launch_bounds__(256) K7_OCC void fmd_smems_kernel(const FmdArgsT<WI
     uint8_t* const my_pat = s_pat + (threadIdx.x >> 2) * kPatLds;
     Ctx<WIDE, PLAIN> cx{a, s_class, s_less, s_comp, s_exc, s_exc_sym, s_sparse_off, t, false, 0xFFFFFFFFu, 0xFFFFu, s_pos};
     k7_plain(s_class, s_pos, cx.plain_codes, cx.plain_dollar);  // (PLAIN: the host looked at the same classes, bg_fm::h_class)
+    if (PLAIN == 2) {  // '$' the only listed symbol, at most twice (the host checked): its rows in registers (Ctx::dollar_row)
+        const uint32_t lo = cx.plain_dollar != 0xFFFFu ? s_sparse_off[cx.plain_dollar] : 0u;
+        const uint32_t nd = cx.plain_dollar != 0xFFFFu ? s_sparse_off[cx.plain_dollar + 1] - lo : 0u;
+        if (nd > 0) cx.dollar_row[0] = s_exc_sym[lo];
+        if (nd > 1) cx.dollar_row[1] = s_exc_sym[lo + 1];
+    }
 
     enum : uint32_t { PH_LOAD, PH_START, PH_FWD, PH_K, PH_BWD, PH_AFTER, PH_FINISH, PH_DONE };
     uint32_t phase = PH_LOAD;
@@ -591,6 +629,16 @@ int smems_dev(bg_fm* fm, bool out64, int all, uint64_t n_p, const uint8_t* d_pat
         plain = plain && (cd == kClsZero || (cd >= kClsSparse && cd < kClsDense));
         if (getenv("BG_K7_GENERAL")) plain = false;  // (tests, A/B)
     }
+    // ... and '$' the only listed symbol, with at most two rows (every T$ / T$R$ index): the exceptions of the code stream are
+    // exactly those rows
+    bool dollar2 = plain && !getenv("BG_K7_PLAIN1");
+    {
+        uint32_t listed = 0;
+        for (uint32_t b = 0; b < 256; b++) listed += fm->h_class[b] >= kClsSparse && fm->h_class[b] < kClsDense;
+        const uint16_t cd = fm->h_class[(uint8_t)'$'];
+        const uint32_t want = (cd >= kClsSparse && cd < kClsDense) ? 1u : 0u;
+        dollar2 = dollar2 && listed == want;
+    }
     auto fill = [&](auto& a) {
         a.n_p = n_p;
         a.pat = d_pat;
@@ -616,18 +664,19 @@ int smems_dev(bg_fm* fm, bool out64, int all, uint64_t n_p, const uint8_t* d_pat
         return BG_OK;
     };
     int rc;
-    if (fm->wide) {
-        auto a = k7_args<true>(fm);
+    auto pick = [&](auto a, auto wide_tag, auto out_tag) -> int {
+        constexpr bool W = decltype(wide_tag)::value, O64 = decltype(out_tag)::value;
         fill(a);
-        rc = plain ? launch(fmd_smems_kernel<true, true, true>, a) : launch(fmd_smems_kernel<true, true, false>, a);
-    } else {
-        auto a = k7_args<false>(fm);
-        fill(a);
-        if (out64)
-            rc = plain ? launch(fmd_smems_kernel<false, true, true>, a) : launch(fmd_smems_kernel<false, true, false>, a);
-        else
-            rc = plain ? launch(fmd_smems_kernel<false, false, true>, a) : launch(fmd_smems_kernel<false, false, false>, a);
-    }
+        if (plain && dollar2 && a.fm.n_exc <= 2) return launch(fmd_smems_kernel<W, O64, 2>, a);
+        if (plain) return launch(fmd_smems_kernel<W, O64, 1>, a);
+        return launch(fmd_smems_kernel<W, O64, 0>, a);
+    };
+    if (fm->wide)
+        rc = pick(k7_args<true>(fm), std::true_type{}, std::true_type{});
+    else if (out64)
+        rc = pick(k7_args<false>(fm), std::false_type{}, std::true_type{});
+    else
+        rc = pick(k7_args<false>(fm), std::false_type{}, std::false_type{});
     if (rc) return rc;
     BG_HIP(hipGetLastError());
     return BG_OK;

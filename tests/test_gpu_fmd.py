@@ -60,14 +60,18 @@ def test_all_smems_doctest_and_issue39():
         assert [p for iv, _, _ in r for p in iv.forward().occ(sa)] == [c["read_pos"]], i
 
 
-@pytest.mark.parametrize("with_n", [True, False])
-def test_random_reads_vs_oracle(with_n):
-    """(with N: the general extension; without: K7's plain-DNA instantiation — bg_fm::h_class decides at launch)"""
+@pytest.mark.parametrize("flavour", ["general", "plain_two_dollars", "plain_four_dollars"])
+def test_random_reads_vs_oracle(flavour):
+    """K7's three instantiations, chosen at launch from the index's symbol classes (bg_fm::h_class): with N in the text the
+    general extension; an ACGT text as T$R$ the plain-DNA one with the two '$' rows in registers; two sequences (four '$') the
+    plain-DNA one that ranks '$' in its list."""
     rng = np.random.default_rng(13)
     g = synth.random_dna(20_000, seed=8).copy()
-    if with_n:
+    if flavour == "general":
         g[rng.integers(0, len(g), size=10)] = ord("N")
     fwd = g.tobytes()
+    if flavour == "plain_four_dollars":
+        fwd = fwd[:9_000] + b"$" + fwd[9_000:]
     text = fwd + b"$" + revcomp(fwd) + b"$"
     sa, b, ls, fmd = build(text, k=16)
     ofmd = orc.FMDIndex(b, ls, orc.Occ(b, 16, ALPHA))
@@ -75,7 +79,7 @@ def test_random_reads_vs_oracle(with_n):
     acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
     for _ in range(400):
         s = int(rng.integers(0, len(fwd) - 120))
-        r = np.frombuffer(fwd[s:s + int(rng.integers(20, 120))], dtype=np.uint8).copy()
+        r = np.frombuffer(fwd[s:s + int(rng.integers(20, 120))].replace(b"$", b"A"), dtype=np.uint8).copy()
         nm = int(rng.integers(0, 4))
         r[rng.integers(0, len(r), size=nm)] = acgt[rng.integers(0, 4, size=nm)]
         rb = r.tobytes()
