@@ -1198,7 +1198,7 @@ def seed_extend_leg(args, ctx, dev, stream, rank, world, do_cpu, orc, threads, p
                 kind = (oops.reshape(k, ostride) & np.uint64(0xFF)).astype(np.uint8)
                 ok = bool((hops[dev_mask] == kind[or_mask]).all())
         parity.update({"seed_extend_reads_checked": n_chk, "seed_extend_reads_total": Rp, "seed_extend_bit_exact": bool(ok),
-                       "seed_extend_sample": "first and last n/2 reads (the last pass of 2^20 included) + ops_off of every read"})
+                       "seed_extend_sample": "first and last n/2 reads + ops_off of every read"})
         hr = reads[:n_chk * L].cpu().numpy()
         ho = np.arange(n_chk + 1, dtype=np.uint64) * np.uint64(L)
         ns = min(n_chk, 2_000 * threads)
