@@ -1159,6 +1159,23 @@ def seed_extend_leg(args, ctx, dev, stream, rank, world, do_cpu, orc, threads, p
                          "gathered_records": int(holder["all"].shape[0]), "collective_proof": GATHER.proof(holder["rec"], counts),
                          "note": "records only (score + reference span); the winners' operations stay on the rank that "
                                  "computed them (INTEGRATION.md section 3)"}
+        if world == 1:
+            # an eighth of the reads in one call: what one GPU of eight sees of configs[4] in the strong leg — bounds the 8-GPU
+            # strong figure from one GPU (the weak leg above when it has Rt / 8 reads, else a call of its own)
+            Re = Rt // 8
+            if Re == Rp:
+                t_e = pipe_t / args.steps
+            else:
+                e_hits = torch.empty(max(Re, 1) * 96, dtype=torch.uint8, device=dev)
+                e_ops = torch.empty(max(Re, 1) * stride, dtype=torch.uint8, device=dev)
+
+                def eighth_step():
+                    seed_extend_dev(fm, sc, Re, s_reads.data_ptr(), s_roff.data_ptr(), L, e_hits.data_ptr(), e_ops.data_ptr(), stride, prm, stream, None)
+
+                t_e = timed_steps(eighth_step, s_steps, s_warm, dev) / s_steps
+                del e_hits, e_ops
+            leg["strong"]["eighth_of_the_batch"] = {"reads": Re, "ms": round(t_e * 1e3, 3), "reads_per_s": round(Re / t_e, 1),
+                                                    "frac_of_full_batch_rate": round((Re / t_e) / (float(Rt) * s_steps / st_t), 3)}
         if world > 1:  # the gathered records of the sharded run must be the unsharded answer
             leg["strong"]["capi_gather_equals_torch_gather"] = GATHER.check(holder["rec"], counts)
             f_roff = torch.arange(Rt + 1, dtype=torch.int64, device=dev) * L
@@ -1174,7 +1191,7 @@ def seed_extend_leg(args, ctx, dev, stream, rank, world, do_cpu, orc, threads, p
         occ = orc.Occ(b, 128, N_ALPHABET)
         osc = orc.make_scoring(-5, -1, 1, -1)
         n_chk = max(2, int(min(Rp, 100_000) * args.parity_frac))
-        # the first and the LAST reads of the batch: the call walks the reads in passes of 2^20, the tail belongs to the last pass
+        # the first and the LAST reads of the batch: the call walks the reads in passes, the tail belongs to the last one
         segs = [(0, n_chk // 2), (Rp - (n_chk - n_chk // 2), n_chk - n_chk // 2)]
         hv64 = d_hits.view(torch.int64).view(Rp, 12)
         # every read's operations end at the end of its own slot of the caller's buffer (biogpu.h)
