@@ -480,7 +480,10 @@ uint64_t bg_sparse_expand_kmer_matches(const uint8_t* x, uint64_t m, const uint8
  *   seeds        read[o .. o + seed_len) for o = 0, stride, 2 stride, ... while the window fits in the read;
  *   votes        a seed votes when its search is Complete and its interval holds 1 ..= max_occ rows;
  *   proposals    hit position p of the seed at offset o proposes the read start s = p - o; s < 0 or s >= n_text
- *                (the text without its final sentinel) is dropped, equal (read, s) proposals are merged;
+ *                (the text without its final sentinel) is dropped, equal (read, s) proposals are merged; of the sorted starts
+ *                of a read, one within pad / 2 of the last start kept is merged into it as well (the seeds either side of an
+ *                indel propose the same locus a few bases apart, and the +- pad window of the first holds both alignments;
+ *                pad / 2 = 0: only equal starts merge — the definition of rounds 3-5);
  *   extension    Aligner::semiglobal(x = read, y = text[max(0, s - pad) .. min(n_text, s + read_len + pad)));
  *   best hit     per read the highest score, the smallest s among equal scores; a read without candidates
  *                reports score BG_MIN_SCORE, ref positions UINT64_MAX and no operations.

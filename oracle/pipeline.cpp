@@ -11,7 +11,8 @@
 //   * seeds: read[o .. o + seed_len) for o = 0, stride, 2*stride, ... while the window fits in the read;
 //   * a seed votes when its search is Complete and its interval holds 1 ..= max_occ rows;
 //   * hit position p of the seed at offset o proposes the read start s = p - o; proposals with s < 0 or
-//     s >= n_text are dropped, equal (read, s) proposals are merged;
+//     s >= n_text are dropped, equal (read, s) proposals are merged, and so are, in ascending order, starts within pad / 2
+//     of the last start kept (the seeds either side of an indel propose one locus a few bases apart);
 //   * candidate window = text[max(0, s - pad) .. min(n_text, s + read_len + pad)), n_text = the text without
 //     its final sentinel; the read is x, the window is y of Aligner::semiglobal;
 //   * per read the candidate with the highest score wins, the smallest s among equal scores; a read without
@@ -62,6 +63,12 @@ static int seed_extend_impl(const uint8_t* bwt, uint64_t n, const uint64_t* less
             }
             std::sort(cand.begin(), cand.end());
             cand.erase(std::unique(cand.begin(), cand.end()), cand.end());
+            {  // starts within pad / 2 of the last one kept are the same locus (its window holds both alignments): merged, in order
+                size_t kept = 0;
+                for (size_t i = 0; i < cand.size(); i++)
+                    if (kept == 0 || cand[i] - cand[kept - 1] > pad / 2) cand[kept++] = cand[i];
+                cand.resize(kept);
+            }
             orc_seed_hit_t h{};
             h.aln.score = ORC_MIN_SCORE;
             h.ref_start = h.ref_end = h.window_start = UINT64_MAX;

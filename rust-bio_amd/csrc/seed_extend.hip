@@ -61,8 +61,9 @@ __global__ __launch_bounds__(256) void se_votes_kernel(uint64_t n_q, const uint8
 }
 
 // S4: one wavefront per read.  The read's hits are pos[hoff[r * S] .. hoff[(r + 1) * S)), grouped by seed slot.  Every
-// hit proposes s = p - k * stride (dropped if negative or >= n_text); the proposals are sorted, merged, and written
-// back over the read's own slice of `pos` (as the sorted unique starts); per read: candidates, hits, y bytes, x bytes.
+// hit proposes s = p - k * stride (dropped if negative or >= n_text); the proposals are sorted, merged (equal ones, and those
+// within pad / 2 of the last start kept), and written back over the read's own slice of `pos`; per read: candidates, hits,
+// y bytes, x bytes.
 template <typename T>
 __global__ __launch_bounds__(64) void se_propose_kernel(SeedPrm prm, uint64_t n_reads, const uint64_t* __restrict__ read_off,
                                                         const uint64_t* __restrict__ hoff, uint64_t* __restrict__ pos,
@@ -112,17 +113,35 @@ __global__ __launch_bounds__(64) void se_propose_kernel(SeedPrm prm, uint64_t n_
                 __syncthreads();
             }
         }
-        // merge equal proposals; the unique starts go back over the read's own slots of `pos`
+        // merge equal proposals (compacted in place: a value never moves up, and a step reads before it writes) ...
         uint32_t base = 0;
         for (uint32_t b0 = 0; b0 < P; b0 += 64) {
             const uint32_t i = b0 + lane;
             const T v = s_val[i];
             const bool keep = v != kNoStart && (i == 0 || s_val[i - 1] != v);
             const uint64_t m = __ballot(keep);
-            if (keep) pos[h0 + base + (uint32_t)__popcll(m & ((1ull << lane) - 1))] = v;
+            if (keep) s_val[base + (uint32_t)__popcll(m & ((1ull << lane) - 1))] = v;
             base += (uint32_t)__popcll(m);
         }
-        n_unique = base;
+        __syncthreads();
+        // ... and starts within pad / 2 of the last one kept (the seeds either side of an indel propose the same locus a few
+        // bases apart: its window holds both alignments) — in order, so a run of proposals a few bases apart each (a tandem
+        // repeat) keeps a start every pad / 2 + 1 bases; the kept starts go back over the read's own slots of `pos`
+        if (lane == 0) {
+            const T merge = (T)(prm.pad / 2);
+            uint32_t kept = 0;
+            T last = 0;
+            for (uint32_t i = 0; i < base; i++) {
+                const T v = s_val[i];
+                if (kept == 0 || v - last > merge) {
+                    pos[h0 + kept++] = v;
+                    last = v;
+                }
+            }
+            s_off[0] = kept;  // (s_off is not read again)
+        }
+        __syncthreads();
+        n_unique = (uint32_t)s_off[0];
     }
     // window bytes of this read's candidates (second pass: the starts are final now)
     __syncthreads();

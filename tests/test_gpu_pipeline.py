@@ -176,3 +176,53 @@ def test_seed_extend_in_several_passes_keeps_global_operation_offsets(chunk):
     dh = d_hits.cpu().numpy().view(_lib.SEED_HIT_DTYPE)
     assert (dh["aln"]["ops_off"] == (np.arange(R) + 1) * stride - dh["aln"]["n_ops"]).all()
     compare(dh, d_ops.cpu().numpy(), ohits, oops, ostride)
+
+
+@pytest.mark.parametrize("pad", [0, 1, 9, 25])
+def test_proposals_close_together_are_one_candidate(pad):
+    """Round 6: of a read's sorted proposals, one within pad / 2 of the last start KEPT is merged into it (include/biogpu.h) —
+    in order: a tandem repeat's run of proposals ten bases apart keeps a start every pad / 2 + 1 bases or more, not only the first.
+    The device and the oracle agree read by read (candidate counts, windows, winners), and the counts are the rule's, restated
+    here on the proposals themselves (seeds -> exact occurrences by numpy)."""
+    rng = np.random.default_rng(17)
+    n_text, L = 60_000, 120
+    g = synth.random_dna(n_text, seed=41).copy()
+    unit = synth.random_dna(10, seed=42)
+    g[30_000:30_150] = np.tile(unit, 15)  # a tandem repeat of period 10: a 20-mer inside it occurs 13 times
+    text = np.append(g, np.uint8(ord("$")))
+    starts = rng.integers(0, n_text - L, size=600)
+    starts[:40] = 29_940 + np.arange(40) * 3  # reads over the repeat
+    refs = np.stack([g[s:s + L] for s in starts])
+    reads, _ = synth.mutate_fixed(refs, 78, 0.02, 0.015, 0.015)  # indels: the seeds of a read sit on several diagonals
+    flat = np.ascontiguousarray(reads.reshape(-1))
+    off = np.arange(len(starts) + 1, dtype=np.uint64) * np.uint64(L)
+    sa, b, ls, fm = build(text, 0)
+    attach_text(fm, text)
+    prm = SeedParams(seed_len=20, stride=10, max_occ=16, pad=pad)
+    sc = Scoring.from_scores(-5, -1, 1, -1)
+    hits, ops = seed_extend_arrays(fm, sc, flat, off, params=prm)
+    occ = orc.Occ(b, 64, ALPHA)
+    ohits, oops, ostride = orc.seed_extend_batch(b, ls, occ, sa, text, n_text, orc.make_scoring(-5, -1, 1, -1), flat, off,
+                                                 seed_len=20, stride=10, max_occ=16, pad=pad, threads=8)
+    compare(hits, ops, ohits, oops, ostride)
+    # the rule on the proposals themselves
+    tb = g.tobytes()
+    want = []
+    for r in range(len(starts)):
+        props = set()
+        for o in range(0, L - 20 + 1, 10):
+            seed = reads[r, o:o + 20].tobytes()
+            occs, at = [], tb.find(seed)
+            while at >= 0:
+                occs.append(at)
+                at = tb.find(seed, at + 1)
+            if 1 <= len(occs) <= 16:
+                props.update(p - o for p in occs if p >= o)
+        kept = []
+        for s in sorted(props):
+            if not kept or s - kept[-1] > pad // 2:
+                kept.append(s)
+        want.append(len(kept))
+    assert (hits["n_candidates"] == np.array(want)).all()
+    if pad >= 9:
+        assert (hits["n_candidates"][:40] >= 2).any()  # the repeat's run is not collapsed into its first start
