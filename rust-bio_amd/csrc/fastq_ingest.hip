@@ -72,27 +72,57 @@ __global__ __launch_bounds__(256) void fq_count_newlines_kernel(const uint8_t* _
         hi[blockIdx.x] = (uint8_t)(sh[0] | sh[1] | sh[2] | sh[3]);
     }
 }
-// exclusive scan of up to 2^32 items by one block (items are per-chunk / per-block partial sums: few)
+// exclusive scan of up to 2^32 items by one block (items are per-chunk / per-block partial sums: few).  4096 items per trip:
+// four per thread, wavefront scans by shuffles, the sixteen wavefront totals scanned by the first wavefront — three barriers a
+// trip.  (Until round 6 a Hillis-Steele scan in LDS, twenty barriers per 1024 items: 320 us for the 14 000 partial sums of a
+// seed-and-extend pass, four times per pass.)
 template <typename T>
 __global__ __launch_bounds__(1024) void fq_scan_small_kernel(const T* __restrict__ in, uint64_t* __restrict__ out, uint64_t n, uint64_t* total) {
-    __shared__ uint64_t s[1024];
+    __shared__ uint64_t s_w[16], s_wb[17];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    auto shfl_up64 = [](uint64_t v, int o) {
+        const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)v, o), hi = (uint32_t)__shfl_up((int)(uint32_t)(v >> 32), o);
+        return (uint64_t)hi << 32 | lo;
+    };
     uint64_t carry = 0;
-    for (uint64_t b = 0; b < n; b += 1024) {
-        const uint64_t i = b + threadIdx.x;
-        const uint64_t v = i < n ? (uint64_t)in[i] : 0;
-        s[threadIdx.x] = v;
-        __syncthreads();
-        for (int o = 1; o < 1024; o <<= 1) {
-            const uint64_t u = threadIdx.x >= (unsigned)o ? s[threadIdx.x - o] : 0;
-            __syncthreads();
-            s[threadIdx.x] += u;
-            __syncthreads();
+    for (uint64_t b = 0; b < n; b += 4096) {
+        const uint64_t i0 = b + (uint64_t)tid * 4;
+        uint64_t v[4], tsum = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            v[k] = i0 + k < n ? (uint64_t)in[i0 + k] : 0;
+            tsum += v[k];
         }
-        if (i < n) out[i] = carry + s[threadIdx.x] - v;
-        carry += s[1023];
+        uint64_t incl = tsum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint64_t u = shfl_up64(incl, o);
+            if ((int)lane >= o) incl += u;
+        }
+        if (lane == 63) s_w[wave] = incl;
+        __syncthreads();
+        if (wave == 0) {
+            const uint64_t w = lane < 16 ? s_w[lane] : 0;
+            uint64_t wi = w;
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) {
+                const uint64_t u = shfl_up64(wi, o);
+                if ((int)lane >= o) wi += u;
+            }
+            if (lane < 16) s_wb[lane] = wi - w;
+            if (lane == 15) s_wb[16] = wi;
+        }
+        __syncthreads();
+        uint64_t run = carry + s_wb[wave] + incl - tsum;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (i0 + k < n) out[i0 + k] = run;
+            run += v[k];
+        }
+        carry += s_wb[16];
         __syncthreads();
     }
-    if (threadIdx.x == 0 && total) *total = carry;
+    if (tid == 0 && total) *total = carry;
 }
 __global__ __launch_bounds__(256) void fq_line_starts_kernel(const uint8_t* __restrict__ t, uint64_t len, const uint64_t* __restrict__ base,
                                                              uint64_t* __restrict__ ls) {
@@ -694,9 +724,9 @@ __global__ __launch_bounds__(256) void fq_fused_kernel(const FusedArgs a) {
     __shared__ uint64_t s_lb[24];
     __shared__ uint64_t s_bc[8];  // [4] irregular: seen before the records are looked at, [5] irregular: seen later, [6] phases of the line index the tile's lines rule out
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // (one tile per block.  Persistent blocks that take tile after tile were measured, profiles/r06_ingest_experiments.txt:
-    //  0.74 ms per call against 0.65 — and 1.86 / 1.15 / 0.81 / 0.74 ms with 1 / 2 / 4 / 8 blocks per CU: a tile's own chain of
-    //  round trips is ~24 us, beyond four blocks per CU the copy phase's throughput bounds the kernel)
+    // (one tile per block.  Persistent blocks that take tile after tile were measured on the round's first one-pass build,
+    //  profiles/r06_ingest_experiments.txt: 0.74 ms per call against 0.65 — and 1.86 / 1.15 / 0.81 / 0.74 ms with 1 / 2 / 4 / 8
+    //  blocks per CU: a tile's own chain of round trips is what a block's life consists of, ~30 us)
     if (tid == 0) s_bc[4] = s_bc[5] = s_bc[6] = 0;
     __syncthreads();
     const uint32_t tile = blockIdx.x;
@@ -1093,7 +1123,7 @@ __global__ __launch_bounds__(256) void fq_fused_kernel(const FusedArgs a) {
             const bool tab = SEQ ? tab_s : tab_q;
             auto rel_of = [&](uint32_t i) { return SEQ ? s_rec[i].seq_rel : s_rec[i].qual_rel; };
             auto dst_of = [&](uint32_t i) { return SEQ ? s_rec[i].seq_dst : s_rec[i].qual_dst; };
-            auto end_of = [&](uint32_t i) { return SEQ ? s_rec[i].seq_dst + s_rec[i].seq_n : s_rec[i].qual_dst + s_rec[i].qual_n; };
+            auto end_of = [&](uint32_t i) -> uint32_t { return SEQ ? (uint32_t)s_rec[i].seq_dst + s_rec[i].seq_n : (uint32_t)s_rec[i].qual_dst + s_rec[i].qual_n; };
             auto flag = [&](uint32_t i, bool hi, bool bad) {
                 const uint32_t f = (hi ? (SEQ ? 2u : 8u) : 0u) | (bad ? 4u : 0u);
                 if (f) atomicOr(&s_rec[i].flags, f);
