@@ -7,7 +7,7 @@
 #   tests                 pytest -m gpu (the whole suite)        tests:<expr>  pytest -m gpu -k <expr>
 #   smoke                 __graft_entry__.smoke()
 #   fuzz_fm:<seed>:<s>    tests/fuzz_fm.py            fuzz_fm_wide:<seed>:<s>   the same on the forced 64-bit layout
-#   fuzz_banded:<seed>:<s>[:k3p]   fuzz_banded_long:<seed>:<s>:<len>   fuzz_pairwise:<seed>:<s>   fuzz_pk16:<seed>:<s>   fuzz_fastq:<seed>:<s>
+#   fuzz_banded:<seed>:<s>[:k3p]   fuzz_banded_long:<seed>:<s>:<len>   fuzz_pairwise:<seed>:<s>   fuzz_pk16:<seed>:<s>   fuzz_fastq:<seed>:<s>   fuzz_pipeline:<seed>:<s>
 #   bench[:args]          python bench.py [args ...] (args separated by ',')  -> <tag>/bench.json
 #   profiles              tools/collect_profiles.sh <tag>  (kernel stats + PMC passes of the default bench command)
 #   py:<script>[:args]    python <script> [args ...] (args separated by ',')  -> <tag>/<script basename>.json (stdout)
@@ -41,6 +41,7 @@ PY
     fuzz_banded_long) timeout $((b + 300)) python tests/fuzz_banded_long.py "$a" "$b" "$c" > "$O/fuzz_banded_long_$a.log" 2>&1; say "fuzz_banded_long $a $b $c: $(last "$O/fuzz_banded_long_$a.log")" ;;
     fuzz_pairwise) timeout $((b + 200)) python tests/fuzz_pairwise.py "$a" "$b" > "$O/fuzz_pairwise_$a.log" 2>&1; say "fuzz_pairwise $a $b: $(last "$O/fuzz_pairwise_$a.log")" ;;
     fuzz_fastq) timeout $((b + 200)) python tests/fuzz_fastq.py "$a" "$b" > "$O/fuzz_fastq_$a.log" 2>&1; say "fuzz_fastq $a $b: $(grep MISMATCH "$O/fuzz_fastq_$a.log" | head -3) $(last "$O/fuzz_fastq_$a.log")" ;;
+    fuzz_pipeline) timeout $((b + 200)) python tests/fuzz_pipeline.py "$a" "$b" > "$O/fuzz_pipeline_$a.log" 2>&1; say "fuzz_pipeline $a $b: $(grep -E "MISMATCH|Error" "$O/fuzz_pipeline_$a.log" | head -3) $(last "$O/fuzz_pipeline_$a.log")" ;;
     fuzz_pk16) timeout $((b + 200)) python tests/fuzz_pk16.py "$a" "$b" > "$O/fuzz_pk16_$a.log" 2>&1; say "fuzz_pk16 $a $b: $(last "$O/fuzz_pk16_$a.log")" ;;
     bench) timeout 1500 python bench.py ${a//,/ } > "$O/bench.json" 2> "$O/bench.err"; say "bench ${a}: $(head -c 600 "$O/bench.json")" ;;
     profiles) timeout 3000 bash tools/collect_profiles.sh "$TAG" > "$O/profiles.log" 2>&1; say "profiles: $(ls gpurun_out/profiles_$TAG 2>/dev/null | tr '\n' ' ')" ;;
