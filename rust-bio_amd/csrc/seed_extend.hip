@@ -84,7 +84,7 @@ __global__ __launch_bounds__(64) void se_propose_kernel(SeedPrm prm, uint64_t n_
     if (nh) {
         uint32_t P = 64;
         while (P < nh) P <<= 1;
-        for (uint32_t i = lane; i < P; i += 64) {
+        auto proposal = [&](uint32_t i) -> T {
             T v = kNoStart;
             if (i < nh) {
                 uint32_t k = 0;  // the seed slot of hit i: last k with s_off[k] - h0 <= i
@@ -93,8 +93,26 @@ __global__ __launch_bounds__(64) void se_propose_kernel(SeedPrm prm, uint64_t n_
                 const uint64_t o = (uint64_t)k * prm.stride;
                 if (p >= o && p - o < prm.n_text) v = (T)(p - o);  // also drops BG_SA_NONE / BG_SA_PANIC
             }
-            s_val[i] = v;
-        }
+            return v;
+        };
+        if (nh <= 64) {
+            // the usual read (a handful of hits): every lane finds its proposal's rank among the wavefront's by looking at each
+            // of the nh values once (a broadcast per value) — no LDS passes, no barriers (the bitonic network below takes 21)
+            const T v = proposal(lane);
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < nh; j++) {
+                T u;
+                if constexpr (sizeof(T) == 8)
+                    u = (T)((uint64_t)(uint32_t)__shfl((int)(uint32_t)((uint64_t)v >> 32), (int)j) << 32 | (uint32_t)__shfl((int)(uint32_t)v, (int)j));
+                else
+                    u = (T)(uint32_t)__shfl((int)(uint32_t)v, (int)j);
+                rank += (u < v || (u == v && j < lane)) ? 1u : 0u;
+            }
+            // (lanes >= nh hold kNoStart, the largest value: their ranks are nh .. 63 in lane order)
+            s_val[lane < nh ? rank : lane] = v;
+            __syncthreads();
+        } else {
+        for (uint32_t i = lane; i < P; i += 64) s_val[i] = proposal(i);
         __syncthreads();
         // bitonic sort of P values by the 64 lanes
         for (uint32_t k2 = 2; k2 <= P; k2 <<= 1) {
@@ -112,6 +130,7 @@ __global__ __launch_bounds__(64) void se_propose_kernel(SeedPrm prm, uint64_t n_
                 }
                 __syncthreads();
             }
+        }
         }
         // merge equal proposals (compacted in place: a value never moves up, and a step reads before it writes) ...
         uint32_t base = 0;
